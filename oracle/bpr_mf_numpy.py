@@ -1,0 +1,261 @@
+"""CPU oracle (numpy) for the MF + BPR training hot path of AmazingDD/daisyRec.
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import
+it; the product path (``daisyrec_amd``) never does and fails loudly when the HIP
+library is missing.
+
+Every function restates, in closed form, what the reference computes through
+``torch.nn.Embedding`` + autograd + ``torch.optim`` (file:line relative to
+/root/reference):
+
+* forward            daisy/model/MFRecommender.py:63-68
+* loss               daisy/model/MFRecommender.py:70-97, daisy/utils/loss.py:5-33
+* backward + step    daisy/model/AbstractRecommender.py:48-67,119,125-126
+* rank / full_rank   daisy/model/MFRecommender.py:106-133
+* negative sampler   daisy/utils/sampler.py:55-103 (uniform branch :82-89)
+
+Parity status: PINNED.  ``tests/golden/make_golden.py`` imports the real
+reference (CPU PyTorch) in the build container and writes known-answer vectors
+(per-step and ml-100k end-to-end) that ``tests/test_oracle_golden.py`` checks
+this file against.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+LOSS_BPR, LOSS_HL, LOSS_TL = 0, 1, 2
+LOSS_IDS = {"BPR": LOSS_BPR, "HL": LOSS_HL, "TL": LOSS_TL}
+
+
+def _sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def pair_loss_coef(pos, neg, loss_type=LOSS_BPR, gamma=1e-10):
+    """Per-sample loss terms and d(loss)/d(pos_score), d(loss)/d(neg_score).
+
+    BPR  loss.py:10-13   -(gamma + sigmoid(pos-neg)).log().sum()
+    HL   loss.py:20-23   clamp(1-(pos-neg), min=0).sum()   (grad passes at ==0)
+    TL   loss.py:30-33   sigmoid(neg-pos).sum() + sigmoid(neg**2).sum()
+    """
+    x = pos - neg
+    if loss_type == LOSS_BPR:
+        s = _sigmoid(x)
+        terms = -np.log(gamma + s)
+        c = -(s * (1.0 - s)) / (gamma + s)
+        return terms, c, -c
+    if loss_type == LOSS_HL:
+        terms = np.maximum(1.0 - x, 0.0)
+        c = np.where((1.0 - x) >= 0.0, -1.0, 0.0).astype(x.dtype)
+        return terms, c, -c
+    if loss_type == LOSS_TL:
+        s1 = _sigmoid(neg - pos)
+        s2 = _sigmoid(neg * neg)
+        terms = s1 + s2
+        d1 = s1 * (1.0 - s1)
+        cp = -d1
+        cn = d1 + 2.0 * neg * s2 * (1.0 - s2)
+        return terms, cp, cn
+    raise NotImplementedError(f"Invalid loss type: {loss_type}")
+
+
+def mf_forward(P, Q, u, i):
+    """MFRecommender.py:63-68  pred[b] = sum_k P[u_b,k] * Q[i_b,k]."""
+    return np.einsum("bk,bk->b", P[u], Q[i])
+
+
+def mf_pair_grad(P, Q, u, i, j, reg_1, reg_2, loss_type=LOSS_BPR, gamma=1e-10,
+                 dtype=np.float64):
+    """Loss (scalar) and the DENSE gradients autograd produces for one batch.
+
+    MFRecommender.py:70-97: the regularisers are non-squared norms over the
+    whole gathered (B x d) matrices, duplicates counted:
+        reg_1*(|Q[i]|_1 + |Q[j]|_1 + |P[u]|_1) + reg_2*(|Q[i]|_F + |Q[j]|_F + |P[u]|_F)
+    d|X|_F/dX = X/|X|_F (0 when the norm is 0: torch's subgradient),
+    d|X|_1/dX = sign(X).
+    """
+    P = np.asarray(P, dtype=dtype)
+    Q = np.asarray(Q, dtype=dtype)
+    u = np.asarray(u, dtype=np.int64)
+    i = np.asarray(i, dtype=np.int64)
+    j = np.asarray(j, dtype=np.int64)
+    pu, qi, qj = P[u], Q[i], Q[j]
+    pos = np.einsum("bk,bk->b", pu, qi)
+    neg = np.einsum("bk,bk->b", pu, qj)
+    terms, cp, cn = pair_loss_coef(pos, neg, loss_type, dtype(gamma))
+    nU = np.sqrt((pu * pu).sum(dtype=dtype))
+    nI = np.sqrt((qi * qi).sum(dtype=dtype))
+    nJ = np.sqrt((qj * qj).sum(dtype=dtype))
+    loss = terms.sum(dtype=dtype)
+    loss += reg_1 * (np.abs(qi).sum(dtype=dtype) + np.abs(qj).sum(dtype=dtype))
+    loss += reg_2 * (nI + nJ)
+    loss += reg_1 * np.abs(pu).sum(dtype=dtype)
+    loss += reg_2 * nU
+
+    def _fro(x, n):
+        return x / n if n > 0 else np.zeros_like(x)
+
+    gP = np.zeros_like(P)
+    gQ = np.zeros_like(Q)
+    np.add.at(gP, u, cp[:, None] * qi + cn[:, None] * qj
+              + reg_1 * np.sign(pu) + reg_2 * _fro(pu, nU))
+    np.add.at(gQ, i, cp[:, None] * pu + reg_1 * np.sign(qi) + reg_2 * _fro(qi, nI))
+    np.add.at(gQ, j, cn[:, None] * pu + reg_1 * np.sign(qj) + reg_2 * _fro(qj, nJ))
+    return loss, gP, gQ
+
+
+def mf_sgd_step(P, Q, u, i, j, lr, reg_1, reg_2, loss_type=LOSS_BPR, gamma=1e-10,
+                dtype=np.float64):
+    """One `zero_grad / calc_loss / backward / SGD.step` (AbstractRecommender.py:119-126).
+
+    Returns (loss, P_new, Q_new) with the tables cast back to float32 like the
+    reference's parameters.  With dtype=float64 this is the "exact" batch
+    synchronous result rounded once.
+    """
+    loss, gP, gQ = mf_pair_grad(P, Q, u, i, j, reg_1, reg_2, loss_type, gamma, dtype)
+    Pn = (np.asarray(P, dtype=dtype) - dtype(lr) * gP).astype(np.float32)
+    Qn = (np.asarray(Q, dtype=dtype) - dtype(lr) * gQ).astype(np.float32)
+    return float(loss), Pn, Qn
+
+
+class DenseAdam:
+    """torch.optim.Adam defaults (AbstractRecommender.py:54): betas (0.9, 0.999),
+    eps 1e-8, no weight decay, no amsgrad, DENSE (every row moves every step)."""
+
+    def __init__(self, shapes, lr, b1=0.9, b2=0.999, eps=1e-8, dtype=np.float64):
+        self.lr, self.b1, self.b2, self.eps, self.t = lr, b1, b2, eps, 0
+        self.m = [np.zeros(s, dtype=dtype) for s in shapes]
+        self.v = [np.zeros(s, dtype=dtype) for s in shapes]
+        self.dtype = dtype
+
+    def step(self, params, grads):
+        self.t += 1
+        bc1 = 1.0 - self.b1 ** self.t
+        bc2 = 1.0 - self.b2 ** self.t
+        out = []
+        for k, (w, g) in enumerate(zip(params, grads)):
+            w = np.asarray(w, dtype=self.dtype)
+            self.m[k] = self.b1 * self.m[k] + (1 - self.b1) * g
+            self.v[k] = self.b2 * self.v[k] + (1 - self.b2) * g * g
+            denom = np.sqrt(self.v[k]) / np.sqrt(bc2) + self.eps
+            out.append((w - (self.lr / bc1) * self.m[k] / denom).astype(np.float32))
+        return out
+
+
+def mf_rank(P, Q, us, cands, topk):
+    """MFRecommender.py:106-123: scores = bmm; argsort(descending); gather ids;
+    first topk.  Ties broken by candidate position (stable), ids returned as
+    float32 like the reference's `torch.tensor([])` concatenation."""
+    P = np.asarray(P, dtype=np.float32)
+    Q = np.asarray(Q, dtype=np.float32)
+    us = np.asarray(us, dtype=np.int64)
+    cands = np.asarray(cands, dtype=np.int64)
+    scores = np.einsum("bk,bck->bc", P[us], Q[cands])
+    order = np.argsort(-scores, axis=1, kind="stable")
+    return np.take_along_axis(cands, order, axis=1)[:, :topk].astype(np.float32), scores
+
+
+def mf_full_rank(P, Q, u, topk):
+    """MFRecommender.py:126-133."""
+    scores = np.asarray(Q, np.float32) @ np.asarray(P, np.float32)[u]
+    return np.argsort(-scores, kind="stable")[:topk].astype(np.int64)
+
+
+# --------------------------------------------------------------------------
+# Uniform negative sampler (sampler.py:82-89): one `num_ng` vector per user,
+# drawn with replacement, uniformly over {0..I-1} minus the user's train items.
+# numpy's MT19937 stream cannot be matched by a counter-based device generator,
+# so the oracle restates the DISTRIBUTION with the same counter-based generator
+# the HIP kernel uses (Philox4x32-10), which makes the comparison bit-exact.
+# --------------------------------------------------------------------------
+_PHILOX_M0 = np.uint64(0xD2511F53)
+_PHILOX_M1 = np.uint64(0xCD9E8D57)
+_PHILOX_W0 = 0x9E3779B9
+_PHILOX_W1 = 0xBB67AE85
+_M32 = 0xFFFFFFFF
+
+
+def philox4x32_10(ctr, key):
+    """Philox4x32-10 (Salmon et al., SC'11).  ctr: 4 uint32, key: 2 uint32."""
+    c0, c1, c2, c3 = (int(x) & _M32 for x in ctr)
+    k0, k1 = (int(x) & _M32 for x in key)
+    for _ in range(10):
+        p0 = 0xD2511F53 * c0
+        p1 = 0xCD9E8D57 * c2
+        hi0, lo0 = (p0 >> 32) & _M32, p0 & _M32
+        hi1, lo1 = (p1 >> 32) & _M32, p1 & _M32
+        c0, c1, c2, c3 = (hi1 ^ c1 ^ k0) & _M32, lo1, (hi0 ^ c3 ^ k1) & _M32, lo0
+        k0 = (k0 + _PHILOX_W0) & _M32
+        k1 = (k1 + _PHILOX_W1) & _M32
+    return c0, c1, c2, c3
+
+
+def _draw_u64(seed, stream, index):
+    """64 random bits for (seed, stream, index): counter = (index_lo, index_hi,
+    stream_lo, stream_hi), key = (seed_lo, seed_hi); take words 0 and 1."""
+    r = philox4x32_10((index & _M32, (index >> 32) & _M32, stream & _M32, (stream >> 32) & _M32),
+                      (seed & _M32, (seed >> 32) & _M32))
+    return (r[1] << 32) | r[0]
+
+
+def kth_in_complement(row_sorted, r):
+    """r-th (0-based) element of {0,1,...} minus the sorted, duplicate-free
+    `row_sorted`: smallest t with row[t]-t > r, answer r+t."""
+    lo, hi = 0, len(row_sorted)
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if int(row_sorted[mid]) - mid > r:
+            hi = mid
+        else:
+            lo = mid + 1
+    return r + lo
+
+
+def sample_uniform_neg_per_user(indptr, items, item_num, num_ng, seed, epoch=0):
+    """js[u, k] for every user id (sampler.py:63,84-89 loops over ALL user ids).
+    stream = epoch, index = u*num_ng + k.  A user whose train row covers every
+    item gets -1 (numpy would raise on an empty population)."""
+    U = len(indptr) - 1
+    out = np.empty((U, num_ng), dtype=np.int32)
+    for u in range(U):
+        row = items[indptr[u]:indptr[u + 1]]
+        free = item_num - len(row)
+        for k in range(num_ng):
+            if free <= 0:
+                out[u, k] = -1
+                continue
+            x = _draw_u64(seed, epoch, u * num_ng + k)
+            r = (x * free) >> 64          # Lemire multiply-shift on 64 bits
+            out[u, k] = kth_in_complement(row, r)
+    return out
+
+
+def sample_uniform_neg_per_interaction(indptr, items, users, item_num, num_ng, seed, epoch=0):
+    """Per-interaction variant (one draw per (interaction, k)); stream = epoch | 1<<63."""
+    n = len(users)
+    out = np.empty((n, num_ng), dtype=np.int32)
+    stream = epoch | (1 << 63)
+    for e in range(n):
+        u = int(users[e])
+        row = items[indptr[u]:indptr[u + 1]]
+        free = item_num - len(row)
+        for k in range(num_ng):
+            if free <= 0:
+                out[e, k] = -1
+                continue
+            x = _draw_u64(seed, stream, e * num_ng + k)
+            out[e, k] = kth_in_complement(row, (x * free) >> 64)
+    return out
+
+
+def expand_triples(users, pos_items, js):
+    """sampler.py:91,100-101: df['neg_set']=js[user]; explode -> int32 (N*num_ng, 3)
+    in train_set row order, each row repeated num_ng times consecutively."""
+    users = np.asarray(users, dtype=np.int64)
+    num_ng = js.shape[1]
+    out = np.empty((len(users) * num_ng, 3), dtype=np.int32)
+    out[:, 0] = np.repeat(users, num_ng)
+    out[:, 1] = np.repeat(np.asarray(pos_items), num_ng)
+    out[:, 2] = js[users].reshape(-1)
+    return out
