@@ -1,0 +1,102 @@
+"""ctypes binding of ``libdaisyrec_hip.so`` (declared in ``include/daisyrec_amd.h``).
+
+The HIP library IS the product: there is no CPU or PyTorch fallback.  Importing
+this module without the built library raises ``ImportError`` with the build
+command, and every call checks the status code and raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdaisyrec_hip.so")
+
+DAISY_OK, DAISY_ERR_ARG, DAISY_ERR_HIP, DAISY_ERR_STATE = 0, 1, 2, 3
+LOSS_BPR, LOSS_HL, LOSS_TL = 0, 1, 2
+ITEM_ATOMIC, ITEM_SORTED = 0, 1
+STATS_LEN = 16
+ST_LOSS_DATA, ST_L1_U, ST_L1_I, ST_L1_J, ST_SQ_U, ST_SQ_I, ST_SQ_J = range(7)
+ST_LOSS, ST_NORM_U, ST_NORM_I, ST_NORM_J = 7, 8, 9, 10
+ABI_VERSION = 1
+
+_p = C.c_void_p
+_i32, _i64, _u64, _f32, _sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
+
+# name -> (restype, argtypes); every symbol include/daisyrec_amd.h declares
+SIGNATURES = {
+    "daisy_last_error": (C.c_char_p, []),
+    "daisy_abi_version": (C.c_int, []),
+    "daisy_bpr_ctx_create": (C.c_int, [C.POINTER(_p), _i64, _i32, _i64, _i64]),
+    "daisy_bpr_ctx_destroy": (C.c_int, [_p]),
+    "daisy_bpr_ctx_scratch_bytes": (_sz, [_p]),
+    "daisy_bpr_set_batch_from_triples": (C.c_int, [_p, _p, _i64, _p, _i64, _i64, _i32, _p]),
+    "daisy_bpr_set_batch": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p]),
+    "daisy_bpr_forward": (C.c_int, [_p, _p, _p, _i32, _f32, _p, _p]),
+    "daisy_bpr_finalize": (C.c_int, [_p, _p, _f32, _f32, _p, _p, _p]),
+    "daisy_bpr_item_grad": (C.c_int, [_p, _p, _p, _p, _f32, _f32, _p, _i32, _p]),
+    "daisy_bpr_user_sgd": (C.c_int, [_p, _p, _p, _p, _f32, _f32, _f32, _p]),
+    "daisy_bpr_user_grad": (C.c_int, [_p, _p, _p, _p, _f32, _f32, _p, _p]),
+    "daisy_bpr_item_sgd_apply": (C.c_int, [_p, _p, _p, _f32, _i32, _p]),
+    "daisy_adam_dense": (C.c_int, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _i64, _p]),
+    "daisy_bpr_sgd_step": (C.c_int, [_p, _p, _p, _i32, _f32, _f32, _f32, _f32, _p, _p, _p, _p,
+                                     _i32, _p]),
+    "daisy_bpr_fit_epoch_sgd": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _f32, _f32,
+                                          _f32, _f32, _p, _p, _p, _p, _i32, _p]),
+    "daisy_mf_predict": (C.c_int, [_p, _p, _i32, _p, _p, _i64, _p, _p]),
+    "daisy_mf_rank_workspace_bytes": (_sz, [_i64, _i64]),
+    "daisy_mf_rank_topk": (C.c_int, [_p, _p, _i32, _p, _p, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),
+    "daisy_mf_full_rank_workspace_bytes": (_sz, [_i64]),
+    "daisy_mf_full_rank": (C.c_int, [_p, _p, _i32, _i64, _i64, _i32, _p, _p, _sz, _p]),
+    "daisy_csr_workspace_bytes": (_sz, [_i64]),
+    "daisy_build_user_csr": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _sz, _p]),
+    "daisy_sample_neg_per_user": (C.c_int, [_p, _p, _i64, _i64, _i32, _u64, _u64, _p, _p]),
+    "daisy_expand_triples": (C.c_int, [_p, _p, _i64, _p, _i32, _p, _p]),
+    "daisy_resample_neg_per_interaction": (C.c_int, [_p, _p, _i64, _p, _i64, _u64, _u64, _p]),
+    "daisy_randperm_workspace_bytes": (_sz, [_i64]),
+    "daisy_randperm": (C.c_int, [_i64, _u64, _u64, _p, _p, _sz, _p]),
+    "daisy_membench": (C.c_int, [_i32, _p, _i64, _i32, _p, _i64, _p, _p]),
+}
+
+
+class DaisyHipError(RuntimeError):
+    """A HIP runtime call inside the native library failed."""
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension is the product path and has no "
+            "fallback.  Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C daisyrec_amd/csrc` (needs hipcc, targets gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    got = lib.daisy_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError(f"{LIB_PATH}: ABI version {got}, binding expects {ABI_VERSION}; rebuild")
+    return lib
+
+
+lib = _load()
+
+
+def last_error() -> str:
+    msg = lib.daisy_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int) -> None:
+    """Map the C status code to the Python exception the reference path would raise."""
+    if rc == DAISY_OK:
+        return
+    msg = last_error()
+    if rc == DAISY_ERR_ARG:
+        if msg.startswith("Invalid loss type"):
+            raise NotImplementedError(msg)          # MFRecommender.py:90-91
+        raise ValueError(msg)
+    if rc == DAISY_ERR_HIP:
+        raise DaisyHipError(msg)
+    raise RuntimeError(msg)

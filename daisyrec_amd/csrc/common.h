@@ -1,0 +1,214 @@
+// Internal helpers shared by the HIP translation units (gfx950 / CDNA4 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/daisyrec_amd.h"
+
+namespace daisy {
+
+void set_error(const char *fmt, ...);
+
+#define DAISY_CHECK_ARG(cond, ...)          \
+    do {                                    \
+        if (!(cond)) {                      \
+            ::daisy::set_error(__VA_ARGS__); \
+            return DAISY_ERR_ARG;           \
+        }                                   \
+    } while (0)
+
+#define DAISY_HIP(expr)                                                                    \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) {                                                            \
+            ::daisy::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),      \
+                               __FILE__, __LINE__);                                        \
+            return DAISY_ERR_HIP;                                                          \
+        }                                                                                  \
+    } while (0)
+
+#define DAISY_LAUNCH_CHECK() DAISY_HIP(hipGetLastError())
+
+constexpr int kWave = 64;        // CDNA wavefront
+constexpr int kBlock = 256;      // 4 waves per workgroup
+constexpr int kMaxGrid = 2048;   // 256 CUs x 8 workgroups: grid-stride beyond that
+constexpr int kMaxD = 512;
+
+inline int grid_for(int64_t work_items, int items_per_block) {
+    int64_t g = (work_items + items_per_block - 1) / items_per_block;
+    if (g < 1) g = 1;
+    if (g > kMaxGrid) g = kMaxGrid;
+    return (int)g;
+}
+
+// ----------------------------------------------------------------------------
+// Row fragments.  A d-float table row is spread over LPR consecutive lanes of a
+// wave; each lane owns NV chunks of VEC floats: chunk c of lane l covers
+// elements [(c*LPR + l)*VEC, +VEC).  With VEC=4 a chunk is one 16-byte
+// global_load_dwordx4 and LPR lanes read LPR*16 contiguous bytes: d=64 -> 16
+// lanes x 16 B = one 256-B row per quarter wave, fully coalesced.
+// ----------------------------------------------------------------------------
+template <int LPR_, int VEC_, int NV_>
+struct RowCfg {
+    static constexpr int LPR = LPR_;
+    static constexpr int VEC = VEC_;
+    static constexpr int NV = NV_;
+    static constexpr int NE = VEC_ * NV_;            // floats per lane
+    static constexpr int GROUPS_PER_WAVE = kWave / LPR_;
+    static constexpr int GROUPS_PER_BLOCK = kBlock / LPR_;
+};
+
+template <class C>
+struct Row {
+    float v[C::NE];
+
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int k = 0; k < C::NE; ++k) v[k] = 0.f;
+    }
+    // lane = index of this lane inside its LPR-lane group
+    __device__ __forceinline__ void load(const float *__restrict__ row, int lane, int d) {
+#pragma unroll
+        for (int c = 0; c < C::NV; ++c) {
+            const int e = (c * C::LPR + lane) * C::VEC;
+            if constexpr (C::VEC == 4) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (e < d) t = *reinterpret_cast<const float4 *>(row + e);
+                v[c * 4 + 0] = t.x; v[c * 4 + 1] = t.y; v[c * 4 + 2] = t.z; v[c * 4 + 3] = t.w;
+            } else {
+                v[c] = (e < d) ? row[e] : 0.f;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float *__restrict__ row, int lane, int d) const {
+#pragma unroll
+        for (int c = 0; c < C::NV; ++c) {
+            const int e = (c * C::LPR + lane) * C::VEC;
+            if (e < d) {
+                if constexpr (C::VEC == 4) {
+                    *reinterpret_cast<float4 *>(row + e) =
+                        make_float4(v[c * 4 + 0], v[c * 4 + 1], v[c * 4 + 2], v[c * 4 + 3]);
+                } else {
+                    row[e] = v[c];
+                }
+            }
+        }
+    }
+    // fp32 hardware atomics (global_atomic_add_f32), no return value
+    __device__ __forceinline__ void atomic_add_to(float *__restrict__ row, int lane, int d) const {
+#pragma unroll
+        for (int c = 0; c < C::NV; ++c) {
+            const int e = (c * C::LPR + lane) * C::VEC;
+            if (e < d) {
+#pragma unroll
+                for (int k = 0; k < C::VEC; ++k) unsafeAtomicAdd(row + e + k, v[c * C::VEC + k]);
+            }
+        }
+    }
+};
+
+template <class C>
+__device__ __forceinline__ float group_sum(float x) {
+#pragma unroll
+    for (int off = C::LPR / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
+    return x;
+}
+
+template <class C>
+__device__ __forceinline__ float row_dot(const Row<C> &a, const Row<C> &b) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < C::NE; ++k) s = fmaf(a.v[k], b.v[k], s);
+    return group_sum<C>(s);
+}
+
+__device__ __forceinline__ float sgn(float x) { return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f); }
+
+__device__ __forceinline__ double wave_sum_f64(double x) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
+    return x;
+}
+
+// Pick the fragment shape for a runtime d.  F is a generic lambda taking a RowCfg tag.
+template <class F>
+inline int dispatch_d(int d, F &&f) {
+    if (d <= 0 || d > kMaxD) {
+        set_error("unsupported factor count d=%d (1..%d)", d, kMaxD);
+        return DAISY_ERR_ARG;
+    }
+    if (d % 4 == 0) {
+        if (d <= 32) return f(RowCfg<8, 4, 1>{});
+        if (d <= 64) return f(RowCfg<16, 4, 1>{});
+        if (d <= 128) return f(RowCfg<16, 4, 2>{});
+        if (d <= 256) return f(RowCfg<16, 4, 4>{});
+        return f(RowCfg<32, 4, 4>{});
+    }
+    if (d <= 64) return f(RowCfg<16, 1, 4>{});
+    if (d <= 256) return f(RowCfg<16, 1, 16>{});
+    return f(RowCfg<32, 1, 16>{});
+}
+
+// ----------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11) — identical to oracle/bpr_mf_numpy.py
+// ----------------------------------------------------------------------------
+struct Philox4 {
+    uint32_t x, y, z, w;
+};
+__host__ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2,
+                                                          uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return Philox4{c0, c1, c2, c3};
+}
+__host__ __device__ __forceinline__ uint64_t philox_u64(uint64_t seed, uint64_t stream,
+                                                        uint64_t index) {
+    Philox4 r = philox4x32_10((uint32_t)index, (uint32_t)(index >> 32), (uint32_t)stream,
+                              (uint32_t)(stream >> 32), (uint32_t)seed, (uint32_t)(seed >> 32));
+    return ((uint64_t)r.y << 32) | r.x;
+}
+
+// ----------------------------------------------------------------------------
+// rocPRIM wrappers live in sort.hip (keeps the heavy headers in one TU)
+// ----------------------------------------------------------------------------
+size_t sort_pairs_i32_temp_bytes(int64_t n);
+// stable LSD radix sort of (key,val) int32 pairs on bits [0,end_bit)
+int sort_pairs_i32(void *temp, size_t temp_bytes, const int32_t *kin, int32_t *kout,
+                   const int32_t *vin, int32_t *vout, int64_t n, int end_bit, hipStream_t s);
+size_t sort_pairs_u64_i64_temp_bytes(int64_t n);
+int sort_pairs_u64_i64(void *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout,
+                       const int64_t *vin, int64_t *vout, int64_t n, int end_bit, hipStream_t s);
+size_t sort_keys_u64_temp_bytes(int64_t n);
+int sort_keys_u64(void *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout, int64_t n,
+                  int end_bit, hipStream_t s);
+size_t seg_sort_desc_f32_i64_temp_bytes(int64_t n, int64_t segs);
+// per-segment stable descending sort of float keys with int64 payload; segment s = [s*C,(s+1)*C)
+int seg_sort_desc_f32_i64(void *temp, size_t temp_bytes, const float *kin, float *kout,
+                          const int64_t *vin, int64_t *vout, int64_t segs, int64_t C, hipStream_t s);
+
+size_t sort_pairs_desc_f32_i64_temp_bytes(int64_t n);
+// whole-array stable descending sort of float keys with int64 payload
+int sort_pairs_desc_f32_i64(void *temp, size_t temp_bytes, const float *kin, float *kout,
+                            const int64_t *vin, int64_t *vout, int64_t n, hipStream_t s);
+
+inline int bits_for(int64_t n) {  // number of bits needed for values in [0, n)
+    int b = 1;
+    while (b < 63 && ((int64_t)1 << b) < n) ++b;
+    return b;
+}
+
+inline size_t align_up(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+
+}  // namespace daisy

@@ -1,0 +1,205 @@
+// Uniform negative sampler + CSR builder + epoch permutation.
+//
+// Reference: daisy/utils/sampler.py:55-103 (uniform branch :82-89) draws, for
+// EVERY user id, `num_ng` items uniformly WITH replacement from
+// setdiff1d(arange(item_num), train_ur[u]) — an O(U*I) host loop.  Here each
+// (user, k) is one thread: a counter-based Philox4x32-10 draw r in
+// [0, I-deg(u)) is mapped to the r-th element of the complement by a binary
+// search over the user's sorted CSR row (exactly uniform, no rejection loop,
+// O(log deg)).  daisy/utils/utils.py:19-34 (get_ur) becomes a device CSR build.
+#include "common.h"
+
+namespace daisy {
+
+__global__ void k_pack_pairs(const int32_t *__restrict__ users, const int32_t *__restrict__ items,
+                             int64_t n, uint64_t *__restrict__ keys) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
+         e += (int64_t)gridDim.x * blockDim.x)
+        keys[e] = ((uint64_t)(uint32_t)users[e] << 32) | (uint32_t)items[e];
+}
+
+__global__ void k_unpack_items(const uint64_t *__restrict__ keys, int64_t n,
+                               int32_t *__restrict__ csr_items) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
+         e += (int64_t)gridDim.x * blockDim.x)
+        csr_items[e] = (int32_t)(uint32_t)keys[e];
+}
+
+// indptr[u] = first position whose user >= u  (u = 0..U)
+__global__ void k_indptr(const uint64_t *__restrict__ keys, int64_t n, int64_t U,
+                         int64_t *__restrict__ indptr) {
+    for (int64_t u = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; u <= U;
+         u += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t target = (uint64_t)u << 32;
+        int64_t lo = 0, hi = n;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (keys[mid] < target) lo = mid + 1;
+            else hi = mid;
+        }
+        indptr[u] = lo;
+    }
+}
+
+// r-th (0-based) element of {0,1,..} \ row  (row sorted, duplicate free):
+// smallest t with row[t]-t > r, answer r+t
+__device__ __forceinline__ int32_t kth_in_complement(const int32_t *__restrict__ row, int64_t deg,
+                                                     int64_t r) {
+    int64_t lo = 0, hi = deg;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)row[mid] - mid > r) hi = mid;
+        else lo = mid + 1;
+    }
+    return (int32_t)(r + lo);
+}
+
+__global__ void k_sample_per_user(const int64_t *__restrict__ indptr,
+                                  const int32_t *__restrict__ csr_items, int64_t U, int64_t I,
+                                  int num_ng, uint64_t seed, uint64_t epoch,
+                                  int32_t *__restrict__ js) {
+    const int64_t n = U * num_ng;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t u = e / num_ng;
+        const int64_t lo = indptr[u], deg = indptr[u + 1] - lo;
+        const int64_t free_ = I - deg;
+        if (free_ <= 0) { js[e] = -1; continue; }
+        const uint64_t x = philox_u64(seed, epoch, (uint64_t)e);
+        const int64_t r = (int64_t)__umul64hi(x, (uint64_t)free_);
+        js[e] = kth_in_complement(csr_items + lo, deg, r);
+    }
+}
+
+__global__ void k_expand_triples(const int32_t *__restrict__ users, const int32_t *__restrict__ items,
+                                 int64_t n, const int32_t *__restrict__ js, int num_ng,
+                                 int32_t *__restrict__ triples) {
+    const int64_t m = n * num_ng;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < m;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = e / num_ng;
+        const int k = (int)(e % num_ng);
+        const int32_t u = users[row];
+        triples[3 * e + 0] = u;
+        triples[3 * e + 1] = items[row];
+        triples[3 * e + 2] = js[(int64_t)u * num_ng + k];
+    }
+}
+
+__global__ void k_resample_per_interaction(const int64_t *__restrict__ indptr,
+                                           const int32_t *__restrict__ csr_items, int64_t I,
+                                           int32_t *__restrict__ triples, int64_t n, uint64_t seed,
+                                           uint64_t stream) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t u = triples[3 * e];
+        const int64_t lo = indptr[u], deg = indptr[u + 1] - lo;
+        const int64_t free_ = I - deg;
+        if (free_ <= 0) { triples[3 * e + 2] = -1; continue; }
+        const uint64_t x = philox_u64(seed, stream, (uint64_t)e);
+        const int64_t r = (int64_t)__umul64hi(x, (uint64_t)free_);
+        triples[3 * e + 2] = kth_in_complement(csr_items + lo, deg, r);
+    }
+}
+
+__global__ void k_perm_keys(int64_t n, uint64_t seed, uint64_t stream, uint64_t *__restrict__ keys,
+                            int64_t *__restrict__ vals) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        keys[e] = philox_u64(seed, stream, (uint64_t)e);
+        vals[e] = e;
+    }
+}
+
+static inline hipStream_t S(daisy_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+constexpr uint64_t kStreamInteraction = 1ull << 63;
+constexpr uint64_t kStreamPerm = 1ull << 62;
+
+}  // namespace daisy
+
+using namespace daisy;
+
+extern "C" {
+
+size_t daisy_csr_workspace_bytes(int64_t n) {
+    if (n <= 0) return 0;
+    return align_up((size_t)n * 8) * 2 + align_up(sort_keys_u64_temp_bytes(n));
+}
+
+int daisy_build_user_csr(const int32_t *users, const int32_t *items, int64_t n, int64_t user_num,
+                         int64_t *indptr, int32_t *csr_items, void *workspace, size_t workspace_bytes,
+                         daisy_stream_t stream) {
+    DAISY_CHECK_ARG(users && items && indptr && csr_items && workspace && n > 0 && user_num > 0,
+                    "build_user_csr: bad argument");
+    DAISY_CHECK_ARG(workspace_bytes >= daisy_csr_workspace_bytes(n), "build_user_csr: workspace too small");
+    hipStream_t s = S(stream);
+    char *w = (char *)workspace;
+    uint64_t *kin = (uint64_t *)w;   w += align_up((size_t)n * 8);
+    uint64_t *kout = (uint64_t *)w;  w += align_up((size_t)n * 8);
+    hipLaunchKernelGGL(k_pack_pairs, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, users, items, n, kin);
+    DAISY_LAUNCH_CHECK();
+    int rc = sort_keys_u64(w, sort_keys_u64_temp_bytes(n), kin, kout, n, 32 + bits_for(user_num), s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_unpack_items, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, kout, n, csr_items);
+    DAISY_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_indptr, dim3(grid_for(user_num + 1, kBlock)), dim3(kBlock), 0, s, kout, n,
+                       user_num, indptr);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int daisy_sample_neg_per_user(const int64_t *indptr, const int32_t *csr_items, int64_t user_num,
+                              int64_t item_num, int32_t num_ng, uint64_t seed, uint64_t epoch,
+                              int32_t *js, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(indptr && csr_items && js && user_num > 0 && item_num > 0 && num_ng > 0,
+                    "sample_neg_per_user: bad argument");
+    DAISY_CHECK_ARG(epoch < kStreamPerm, "sample_neg_per_user: epoch out of range");
+    hipLaunchKernelGGL(k_sample_per_user, dim3(grid_for(user_num * num_ng, kBlock)), dim3(kBlock), 0,
+                       S(stream), indptr, csr_items, user_num, item_num, (int)num_ng, seed, epoch, js);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int daisy_expand_triples(const int32_t *users, const int32_t *items, int64_t n, const int32_t *js,
+                         int32_t num_ng, int32_t *triples, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(users && items && js && triples && n > 0 && num_ng > 0, "expand_triples: bad argument");
+    hipLaunchKernelGGL(k_expand_triples, dim3(grid_for(n * num_ng, kBlock)), dim3(kBlock), 0, S(stream),
+                       users, items, n, js, (int)num_ng, triples);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int daisy_resample_neg_per_interaction(const int64_t *indptr, const int32_t *csr_items,
+                                       int64_t item_num, int32_t *triples, int64_t n, uint64_t seed,
+                                       uint64_t epoch, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(indptr && csr_items && triples && n > 0 && item_num > 0,
+                    "resample_neg_per_interaction: bad argument");
+    DAISY_CHECK_ARG(epoch < kStreamPerm, "resample_neg_per_interaction: epoch out of range");
+    hipLaunchKernelGGL(k_resample_per_interaction, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, S(stream),
+                       indptr, csr_items, item_num, triples, n, seed, epoch | kStreamInteraction);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+size_t daisy_randperm_workspace_bytes(int64_t n) {
+    if (n <= 0) return 0;
+    return align_up((size_t)n * 8) * 3 + align_up(sort_pairs_u64_i64_temp_bytes(n));
+}
+
+int daisy_randperm(int64_t n, uint64_t seed, uint64_t epoch, int64_t *perm, void *workspace,
+                   size_t workspace_bytes, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(perm && workspace && n > 0, "randperm: bad argument");
+    DAISY_CHECK_ARG(epoch < kStreamPerm, "randperm: epoch out of range");
+    DAISY_CHECK_ARG(workspace_bytes >= daisy_randperm_workspace_bytes(n), "randperm: workspace too small");
+    hipStream_t s = S(stream);
+    char *w = (char *)workspace;
+    uint64_t *kin = (uint64_t *)w;   w += align_up((size_t)n * 8);
+    uint64_t *kout = (uint64_t *)w;  w += align_up((size_t)n * 8);
+    int64_t *vin = (int64_t *)w;     w += align_up((size_t)n * 8);
+    hipLaunchKernelGGL(k_perm_keys, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, n, seed,
+                       epoch | kStreamPerm, kin, vin);
+    DAISY_LAUNCH_CHECK();
+    return sort_pairs_u64_i64(w, sort_pairs_u64_i64_temp_bytes(n), kin, kout, vin, perm, n, 64, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+// rocPRIM (AMD's native device primitives) wrappers.  Only index preparation
+// goes through these radix sorts (grouping a batch by user / by item, the
+// epoch permutation, argsort of candidate scores); the gather / dot / update
+// kernels of the hot path are hand written in bpr_train.hip.
+#include <cstring>
+
+#include <rocprim/rocprim.hpp>
+
+#include "common.h"
+
+namespace daisy {
+
+size_t sort_pairs_i32_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const int32_t *)nullptr, (int32_t *)nullptr,
+                                    (const int32_t *)nullptr, (int32_t *)nullptr, (size_t)n, 0, 32);
+    return bytes;
+}
+
+int sort_pairs_i32(void *temp, size_t temp_bytes, const int32_t *kin, int32_t *kout,
+                   const int32_t *vin, int32_t *vout, int64_t n, int end_bit, hipStream_t s) {
+    // keys are non-negative ids, so unsigned ordering == signed ordering
+    DAISY_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, reinterpret_cast<const uint32_t *>(kin),
+                                        reinterpret_cast<uint32_t *>(kout), vin, vout, (size_t)n, 0,
+                                        (unsigned)end_bit, s));
+    return DAISY_OK;
+}
+
+size_t sort_pairs_u64_i64_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+                                    (const int64_t *)nullptr, (int64_t *)nullptr, (size_t)n, 0, 64);
+    return bytes;
+}
+
+int sort_pairs_u64_i64(void *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout,
+                       const int64_t *vin, int64_t *vout, int64_t n, int end_bit, hipStream_t s) {
+    DAISY_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)n, 0,
+                                        (unsigned)end_bit, s));
+    return DAISY_OK;
+}
+
+size_t sort_keys_u64_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_keys(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+                                   (size_t)n, 0, 64);
+    return bytes;
+}
+
+int sort_keys_u64(void *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout, int64_t n,
+                  int end_bit, hipStream_t s) {
+    DAISY_HIP(rocprim::radix_sort_keys(temp, temp_bytes, kin, kout, (size_t)n, 0, (unsigned)end_bit,
+                                       s));
+    return DAISY_OK;
+}
+
+namespace {
+struct MulBy {
+    int64_t c;
+    __host__ __device__ int64_t operator()(int64_t x) const { return x * c; }
+};
+using OffIt = rocprim::transform_iterator<rocprim::counting_iterator<int64_t>, MulBy, int64_t>;
+inline OffIt offsets(int64_t C) {
+    return rocprim::make_transform_iterator(rocprim::make_counting_iterator<int64_t>(0), MulBy{C});
+}
+}  // namespace
+
+size_t seg_sort_desc_f32_i64_temp_bytes(int64_t n, int64_t segs) {
+    size_t bytes = 0;
+    OffIt off = offsets(n / (segs > 0 ? segs : 1));
+    (void)rocprim::segmented_radix_sort_pairs_desc(nullptr, bytes, (const float *)nullptr,
+                                                   (float *)nullptr, (const int64_t *)nullptr,
+                                                   (int64_t *)nullptr, (unsigned)n, (unsigned)segs,
+                                                   off, off + 1, 0, 32);
+    return bytes;
+}
+
+int seg_sort_desc_f32_i64(void *temp, size_t temp_bytes, const float *kin, float *kout,
+                          const int64_t *vin, int64_t *vout, int64_t segs, int64_t C,
+                          hipStream_t s) {
+    OffIt off = offsets(C);
+    DAISY_HIP(rocprim::segmented_radix_sort_pairs_desc(temp, temp_bytes, kin, kout, vin, vout,
+                                                       (unsigned)(segs * C), (unsigned)segs, off,
+                                                       off + 1, 0, 32, s));
+    return DAISY_OK;
+}
+
+size_t sort_pairs_desc_f32_i64_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs_desc(nullptr, bytes, (const float *)nullptr, (float *)nullptr,
+                                         (const int64_t *)nullptr, (int64_t *)nullptr, (size_t)n, 0,
+                                         32);
+    return bytes;
+}
+
+int sort_pairs_desc_f32_i64(void *temp, size_t temp_bytes, const float *kin, float *kout,
+                            const int64_t *vin, int64_t *vout, int64_t n, hipStream_t s) {
+    DAISY_HIP(rocprim::radix_sort_pairs_desc(temp, temp_bytes, kin, kout, vin, vout, (size_t)n, 0, 32,
+                                             s));
+    return DAISY_OK;
+}
+
+}  // namespace daisy

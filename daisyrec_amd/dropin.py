@@ -1,0 +1,24 @@
+"""Make an unmodified daisyRec driver (run_examples/test.py, tune.py) train MF through
+the HIP path: rebinds the names those scripts import (test.py:4,21-22; tune.py:7).
+
+    import daisyrec_amd.dropin as d; d.install()          # before `import run_examples.test`
+
+or, where the reference checkout exists:  python tools/run_reference_driver.py --algo_name mf ...
+"""
+from __future__ import annotations
+
+import importlib
+
+
+def install(sampler=False):
+    """Patch `daisy.model.MFRecommender.MF` (and optionally the sampler) in place."""
+    from .model.MFRecommender import MF
+
+    ref_mf = importlib.import_module("daisy.model.MFRecommender")
+    ref_mf.MF = MF
+    if sampler:
+        from .utils.sampler import BasicNegtiveSampler
+
+        ref_s = importlib.import_module("daisy.utils.sampler")
+        ref_s.BasicNegtiveSampler = BasicNegtiveSampler
+    return MF

@@ -1,0 +1,222 @@
+"""Host-side mirror of the reference's recommender base classes for the MF hot
+path (reference: daisy/model/AbstractRecommender.py:10-137).
+
+Same class names, constructor keys, attributes and method set, so callers such
+as run_examples/test.py:90-95,120 keep working; but ``GeneralRecommender.fit``
+drives the HIP kernels of ``libdaisyrec_hip.so`` instead of autograd +
+``torch.optim``.  There is no CPU path: ``fit``/``rank`` raise when no HIP
+device is present.
+"""
+from __future__ import annotations
+
+import logging
+import os
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from .. import _native as N
+
+try:  # the reference shows a tqdm bar (AbstractRecommender.py:116); optional here
+    from tqdm import tqdm as _tqdm
+except Exception:  # pragma: no cover
+    _tqdm = None
+
+NATIVE_OPTIMIZERS = ("sgd", "adam")
+KNOWN_OPTIMIZERS = ("adam", "sgd", "adagrad", "rmsprop", "sparse_adam")
+
+
+class AbstractRecommender(nn.Module):
+    """Reference: AbstractRecommender.py:10-93."""
+
+    def __init__(self):
+        super().__init__()
+        self.optimizer = None
+        self.initializer = None
+        self.loss_type = None
+        self.lr = 0.01
+        self.logger = None
+        # AbstractRecommender.py:19-31
+        self.initializer_param_config = {
+            "normal": {"mean": 0.0, "std": 0.01},
+            "uniform": {"a": 0.0, "b": 1.0},
+            "xavier_normal": {"gain": 1.0},
+            "xavier_uniform": {"gain": 1.0},
+        }
+        self.initializer_config = {
+            "normal": nn.init.normal_,
+            "uniform": nn.init.uniform_,
+            "xavier_normal": nn.init.xavier_normal_,
+            "xavier_uniform": nn.init.xavier_uniform_,
+        }
+
+    # abstract surface, AbstractRecommender.py:33-46
+    def calc_loss(self, batch):
+        raise NotImplementedError
+
+    def fit(self, train_loader):
+        raise NotImplementedError
+
+    def rank(self, test_loader):
+        raise NotImplementedError
+
+    def full_rank(self, u):
+        raise NotImplementedError
+
+    def predict(self, u, i):
+        raise NotImplementedError
+
+    def _resolve_optimizer(self, name=None):
+        """AbstractRecommender.py:48-67: unknown names fall back to Adam with a log
+        line.  Known torch optimisers without a HIP kernel are refused loudly
+        instead of silently running something else."""
+        name = str(self.optimizer if name is None else name).lower()
+        if name not in KNOWN_OPTIMIZERS:
+            if self.logger is not None:
+                self.logger.info("Received unrecognized optimizer, set default Adam optimizer")
+            name = "adam"
+        if name not in NATIVE_OPTIMIZERS:
+            raise NotImplementedError(
+                f"optimizer '{name}' has no HIP kernel on the MF hot path (native: {NATIVE_OPTIMIZERS})")
+        return name
+
+    def _init_weight(self, m):
+        """AbstractRecommender.py:69-77 (applied in module order from the global torch RNG)."""
+        if isinstance(m, nn.Linear):
+            self.initializer_config[self.initializer](m.weight, **self.initializer_param_config[self.initializer])
+            if m.bias is not None:
+                nn.init.constant_(m.bias.data, 0.0)
+        elif isinstance(m, nn.Embedding):
+            self.initializer_config[self.initializer](m.weight, **self.initializer_param_config[self.initializer])
+
+    def _build_criterion(self, loss_type):
+        """AbstractRecommender.py:79-93.  Pairwise losses are an epilogue of the
+        forward kernel; the returned value is the native loss id."""
+        key = str(loss_type).upper()
+        if key in ("CL", "SL"):
+            raise NotImplementedError(
+                f"point-wise loss {key} is outside the BPR hot path (SURVEY.md section 8f, next rows)")
+        if key not in ops.LOSS_IDS:
+            raise NotImplementedError(f"Invalid loss type: {self.loss_type}...")
+        return ops.LOSS_IDS[key]
+
+
+class GeneralRecommender(AbstractRecommender):
+    """Reference: AbstractRecommender.py:95-137 (device selection + the training loop)."""
+
+    def __init__(self, config):
+        super().__init__()
+        os.environ["CUDA_VISIBLE_DEVICES"] = config["gpu"]          # AbstractRecommender.py:99
+        self.device = "cuda" if torch.cuda.is_available() else "cpu"
+        self.logger = config.get("logger") or logging.getLogger("daisyrec_amd")
+        # knobs of the native path (absent from the reference config: defaults keep its behaviour)
+        self.item_mode = str(config.get("item_mode", "sorted")).lower()   # 'sorted' = reproducible
+        self.show_progress = bool(config.get("progress", True))
+        self.epoch_losses = []
+
+    # -- helpers ---------------------------------------------------------------
+    def _require_device(self):
+        if self.device != "cuda":
+            raise RuntimeError("daisyrec_amd: no HIP device visible; the MF hot path has no CPU fallback")
+
+    @staticmethod
+    def _epoch_order(train_loader, n):
+        """The index order one `for batch in DataLoader` pass would use, consuming the
+        global torch RNG exactly like the reference run (dataset.py:5-7 ->
+        torch DataLoader): `_BaseDataLoaderIter.__init__` draws `_base_seed`, then
+        RandomSampler draws its own seed and calls torch.randperm(n, generator)."""
+        from torch.utils.data import RandomSampler, SequentialSampler
+
+        torch.empty((), dtype=torch.int64).random_(generator=train_loader.generator)  # _base_seed
+        sampler = train_loader.sampler
+        if isinstance(sampler, SequentialSampler):
+            return None
+        if isinstance(sampler, RandomSampler) and not sampler.replacement and sampler.num_samples == n:
+            if sampler.generator is None:
+                seed = int(torch.empty((), dtype=torch.int64).random_().item())
+                gen = torch.Generator()
+                gen.manual_seed(seed)
+            else:
+                gen = sampler.generator
+            return torch.randperm(n, generator=gen)
+        return torch.as_tensor(list(iter(sampler)), dtype=torch.int64)
+
+    def fit(self, train_loader):
+        """AbstractRecommender.py:103-137, natively: one enqueue per epoch, one host
+        sync per epoch (for the loss the early-stop rule needs)."""
+        self._require_device()
+        self.to(self.device)
+        opt = self._resolve_optimizer()
+        loss_id = self._build_criterion(self.loss_type)
+        item_mode = ops.ITEM_MODES[self.item_mode]
+        data = getattr(train_loader.dataset, "data", None)
+        if data is None:
+            raise TypeError("fit expects a DataLoader over BasicDataset (dataset.data = int32 [N,3] triples)")
+        triples = torch.as_tensor(data).to(torch.int32).contiguous().to(self.device)
+        n = triples.shape[0]
+        B = int(train_loader.batch_size)
+        if train_loader.drop_last:
+            n = (n // B) * B
+        P, Q = self.embed_user.weight.data, self.embed_item.weight.data
+        ctx = ops.BprContext(min(B, max(n, 1)), P.shape[1], P.shape[0], Q.shape[0], device=P.device)
+        adam = _AdamState(P, Q, self.lr) if opt == "adam" else None
+        self.epoch_losses = []
+        last_loss = 0.0
+        try:
+            epochs = range(1, self.epochs + 1)
+            bar = _tqdm(epochs) if (_tqdm is not None and self.show_progress) else None
+            for epoch in (bar if bar is not None else epochs):
+                self.train()
+                perm = self._epoch_order(train_loader, triples.shape[0])
+                if perm is not None:
+                    perm = perm[:n].to(self.device)
+                ctx.epoch_acc.zero_()
+                if adam is None:
+                    ctx.fit_epoch_sgd(P, Q, triples, perm, B, self.lr, self.reg_1, self.reg_2,
+                                      loss_type=loss_id, item_mode=item_mode, n_triples=n)
+                else:
+                    for start in range(0, n, B):
+                        bsz = min(B, n - start)
+                        ctx.set_batch_from_triples(triples, None if perm is None else perm[start:start + bsz],
+                                                   start=start, B=bsz)
+                        adam.step(ctx, P, Q, self.reg_1, self.reg_2, loss_id, item_mode)
+                acc = ctx.epoch_acc.cpu()
+                current_loss = float(acc[0])
+                if float(acc[1]) > 0 or current_loss != current_loss:
+                    # AbstractRecommender.py:122-123 (checked once per epoch instead of per batch)
+                    raise ValueError("Loss=Nan or Infinity: current settings does not fit the recommender")
+                self.epoch_losses.append(current_loss)
+                if bar is not None:
+                    bar.set_description(f"[Epoch {epoch:03d}]")
+                    bar.set_postfix(loss=current_loss)
+                self.eval()
+                delta_loss = float(current_loss - last_loss)
+                if (abs(delta_loss) < 1e-5) and self.early_stop:       # AbstractRecommender.py:132-137
+                    self.logger.info("Satisfy early stop mechanism")
+                    break
+                last_loss = current_loss
+        finally:
+            torch.cuda.synchronize()
+            ctx.close()
+
+
+class _AdamState:
+    """Dense torch.optim.Adam state for the two tables (AbstractRecommender.py:54)."""
+
+    def __init__(self, P, Q, lr):
+        self.lr, self.t = lr, 0
+        self.gP = torch.zeros_like(P)
+        self.mP, self.vP = torch.zeros_like(P), torch.zeros_like(P)
+        self.mQ, self.vQ = torch.zeros_like(Q), torch.zeros_like(Q)
+
+    def step(self, ctx, P, Q, reg_1, reg_2, loss_id, item_mode):
+        self.t += 1
+        ctx.forward(P, Q, loss_id)
+        ctx.finalize(reg_1, reg_2)
+        ctx.item_grad(P, Q, reg_1, reg_2, item_mode)
+        ctx.user_grad(P, Q, reg_1, reg_2, self.gP)
+        ops.adam_dense(P, self.gP, self.mP, self.vP, self.lr, self.t)
+        ops.adam_dense(Q, ctx.gQ, self.mQ, self.vQ, self.lr, self.t)
+        # gQ was zeroed densely by the Adam pass; forget the touched-row marks too
+        ctx.item_sgd_apply(Q, 0.0, dense=False)

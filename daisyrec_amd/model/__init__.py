@@ -1,0 +1,2 @@
+from .AbstractRecommender import AbstractRecommender, GeneralRecommender  # noqa: F401
+from .MFRecommender import MF  # noqa: F401

@@ -1,0 +1,251 @@
+"""Tensor-level operators over the C ABI (``include/daisyrec_amd.h``).
+
+PyTorch is plumbing here: it owns device memory and streams; every operator
+hands raw device pointers + the current HIP stream to ``libdaisyrec_hip.so``.
+Nothing in this module computes on the host or falls back to torch ops.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _native as N
+from ._native import check, lib
+
+LOSS_IDS = {"BPR": N.LOSS_BPR, "HL": N.LOSS_HL, "TL": N.LOSS_TL}
+ITEM_MODES = {"atomic": N.ITEM_ATOMIC, "sorted": N.ITEM_SORTED}
+
+
+def loss_id(loss_type: str) -> int:
+    key = str(loss_type).upper()
+    if key not in LOSS_IDS:
+        # MFRecommender.py:90-91 / AbstractRecommender.py:91
+        raise NotImplementedError(f"Invalid loss type: {loss_type}")
+    return LOSS_IDS[key]
+
+
+def _ptr(t, dtype, name):
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name}: tensor is on {t.device}; the HIP path needs device memory "
+                           "(there is no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+class BprContext:
+    """Owner of a native ``daisy_bpr_ctx`` (per-step scratch on one GPU)."""
+
+    def __init__(self, max_batch: int, d: int, user_num: int, item_num: int, device="cuda"):
+        self.max_batch, self.d, self.user_num, self.item_num = int(max_batch), int(d), int(user_num), int(item_num)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("BprContext needs a HIP device (no CPU fallback)")
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib.daisy_bpr_ctx_create(C.byref(self._h), self.max_batch, self.d, self.user_num,
+                                           self.item_num))
+        # caller-owned (so torch.distributed can all-reduce them)
+        self.stats = torch.zeros(N.STATS_LEN, dtype=torch.float64, device=self.device)
+        self.epoch_acc = torch.zeros(2, dtype=torch.float64, device=self.device)
+        self.gQ = torch.zeros(self.item_num, self.d, dtype=torch.float32, device=self.device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            check(lib.daisy_bpr_ctx_destroy(self._h))
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def scratch_bytes(self):
+        return int(lib.daisy_bpr_ctx_scratch_bytes(self._h))
+
+    # -- batch -------------------------------------------------------------
+    def set_batch_from_triples(self, triples, idx=None, start=0, B=None, user_base=0):
+        n = triples.shape[0]
+        if B is None:
+            B = idx.numel() if idx is not None else n - start
+        check(lib.daisy_bpr_set_batch_from_triples(
+            self._h, _ptr(triples, torch.int32, "triples"), n,
+            _ptr(idx, torch.int64, "idx"), int(start), int(B), int(user_base), _stream()))
+
+    def set_batch(self, u, i, j, pre_grouped=False):
+        check(lib.daisy_bpr_set_batch(self._h, _ptr(u, torch.int32, "u"), _ptr(i, torch.int32, "i"),
+                                      _ptr(j, torch.int32, "j"), u.numel(), int(pre_grouped),
+                                      _stream()))
+
+    # -- phases --------------------------------------------------------------
+    def forward(self, P, Q, loss_type=N.LOSS_BPR, gamma=1e-10):
+        check(lib.daisy_bpr_forward(self._h, _ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"),
+                                    int(loss_type), float(gamma),
+                                    _ptr(self.stats, torch.float64, "stats"), _stream()))
+
+    def finalize(self, reg_1, reg_2, step_loss=None, accumulate=True):
+        check(lib.daisy_bpr_finalize(self._h, _ptr(self.stats, torch.float64, "stats"), float(reg_1),
+                                     float(reg_2),
+                                     _ptr(self.epoch_acc, torch.float64, "epoch_acc") if accumulate else None,
+                                     _ptr(step_loss, torch.float64, "step_loss"), _stream()))
+
+    def item_grad(self, P, Q, reg_1, reg_2, item_mode=N.ITEM_ATOMIC, gQ=None):
+        gQ = self.gQ if gQ is None else gQ
+        check(lib.daisy_bpr_item_grad(self._h, _ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"),
+                                      _ptr(self.stats, torch.float64, "stats"), float(reg_1),
+                                      float(reg_2), _ptr(gQ, torch.float32, "gQ"), int(item_mode),
+                                      _stream()))
+
+    def user_sgd(self, P, Q, lr, reg_1, reg_2):
+        check(lib.daisy_bpr_user_sgd(self._h, _ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"),
+                                     _ptr(self.stats, torch.float64, "stats"), float(lr), float(reg_1),
+                                     float(reg_2), _stream()))
+
+    def user_grad(self, P, Q, reg_1, reg_2, gP):
+        check(lib.daisy_bpr_user_grad(self._h, _ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"),
+                                      _ptr(self.stats, torch.float64, "stats"), float(reg_1),
+                                      float(reg_2), _ptr(gP, torch.float32, "gP"), _stream()))
+
+    def item_sgd_apply(self, Q, lr, dense=False, gQ=None):
+        gQ = self.gQ if gQ is None else gQ
+        check(lib.daisy_bpr_item_sgd_apply(self._h, _ptr(Q, torch.float32, "Q"),
+                                           _ptr(gQ, torch.float32, "gQ"), float(lr), int(dense),
+                                           _stream()))
+
+    def sgd_step(self, P, Q, lr, reg_1, reg_2, loss_type=N.LOSS_BPR, gamma=1e-10,
+                 item_mode=N.ITEM_ATOMIC, step_loss=None, accumulate=True):
+        check(lib.daisy_bpr_sgd_step(
+            self._h, _ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"), int(loss_type),
+            float(gamma), float(lr), float(reg_1), float(reg_2), _ptr(self.gQ, torch.float32, "gQ"),
+            _ptr(self.stats, torch.float64, "stats"),
+            _ptr(self.epoch_acc, torch.float64, "epoch_acc") if accumulate else None,
+            _ptr(step_loss, torch.float64, "step_loss"), int(item_mode), _stream()))
+
+    def fit_epoch_sgd(self, P, Q, triples, perm, batch_size, lr, reg_1, reg_2,
+                      loss_type=N.LOSS_BPR, gamma=1e-10, item_mode=N.ITEM_ATOMIC, user_base=0,
+                      step_losses=None, n_triples=None):
+        n = triples.shape[0] if n_triples is None else int(n_triples)
+        check(lib.daisy_bpr_fit_epoch_sgd(
+            self._h, _ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"),
+            _ptr(triples, torch.int32, "triples"), n, _ptr(perm, torch.int64, "perm"),
+            int(batch_size), int(user_base), int(loss_type), float(gamma), float(lr), float(reg_1),
+            float(reg_2), _ptr(self.gQ, torch.float32, "gQ"), _ptr(self.stats, torch.float64, "stats"),
+            _ptr(self.epoch_acc, torch.float64, "epoch_acc"),
+            _ptr(step_losses, torch.float64, "step_losses"), int(item_mode), _stream()))
+
+
+def adam_dense(W, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
+    check(lib.daisy_adam_dense(_ptr(W, torch.float32, "W"), _ptr(g, torch.float32, "g"),
+                               _ptr(m, torch.float32, "m"), _ptr(v, torch.float32, "v"), W.numel(),
+                               float(lr), float(beta1), float(beta2), float(eps), int(step), _stream()))
+
+
+def mf_predict(P, Q, u, i):
+    """MF.forward (MFRecommender.py:63-68)."""
+    u = u.to(torch.int64).contiguous()
+    i = i.to(torch.int64).contiguous()
+    out = torch.empty(u.numel(), dtype=torch.float32, device=P.device)
+    if u.numel() == 0:
+        return out
+    check(lib.daisy_mf_predict(_ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"), P.shape[1],
+                               _ptr(u, torch.int64, "u"), _ptr(i, torch.int64, "i"), u.numel(),
+                               _ptr(out, torch.float32, "out"), _stream()))
+    return out.view(u.shape)
+
+
+def mf_rank_topk(P, Q, us, cands, topk, return_scores=False):
+    """One batch of MF.rank (MFRecommender.py:109-121) -> int64 [B, topk]."""
+    us = us.to(torch.int64).contiguous()
+    cands = cands.to(torch.int64).contiguous()
+    B, Cn = cands.shape
+    out = torch.empty(B, topk, dtype=torch.int64, device=P.device)
+    scores = torch.empty(B, Cn, dtype=torch.float32, device=P.device) if return_scores else None
+    nbytes = lib.daisy_mf_rank_workspace_bytes(B, Cn)
+    ws = _ws(nbytes, P.device)
+    check(lib.daisy_mf_rank_topk(_ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"), P.shape[1],
+                                 _ptr(us, torch.int64, "us"), _ptr(cands, torch.int64, "cands"), B, Cn,
+                                 int(topk), _ptr(out, torch.int64, "out"),
+                                 _ptr(scores, torch.float32, "scores"), _ptr(ws, torch.uint8, "ws"),
+                                 ws.numel(), _stream()))
+    return (out, scores) if return_scores else out
+
+
+def mf_full_rank(P, Q, u, topk):
+    """MF.full_rank (MFRecommender.py:126-133) -> int64 [topk]."""
+    I = Q.shape[0]
+    out = torch.empty(topk, dtype=torch.int64, device=P.device)
+    ws = _ws(lib.daisy_mf_full_rank_workspace_bytes(I), P.device)
+    check(lib.daisy_mf_full_rank(_ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"), P.shape[1], I,
+                                 int(u), int(topk), _ptr(out, torch.int64, "out"),
+                                 _ptr(ws, torch.uint8, "ws"), ws.numel(), _stream()))
+    return out
+
+
+def build_user_csr(users, items, user_num):
+    """get_ur (utils.py:19-34) as a device CSR: (indptr int64[U+1], sorted items int32[n])."""
+    n = users.numel()
+    indptr = torch.empty(user_num + 1, dtype=torch.int64, device=users.device)
+    csr_items = torch.empty(n, dtype=torch.int32, device=users.device)
+    ws = _ws(lib.daisy_csr_workspace_bytes(n), users.device)
+    check(lib.daisy_build_user_csr(_ptr(users, torch.int32, "users"), _ptr(items, torch.int32, "items"),
+                                   n, int(user_num), _ptr(indptr, torch.int64, "indptr"),
+                                   _ptr(csr_items, torch.int32, "csr_items"), _ptr(ws, torch.uint8, "ws"),
+                                   ws.numel(), _stream()))
+    return indptr, csr_items
+
+
+def sample_neg_per_user(indptr, csr_items, item_num, num_ng, seed, epoch=0):
+    U = indptr.numel() - 1
+    js = torch.empty(U, num_ng, dtype=torch.int32, device=indptr.device)
+    check(lib.daisy_sample_neg_per_user(_ptr(indptr, torch.int64, "indptr"),
+                                        _ptr(csr_items, torch.int32, "csr_items"), U, int(item_num),
+                                        int(num_ng), int(seed), int(epoch), _ptr(js, torch.int32, "js"),
+                                        _stream()))
+    return js
+
+
+def expand_triples(users, items, js):
+    n, num_ng = users.numel(), js.shape[1]
+    out = torch.empty(n * num_ng, 3, dtype=torch.int32, device=users.device)
+    check(lib.daisy_expand_triples(_ptr(users, torch.int32, "users"), _ptr(items, torch.int32, "items"),
+                                   n, _ptr(js, torch.int32, "js"), num_ng,
+                                   _ptr(out, torch.int32, "triples"), _stream()))
+    return out
+
+
+def resample_neg_per_interaction(indptr, csr_items, item_num, triples, seed, epoch=0):
+    check(lib.daisy_resample_neg_per_interaction(
+        _ptr(indptr, torch.int64, "indptr"), _ptr(csr_items, torch.int32, "csr_items"), int(item_num),
+        _ptr(triples, torch.int32, "triples"), triples.shape[0], int(seed), int(epoch), _stream()))
+    return triples
+
+
+def randperm(n, seed, epoch=0, device="cuda"):
+    perm = torch.empty(n, dtype=torch.int64, device=device)
+    ws = _ws(lib.daisy_randperm_workspace_bytes(n), perm.device)
+    check(lib.daisy_randperm(int(n), int(seed), int(epoch), _ptr(perm, torch.int64, "perm"),
+                             _ptr(ws, torch.uint8, "ws"), ws.numel(), _stream()))
+    return perm
+
+
+def membench(what, table, idx, out):
+    check(lib.daisy_membench(int(what), _ptr(table, torch.float32, "table"), table.shape[0],
+                             table.shape[1], _ptr(idx, torch.int32, "idx"), idx.numel(),
+                             _ptr(out, torch.float32, "out"), _stream()))

@@ -1,0 +1,79 @@
+"""Uniform negative sampler with the reference's interface, run on the GPU.
+
+Mirror of daisy/utils/sampler.py:3-103 (``AbstractSampler`` / ``BasicNegtiveSampler``
+[sic]): same constructor (df, config), same ``sampling()`` result — an int32
+``(N*num_ng, 3)`` array of ``(user, pos_item, neg_item)`` in train-set row order where
+every interaction of user ``u`` carries the same ``num_ng`` negatives, drawn uniformly
+with replacement from the items ``u`` has not interacted with (sampler.py:84-89,91,100-101).
+
+Not reproduced: numpy's MT19937 stream (a device generator cannot follow it; the draws
+are Philox4x32-10 keyed by config['seed']), the popularity-mixed branches and the
+point-wise CL/SL layouts (sampler.py:64-80,93-98) — outside the BPR hot path.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .. import ops
+
+
+class AbstractSampler(object):
+    def __init__(self, config):
+        self.uid_name = config["UID_NAME"]
+        self.iid_name = config["IID_NAME"]
+        self.item_num = config["item_num"]
+        self.ur = config.get("train_ur")
+
+    def sampling(self):
+        raise NotImplementedError
+
+
+class BasicNegtiveSampler(AbstractSampler):
+    def __init__(self, df, config):
+        super().__init__(config)
+        self.user_num = config["user_num"]
+        self.num_ng = config["num_ng"]
+        self.inter_name = config.get("INTER_NAME", "rating")
+        self.sample_method = config.get("sample_method", "uniform")
+        self.sample_ratio = config.get("sample_ratio", 0)
+        self.loss_type = str(config["loss_type"]).upper()
+        self.seed = int(config.get("seed", 2022))
+        self.epoch = int(config.get("sampler_epoch", 0))
+        self.device = config.get("device", "cuda")
+        assert self.sample_method in ["uniform", "low-pop", "high-pop"], \
+            f"Invalid sampling method: {self.sample_method}"
+        assert 0 <= self.sample_ratio <= 1, "Invalid sample ratio value"
+        if self.sample_method != "uniform" and self.sample_ratio > 0:
+            raise NotImplementedError("popularity-mixed negative sampling is outside the uniform hot path")
+        self.df = df
+
+    def _train_pairs(self):
+        """(users, items) that define each user's positives: config['train_ur'] when the
+        caller provides it (test.py:70-71, tune.py use the total train set), else df."""
+        if self.ur is not None:
+            us = np.fromiter((u for u, s in self.ur.items() for _ in s), dtype=np.int32)
+            it = np.fromiter((i for _, s in self.ur.items() for i in s), dtype=np.int32)
+            return us, it
+        return (self.df[self.uid_name].to_numpy().astype(np.int32),
+                self.df[self.iid_name].to_numpy().astype(np.int32))
+
+    def sampling_device(self):
+        """Triples as an int32 [N*num_ng, 3] DEVICE tensor."""
+        if self.num_ng == 0:
+            raise NotImplementedError("loss function (BPR, TL, HL) need num_ng > 0")   # sampler.py:61
+        if self.loss_type not in ("BPR", "HL", "TL"):
+            raise NotImplementedError(f"{self.loss_type}: point-wise sample layout is outside the BPR hot path")
+        if not torch.cuda.is_available():
+            raise RuntimeError("daisyrec_amd sampler needs a HIP device (no CPU fallback)")
+        pu, pi = self._train_pairs()
+        indptr, csr = ops.build_user_csr(torch.from_numpy(pu).to(self.device),
+                                         torch.from_numpy(pi).to(self.device), self.user_num)
+        js = ops.sample_neg_per_user(indptr, csr, self.item_num, self.num_ng, self.seed, self.epoch)
+        users = torch.from_numpy(self.df[self.uid_name].to_numpy().astype(np.int32)).to(self.device)
+        items = torch.from_numpy(self.df[self.iid_name].to_numpy().astype(np.int32)).to(self.device)
+        return ops.expand_triples(users, items, js)
+
+    def sampling(self):
+        """np.int32 (N*num_ng, 3) like sampler.py:100-101."""
+        return self.sampling_device().cpu().numpy()

@@ -1,0 +1,219 @@
+/*
+ * daisyrec_amd.h — C ABI of the MI355X-native MF + BPR training hot path.
+ *
+ * This is the drop-in boundary: every entry point takes plain device pointers,
+ * sizes and a HIP stream (void* == hipStream_t).  No torch / C++ types cross
+ * it.  The reference (AmazingDD/daisyRec v2.3.0) is pure Python; each function
+ * below names the reference interface it replaces (file:line relative to the
+ * reference checkout).  INTEGRATION.md shows the ctypes binding a daisyRec
+ * maintainer would add.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in `_host`
+ *   - tables are row-major fp32  P[user_num][d], Q[item_num][d]
+ *     (nn.Embedding.weight, MFRecommender.py:53-54); they are updated IN PLACE
+ *   - indices are int32 (`.astype(np.int32)`, sampler.py:101) unless stated
+ *   - every call only ENQUEUES work on `stream`; nothing synchronises the host
+ *   - return value: 0 = ok, otherwise an error code; daisy_last_error() gives
+ *     the message (thread local)
+ */
+#ifndef DAISYREC_AMD_H
+#define DAISYREC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DAISY_ABI_VERSION 1
+
+typedef void *daisy_stream_t; /* hipStream_t */
+
+enum daisy_status {
+    DAISY_OK = 0,
+    DAISY_ERR_ARG = 1,  /* bad argument (null pointer, size out of range, unsupported d) */
+    DAISY_ERR_HIP = 2,  /* a HIP runtime call failed */
+    DAISY_ERR_STATE = 3 /* call order violated (e.g. step before set_batch) */
+};
+
+/* daisy/utils/loss.py:5-33.  (AbstractRecommender.py:79-93 builds them.) */
+enum daisy_loss {
+    DAISY_LOSS_BPR = 0, /* -(gamma + sigmoid(pos-neg)).log().sum()          loss.py:10-13 */
+    DAISY_LOSS_HL = 1,  /* clamp(1-(pos-neg), min=0).sum()                  loss.py:20-23 */
+    DAISY_LOSS_TL = 2   /* sigmoid(neg-pos).sum()+sigmoid(neg**2).sum()     loss.py:30-33 */
+};
+
+/* how the item-side gradient is accumulated */
+enum daisy_item_mode {
+    DAISY_ITEM_ATOMIC = 0, /* fp32 atomics into gQ (throughput mode; sum order not fixed) */
+    DAISY_ITEM_SORTED = 1  /* sort by item, one owner per row, fixed order (bitwise reproducible) */
+};
+
+/* layout of the caller-owned `stats` vector (device, double[DAISY_STATS_LEN]) */
+enum daisy_stats_slot {
+    DAISY_ST_LOSS_DATA = 0, /* sum of per-sample loss terms                    */
+    DAISY_ST_L1_U = 1,      /* |P[u]|_1  over the gathered batch               */
+    DAISY_ST_L1_I = 2,      /* |Q[i]|_1                                        */
+    DAISY_ST_L1_J = 3,      /* |Q[j]|_1                                        */
+    DAISY_ST_SQ_U = 4,      /* sum P[u]^2  (slots 0..6 are SUMS: all-reducible)*/
+    DAISY_ST_SQ_I = 5,
+    DAISY_ST_SQ_J = 6,
+    DAISY_ST_LOSS = 7,      /* total loss of the step (written by finalize)    */
+    DAISY_ST_NORM_U = 8,    /* |P[u]|_F (written by finalize)                  */
+    DAISY_ST_NORM_I = 9,
+    DAISY_ST_NORM_J = 10,
+    DAISY_STATS_LEN = 16
+};
+
+const char *daisy_last_error(void);
+int daisy_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * Training context: owns the per-step scratch (grouped batch, coefficients,
+ * sort buffers, partial sums).  One per (process, GPU).
+ * ---------------------------------------------------------------------- */
+typedef struct daisy_bpr_ctx daisy_bpr_ctx;
+
+int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int64_t user_num,
+                         int64_t item_num);
+int daisy_bpr_ctx_destroy(daisy_bpr_ctx *ctx);
+/* bytes of device scratch the context holds (for reporting) */
+size_t daisy_bpr_ctx_scratch_bytes(const daisy_bpr_ctx *ctx);
+
+/* Replaces BasicDataset.__getitem__ + default collate + `.to(device)`
+ * (dataset.py:10-27, MFRecommender.py:71-72,83): gathers rows idx[0..B) of the
+ * int32 [N,3] triple array (idx == NULL: rows start..start+B) and groups the
+ * batch by user (stable), which the update kernels rely on.
+ * user_base is subtracted from the user ids (user-sharded tables). */
+int daisy_bpr_set_batch_from_triples(daisy_bpr_ctx *ctx, const int32_t *triples, int64_t n_triples,
+                                     const int64_t *idx, int64_t start, int64_t B,
+                                     int32_t user_base, daisy_stream_t stream);
+/* Same from three separate int32 arrays (one collated batch). */
+int daisy_bpr_set_batch(daisy_bpr_ctx *ctx, const int32_t *u, const int32_t *i, const int32_t *j,
+                        int64_t B, int32_t pre_grouped, daisy_stream_t stream);
+
+/* MF.forward x2 + criterion (MFRecommender.py:63-68,73,83-85; loss.py): per-sample
+ * d(loss)/d(pos), d(loss)/d(neg) kept in the context; the seven batch SUMS go
+ * to stats[0..6]. */
+int daisy_bpr_forward(daisy_bpr_ctx *ctx, const float *P, const float *Q, int32_t loss_type,
+                      float gamma, double *stats, daisy_stream_t stream);
+
+/* Regulariser + total loss of MF.calc_loss (MFRecommender.py:88-89,94-95) from the
+ * (possibly all-reduced) sums: stats[7..10].  epoch_acc (device double[2], may
+ * be NULL): [0] += loss  (`current_loss += loss.item()`, AbstractRecommender.py:128),
+ * [1] += isnan(loss)     (AbstractRecommender.py:122-123).
+ * step_loss (may be NULL) receives the step's loss. */
+int daisy_bpr_finalize(daisy_bpr_ctx *ctx, double *stats, float reg_1, float reg_2,
+                       double *epoch_acc, double *step_loss, daisy_stream_t stream);
+
+/* autograd backward w.r.t. embed_item.weight, restricted to the touched rows
+ * (AbstractRecommender.py:125): gQ[I][d] += dL/dQ.  gQ must be zero on entry for
+ * untouched rows; touched rows are recorded in the context. */
+int daisy_bpr_item_grad(daisy_bpr_ctx *ctx, const float *P, const float *Q, const double *stats,
+                        float reg_1, float reg_2, float *gQ, int32_t item_mode,
+                        daisy_stream_t stream);
+
+/* backward w.r.t. embed_user.weight + optim.SGD.step on the touched user rows
+ * (AbstractRecommender.py:125-126).  Reads Q, so it must run BEFORE the item
+ * rows are committed. */
+int daisy_bpr_user_sgd(daisy_bpr_ctx *ctx, float *P, const float *Q, const double *stats, float lr,
+                       float reg_1, float reg_2, daisy_stream_t stream);
+/* same gradient written to gP[U][d] instead (dense optimisers) */
+int daisy_bpr_user_grad(daisy_bpr_ctx *ctx, const float *P, const float *Q, const double *stats,
+                        float reg_1, float reg_2, float *gP, daisy_stream_t stream);
+
+/* optim.SGD.step on the item table: Q[r] -= lr*gQ[r]; gQ[r] = 0 for the rows
+ * recorded by daisy_bpr_item_grad (dense != 0: every row, used after an
+ * all-reduce of gQ). */
+int daisy_bpr_item_sgd_apply(daisy_bpr_ctx *ctx, float *Q, float *gQ, float lr, int32_t dense,
+                             daisy_stream_t stream);
+
+/* torch.optim.Adam.step (defaults, AbstractRecommender.py:54), DENSE like the
+ * reference: every element moves every step.  g is zeroed.  step is 1-based. */
+int daisy_adam_dense(float *W, float *g, float *m, float *v, int64_t n, float lr, float beta1,
+                     float beta2, float eps, int64_t step, daisy_stream_t stream);
+
+/* One whole `zero_grad / calc_loss / backward / SGD.step` on one GPU
+ * (AbstractRecommender.py:119-128) for the batch set by daisy_bpr_set_batch*. */
+int daisy_bpr_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t loss_type, float gamma,
+                       float lr, float reg_1, float reg_2, float *gQ, double *stats,
+                       double *epoch_acc, double *step_loss, int32_t item_mode,
+                       daisy_stream_t stream);
+
+/* The inner `for batch in pbar` loop of GeneralRecommender.fit
+ * (AbstractRecommender.py:118-128) for one epoch, enqueued natively with no
+ * host synchronisation: batch k = rows perm[k*B .. (k+1)*B) of `triples`
+ * (perm == NULL: identity order); the last batch is partial like DataLoader's
+ * (drop_last=False).  step_losses (may be NULL) gets one loss per step. */
+int daisy_bpr_fit_epoch_sgd(daisy_bpr_ctx *ctx, float *P, float *Q, const int32_t *triples,
+                            int64_t n_triples, const int64_t *perm, int64_t batch_size,
+                            int32_t user_base, int32_t loss_type, float gamma, float lr,
+                            float reg_1, float reg_2, float *gQ, double *stats, double *epoch_acc,
+                            double *step_losses, int32_t item_mode, daisy_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Scoring / ranking  (MFRecommender.py:99-133)
+ * ---------------------------------------------------------------------- */
+/* MF.forward (MFRecommender.py:63-68): out[b] = <P[u_b], Q[i_b]> */
+int daisy_mf_predict(const float *P, const float *Q, int32_t d, const int64_t *u, const int64_t *i,
+                     int64_t B, float *out, daisy_stream_t stream);
+size_t daisy_mf_rank_workspace_bytes(int64_t B, int64_t C);
+/* MF.rank inner loop (MFRecommender.py:109-121): scores = bmm, argsort descending
+ * (stable), gather candidate ids, first topk -> out_ids int64 [B][topk].
+ * scores_out (may be NULL) receives the fp32 [B][C] score matrix. */
+int daisy_mf_rank_topk(const float *P, const float *Q, int32_t d, const int64_t *us,
+                       const int64_t *cands, int64_t B, int64_t C, int32_t topk, int64_t *out_ids,
+                       float *scores_out, void *workspace, size_t workspace_bytes,
+                       daisy_stream_t stream);
+size_t daisy_mf_full_rank_workspace_bytes(int64_t item_num);
+/* MF.full_rank (MFRecommender.py:126-133): argsort(P[u] @ Q^T, descending)[:topk] */
+int daisy_mf_full_rank(const float *P, const float *Q, int32_t d, int64_t item_num, int64_t u,
+                       int32_t topk, int64_t *out_ids, void *workspace, size_t workspace_bytes,
+                       daisy_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Uniform negative sampler (sampler.py:55-103, uniform branch :82-89)
+ * ---------------------------------------------------------------------- */
+size_t daisy_csr_workspace_bytes(int64_t n);
+/* get_ur (utils.py:19-34) as a CSR: for n (user,item) pairs build indptr int64[U+1]
+ * and the per-user SORTED item lists int32[n] (pairs must be duplicate free,
+ * as loader.py:201 guarantees). */
+int daisy_build_user_csr(const int32_t *users, const int32_t *items, int64_t n, int64_t user_num,
+                         int64_t *indptr, int32_t *csr_items, void *workspace,
+                         size_t workspace_bytes, daisy_stream_t stream);
+/* js[u][k], k<num_ng, for EVERY user id (sampler.py:63,84-89): uniform with
+ * replacement over {0..item_num-1} minus the user's CSR row; -1 if that set is
+ * empty.  Counter-based Philox4x32-10: stream = epoch, index = u*num_ng+k. */
+int daisy_sample_neg_per_user(const int64_t *indptr, const int32_t *csr_items, int64_t user_num,
+                              int64_t item_num, int32_t num_ng, uint64_t seed, uint64_t epoch,
+                              int32_t *js, daisy_stream_t stream);
+/* df.explode('neg_set') (sampler.py:91,100-101): triples int32 [n*num_ng][3] in
+ * train-set row order, each interaction repeated num_ng times. */
+int daisy_expand_triples(const int32_t *users, const int32_t *items, int64_t n, const int32_t *js,
+                         int32_t num_ng, int32_t *triples, daisy_stream_t stream);
+/* per-interaction variant (fresh negatives for every triple, re-drawable per
+ * epoch): rewrites column 2 of triples [n][3] in place. */
+int daisy_resample_neg_per_interaction(const int64_t *indptr, const int32_t *csr_items,
+                                       int64_t item_num, int32_t *triples, int64_t n,
+                                       uint64_t seed, uint64_t epoch, daisy_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Device-side epoch order (replaces RandomSampler's torch.randperm for the
+ * throughput loader; dataset.py:5-7 shuffle=True): perm = a uniformly random
+ * permutation of 0..n-1 derived from (seed, epoch) by sorting Philox keys.
+ * ---------------------------------------------------------------------- */
+size_t daisy_randperm_workspace_bytes(int64_t n);
+int daisy_randperm(int64_t n, uint64_t seed, uint64_t epoch, int64_t *perm, void *workspace,
+                   size_t workspace_bytes, daisy_stream_t stream);
+
+/* micro-benchmarks of the memory system used to place the kernels on the
+ * roofline (tools/membench.py); not part of the reference surface. */
+int daisy_membench(int32_t what, float *table, int64_t rows, int32_t d, const int32_t *idx,
+                   int64_t n, float *out, daisy_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DAISYREC_AMD_H */

@@ -1,0 +1,65 @@
+"""Host-side mirror of the reference interface (no GPU): construction, init parity,
+DataLoader order replay, error behaviour."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import mf_config
+
+
+def test_mf_init_matches_reference(ml100k):
+    """MFRecommender.py:53-61: tables are normal(0,0.01) from the global torch RNG, user first."""
+    from daisyrec_amd.model.MFRecommender import MF
+    g = ml100k
+    torch.manual_seed(int(g["seed"]))
+    m = MF(mf_config(user_num=int(g["user_num"]), item_num=int(g["item_num"])))
+    np.testing.assert_array_equal(m.embed_user.weight.detach().numpy(), g["P0"])
+    np.testing.assert_array_equal(m.embed_item.weight.detach().numpy(), g["Q0"])
+    assert m.optimizer == "sgd" and m.initializer == "normal" and m.loss_type == "BPR"
+    assert set(m.state_dict()) == {"embed_user.weight", "embed_item.weight"}
+
+
+@pytest.mark.parametrize("num_workers", [0, 2])
+def test_epoch_order_replays_dataloader(num_workers):
+    """GeneralRecommender._epoch_order consumes the global RNG exactly like iterating the
+    reference's DataLoader (dataset.py:5-7), for every epoch."""
+    from daisyrec_amd.model.AbstractRecommender import GeneralRecommender
+    from daisyrec_amd.utils.dataset import BasicDataset, get_dataloader
+    n, B = 1000, 64
+    data = np.stack([np.arange(n), np.arange(n) + 1, np.arange(n) + 2], 1).astype(np.int32)
+    torch.manual_seed(123)
+    loader = get_dataloader(BasicDataset(data), batch_size=B, shuffle=True, num_workers=num_workers)
+    want = []
+    for _ in range(3):
+        want.append(torch.cat([b[0] for b in loader]).numpy())
+    torch.manual_seed(123)
+    loader2 = get_dataloader(BasicDataset(data), batch_size=B, shuffle=True, num_workers=0)
+    for ep in range(3):
+        perm = GeneralRecommender._epoch_order(loader2, n)
+        np.testing.assert_array_equal(data[perm.numpy(), 0], want[ep])
+    seq = get_dataloader(BasicDataset(data), batch_size=B, shuffle=False, num_workers=0)
+    assert GeneralRecommender._epoch_order(seq, n) is None
+
+
+def test_error_behaviour_matches_reference():
+    from daisyrec_amd.model.MFRecommender import MF
+    m = MF(mf_config(user_num=5, item_num=7, loss_type="XX"))
+    with pytest.raises(NotImplementedError):          # AbstractRecommender.py:91
+        m._build_criterion(m.loss_type)
+    m = MF(mf_config(user_num=5, item_num=7, optimizer="nonsense"))
+    assert m._resolve_optimizer() == "adam"           # AbstractRecommender.py:63-65
+    m = MF(mf_config(user_num=5, item_num=7, optimizer="rmsprop"))
+    with pytest.raises(NotImplementedError):
+        m._resolve_optimizer()
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            m.fit(None)
+
+
+def test_ops_reject_host_tensors():
+    from daisyrec_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.mf_predict(torch.zeros(4, 8), torch.zeros(4, 8), torch.zeros(2, dtype=torch.int64),
+                       torch.zeros(2, dtype=torch.int64))
+    with pytest.raises(NotImplementedError):
+        ops.loss_id("CLX")

@@ -1,0 +1,138 @@
+"""The oracle against the golden vectors the REAL reference produced
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bpr_mf_numpy as O
+
+
+def _run_case(g, name, dtype):
+    U, I, d, B, ns = g[f"{name}/meta"]
+    lr, r1, r2 = g[f"{name}/hyper"]
+    lt = O.LOSS_IDS[str(g[f"{name}/loss_type"])]
+    opt = str(g[f"{name}/optimizer"])
+    P, Q = g[f"{name}/P0"], g[f"{name}/Q0"]
+    adam = O.DenseAdam([P.shape, Q.shape], lr, dtype=dtype) if opt == "adam" else None
+    for s in range(ns):
+        u, i, j = g[f"{name}/u"][s], g[f"{name}/i"][s], g[f"{name}/j"][s]
+        if adam is None:
+            loss, P, Q = O.mf_sgd_step(P, Q, u, i, j, lr, r1, r2, lt, dtype=dtype)
+        else:
+            loss, gP, gQ = O.mf_pair_grad(P, Q, u, i, j, r1, r2, lt, dtype=dtype)
+            P, Q = adam.step([P, Q], [gP, gQ])
+        yield s, loss, P, Q
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_kat_steps(kat_steps, dtype):
+    g = kat_steps
+    for name in g["names"]:
+        name = str(name)
+        for s, loss, P, Q in _run_case(g, name, dtype):
+            ref_loss = g[f"{name}/loss"][s]
+            assert abs(loss - ref_loss) <= 2e-6 * abs(ref_loss), (name, s)
+            scale = max(1.0, float(np.abs(g[f"{name}/P0"]).max()))
+            np.testing.assert_allclose(P, g[f"{name}/P"][s], rtol=0, atol=1e-6 * scale, err_msg=name)
+            np.testing.assert_allclose(Q, g[f"{name}/Q"][s], rtol=0, atol=1e-6 * scale, err_msg=name)
+
+
+def test_rank_kat(rank_kat):
+    r = rank_kat
+    pred, _ = O.mf_rank(r["P"], r["Q"], r["us"], r["cands"], int(r["topk"]))
+    assert pred.dtype == np.float32
+    np.testing.assert_array_equal(pred, r["preds"])
+    full = np.stack([O.mf_full_rank(r["P"], r["Q"], int(u), int(r["topk"])) for u in r["us"]])
+    np.testing.assert_array_equal(full, r["full"])
+    pp = O.mf_forward(r["P"], r["Q"], r["us"], r["cands"][:, 0])
+    np.testing.assert_allclose(pp, r["predict"], rtol=1e-5, atol=1e-7)
+
+
+def ml100k_epoch_orders(g):
+    """Batch order of the reference run, from the saved torch RNG state."""
+    n = len(g["samples"])
+    torch.set_rng_state(torch.from_numpy(g["rng_state_before_fit"]))
+    for _ in range(int(g["epochs"])):
+        torch.empty((), dtype=torch.int64).random_()                      # _base_seed
+        seed = int(torch.empty((), dtype=torch.int64).random_().item())   # RandomSampler seed
+        gen = torch.Generator()
+        gen.manual_seed(seed)
+        yield torch.randperm(n, generator=gen).numpy()
+
+
+def test_ml100k_end_to_end(ml100k):
+    """BASELINE config C1: epoch losses within 1e-5 (relative) and identical top-N."""
+    g = ml100k
+    samples, B = g["samples"], int(g["batch_size"])
+    lr, r1, r2 = g["hyper"]
+    P, Q = g["P0"].copy(), g["Q0"].copy()
+    for ep, perm in enumerate(ml100k_epoch_orders(g)):
+        tot = 0.0
+        for s in range(0, len(samples), B):
+            idx = perm[s:s + B]
+            loss, P, Q = O.mf_sgd_step(P, Q, samples[idx, 0], samples[idx, 1], samples[idx, 2],
+                                       lr, r1, r2)
+            tot += loss
+        ref = g["epoch_losses"][ep]
+        assert abs(tot - ref) <= 1e-5 * abs(ref)
+    np.testing.assert_allclose(P, g["P1"], atol=2e-4)
+    np.testing.assert_allclose(Q, g["Q1"], atol=2e-4)
+    pred, _ = O.mf_rank(P, Q, g["test_u"], g["cands"], int(g["topk"]))
+    np.testing.assert_array_equal(pred, g["preds"])
+    full = np.stack([O.mf_full_rank(P, Q, int(u), int(g["topk"])) for u in g["test_u"][:16]])
+    np.testing.assert_array_equal(full, g["full_rank16"])
+
+
+# ---- sampler -----------------------------------------------------------------
+def test_philox_known_answers():
+    """Random123 kat_vectors for philox4x32-10."""
+    assert O.philox4x32_10((0, 0, 0, 0), (0, 0)) == (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)
+    f = 0xFFFFFFFF
+    assert O.philox4x32_10((f, f, f, f), (f, f)) == (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)
+    assert O.philox4x32_10((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344),
+                           (0xa4093822, 0x299f31d0)) == (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1)
+
+
+def test_kth_in_complement_exhaustive():
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        I = int(rng.integers(1, 40))
+        row = np.sort(rng.choice(I, size=int(rng.integers(0, I + 1)), replace=False))
+        comp = np.setdiff1d(np.arange(I), row)
+        for r, want in enumerate(comp):
+            assert O.kth_in_complement(row, r) == want
+
+
+def test_sampler_semantics(ml100k):
+    """sampler.py:84-89 semantics on the ml-100k train set: never a train positive,
+    all ids (even users without train rows) get negatives, empirical distribution uniform."""
+    g = ml100k
+    U, I = int(g["user_num"]), int(g["item_num"])
+    users, items = g["train_users"].astype(np.int64), g["train_items"]
+    order = np.lexsort((items, users))
+    indptr = np.zeros(U + 1, dtype=np.int64)
+    np.add.at(indptr, users + 1, 1)
+    indptr = np.cumsum(indptr)
+    csr = items[order]
+    js = O.sample_uniform_neg_per_user(indptr, csr, I, 4, seed=2022)
+    assert js.shape == (U, 4) and js.min() >= 0 and js.max() < I
+    for u in range(U):
+        row = set(csr[indptr[u]:indptr[u + 1]].tolist())
+        assert not (set(js[u].tolist()) & row)
+    tri = O.expand_triples(users, items, js)
+    assert tri.shape == (len(users) * 4, 3) and tri.dtype == np.int32
+    np.testing.assert_array_equal(tri[::4, 0], users)
+    np.testing.assert_array_equal(tri[1::4, 1], items)
+    np.testing.assert_array_equal(tri[:, 2].reshape(-1, 4), js[users])
+    # uniformity for one user with many draws (chi-square, 5 sigma)
+    u = int(np.argmax(np.diff(indptr)))
+    row = csr[indptr[u]:indptr[u + 1]]
+    ip1 = np.array([0, len(row)])
+    draws = O.sample_uniform_neg_per_user(ip1, row, I, 20000, seed=7)[0]
+    comp = np.setdiff1d(np.arange(I), row)
+    cnt = np.bincount(draws, minlength=I)[comp]
+    assert cnt.sum() == 20000
+    exp = 20000 / len(comp)
+    chi2 = ((cnt - exp) ** 2 / exp).sum()
+    dof = len(comp) - 1
+    assert abs(chi2 - dof) < 5 * np.sqrt(2 * dof)
