@@ -1,0 +1,46 @@
+"""CPU/PyTorch restatement of the reference's MF + BPR training step, used ONLY as the
+`cpu_baseline` leg of bench.py and in tests (TEST INFRASTRUCTURE — the product path never
+imports it).
+
+It composes the same stock PyTorch pieces in the same order as the reference does, so its
+host-side cost profile is the reference's (dense `[U,d]`/`[I,d]` gradients through
+`embedding_dense_backward`, dense `optim.SGD.step`):
+    tables       nn.Embedding x2, normal(0, 0.01)     MFRecommender.py:53-54,61
+    forward      (E_u[u] * E_i[i]).sum(-1)            MFRecommender.py:63-68
+    loss         -(gamma + sigmoid(pos-neg)).log().sum() + reg_1*L1 + reg_2*Frobenius
+                                                      loss.py:10-13, MFRecommender.py:88-95
+    step         zero_grad / backward / SGD.step      AbstractRecommender.py:119-126
+Parity: pinned by tests/test_oracle_golden.py::test_torch_port_matches_golden.
+"""
+import torch
+import torch.nn as nn
+
+
+class TorchMFBPR(nn.Module):
+    def __init__(self, user_num, item_num, d, lr=0.01, reg_1=0.001, reg_2=0.001, gamma=1e-10):
+        super().__init__()
+        self.embed_user = nn.Embedding(user_num, d)
+        self.embed_item = nn.Embedding(item_num, d)
+        nn.init.normal_(self.embed_user.weight, mean=0.0, std=0.01)
+        nn.init.normal_(self.embed_item.weight, mean=0.0, std=0.01)
+        self.reg_1, self.reg_2, self.gamma = reg_1, reg_2, gamma
+        self.opt = torch.optim.SGD(self.parameters(), lr=lr)
+
+    def score(self, u, i):
+        return (self.embed_user(u) * self.embed_item(i)).sum(dim=-1)
+
+    def loss(self, u, i, j):
+        pos, neg = self.score(u, i), self.score(u, j)
+        out = -(self.gamma + torch.sigmoid(pos - neg)).log().sum()
+        out = out + self.reg_1 * (self.embed_item(i).norm(p=1) + self.embed_item(j).norm(p=1))
+        out = out + self.reg_2 * (self.embed_item(i).norm() + self.embed_item(j).norm())
+        out = out + self.reg_1 * self.embed_user(u).norm(p=1)
+        out = out + self.reg_2 * self.embed_user(u).norm()
+        return out
+
+    def step(self, u, i, j):
+        self.zero_grad()
+        out = self.loss(u, i, j)
+        out.backward()
+        self.opt.step()
+        return float(out.item())

@@ -1,0 +1,66 @@
+"""CPU stand-in for `daisyrec_amd.ops.BprContext` built on the numpy oracle, used ONLY by the
+gloo tests to exercise the multi-rank protocol of `daisyrec_amd.sharding` without a GPU."""
+import numpy as np
+import torch
+
+from oracle import bpr_mf_numpy as O
+
+
+class OracleContext:
+    def __init__(self, max_batch, d, user_num, item_num):
+        self.d, self.user_num, self.item_num = d, user_num, item_num
+        self.stats = torch.zeros(16, dtype=torch.float64)
+        self.epoch_acc = torch.zeros(2, dtype=torch.float64)
+        self.gQ = torch.zeros(item_num, d, dtype=torch.float32)
+
+    def set_batch_from_triples(self, triples, idx=None, start=0, B=None, user_base=0):
+        t = triples.numpy() if isinstance(triples, torch.Tensor) else triples
+        rows = t[idx.numpy()] if idx is not None else t[start:start + (B if B is not None else len(t) - start)]
+        self.u = rows[:, 0].astype(np.int64) - user_base
+        self.i, self.j = rows[:, 1].astype(np.int64), rows[:, 2].astype(np.int64)
+
+    def set_batch(self, u, i, j, pre_grouped=False):
+        self.u, self.i, self.j = (np.asarray(x).astype(np.int64) for x in (u, i, j))
+
+    def forward(self, P, Q, loss_type=0, gamma=1e-10):
+        P64, Q64 = P.numpy().astype(np.float64), Q.numpy().astype(np.float64)
+        pu, qi, qj = P64[self.u], Q64[self.i], Q64[self.j]
+        terms, cp, cn = O.pair_loss_coef((pu * qi).sum(1), (pu * qj).sum(1), loss_type, gamma)
+        self.cp, self.cn = cp, cn
+        s = self.stats
+        s[0] = terms.sum()
+        s[1], s[2], s[3] = np.abs(pu).sum(), np.abs(qi).sum(), np.abs(qj).sum()
+        s[4], s[5], s[6] = (pu * pu).sum(), (qi * qi).sum(), (qj * qj).sum()
+
+    def finalize(self, reg_1, reg_2, step_loss=None, accumulate=True):
+        s = self.stats
+        s[8], s[9], s[10] = s[4].sqrt(), s[5].sqrt(), s[6].sqrt()
+        s[7] = s[0] + reg_1 * (s[1] + s[2] + s[3]) + reg_2 * (s[8] + s[9] + s[10])
+        if accumulate:
+            self.epoch_acc[0] += s[7]
+
+    @staticmethod
+    def _fro(x, n):
+        return x / n if n > 0 else np.zeros_like(x)
+
+    def item_grad(self, P, Q, reg_1, reg_2, item_mode=0, gQ=None):
+        P64, Q64 = P.numpy().astype(np.float64), Q.numpy().astype(np.float64)
+        pu, qi, qj = P64[self.u], Q64[self.i], Q64[self.j]
+        nI, nJ = float(self.stats[9]), float(self.stats[10])
+        g = np.zeros((self.item_num, self.d))
+        np.add.at(g, self.i, self.cp[:, None] * pu + reg_1 * np.sign(qi) + reg_2 * self._fro(qi, nI))
+        np.add.at(g, self.j, self.cn[:, None] * pu + reg_1 * np.sign(qj) + reg_2 * self._fro(qj, nJ))
+        self.gQ += torch.from_numpy(g.astype(np.float32))
+
+    def user_sgd(self, P, Q, lr, reg_1, reg_2):
+        P64, Q64 = P.numpy().astype(np.float64), Q.numpy().astype(np.float64)
+        pu, qi, qj = P64[self.u], Q64[self.i], Q64[self.j]
+        nU = float(self.stats[8])
+        g = np.zeros_like(P64)
+        np.add.at(g, self.u, self.cp[:, None] * qi + self.cn[:, None] * qj + reg_1 * np.sign(pu)
+                  + reg_2 * self._fro(pu, nU))
+        P.copy_(torch.from_numpy((P64 - lr * g).astype(np.float32)))
+
+    def item_sgd_apply(self, Q, lr, dense=False, gQ=None):
+        Q.sub_(lr * self.gQ)
+        self.gQ.zero_()

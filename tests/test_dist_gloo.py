@@ -1,0 +1,83 @@
+"""world_size-2 `gloo` test of the user-sharded protocol (daisyrec_amd/sharding.py) on CPU:
+two ranks, each with its user range and the oracle-backed step backend, must reproduce the
+single-process oracle step on the UNION batch (tables and global loss)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import bpr_mf_numpy as O
+
+U, I, D, B, STEPS = 40, 30, 16, 96, 3
+LR, R1, R2 = 0.05, 0.01, 0.02
+
+
+def _data():
+    rng = np.random.default_rng(9)
+    P0 = (rng.standard_normal((U, D)) * 0.2).astype(np.float32)
+    Q0 = (rng.standard_normal((I, D)) * 0.2).astype(np.float32)
+    batches = [np.stack([rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)], 1)
+               .astype(np.int32) for _ in range(STEPS)]
+    return P0, Q0, batches
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from daisyrec_amd.sharding import UserShardedBprTrainer, shard_triples, user_range
+    from oracle_backend import OracleContext
+    P0, Q0, batches = _data()
+    lo, hi = user_range(U, world, rank)
+    P = torch.from_numpy(P0[lo:hi].copy())
+    Q = torch.from_numpy(Q0.copy())
+    ctx = OracleContext(B, D, hi - lo, I)
+    tr = UserShardedBprTrainer(ctx, P, Q, lo, LR, R1, R2, overlap=(rank % 2 == 0))
+    losses = []
+    for b in batches:
+        mine = shard_triples(b, U, world, rank)
+        stats = tr.step_from_triples(torch.from_numpy(mine))
+        losses.append(float(stats[7]))
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), P=P.numpy(), Q=Q.numpy(), lo=lo, hi=hi,
+             losses=np.array(losses), acc=float(ctx.epoch_acc[0]))
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_user_sharding_equals_single_process(tmp_path):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    P, Q, batches = _data()
+    ref_losses = []
+    for b in batches:
+        loss, P, Q = O.mf_sgd_step(P, Q, b[:, 0], b[:, 1], b[:, 2], LR, R1, R2)
+        ref_losses.append(loss)
+    outs = [np.load(os.path.join(str(tmp_path), f"r{r}.npz")) for r in range(world)]
+    for o in outs:
+        np.testing.assert_allclose(o["losses"], ref_losses, rtol=1e-9)       # every rank sees the GLOBAL loss
+        np.testing.assert_allclose(o["Q"], Q, atol=2e-6)                     # replicas stay identical
+        np.testing.assert_allclose(o["P"], P[int(o["lo"]):int(o["hi"])], atol=2e-6)
+        assert abs(float(o["acc"]) - sum(ref_losses)) < 1e-6
+    np.testing.assert_array_equal(outs[0]["Q"], outs[1]["Q"])
+
+
+def test_user_range_partition():
+    from daisyrec_amd.sharding import shard_triples, user_range
+    for U_, W in ((10, 3), (8, 8), (1000003, 8), (5, 8)):
+        r = [user_range(U_, W, k) for k in range(W)]
+        assert r[0][0] == 0 and r[-1][1] == U_
+        assert all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
+    t = np.array([[0, 1, 2], [9, 1, 2], [4, 0, 0]], dtype=np.int32)
+    assert sum(len(shard_triples(t, 10, 3, k)) for k in range(3)) == 3

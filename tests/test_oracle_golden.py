@@ -136,3 +136,21 @@ def test_sampler_semantics(ml100k):
     chi2 = ((cnt - exp) ** 2 / exp).sum()
     dof = len(comp) - 1
     assert abs(chi2 - dof) < 5 * np.sqrt(2 * dof)
+
+
+def test_torch_port_matches_golden(kat_steps):
+    """oracle/torch_port.py (bench.py's cpu_baseline) is the same computation as the reference."""
+    from oracle.torch_port import TorchMFBPR
+    g, name = kat_steps, "bpr_d64"
+    U, I, d, B, ns = (int(x) for x in g[f"{name}/meta"])
+    lr, r1, r2 = (float(x) for x in g[f"{name}/hyper"])
+    m = TorchMFBPR(U, I, d, lr, r1, r2)
+    with torch.no_grad():
+        m.embed_user.weight.copy_(torch.from_numpy(g[f"{name}/P0"]))
+        m.embed_item.weight.copy_(torch.from_numpy(g[f"{name}/Q0"]))
+    for s in range(ns):
+        u, i, j = (torch.from_numpy(g[f"{name}/{k}"][s]).long() for k in "uij")
+        loss = m.step(u, i, j)
+        assert abs(loss - g[f"{name}/loss"][s]) <= 1e-6 * abs(g[f"{name}/loss"][s])
+        np.testing.assert_allclose(m.embed_user.weight.detach().numpy(), g[f"{name}/P"][s], atol=1e-7)
+        np.testing.assert_allclose(m.embed_item.weight.detach().numpy(), g[f"{name}/Q"][s], atol=1e-7)

@@ -1,0 +1,100 @@
+#!/usr/bin/env python
+"""Memory-system and per-phase probes on one MI355X (used to place the kernels on the
+roofline; results are quoted in DESIGN.md).  Run on the GPU box:  python tools/gpu_probe.py"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from daisyrec_amd import ops  # noqa: E402
+
+dev = "cuda"
+
+
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+
+
+def membench():
+    d, n = 64, 1 << 22
+    out = torch.zeros(8, device=dev)
+    print("== random 256-B row access, n = 4M rows per launch ==")
+    for rows in (100_000, 1_000_000, 4_000_000, 16_000_000):
+        table = torch.zeros(rows, d, device=dev)
+        idx = torch.randint(0, rows, (n,), device=dev, dtype=torch.int32)
+        for what, nm in ((0, "gather"), (1, "atomic"), (2, "store"), (3, "rmw")):
+            ms = timeit(lambda: ops.membench(what, table, idx, out))
+            mult = 2 if what == 3 else 1
+            print(f"rows={rows:>9} ({rows * 256 / 1e6:7.1f} MB) {nm:7s} {ms:7.3f} ms  "
+                  f"{n * 256 * mult / ms / 1e6:8.1f} GB/s  {n / ms / 1e6:6.2f} Grows/s")
+        sidx = torch.sort(idx).values
+        for what, nm in ((0, "gather-sorted"), (1, "atomic-sorted")):
+            ms = timeit(lambda: ops.membench(what, table, sidx, out))
+            print(f"rows={rows:>9} {nm:14s} {ms:7.3f} ms  {n * 256 / ms / 1e6:8.1f} GB/s")
+        del table
+
+
+def phases(U=1_000_000, I=100_000, B=1 << 20, d=64, reg=1e-3):
+    print(f"== per-phase timing, U={U} I={I} B={B} d={d} reg={reg} ==")
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    P = torch.randn(U, d, device=dev, generator=g) * 0.01
+    Q = torch.randn(I, d, device=dev, generator=g) * 0.01
+    u = torch.randint(0, U, (B,), device=dev, generator=g, dtype=torch.int32)
+    i = torch.randint(0, I, (B,), device=dev, generator=g, dtype=torch.int32)
+    j = torch.randint(0, I, (B,), device=dev, generator=g, dtype=torch.int32)
+    tri = torch.stack([u, i, j], 1).contiguous()
+    perm = torch.randperm(B, device=dev)
+    ctx = ops.BprContext(B, d, U, I)
+    algo = (24 * d + 12) * B
+    res = {}
+    res["set_batch(gather+sort+permute)"] = timeit(lambda: ctx.set_batch_from_triples(tri, idx=perm, B=B))
+    res["set_batch(pre_grouped copy)"] = timeit(lambda: ctx.set_batch(u, i, j, pre_grouped=True))
+    ctx.set_batch_from_triples(tri, idx=perm, B=B)
+    res["forward(k_fwd+reduce)"] = timeit(lambda: ctx.forward(P, Q))
+    ctx.finalize(reg, reg)
+    res["finalize"] = timeit(lambda: ctx.finalize(reg, reg, accumulate=False))
+
+    def item_a():
+        ctx.item_grad(P, Q, reg, reg, ops.ITEM_MODES["atomic"])
+    res["item_grad atomic (reg)"] = timeit(item_a)
+    res["item_grad atomic (no reg)"] = timeit(lambda: ctx.item_grad(P, Q, 0.0, 0.0, ops.ITEM_MODES["atomic"]))
+    ctx.gQ.zero_()
+    res["item_grad sorted(sort+kernel)"] = timeit(lambda: ctx.item_grad(P, Q, reg, reg, ops.ITEM_MODES["sorted"]))
+    res["user_sgd (lr=0)"] = timeit(lambda: ctx.user_sgd(P, Q, 0.0, reg, reg))
+    res["item_apply (touched)"] = timeit(lambda: (ctx.item_grad(P, Q, 0.0, 0.0, 0), ctx.item_sgd_apply(Q, 0.0))) \
+        - res["item_grad atomic (no reg)"]
+    res["item_apply dense"] = timeit(lambda: ctx.item_sgd_apply(Q, 0.0, dense=True))
+    res["full sgd_step atomic"] = timeit(lambda: (ctx.set_batch_from_triples(tri, idx=perm, B=B),
+                                                  ctx.sgd_step(P, Q, 1e-9, reg, reg, item_mode=0)))
+    res["full sgd_step sorted"] = timeit(lambda: (ctx.set_batch_from_triples(tri, idx=perm, B=B),
+                                                  ctx.sgd_step(P, Q, 1e-9, reg, reg, item_mode=1)))
+    for k, v in res.items():
+        print(f"{k:34s} {v:8.3f} ms   {B / v / 1e6:8.3f} G inter/s   algo {algo / v / 1e6:8.1f} GB/s ({algo / v / 1e6 / 8000:5.1%} of 8 TB/s)")
+    n = 50_000_000
+    t = timeit(lambda: ops.randperm(n, 1, 0), iters=3, warm=1)
+    print(f"randperm(50M)                      {t:8.3f} ms")
+    ctx.close()
+
+
+if __name__ == "__main__":
+    print(torch.cuda.get_device_name(0), torch.version.hip)
+    t0 = time.time()
+    which = sys.argv[1:] or ["mem", "phases"]
+    if "mem" in which:
+        membench()
+    if "phases" in which:
+        phases()
+        phases(B=1 << 16)
+    print("probe wall", time.time() - t0)
