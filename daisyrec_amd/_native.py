@@ -9,6 +9,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch bundles its own HIP/HSA runtime (torch/lib/libamdhip64.so, SONAME libamdhip64.so.7).
+# It MUST be mapped before our library so that the dynamic linker binds our NEEDED
+# libamdhip64.so.7 to that same copy: two HIP runtimes in one process do not share streams
+# or device state (observed: "no ROCm-capable device is detected" from the second copy).
+import torch  # noqa: F401  (side effect: loads torch's HIP runtime first)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdaisyrec_hip.so")
 
