@@ -20,11 +20,12 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdaisyrec_hip.so")
 
 DAISY_OK, DAISY_ERR_ARG, DAISY_ERR_HIP, DAISY_ERR_STATE = 0, 1, 2, 3
 LOSS_BPR, LOSS_HL, LOSS_TL = 0, 1, 2
-ITEM_ATOMIC, ITEM_SORTED = 0, 1
+ITEM_ATOMIC, ITEM_SORTED, ITEM_CHUNKED = 0, 1, 2
+ORDER_IDENTITY, ORDER_PERM, ORDER_FEISTEL = 0, 1, 2
 STATS_LEN = 16
 ST_LOSS_DATA, ST_L1_U, ST_L1_I, ST_L1_J, ST_SQ_U, ST_SQ_I, ST_SQ_J = range(7)
 ST_LOSS, ST_NORM_U, ST_NORM_I, ST_NORM_J = 7, 8, 9, 10
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _p = C.c_void_p
 _i32, _i64, _u64, _f32, _sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
@@ -37,7 +38,15 @@ SIGNATURES = {
     "daisy_bpr_ctx_destroy": (C.c_int, [_p]),
     "daisy_bpr_ctx_scratch_bytes": (_sz, [_p]),
     "daisy_bpr_set_batch_from_triples": (C.c_int, [_p, _p, _i64, _p, _i64, _i64, _i32, _p]),
-    "daisy_bpr_set_batch": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p]),
+    "daisy_bpr_set_batch": (C.c_int, [_p, _p, _p, _p, _i64, _p]),
+    "daisy_bpr_set_batch_from_plan": (C.c_int, [_p, _p, _i64, _p]),
+    "daisy_epoch_plan_create": (C.c_int, [C.POINTER(_p), _i64, _i64, _i64]),
+    "daisy_epoch_plan_destroy": (C.c_int, [_p]),
+    "daisy_epoch_plan_bytes": (_sz, [_p]),
+    "daisy_epoch_plan_build": (C.c_int, [_p, _p, _i64, _p, _i32, _u64, _u64, _i64, _i32, _p]),
+    "daisy_epoch_plan_num_batches": (_i64, [_p]),
+    "daisy_epoch_plan_read_batch": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, C.POINTER(_i64), _p]),
+    "daisy_feistel_positions": (C.c_int, [_i64, _u64, _u64, _p, _p]),
     "daisy_bpr_forward": (C.c_int, [_p, _p, _p, _i32, _f32, _p, _p]),
     "daisy_bpr_finalize": (C.c_int, [_p, _p, _f32, _f32, _p, _p, _p]),
     "daisy_bpr_item_grad": (C.c_int, [_p, _p, _p, _p, _f32, _f32, _p, _i32, _p]),
@@ -47,8 +56,8 @@ SIGNATURES = {
     "daisy_adam_dense": (C.c_int, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _i64, _p]),
     "daisy_bpr_sgd_step": (C.c_int, [_p, _p, _p, _i32, _f32, _f32, _f32, _f32, _p, _p, _p, _p,
                                      _i32, _p]),
-    "daisy_bpr_fit_epoch_sgd": (C.c_int, [_p, _p, _p, _p, _i64, _p, _i64, _i32, _i32, _f32, _f32,
-                                          _f32, _f32, _p, _p, _p, _p, _i32, _p]),
+    "daisy_bpr_fit_epoch_sgd": (C.c_int, [_p, _p, _p, _p, _i32, _f32, _f32, _f32, _f32, _p, _p, _p,
+                                          _p, _i32, _p]),
     "daisy_mf_predict": (C.c_int, [_p, _p, _i32, _p, _p, _i64, _p, _p]),
     "daisy_mf_rank_workspace_bytes": (_sz, [_i64, _i64]),
     "daisy_mf_rank_topk": (C.c_int, [_p, _p, _i32, _p, _p, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),

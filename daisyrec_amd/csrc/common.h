@@ -181,12 +181,56 @@ __host__ __device__ __forceinline__ uint64_t philox_u64(uint64_t seed, uint64_t 
 }
 
 // ----------------------------------------------------------------------------
+// Keyed bijection of [0, n): 6-round balanced Feistel network on 2h bits with
+// cycle walking (the construction behind thrust::shuffle).  Round keys come from
+// Philox on the host.  Identical to oracle/bpr_mf_numpy.py::feistel_position.
+// ----------------------------------------------------------------------------
+constexpr int kFeistelRounds = 6;
+struct FeistelKey {
+    uint32_t k[kFeistelRounds];
+    int half_bits;
+};
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {  // murmur3 finalizer
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ uint64_t feistel_position(uint64_t x, uint64_t n,
+                                                              const FeistelKey &fk) {
+    const int h = fk.half_bits;
+    const uint64_t mask = ((uint64_t)1 << h) - 1;
+    do {
+        uint64_t L = x >> h, R = x & mask;
+#pragma unroll
+        for (int r = 0; r < kFeistelRounds; ++r) {
+            const uint64_t f = (uint64_t)mix32((uint32_t)R ^ fk.k[r]) & mask;
+            const uint64_t t = L ^ f;
+            L = R;
+            R = t;
+        }
+        x = (L << h) | R;
+    } while (x >= n);
+    return x;
+}
+inline FeistelKey make_feistel_key(uint64_t n, uint64_t seed, uint64_t epoch) {
+    FeistelKey fk;
+    int bits = 2;
+    while (bits < 62 && ((uint64_t)1 << bits) < n) bits += 2;   // even bit count >= log2(n)
+    fk.half_bits = bits / 2;
+    for (int r = 0; r < kFeistelRounds; ++r)
+        fk.k[r] = (uint32_t)philox_u64(seed, epoch | ((uint64_t)1 << 61), (uint64_t)r);
+    return fk;
+}
+
+// ----------------------------------------------------------------------------
 // rocPRIM wrappers live in sort.hip (keeps the heavy headers in one TU)
 // ----------------------------------------------------------------------------
 size_t sort_pairs_i32_temp_bytes(int64_t n);
 // stable LSD radix sort of (key,val) int32 pairs on bits [0,end_bit)
 int sort_pairs_i32(void *temp, size_t temp_bytes, const int32_t *kin, int32_t *kout,
                    const int32_t *vin, int32_t *vout, int64_t n, int end_bit, hipStream_t s);
+size_t sort_pairs_u64_i32_temp_bytes(int64_t n);
+int sort_pairs_u64_i32(void *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout,
+                       const int32_t *vin, int32_t *vout, int64_t n, int end_bit, hipStream_t s);
 size_t sort_pairs_u64_i64_temp_bytes(int64_t n);
 int sort_pairs_u64_i64(void *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout,
                        const int64_t *vin, int64_t *vout, int64_t n, int end_bit, hipStream_t s);

@@ -160,6 +160,7 @@ class GeneralRecommender(AbstractRecommender):
             n = (n // B) * B
         P, Q = self.embed_user.weight.data, self.embed_item.weight.data
         ctx = ops.BprContext(min(B, max(n, 1)), P.shape[1], P.shape[0], Q.shape[0], device=P.device)
+        plan = ops.EpochPlan(n, P.shape[0], Q.shape[0], device=P.device)
         adam = _AdamState(P, Q, self.lr) if opt == "adam" else None
         self.epoch_losses = []
         last_loss = 0.0
@@ -170,16 +171,17 @@ class GeneralRecommender(AbstractRecommender):
                 self.train()
                 perm = self._epoch_order(train_loader, triples.shape[0])
                 if perm is not None:
-                    perm = perm[:n].to(self.device)
+                    perm = perm[:n].contiguous().to(self.device)
+                # one radix-sort pass lays the epoch out batch by batch, in the DataLoader's order
+                plan.build(triples, B, order="identity" if perm is None else "perm", perm=perm,
+                           n_triples=n)
                 ctx.epoch_acc.zero_()
                 if adam is None:
-                    ctx.fit_epoch_sgd(P, Q, triples, perm, B, self.lr, self.reg_1, self.reg_2,
-                                      loss_type=loss_id, item_mode=item_mode, n_triples=n)
+                    ctx.fit_epoch_sgd(plan, P, Q, self.lr, self.reg_1, self.reg_2, loss_type=loss_id,
+                                      item_mode=item_mode)
                 else:
-                    for start in range(0, n, B):
-                        bsz = min(B, n - start)
-                        ctx.set_batch_from_triples(triples, None if perm is None else perm[start:start + bsz],
-                                                   start=start, B=bsz)
+                    for k in range(plan.num_batches):
+                        ctx.set_batch_from_plan(plan, k)
                         adam.step(ctx, P, Q, self.reg_1, self.reg_2, loss_id, item_mode)
                 acc = ctx.epoch_acc.cpu()
                 current_loss = float(acc[0])
@@ -199,6 +201,7 @@ class GeneralRecommender(AbstractRecommender):
         finally:
             torch.cuda.synchronize()
             ctx.close()
+            plan.close()
 
 
 class _AdamState:

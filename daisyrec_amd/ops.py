@@ -14,7 +14,8 @@ from . import _native as N
 from ._native import check, lib
 
 LOSS_IDS = {"BPR": N.LOSS_BPR, "HL": N.LOSS_HL, "TL": N.LOSS_TL}
-ITEM_MODES = {"atomic": N.ITEM_ATOMIC, "sorted": N.ITEM_SORTED}
+ITEM_MODES = {"atomic": N.ITEM_ATOMIC, "sorted": N.ITEM_SORTED, "chunked": N.ITEM_CHUNKED}
+ORDER_MODES = {"identity": N.ORDER_IDENTITY, "perm": N.ORDER_PERM, "feistel": N.ORDER_FEISTEL}
 
 
 def loss_id(loss_type: str) -> int:
@@ -46,6 +47,70 @@ def _stream():
 
 def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+class EpochPlan:
+    """Owner of a native ``daisy_epoch_plan``: one epoch laid out batch by batch in HBM
+    (replaces a pass over DataLoader(BasicDataset(triples)), dataset.py:5-27)."""
+
+    def __init__(self, max_triples: int, user_num: int, item_num: int, device="cuda"):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("EpochPlan needs a HIP device (no CPU fallback)")
+        self.max_triples = int(max_triples)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib.daisy_epoch_plan_create(C.byref(self._h), self.max_triples, int(user_num),
+                                              int(item_num)))
+
+    def build(self, triples, batch_size, order="identity", perm=None, seed=0, epoch=0, user_base=0,
+              n_triples=None):
+        n = triples.shape[0] if n_triples is None else int(n_triples)
+        mode = ORDER_MODES[order] if isinstance(order, str) else int(order)
+        check(lib.daisy_epoch_plan_build(self._h, _ptr(triples, torch.int32, "triples"), n,
+                                         _ptr(perm, torch.int64, "perm"), mode, int(seed), int(epoch),
+                                         int(batch_size), int(user_base), _stream()))
+        return self
+
+    @property
+    def num_batches(self):
+        return int(lib.daisy_epoch_plan_num_batches(self._h))
+
+    def read_batch(self, k, batch_size):
+        """(u, i, j, ent_item, ent_s, ent_u) of batch k as device tensors (inspection / tests)."""
+        dev = self.device
+        u, i, j = (torch.empty(batch_size, dtype=torch.int32, device=dev) for _ in range(3))
+        ei, es, eu = (torch.empty(2 * batch_size, dtype=torch.int32, device=dev) for _ in range(3))
+        B = C.c_int64(0)
+        check(lib.daisy_epoch_plan_read_batch(self._h, int(k), _ptr(u, torch.int32, "u"),
+                                              _ptr(i, torch.int32, "i"), _ptr(j, torch.int32, "j"),
+                                              _ptr(ei, torch.int32, "ent_item"), _ptr(es, torch.int32, "ent_s"),
+                                              _ptr(eu, torch.int32, "ent_u"), C.byref(B), _stream()))
+        b = B.value
+        return u[:b], i[:b], j[:b], ei[:2 * b], es[:2 * b], eu[:2 * b]
+
+    @property
+    def nbytes(self):
+        return int(lib.daisy_epoch_plan_bytes(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            check(lib.daisy_epoch_plan_destroy(self._h))
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def feistel_positions(n, seed, epoch=0, device="cuda"):
+    """pos[t] = position of triple t in the device shuffle of (seed, epoch)."""
+    out = torch.empty(n, dtype=torch.int64, device=device)
+    check(lib.daisy_feistel_positions(int(n), int(seed), int(epoch), _ptr(out, torch.int64, "out"),
+                                      _stream()))
+    return out
 
 
 class BprContext:
@@ -89,10 +154,12 @@ class BprContext:
             self._h, _ptr(triples, torch.int32, "triples"), n,
             _ptr(idx, torch.int64, "idx"), int(start), int(B), int(user_base), _stream()))
 
-    def set_batch(self, u, i, j, pre_grouped=False):
+    def set_batch(self, u, i, j):
         check(lib.daisy_bpr_set_batch(self._h, _ptr(u, torch.int32, "u"), _ptr(i, torch.int32, "i"),
-                                      _ptr(j, torch.int32, "j"), u.numel(), int(pre_grouped),
-                                      _stream()))
+                                      _ptr(j, torch.int32, "j"), u.numel(), _stream()))
+
+    def set_batch_from_plan(self, plan, k):
+        check(lib.daisy_bpr_set_batch_from_plan(self._h, plan._h, int(k), _stream()))
 
     # -- phases --------------------------------------------------------------
     def forward(self, P, Q, loss_type=N.LOSS_BPR, gamma=1e-10):
@@ -106,7 +173,7 @@ class BprContext:
                                      _ptr(self.epoch_acc, torch.float64, "epoch_acc") if accumulate else None,
                                      _ptr(step_loss, torch.float64, "step_loss"), _stream()))
 
-    def item_grad(self, P, Q, reg_1, reg_2, item_mode=N.ITEM_ATOMIC, gQ=None):
+    def item_grad(self, P, Q, reg_1, reg_2, item_mode=N.ITEM_CHUNKED, gQ=None):
         gQ = self.gQ if gQ is None else gQ
         check(lib.daisy_bpr_item_grad(self._h, _ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"),
                                       _ptr(self.stats, torch.float64, "stats"), float(reg_1),
@@ -130,7 +197,7 @@ class BprContext:
                                            _stream()))
 
     def sgd_step(self, P, Q, lr, reg_1, reg_2, loss_type=N.LOSS_BPR, gamma=1e-10,
-                 item_mode=N.ITEM_ATOMIC, step_loss=None, accumulate=True):
+                 item_mode=N.ITEM_CHUNKED, step_loss=None, accumulate=True):
         check(lib.daisy_bpr_sgd_step(
             self._h, _ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"), int(loss_type),
             float(gamma), float(lr), float(reg_1), float(reg_2), _ptr(self.gQ, torch.float32, "gQ"),
@@ -138,15 +205,13 @@ class BprContext:
             _ptr(self.epoch_acc, torch.float64, "epoch_acc") if accumulate else None,
             _ptr(step_loss, torch.float64, "step_loss"), int(item_mode), _stream()))
 
-    def fit_epoch_sgd(self, P, Q, triples, perm, batch_size, lr, reg_1, reg_2,
-                      loss_type=N.LOSS_BPR, gamma=1e-10, item_mode=N.ITEM_ATOMIC, user_base=0,
-                      step_losses=None, n_triples=None):
-        n = triples.shape[0] if n_triples is None else int(n_triples)
+    def fit_epoch_sgd(self, plan, P, Q, lr, reg_1, reg_2, loss_type=N.LOSS_BPR, gamma=1e-10,
+                      item_mode=N.ITEM_CHUNKED, step_losses=None):
+        """Every batch of a built plan (one epoch), enqueued natively."""
         check(lib.daisy_bpr_fit_epoch_sgd(
-            self._h, _ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"),
-            _ptr(triples, torch.int32, "triples"), n, _ptr(perm, torch.int64, "perm"),
-            int(batch_size), int(user_base), int(loss_type), float(gamma), float(lr), float(reg_1),
-            float(reg_2), _ptr(self.gQ, torch.float32, "gQ"), _ptr(self.stats, torch.float64, "stats"),
+            self._h, plan._h, _ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"),
+            int(loss_type), float(gamma), float(lr), float(reg_1), float(reg_2),
+            _ptr(self.gQ, torch.float32, "gQ"), _ptr(self.stats, torch.float64, "stats"),
             _ptr(self.epoch_acc, torch.float64, "epoch_acc"),
             _ptr(step_losses, torch.float64, "step_losses"), int(item_mode), _stream()))
 

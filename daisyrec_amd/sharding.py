@@ -49,7 +49,7 @@ class UserShardedBprTrainer:
     table; both are updated in place."""
 
     def __init__(self, ctx, P_local, Q, user_lo, lr, reg_1, reg_2, loss_type=N.LOSS_BPR,
-                 gamma=1e-10, item_mode=N.ITEM_ATOMIC, group=None, overlap=True):
+                 gamma=1e-10, item_mode=N.ITEM_CHUNKED, group=None, overlap=True):
         self.ctx, self.P, self.Q = ctx, P_local, Q
         self.user_lo = int(user_lo)
         self.lr, self.reg_1, self.reg_2 = float(lr), float(reg_1), float(reg_2)
@@ -67,6 +67,11 @@ class UserShardedBprTrainer:
         """One global step; `triples` are this rank's rows (global user ids)."""
         c = self.ctx
         c.set_batch_from_triples(triples, idx=idx, start=start, B=B, user_base=self.user_lo)
+        return self._step()
+
+    def step_from_plan(self, plan, k):
+        """One global step on batch k of this rank's epoch plan."""
+        self.ctx.set_batch_from_plan(plan, k)
         return self._step()
 
     def step(self, u_local, i, j):

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DAISY_ABI_VERSION 1
+#define DAISY_ABI_VERSION 2
 
 typedef void *daisy_stream_t; /* hipStream_t */
 
@@ -45,10 +45,18 @@ enum daisy_loss {
     DAISY_LOSS_TL = 2   /* sigmoid(neg-pos).sum()+sigmoid(neg**2).sum()     loss.py:30-33 */
 };
 
-/* how the item-side gradient is accumulated */
+/* how the item-side gradient is accumulated (entries of a batch are always sorted by item) */
 enum daisy_item_mode {
-    DAISY_ITEM_ATOMIC = 0, /* fp32 atomics into gQ (throughput mode; sum order not fixed) */
-    DAISY_ITEM_SORTED = 1  /* sort by item, one owner per row, fixed order (bitwise reproducible) */
+    DAISY_ITEM_ATOMIC = 0,  /* one fp32 atomic row per entry (kept for A/B measurements only) */
+    DAISY_ITEM_SORTED = 1,  /* one owner per row, entries summed in plan order: bitwise reproducible */
+    DAISY_ITEM_CHUNKED = 2  /* segmented reduction through LDS accumulators (throughput mode) */
+};
+
+/* order of an epoch (what DataLoader(shuffle=...) decides, dataset.py:5-7) */
+enum daisy_order_mode {
+    DAISY_ORDER_IDENTITY = 0, /* shuffle=False: triples in array order                          */
+    DAISY_ORDER_PERM = 1,     /* explicit permutation: perm[p] = triple served at position p     */
+    DAISY_ORDER_FEISTEL = 2   /* shuffle=True on the device: keyed bijection of (seed, epoch)    */
 };
 
 /* layout of the caller-owned `stats` vector (device, double[DAISY_STATS_LEN]) */
@@ -82,17 +90,49 @@ int daisy_bpr_ctx_destroy(daisy_bpr_ctx *ctx);
 /* bytes of device scratch the context holds (for reporting) */
 size_t daisy_bpr_ctx_scratch_bytes(const daisy_bpr_ctx *ctx);
 
-/* Replaces BasicDataset.__getitem__ + default collate + `.to(device)`
- * (dataset.py:10-27, MFRecommender.py:71-72,83): gathers rows idx[0..B) of the
- * int32 [N,3] triple array (idx == NULL: rows start..start+B) and groups the
- * batch by user (stable), which the update kernels rely on.
- * user_base is subtracted from the user ids (user-sharded tables). */
+/* ------------------------------------------------------------------------
+ * Epoch plan: replaces one pass of `for batch in DataLoader(BasicDataset(triples),
+ * batch_size, shuffle)` (dataset.py:5-27) + `.to(device)` (MFRecommender.py:71-72,83).
+ * One build per epoch lays the epoch out batch by batch in HBM — batch k holds exactly
+ * the triples DataLoader's k-th batch would (last batch partial, drop_last=False) —
+ * each batch grouped by user, plus its item entries sorted by item, so the step
+ * kernels update every table row from a single owner instead of through atomics.
+ * ---------------------------------------------------------------------- */
+typedef struct daisy_epoch_plan daisy_epoch_plan;
+
+int daisy_epoch_plan_create(daisy_epoch_plan **out, int64_t max_triples, int64_t user_num,
+                            int64_t item_num);
+int daisy_epoch_plan_destroy(daisy_epoch_plan *plan);
+size_t daisy_epoch_plan_bytes(const daisy_epoch_plan *plan);
+/* triples: int32 [n_triples][3]; perm: int64 [n_triples], only for DAISY_ORDER_PERM;
+ * (seed, epoch) only for DAISY_ORDER_FEISTEL; user_base is subtracted from the user
+ * ids (user-sharded tables). */
+int daisy_epoch_plan_build(daisy_epoch_plan *plan, const int32_t *triples, int64_t n_triples,
+                           const int64_t *perm, int32_t order_mode, uint64_t seed, uint64_t epoch,
+                           int64_t batch_size, int32_t user_base, daisy_stream_t stream);
+int64_t daisy_epoch_plan_num_batches(const daisy_epoch_plan *plan);
+/* copy batch k of a built plan into caller buffers (inspection / tests): u,i,j int32 [B]
+ * grouped by user; optional item entries [2B] sorted by item: ent_item, ent_s (sample
+ * position | 0x80000000 for the negative slot), ent_u (user of that sample).
+ * *B_out_host (host pointer, may be NULL) receives the batch size. */
+int daisy_epoch_plan_read_batch(const daisy_epoch_plan *plan, int64_t k, int32_t *u, int32_t *i,
+                                int32_t *j, int32_t *ent_item, uint32_t *ent_s, int32_t *ent_u,
+                                int64_t *B_out_host, daisy_stream_t stream);
+/* out[t] = position of triple t in the DAISY_ORDER_FEISTEL order of (seed, epoch) */
+int daisy_feistel_positions(int64_t n, uint64_t seed, uint64_t epoch, int64_t *out,
+                            daisy_stream_t stream);
+
+/* make batch k of a built plan current (no copy) */
+int daisy_bpr_set_batch_from_plan(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, int64_t k,
+                                  daisy_stream_t stream);
+/* One collated batch outside a plan: rows idx[0..B) of the int32 [N,3] triple array
+ * (idx == NULL: rows start..start+B); builds a one-batch plan inside the context. */
 int daisy_bpr_set_batch_from_triples(daisy_bpr_ctx *ctx, const int32_t *triples, int64_t n_triples,
                                      const int64_t *idx, int64_t start, int64_t B,
                                      int32_t user_base, daisy_stream_t stream);
-/* Same from three separate int32 arrays (one collated batch). */
+/* Same from three separate int32 arrays (what default_collate yields). */
 int daisy_bpr_set_batch(daisy_bpr_ctx *ctx, const int32_t *u, const int32_t *i, const int32_t *j,
-                        int64_t B, int32_t pre_grouped, daisy_stream_t stream);
+                        int64_t B, daisy_stream_t stream);
 
 /* MF.forward x2 + criterion (MFRecommender.py:63-68,73,83-85; loss.py): per-sample
  * d(loss)/d(pos), d(loss)/d(neg) kept in the context; the seven batch SUMS go
@@ -143,15 +183,13 @@ int daisy_bpr_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t loss_type
                        daisy_stream_t stream);
 
 /* The inner `for batch in pbar` loop of GeneralRecommender.fit
- * (AbstractRecommender.py:118-128) for one epoch, enqueued natively with no
- * host synchronisation: batch k = rows perm[k*B .. (k+1)*B) of `triples`
- * (perm == NULL: identity order); the last batch is partial like DataLoader's
- * (drop_last=False).  step_losses (may be NULL) gets one loss per step. */
-int daisy_bpr_fit_epoch_sgd(daisy_bpr_ctx *ctx, float *P, float *Q, const int32_t *triples,
-                            int64_t n_triples, const int64_t *perm, int64_t batch_size,
-                            int32_t user_base, int32_t loss_type, float gamma, float lr,
-                            float reg_1, float reg_2, float *gQ, double *stats, double *epoch_acc,
-                            double *step_losses, int32_t item_mode, daisy_stream_t stream);
+ * (AbstractRecommender.py:118-128) for one epoch: every batch of a built plan,
+ * enqueued natively with no host synchronisation.  step_losses (may be NULL)
+ * gets one loss per step. */
+int daisy_bpr_fit_epoch_sgd(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, float *P, float *Q,
+                            int32_t loss_type, float gamma, float lr, float reg_1, float reg_2,
+                            float *gQ, double *stats, double *epoch_acc, double *step_losses,
+                            int32_t item_mode, daisy_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Scoring / ranking  (MFRecommender.py:99-133)

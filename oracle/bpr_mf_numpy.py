@@ -259,3 +259,41 @@ def expand_triples(users, pos_items, js):
     out[:, 1] = np.repeat(np.asarray(pos_items), num_ng)
     out[:, 2] = js[users].reshape(-1)
     return out
+
+
+# --------------------------------------------------------------------------
+# Device shuffle (DAISY_ORDER_FEISTEL): a keyed bijection of [0, n) that stands in
+# for RandomSampler's torch.randperm (dataset.py:5-7, shuffle=True) on the
+# throughput path.  6-round balanced Feistel network on 2h bits, murmur3
+# finaliser as round function, Philox round keys, cycle walking.
+# --------------------------------------------------------------------------
+def _mix32(x):
+    x = np.asarray(x, dtype=np.uint64) & np.uint64(_M32)
+    x ^= x >> np.uint64(16)
+    x = (x * np.uint64(0x85EBCA6B)) & np.uint64(_M32)
+    x ^= x >> np.uint64(13)
+    x = (x * np.uint64(0xC2B2AE35)) & np.uint64(_M32)
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def feistel_positions(n, seed, epoch=0):
+    """pos[t] for t in 0..n-1 (a permutation of 0..n-1)."""
+    bits = 2
+    while bits < 62 and (1 << bits) < n:
+        bits += 2
+    h = np.uint64(bits // 2)
+    mask = np.uint64((1 << (bits // 2)) - 1)
+    keys = [np.uint64(_draw_u64(seed, epoch | (1 << 61), r) & _M32) for r in range(6)]
+    x = np.arange(n, dtype=np.uint64)
+    todo = np.ones(n, dtype=bool)
+    while todo.any():
+        v = x[todo]
+        L, R = v >> h, v & mask
+        for r in range(6):
+            f = _mix32(R ^ keys[r]) & mask
+            L, R = R, L ^ f
+        v = (L << h) | R
+        x[todo] = v
+        todo[todo] = v >= np.uint64(n)
+    return x.astype(np.int64)

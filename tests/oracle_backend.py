@@ -19,7 +19,7 @@ class OracleContext:
         self.u = rows[:, 0].astype(np.int64) - user_base
         self.i, self.j = rows[:, 1].astype(np.int64), rows[:, 2].astype(np.int64)
 
-    def set_batch(self, u, i, j, pre_grouped=False):
+    def set_batch(self, u, i, j):
         self.u, self.i, self.j = (np.asarray(x).astype(np.int64) for x in (u, i, j))
 
     def forward(self, P, Q, loss_type=0, gamma=1e-10):

@@ -28,7 +28,7 @@ def ops():
 
 
 # ------------------------------------------------------------------ per-step KATs
-@pytest.mark.parametrize("item_mode", ["sorted", "atomic"])
+@pytest.mark.parametrize("item_mode", ["sorted", "atomic", "chunked"])
 def test_kat_steps_sgd(ops, kat_steps, item_mode):
     g = kat_steps
     for name in g["names"]:
@@ -89,7 +89,7 @@ def test_step_vs_oracle_shapes(ops, d):
     lr, r1, r2 = 0.05, 0.01, 0.02
     for lt_name in ("BPR", "HL", "TL"):
         loss, Pn, Qn = O.mf_sgd_step(P0, Q0, u, i, j, lr, r1, r2, O.LOSS_IDS[lt_name])
-        for mode in ("sorted", "atomic"):
+        for mode in ("sorted", "atomic", "chunked"):
             P, Q = _t(P0), _t(Q0)
             ctx = ops.BprContext(B, d, U, I)
             sl = torch.zeros(1, dtype=torch.float64, device=DEV)
@@ -112,7 +112,7 @@ def test_step_vs_oracle_batch_sizes(ops, B):
     i = rng.integers(0, I, B).astype(np.int32)
     j = rng.integers(0, I, B).astype(np.int32)
     loss, Pn, Qn = O.mf_sgd_step(P0, Q0, u, i, j, 0.01, 1e-3, 1e-3)
-    for mode in ("sorted", "atomic"):
+    for mode in ("sorted", "atomic", "chunked"):
         P, Q = _t(P0), _t(Q0)
         ctx = ops.BprContext(max(B, 8), d, U, I)
         sl = torch.zeros(1, dtype=torch.float64, device=DEV)
@@ -354,7 +354,7 @@ def test_c2_scale_step_properties(ops):
     Pn.index_add_(0, ul, -lr * (c * (qi - qj) + r1 * pu.sign() + r2 * pu / nU.float()))
     Qn.index_add_(0, il, -lr * (c * pu + r1 * qi.sign() + r2 * qi / nI.float()))
     Qn.index_add_(0, jl, -lr * (-c * pu + r1 * qj.sign() + r2 * qj / nJ.float()))
-    for mode in ("atomic", "sorted"):
+    for mode in ("chunked", "atomic", "sorted"):
         P1, Q1 = P.clone(), Q.clone()
         ctx = ops.BprContext(B, d, U, I)
         sl = torch.zeros(1, dtype=torch.float64, device=DEV)
