@@ -59,8 +59,7 @@ def phases(U=1_000_000, I=100_000, B=1 << 20, d=64, reg=1e-3):
     ctx = ops.BprContext(B, d, U, I)
     algo = (24 * d + 12) * B
     res = {}
-    res["set_batch(gather+sort+permute)"] = timeit(lambda: ctx.set_batch_from_triples(tri, idx=perm, B=B))
-    res["set_batch(pre_grouped copy)"] = timeit(lambda: ctx.set_batch(u, i, j, pre_grouped=True))
+    res["set_batch(one-batch plan)"] = timeit(lambda: ctx.set_batch_from_triples(tri, idx=perm, B=B))
     ctx.set_batch_from_triples(tri, idx=perm, B=B)
     res["forward(k_fwd+reduce)"] = timeit(lambda: ctx.forward(P, Q))
     ctx.finalize(reg, reg)
@@ -71,30 +70,51 @@ def phases(U=1_000_000, I=100_000, B=1 << 20, d=64, reg=1e-3):
     res["item_grad atomic (reg)"] = timeit(item_a)
     res["item_grad atomic (no reg)"] = timeit(lambda: ctx.item_grad(P, Q, 0.0, 0.0, ops.ITEM_MODES["atomic"]))
     ctx.gQ.zero_()
-    res["item_grad sorted(sort+kernel)"] = timeit(lambda: ctx.item_grad(P, Q, reg, reg, ops.ITEM_MODES["sorted"]))
+    res["item_grad sorted"] = timeit(lambda: ctx.item_grad(P, Q, reg, reg, ops.ITEM_MODES["sorted"]))
+    ctx.gQ.zero_()
+    res["item_grad chunked (reg)"] = timeit(lambda: ctx.item_grad(P, Q, reg, reg, ops.ITEM_MODES["chunked"]))
+    ctx.gQ.zero_()
+    res["item_grad chunked (no reg)"] = timeit(lambda: ctx.item_grad(P, Q, 0.0, 0.0, ops.ITEM_MODES["chunked"]))
+    ctx.gQ.zero_()
     res["user_sgd (lr=0)"] = timeit(lambda: ctx.user_sgd(P, Q, 0.0, reg, reg))
     res["item_apply (touched)"] = timeit(lambda: (ctx.item_grad(P, Q, 0.0, 0.0, 0), ctx.item_sgd_apply(Q, 0.0))) \
         - res["item_grad atomic (no reg)"]
     res["item_apply dense"] = timeit(lambda: ctx.item_sgd_apply(Q, 0.0, dense=True))
-    res["full sgd_step atomic"] = timeit(lambda: (ctx.set_batch_from_triples(tri, idx=perm, B=B),
-                                                  ctx.sgd_step(P, Q, 1e-9, reg, reg, item_mode=0)))
-    res["full sgd_step sorted"] = timeit(lambda: (ctx.set_batch_from_triples(tri, idx=perm, B=B),
-                                                  ctx.sgd_step(P, Q, 1e-9, reg, reg, item_mode=1)))
+    res["sgd_step atomic  (batch preset)"] = timeit(lambda: ctx.sgd_step(P, Q, 1e-9, reg, reg, item_mode=0))
+    res["sgd_step sorted  (batch preset)"] = timeit(lambda: ctx.sgd_step(P, Q, 1e-9, reg, reg, item_mode=1))
+    res["sgd_step chunked (batch preset)"] = timeit(lambda: ctx.sgd_step(P, Q, 1e-9, reg, reg, item_mode=2))
     for k, v in res.items():
         print(f"{k:34s} {v:8.3f} ms   {B / v / 1e6:8.3f} G inter/s   algo {algo / v / 1e6:8.1f} GB/s ({algo / v / 1e6 / 8000:5.1%} of 8 TB/s)")
-    n = 50_000_000
-    t = timeit(lambda: ops.randperm(n, 1, 0), iters=3, warm=1)
-    print(f"randperm(50M)                      {t:8.3f} ms")
     ctx.close()
+
+
+def plan_cost(U=1_000_000, I=100_000, n=50_000_000, B=1 << 20):
+    print(f"== epoch plan build, n={n} B={B} ==")
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    tri = torch.stack([torch.randint(0, U, (n,), device=dev, generator=g, dtype=torch.int32),
+                       torch.randint(0, I, (n,), device=dev, generator=g, dtype=torch.int32),
+                       torch.randint(0, I, (n,), device=dev, generator=g, dtype=torch.int32)], 1).contiguous()
+    plan = ops.EpochPlan(n, U, I)
+    print(f"plan bytes {plan.nbytes / 1e9:.2f} GB")
+    for order in ("identity", "feistel"):
+        t = timeit(lambda: plan.build(tri, B, order=order, seed=1, epoch=0), iters=3, warm=1)
+        print(f"plan.build({order:8s})  {t:8.3f} ms  = {t / (n / B):6.3f} ms per {B}-batch")
+    t = timeit(lambda: ops.randperm(n, 1, 0), iters=3, warm=1)
+    print(f"randperm(50M, philox sort)  {t:8.3f} ms")
+    plan.close()
 
 
 if __name__ == "__main__":
     print(torch.cuda.get_device_name(0), torch.version.hip)
     t0 = time.time()
-    which = sys.argv[1:] or ["mem", "phases"]
+    which = sys.argv[1:] or ["phases", "plan"]
     if "mem" in which:
         membench()
     if "phases" in which:
         phases()
         phases(B=1 << 16)
+        phases(I=1_000_000)
+    if "plan" in which:
+        plan_cost()
     print("probe wall", time.time() - t0)
