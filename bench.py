@@ -36,7 +36,7 @@ HBM_PEAK_GBS = 8000.0                                        # MI355X_MICROARCH.
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=48)
+    ap.add_argument("--steps", type=int, default=None, help="default: one epoch of full batches")
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=1 << 20, help="interactions per GPU per step")
     ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c3", "tiny"])
@@ -142,7 +142,10 @@ def main():
     plan = ops.EpochPlan(n, U_loc, I, device=dev)
     item_mode = ops.ITEM_MODES[a.item_mode]
     trainer = UserShardedBprTrainer(ctx, P, Q, 0, lr, reg, reg, item_mode=item_mode) if world > 1 else None
+    user_sorted = ops.triples_user_sorted(triples)      # synthetic triples are generated in CSR order
     full_batches = n // B                      # the bench steps over full batches only (fixed B per step)
+    if a.steps is None:
+        a.steps = full_batches                 # one epoch: exactly one plan build inside the timed region
 
     state = {"epoch": 0, "k": None}
 
@@ -150,7 +153,8 @@ def main():
         if state["k"] is None or state["k"] >= full_batches:
             # DataLoader(shuffle=True) on the device: a fresh keyed permutation per epoch, one
             # radix-sort pass lays the whole epoch out batch by batch (grouped by user / by item)
-            plan.build(triples, B, order="feistel", seed=2022 + rank, epoch=state["epoch"])
+            plan.build(triples, B, order="feistel", seed=2022 + rank, epoch=state["epoch"],
+                       user_sorted=user_sorted)
             state["epoch"] += 1
             state["k"] = 0
         k = state["k"]

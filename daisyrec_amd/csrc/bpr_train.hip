@@ -20,11 +20,10 @@
 //
 // Measured on MI355X (profiles/r01_probe_*): random 256-B row gathers / plain
 // stores run at 5-8 TB/s, fp32 global atomics at 0.3 TB/s.  So every scatter is
-// organised around OWNERSHIP instead of atomics: an EPOCH PLAN (one radix sort
+// organised around OWNERSHIP instead of atomics: an EPOCH PLAN (radix sorts, once
 // per epoch) lays the epoch out batch by batch, each batch grouped by user, plus
 // a per-batch list of item entries sorted by item; the item gradient is then a
-// segmented reduction (LDS accumulators per 128-entry chunk, plain stores for
-// rows a chunk owns, atomics only for the <=2 rows that straddle a chunk edge).
+// segmented reduction over that list.
 //
 // HBM/L2 view: a d=64 row is 256 B = 16 lanes x float4, one coalesced request
 // per quarter wave; four rows are in flight per wave instruction.
@@ -34,12 +33,17 @@ namespace daisy {
 
 constexpr uint32_t kNegBit = 0x80000000u;
 
-// what the step kernels see of the current batch
+// What the step kernels see of the current batch (pointers into an epoch plan).
+//   sample s in [0,B):  user = ukey[s] & umask,  (pos item, neg item) = ij[s]
+//                       samples of one user are contiguous (stable order)
+//   entry  q in [0,2B): item = ekey[q] & imask (ascending, stable),
+//                       esu[q] = (sample position s | kNegBit for the negative slot, user of s)
 struct BatchView {
-    const int32_t *u, *i, *j;    // [B] grouped by user (stable)
-    const int32_t *ent_item;     // [2B] item of entry q, sorted ascending (stable)
-    const uint32_t *ent_s;       // [2B] sample position s | kNegBit for the negative slot
-    const int32_t *ent_u;        // [2B] u[s]
+    const uint32_t *ukey;
+    const int2 *ij;
+    const uint32_t *ekey;
+    const uint2 *esu;
+    uint32_t umask, imask;
     int64_t B;
 };
 
@@ -50,13 +54,17 @@ struct daisy_epoch_plan {
     int64_t max_triples, U, I;
     void *arena;
     size_t arena_bytes, temp_bytes;
-    int32_t *gu, *gi, *gj;              // [n]   plan order
-    int32_t *ent_item, *ent_u;          // [2n]
-    uint32_t *ent_s;                    // [2n]
-    uint64_t *k64a, *k64b;              // [2n]  sort keys
-    int32_t *v32a, *v32b;               // [2n]  sort payloads
+    // double buffers of the two radix sorts
+    uint32_t *k32[2];     // [2n] 32-bit keys
+    uint64_t *k64[2];     // [2n] 64-bit keys (only when batch bits + id bits > 32)
+    uint64_t *v64[2];     // [2n] payloads
+    uint32_t *ukey;       // [n]  sorted sample keys (batch << ubits | user)
+    uint64_t *uval;       // [n]  (i, j)
+    uint32_t *ekey;       // [2n] sorted entry keys (batch << ibits | item)
+    uint64_t *eval;       // [2n] (s | neg, u)
+    uint32_t umask, imask;
     void *temp;
-    int64_t n, batch_size, num_batches; // current build
+    int64_t n, batch_size, num_batches;
     bool built;
 };
 
@@ -64,10 +72,9 @@ struct daisy_bpr_ctx {
     int64_t max_batch, U, I;
     int d;
     void *arena;
-    size_t arena_bytes, bitmap_bytes;
+    size_t arena_bytes;
     float2 *coef;        // (dL/dpos, dL/dneg) per sample   [max_batch]
     double *partials;    // per-workgroup sums              [kMaxGrid*8]
-    uint32_t *bitmap;    // touched item rows               [ceil(I/32)]
     int32_t *tmp_triples;  // [max_batch*3] staging for daisy_bpr_set_batch
     daisy_epoch_plan *own_plan;   // 1-batch plan used by set_batch / set_batch_from_triples
     daisy::BatchView v;
@@ -82,56 +89,48 @@ static inline hipStream_t S(daisy_stream_t s) { return reinterpret_cast<hipStrea
 // epoch plan kernels
 // ---------------------------------------------------------------------------
 // order_mode: 0 identity, 1 explicit permutation (perm[p] = triple at position p), 2 Feistel
+template <class KeyT>
 __global__ void k_plan_keys(const int32_t *__restrict__ triples, const int64_t *__restrict__ perm,
                             int order_mode, FeistelKey fk, int64_t n, int64_t start, int64_t B,
-                            int32_t user_base, int ubits, uint64_t *__restrict__ key,
-                            int32_t *__restrict__ val) {
+                            int32_t user_base, int ubits, KeyT *__restrict__ key,
+                            uint64_t *__restrict__ val) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
          e += (int64_t)gridDim.x * blockDim.x) {
         int64_t t, p;
         if (order_mode == 1) { p = e; t = perm[e]; }
         else if (order_mode == 2) { t = e; p = (int64_t)feistel_position((uint64_t)e, (uint64_t)n, fk); }
         else { t = e; p = e; }
-        t += start;
-        const uint32_t uu = (uint32_t)(triples[3 * t] - user_base);
-        key[e] = ((uint64_t)(p / B) << ubits) | uu;
-        val[e] = (int32_t)(t - start);
+        const int32_t *row = triples + 3 * (t + start);
+        const uint32_t uu = (uint32_t)(row[0] - user_base);
+        key[e] = (KeyT)(((uint64_t)(p / B) << ubits) | uu);
+        val[e] = ((uint64_t)(uint32_t)row[2] << 32) | (uint32_t)row[1];      // (j, i)
     }
 }
 
-__global__ void k_plan_gather(const int32_t *__restrict__ triples, const int32_t *__restrict__ val,
-                              int64_t n, int64_t start, int64_t B, int32_t user_base, int ibits,
-                              int32_t *__restrict__ gu, int32_t *__restrict__ gi,
-                              int32_t *__restrict__ gj, uint64_t *__restrict__ ekey,
-                              int32_t *__restrict__ eval) {
+// from the user-grouped samples: the two item entries of every sample
+template <class KeyT>
+__global__ void k_plan_entries(const KeyT *__restrict__ skey, const uint64_t *__restrict__ sval,
+                               int64_t n, int64_t B, int ibits, uint32_t umask,
+                               KeyT *__restrict__ ekey, uint64_t *__restrict__ eval) {
     for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n;
          p += (int64_t)gridDim.x * blockDim.x) {
-        const int32_t *t = triples + 3 * ((int64_t)val[p] + start);
-        const int32_t uu = t[0] - user_base, ii = t[1], jj = t[2];
-        gu[p] = uu; gi[p] = ii; gj[p] = jj;
         const uint64_t k = (uint64_t)(p / B);
         const uint32_t s = (uint32_t)(p - (int64_t)k * B);
-        ekey[2 * p] = (k << ibits) | (uint32_t)ii;
-        eval[2 * p] = (int32_t)s;
-        ekey[2 * p + 1] = (k << ibits) | (uint32_t)jj;
-        eval[2 * p + 1] = (int32_t)(s | kNegBit);
+        const uint32_t uu = (uint32_t)skey[p] & umask;
+        const uint64_t ij = sval[p];
+        ekey[2 * p] = (KeyT)((k << ibits) | (uint32_t)ij);
+        eval[2 * p] = ((uint64_t)uu << 32) | s;
+        ekey[2 * p + 1] = (KeyT)((k << ibits) | (uint32_t)(ij >> 32));
+        eval[2 * p + 1] = ((uint64_t)uu << 32) | (s | kNegBit);
     }
 }
 
-__global__ void k_plan_entries(const uint64_t *__restrict__ ekey, const int32_t *__restrict__ eval,
-                               const int32_t *__restrict__ gu, int64_t n2, int64_t B, int ibits,
-                               int32_t *__restrict__ ent_item, uint32_t *__restrict__ ent_s,
-                               int32_t *__restrict__ ent_u) {
-    const uint64_t imask = ((uint64_t)1 << ibits) - 1;
-    for (int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; q < n2;
-         q += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t key = ekey[q];
-        const uint32_t sv = (uint32_t)eval[q];
-        const int64_t k = (int64_t)(key >> ibits);
-        ent_item[q] = (int32_t)(key & imask);
-        ent_s[q] = sv;
-        ent_u[q] = gu[k * B + (int64_t)(sv & ~kNegBit)];
-    }
+// 64-bit sort keys -> the 32-bit id arrays the step kernels read
+__global__ void k_narrow_keys(const uint64_t *__restrict__ in, int64_t n, uint64_t mask,
+                              uint32_t *__restrict__ out) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
+         e += (int64_t)gridDim.x * blockDim.x)
+        out[e] = (uint32_t)(in[e] & mask);
 }
 
 __global__ void k_pack_triples(const int32_t *__restrict__ u, const int32_t *__restrict__ i,
@@ -139,6 +138,22 @@ __global__ void k_pack_triples(const int32_t *__restrict__ u, const int32_t *__r
     for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < B;
          s += (int64_t)gridDim.x * blockDim.x) {
         out[3 * s] = u[s]; out[3 * s + 1] = i[s]; out[3 * s + 2] = j[s];
+    }
+}
+
+__global__ void k_unpack_batch(BatchView v, int32_t *__restrict__ u, int32_t *__restrict__ i,
+                               int32_t *__restrict__ j, int32_t *__restrict__ ent_item,
+                               uint32_t *__restrict__ ent_s, int32_t *__restrict__ ent_u) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < 2 * v.B;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < v.B) {
+            u[e] = (int32_t)(v.ukey[e] & v.umask);
+            i[e] = v.ij[e].x;
+            j[e] = v.ij[e].y;
+        }
+        if (ent_item) ent_item[e] = (int32_t)(v.ekey[e] & v.imask);
+        if (ent_s) ent_s[e] = v.esu[e].x;
+        if (ent_u) ent_u[e] = (int32_t)v.esu[e].y;
     }
 }
 
@@ -181,10 +196,7 @@ __device__ __forceinline__ void pair_coef(int loss_type, float pos, float neg, f
 // ---------------------------------------------------------------------------
 template <class C>
 __global__ __launch_bounds__(kBlock) void k_fwd(const float *__restrict__ P,
-                                                const float *__restrict__ Q,
-                                                const int32_t *__restrict__ u,
-                                                const int32_t *__restrict__ i,
-                                                const int32_t *__restrict__ j, int64_t B, int d,
+                                                const float *__restrict__ Q, BatchView v, int d,
                                                 int loss_type, float gamma,
                                                 float2 *__restrict__ coef,
                                                 double *__restrict__ partials) {
@@ -192,12 +204,13 @@ __global__ __launch_bounds__(kBlock) void k_fwd(const float *__restrict__ P,
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
     float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int64_t s = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; s < B; s += gstride) {
-        const int32_t uu = u[s], ii = i[s], jj = j[s];
+    for (int64_t s = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; s < v.B; s += gstride) {
+        const int64_t uu = v.ukey[s] & v.umask;
+        const int2 ij = v.ij[s];
         Row<C> p, qi, qj;
-        p.load(P + (int64_t)uu * d, lane, d);
-        qi.load(Q + (int64_t)ii * d, lane, d);
-        qj.load(Q + (int64_t)jj * d, lane, d);
+        p.load(P + uu * d, lane, d);
+        qi.load(Q + (int64_t)ij.x * d, lane, d);
+        qj.load(Q + (int64_t)ij.y * d, lane, d);
         const float pos = row_dot<C>(p, qi);
         const float neg = row_dot<C>(p, qj);
 #pragma unroll
@@ -286,24 +299,24 @@ __device__ __forceinline__ float inv_or_zero(double n, float reg_2) {
 // ---------------------------------------------------------------------------
 template <class C, bool REG>
 __global__ __launch_bounds__(kBlock) void k_item_grad_atomic(
-    const float *__restrict__ P, const float *__restrict__ Q, const int32_t *__restrict__ u,
-    const int32_t *__restrict__ i, const int32_t *__restrict__ j, const float2 *__restrict__ coef,
-    int64_t B, int d, const double *__restrict__ stats, float reg_1, float reg_2,
-    float *__restrict__ gQ, uint32_t *__restrict__ bitmap) {
+    const float *__restrict__ P, const float *__restrict__ Q, BatchView v,
+    const float2 *__restrict__ coef, int d, const double *__restrict__ stats, float reg_1,
+    float reg_2, float *__restrict__ gQ) {
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
     const float rI = REG ? inv_or_zero(stats[DAISY_ST_NORM_I], reg_2) : 0.f;
     const float rJ = REG ? inv_or_zero(stats[DAISY_ST_NORM_J], reg_2) : 0.f;
-    for (int64_t s = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; s < B; s += gstride) {
-        const int32_t uu = u[s], ii = i[s], jj = j[s];
+    for (int64_t s = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; s < v.B; s += gstride) {
+        const int64_t uu = v.ukey[s] & v.umask;
+        const int2 ij = v.ij[s];
         const float2 c = coef[s];
         Row<C> p, gi, gj;
-        p.load(P + (int64_t)uu * d, lane, d);
+        p.load(P + uu * d, lane, d);
         if constexpr (REG) {
             Row<C> qi, qj;
-            qi.load(Q + (int64_t)ii * d, lane, d);
-            qj.load(Q + (int64_t)jj * d, lane, d);
+            qi.load(Q + (int64_t)ij.x * d, lane, d);
+            qj.load(Q + (int64_t)ij.y * d, lane, d);
 #pragma unroll
             for (int k = 0; k < C::NE; ++k) {
                 gi.v[k] = fmaf(c.x, p.v[k], fmaf(rI, qi.v[k], reg_1 * sgn(qi.v[k])));
@@ -316,12 +329,8 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_atomic(
                 gj.v[k] = c.y * p.v[k];
             }
         }
-        gi.atomic_add_to(gQ + (int64_t)ii * d, lane, d);
-        gj.atomic_add_to(gQ + (int64_t)jj * d, lane, d);
-        if (lane == 0) {
-            atomicOr(bitmap + (ii >> 5), 1u << (ii & 31));
-            atomicOr(bitmap + (jj >> 5), 1u << (jj & 31));
-        }
+        gi.atomic_add_to(gQ + (int64_t)ij.x * d, lane, d);
+        gj.atomic_add_to(gQ + (int64_t)ij.y * d, lane, d);
     }
 }
 
@@ -333,29 +342,29 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_atomic(
 template <class C>
 __global__ __launch_bounds__(kBlock) void k_item_grad_sorted(
     const float *__restrict__ P, const float *__restrict__ Q, const float2 *__restrict__ coef,
-    const int32_t *__restrict__ ent_item, const uint32_t *__restrict__ ent_s,
-    const int32_t *__restrict__ ent_u, int64_t n, int d, const double *__restrict__ stats,
-    float reg_1, float reg_2, float *__restrict__ gQ, uint32_t *__restrict__ bitmap) {
+    BatchView v, int d, const double *__restrict__ stats, float reg_1, float reg_2,
+    float *__restrict__ gQ) {
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
+    const int64_t n = 2 * v.B;
     const float rI = inv_or_zero(stats[DAISY_ST_NORM_I], reg_2);
     const float rJ = inv_or_zero(stats[DAISY_ST_NORM_J], reg_2);
     for (int64_t pos = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; pos < n; pos += gstride) {
-        const int32_t r = ent_item[pos];
-        if (pos > 0 && ent_item[pos - 1] == r) continue;  // not a segment head
+        const uint32_t r = v.ekey[pos] & v.imask;
+        if (pos > 0 && (v.ekey[pos - 1] & v.imask) == r) continue;  // not a segment head
         Row<C> acc;
         acc.zero();
         float n_pos = 0.f, n_neg = 0.f;
-        for (int64_t q = pos; q < n && ent_item[q] == r; ++q) {
-            const uint32_t sv = ent_s[q];
-            const bool is_neg = (sv & kNegBit) != 0;
-            const float2 c2 = coef[sv & ~kNegBit];
+        for (int64_t q = pos; q < n && (v.ekey[q] & v.imask) == r; ++q) {
+            const uint2 su = v.esu[q];
+            const bool is_neg = (su.x & kNegBit) != 0;
+            const float2 c2 = coef[su.x & ~kNegBit];
             const float c = is_neg ? c2.y : c2.x;
             n_pos += is_neg ? 0.f : 1.f;
             n_neg += is_neg ? 1.f : 0.f;
             Row<C> p;
-            p.load(P + (int64_t)ent_u[q] * d, lane, d);
+            p.load(P + (int64_t)su.y * d, lane, d);
 #pragma unroll
             for (int k = 0; k < C::NE; ++k) acc.v[k] = fmaf(c, p.v[k], acc.v[k]);
         }
@@ -366,150 +375,186 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_sorted(
 #pragma unroll
         for (int k = 0; k < C::NE; ++k) acc.v[k] += fmaf(w2, qr.v[k], w1 * sgn(qr.v[k]));
         acc.store(gQ + (int64_t)r * d, lane, d);
-        if (lane == 0) atomicOr(bitmap + (r >> 5), 1u << (r & 31));
     }
 }
 
 // ---------------------------------------------------------------------------
 // item gradient, throughput mode: segmented reduction over the item-sorted
-// entries.  A workgroup takes a chunk of E consecutive entries; every lane
-// group streams RUN of them (row gathers 4 deep), keeps the running sum of the
-// current item in registers and adds it to that item's LDS accumulator when the
-// item changes; after a barrier each accumulator is written once: plain store
-// when the chunk holds the whole run of that item, fp32 atomics only for the
-// first/last item when its run continues in the neighbouring chunk.
+// entries (data term  sum_e c_e * p_u(e)  only; the regulariser share is added
+// by k_item_reg or folded into the commit kernel).
+// A workgroup takes a chunk of G*RUN consecutive entries, every lane group a
+// run of RUN of them: one load fetches the run's metadata (lane x <- entry x),
+// then all RUN row gathers are in flight together.  A segment (= all entries of
+// one item) that lies inside one run is summed in registers and stored straight
+// to gQ by its group (single owner, no atomics, no LDS).  Only segments that
+// cross a run boundary - at most one per boundary - go through an LDS
+// accumulator slot (slot s>0: the segment that starts in run s-1; slot 0: the
+// segment inherited from the previous chunk); after a barrier each used slot is
+// written once: plain store if the segment lies inside the chunk, fp32 atomics
+// only when it is shared with a neighbouring chunk (<= 2 rows per chunk).
 // ---------------------------------------------------------------------------
 template <class C>
-struct ChunkCfg {
-    static constexpr int ROWF = C::NE * C::LPR;                    // padded floats per row
-    static constexpr int E_RAW = 8192 / ROWF;                      // 32 KB of accumulators
-    static constexpr int E = E_RAW > kBlock ? kBlock : E_RAW;      // entries per chunk
-    static constexpr int RUN = E / C::GROUPS_PER_BLOCK;            // entries per lane group
-    static_assert(RUN >= 1 && E == RUN * C::GROUPS_PER_BLOCK, "chunk geometry");
+struct RunCfg {
+    // needs RUN + 2 <= LPR; RUN*NE row registers are live at once, keep that <= 32
+    static constexpr int RUN_BY_REGS = (C::NE <= 4) ? 8 : ((C::NE <= 8) ? 4 : 2);
+    static constexpr int RUN = (C::LPR >= 16) ? RUN_BY_REGS : (RUN_BY_REGS < C::LPR / 2 ? RUN_BY_REGS : C::LPR / 2);
+    static constexpr int G = C::GROUPS_PER_BLOCK;
+    static constexpr int E = G * RUN;
 };
 
-template <class C, bool REG>
-__global__ __launch_bounds__(kBlock) void k_item_grad_chunked(
-    const float *__restrict__ P, const float *__restrict__ Q, const float2 *__restrict__ coef,
-    const int32_t *__restrict__ ent_item, const uint32_t *__restrict__ ent_s,
-    const int32_t *__restrict__ ent_u, int64_t n, int d, const double *__restrict__ stats,
-    float reg_1, float reg_2, float *__restrict__ gQ, uint32_t *__restrict__ bitmap) {
-    using K = ChunkCfg<C>;
-    constexpr int E = K::E, RUN = K::RUN, ROWF = K::ROWF;
-    __shared__ float acc_lds[E * ROWF];
-    __shared__ int seg_item[E];
-    __shared__ int cnt_pos[E], cnt_neg[E];
-    __shared__ int lidx[E];
-    __shared__ int wave_tot[kBlock / kWave];
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__restrict__ P,
+                                                              const float2 *__restrict__ coef,
+                                                              BatchView v, int d,
+                                                              float *__restrict__ gQ) {
+    constexpr int G = RunCfg<C>::G, RUN = RunCfg<C>::RUN, E = RunCfg<C>::E;
+    constexpr int ROWF = C::NE * C::LPR;
+    __shared__ float slot_acc[(G + 1) * ROWF];
+    __shared__ int slot_item[G + 1], slot_shared[G + 1];
+    __shared__ int run_first[G], run_last[G];
 
     const int tid = threadIdx.x;
     const int lane = tid % C::LPR;
     const int group = tid / C::LPR;
-    const float rI = REG ? inv_or_zero(stats[DAISY_ST_NORM_I], reg_2) : 0.f;
-    const float rJ = REG ? inv_or_zero(stats[DAISY_ST_NORM_J], reg_2) : 0.f;
+    const int64_t n = 2 * v.B;
     const int64_t nchunks = (n + E - 1) / E;
 
     for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const int64_t c0 = chunk * E;
-        // ---- a. local segment index of every entry (block-wide scan of head flags) -------
-        int my_item = -1;
-        bool head = false;
-        if (tid < E && c0 + tid < n) {
-            my_item = ent_item[c0 + tid];
-            head = (tid == 0) || (ent_item[c0 + tid - 1] != my_item);
+        const int64_t t0 = c0 + (int64_t)group * RUN;
+        const int64_t t1 = (t0 + RUN < n) ? (t0 + RUN) : n;
+        const int cnt = (t0 < n) ? (int)(t1 - t0) : 0;       // entries of this run
+
+        // ---- hop 1: the run's metadata, lane x <- entry x; lane RUN <- the entry before
+        // the run, lane RUN+1 <- the entry after it
+        int32_t my_item = -1;
+        uint2 my_su = make_uint2(0u, 0u);
+        if (lane < cnt) {
+            my_item = (int32_t)(v.ekey[t0 + lane] & v.imask);
+            my_su = v.esu[t0 + lane];
+        } else if (lane == RUN && cnt > 0 && t0 > 0) {
+            my_item = (int32_t)(v.ekey[t0 - 1] & v.imask);
+        } else if (lane == RUN + 1 && cnt > 0 && t1 < n) {
+            my_item = (int32_t)(v.ekey[t1] & v.imask);
         }
-        const unsigned long long m = __ballot(head);
-        const int wl = tid % kWave, wv = tid / kWave;
-        const int incl = __popcll(m & ((wl == 63) ? ~0ull : ((1ull << (wl + 1)) - 1)));
-        if (wl == 0) wave_tot[wv] = __popcll(m);
-        __syncthreads();
-        int off = 0;
-        for (int w = 0; w < wv; ++w) off += wave_tot[w];
-        int nseg = 0;
-        for (int w = 0; w < kBlock / kWave; ++w) nseg += wave_tot[w];
-        if (tid < E && c0 + tid < n) {
-            const int l = off + incl - 1;
-            lidx[tid] = l;
-            if (head) { seg_item[l] = my_item; cnt_pos[l] = 0; cnt_neg[l] = 0; }
+        for (int e = tid; e < (G + 1) * ROWF; e += kBlock) slot_acc[e] = 0.f;
+        if (tid <= G) { slot_item[tid] = -1; slot_shared[tid] = 0; }
+        const int32_t item_first = __shfl(my_item, 0, C::LPR);
+        const int32_t item_prev = __shfl(my_item, RUN, C::LPR);
+        const int32_t item_next = __shfl(my_item, RUN + 1, C::LPR);
+        const int32_t item_last = __shfl(my_item, cnt > 0 ? cnt - 1 : 0, C::LPR);
+        if (lane == 0) {
+            run_first[group] = cnt > 0 ? item_first : -2;
+            run_last[group] = cnt > 0 ? item_last : -2;
         }
-        for (int e = tid; e < nseg * ROWF; e += kBlock) acc_lds[e] = 0.f;
+
+        // ---- hop 2: coefficient of entry `lane`, and all row gathers of the run
+        float my_c = 0.f;
+        if (lane < cnt) {
+            const float2 c2 = coef[my_su.x & ~kNegBit];
+            my_c = (my_su.x & kNegBit) ? c2.y : c2.x;
+        }
+        Row<C> p[RUN];
+#pragma unroll
+        for (int x = 0; x < RUN; ++x) {
+            const uint32_t ux = __shfl(my_su.y, x, C::LPR);
+            if (x < cnt) p[x].load(P + (int64_t)ux * d, lane, d);
+            else p[x].zero();
+        }
         __syncthreads();
 
-        // ---- b. stream the entries: RUN per lane group, 4 row gathers in flight ----------
-        {
-            const int t0 = group * RUN;
-            int cur = -1;
+        if (cnt > 0) {
+            const bool cont = (t0 > 0) && (item_prev == item_first);
+            int cur_slot = -1;                      // >= 0: the current segment began before this run
+            if (cont) {
+                if (group == 0) cur_slot = 0;       // inherited from the previous chunk
+                else {
+                    int gs = group - 1;
+                    while (gs > 0 && run_first[gs] == item_first && run_last[gs - 1] == item_first) --gs;
+                    // the segment holds the last entry of run gs; it began there unless run 0 is
+                    // all this item and the chunk itself continues the previous chunk
+                    const bool inherited = (gs == 0) && (run_first[0] == item_first) && (c0 > 0) &&
+                                           ((int32_t)(v.ekey[c0 - 1] & v.imask) == item_first);
+                    cur_slot = inherited ? 0 : gs + 1;
+                }
+            }
+            int32_t cur_item = item_first;
             Row<C> acc;
             acc.zero();
-            int np = 0, nn = 0;
-            auto flush = [&](int l) {
-                if (l < 0) return;
-                float *dst = acc_lds + l * ROWF;
+            auto finish = [&](bool ends_here, bool to_next_chunk) {
+                if (cur_slot < 0 && ends_here) {    // interior: this group owns gQ[cur_item]
+                    acc.store(gQ + (int64_t)cur_item * d, lane, d);
+                } else {                            // crosses a run boundary: LDS slot
+                    const int s = (cur_slot >= 0) ? cur_slot : group + 1;
+                    float *dst = slot_acc + s * ROWF;
 #pragma unroll
-                for (int k = 0; k < C::NE; ++k) atomicAdd(dst + k * C::LPR + lane, acc.v[k]);
-                if (lane == 0) {
-                    if (np) atomicAdd(&cnt_pos[l], np);
-                    if (nn) atomicAdd(&cnt_neg[l], nn);
+                    for (int k = 0; k < C::NE; ++k) atomicAdd(dst + k * C::LPR + lane, acc.v[k]);
+                    if (lane == 0) {
+                        slot_item[s] = cur_item;
+                        if (to_next_chunk) slot_shared[s] = 1;
+                    }
                 }
             };
-            constexpr int UNR = (RUN % 4 == 0) ? 4 : ((RUN % 2 == 0) ? 2 : 1);
-            for (int r0 = 0; r0 < RUN; r0 += UNR) {
-                Row<C> p[UNR];
-                float c[UNR];
-                bool neg[UNR], ok[UNR];
 #pragma unroll
-                for (int x = 0; x < UNR; ++x) {
-                    const int64_t q = c0 + t0 + r0 + x;
-                    ok[x] = q < n;
-                    const uint32_t sv = ok[x] ? ent_s[q] : 0u;
-                    neg[x] = (sv & kNegBit) != 0;
-                    const float2 c2 = ok[x] ? coef[sv & ~kNegBit] : make_float2(0.f, 0.f);
-                    c[x] = neg[x] ? c2.y : c2.x;
-                    if (ok[x]) p[x].load(P + (int64_t)ent_u[q] * d, lane, d);
-                    else p[x].zero();
-                }
-#pragma unroll
-                for (int x = 0; x < UNR; ++x) {
-                    if (!ok[x]) continue;
-                    const int l = lidx[t0 + r0 + x];
-                    if (l != cur) {
-                        flush(cur);
-                        cur = l;
+            for (int x = 0; x < RUN; ++x) {
+                if (x < cnt) {
+                    const int32_t it = __shfl(my_item, x, C::LPR);
+                    const float cx = __shfl(my_c, x, C::LPR);
+                    if (it != cur_item) {           // previous segment ended inside this run
+                        finish(true, false);
+                        cur_item = it;
+                        cur_slot = -1;
                         acc.zero();
-                        np = nn = 0;
                     }
 #pragma unroll
-                    for (int k = 0; k < C::NE; ++k) acc.v[k] = fmaf(c[x], p[x].v[k], acc.v[k]);
-                    if (neg[x]) ++nn; else ++np;
+                    for (int k = 0; k < C::NE; ++k) acc.v[k] = fmaf(cx, p[x].v[k], acc.v[k]);
                 }
             }
-            flush(cur);
+            const bool continues = (t1 < n) && (item_next == cur_item);
+            finish(!continues, continues && (group == G - 1));
         }
         __syncthreads();
 
-        // ---- c. one write per item of the chunk -------------------------------------------
-        const bool first_shared = (c0 > 0) && (ent_item[c0 - 1] == seg_item[0]);
-        const bool last_shared = (c0 + E < n) && (ent_item[c0 + E] == seg_item[nseg - 1]);
-        for (int l = group; l < nseg; l += C::GROUPS_PER_BLOCK) {
-            const int r = seg_item[l];
+        // one write per used slot (G+1 slots over G groups)
+        for (int s = group; s <= G; s += G) {
+            const int r = slot_item[s];
+            if (r < 0) continue;
             Row<C> g;
-            const float *src = acc_lds + l * ROWF;
+            const float *src = slot_acc + s * ROWF;
 #pragma unroll
             for (int k = 0; k < C::NE; ++k) g.v[k] = src[k * C::LPR + lane];
-            if constexpr (REG) {
-                Row<C> qr;
-                qr.load(Q + (int64_t)r * d, lane, d);
-                const float fp = (float)cnt_pos[l], fn = (float)cnt_neg[l];
-                const float w1 = reg_1 * (fp + fn), w2 = fp * rI + fn * rJ;
-#pragma unroll
-                for (int k = 0; k < C::NE; ++k) g.v[k] += fmaf(w2, qr.v[k], w1 * sgn(qr.v[k]));
-            }
-            const bool shared = (l == 0 && first_shared) || (l == nseg - 1 && last_shared);
-            if (shared) g.atomic_add_to(gQ + (int64_t)r * d, lane, d);
+            if (s == 0 || slot_shared[s]) g.atomic_add_to(gQ + (int64_t)r * d, lane, d);
             else g.store(gQ + (int64_t)r * d, lane, d);
-            if (lane == 0) atomicOr(bitmap + (r >> 5), 1u << (r & 31));
         }
-        __syncthreads();   // LDS is reused by the next chunk
+        __syncthreads();   // the slots are reused by the next chunk
+    }
+}
+
+// regulariser share of the item gradient (MFRecommender.py:88-89): the group that sees the
+// head of an item's run counts its positive / negative occurrences and adds
+//   reg_1*(np+nn)*sign(q) + reg_2*(np/|Q[i]|_F + nn/|Q[j]|_F)*q     to gQ[item]
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_item_reg(const float *__restrict__ Q, BatchView v, int d,
+                                                     const double *__restrict__ stats, float reg_1,
+                                                     float reg_2, float *__restrict__ gQ) {
+    const int lane = threadIdx.x % C::LPR;
+    const int group = threadIdx.x / C::LPR;
+    const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
+    const int64_t n = 2 * v.B;
+    const float rI = inv_or_zero(stats[DAISY_ST_NORM_I], reg_2);
+    const float rJ = inv_or_zero(stats[DAISY_ST_NORM_J], reg_2);
+    for (int64_t pos = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; pos < n; pos += gstride) {
+        const int32_t r = (int32_t)(v.ekey[pos] & v.imask);
+        if (pos > 0 && (int32_t)(v.ekey[pos - 1] & v.imask) == r) continue;
+        Row<C> g, q;
+        g.load(gQ + (int64_t)r * d, lane, d);
+        q.load(Q + (int64_t)r * d, lane, d);
+        float fp, fn;
+        count_run<C>(v.ekey, v.imask, v.esu, pos, n, r, lane, fp, fn);
+        const float w1 = reg_1 * (fp + fn), w2 = fp * rI + fn * rJ;
+#pragma unroll
+        for (int k = 0; k < C::NE; ++k) g.v[k] += fmaf(w2, q.v[k], w1 * sgn(q.v[k]));
+        g.store(gQ + (int64_t)r * d, lane, d);
     }
 }
 
@@ -520,28 +565,26 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(
 // ---------------------------------------------------------------------------
 template <class C, bool SGD>
 __global__ __launch_bounds__(kBlock) void k_user(float *__restrict__ P, const float *__restrict__ Q,
-                                                 const int32_t *__restrict__ u,
-                                                 const int32_t *__restrict__ i,
-                                                 const int32_t *__restrict__ j,
-                                                 const float2 *__restrict__ coef, int64_t B, int d,
+                                                 BatchView v, const float2 *__restrict__ coef, int d,
                                                  const double *__restrict__ stats, float lr,
                                                  float reg_1, float reg_2, float *__restrict__ gP) {
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
     const float rU = inv_or_zero(stats[DAISY_ST_NORM_U], reg_2);
-    for (int64_t pos = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; pos < B; pos += gstride) {
-        const int32_t uu = u[pos];
-        if (pos > 0 && u[pos - 1] == uu) continue;  // not the head of this user's run
+    for (int64_t pos = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; pos < v.B; pos += gstride) {
+        const uint32_t uu = v.ukey[pos] & v.umask;
+        if (pos > 0 && (v.ukey[pos - 1] & v.umask) == uu) continue;  // not the head of this user's run
         Row<C> p, acc;
         p.load(P + (int64_t)uu * d, lane, d);
         acc.zero();
         float n = 0.f;
-        for (int64_t q = pos; q < B && u[q] == uu; ++q) {
+        for (int64_t q = pos; q < v.B && (v.ukey[q] & v.umask) == uu; ++q) {
             const float2 c = coef[q];
+            const int2 ij = v.ij[q];
             Row<C> qi, qj;
-            qi.load(Q + (int64_t)i[q] * d, lane, d);
-            qj.load(Q + (int64_t)j[q] * d, lane, d);
+            qi.load(Q + (int64_t)ij.x * d, lane, d);
+            qj.load(Q + (int64_t)ij.y * d, lane, d);
 #pragma unroll
             for (int k = 0; k < C::NE; ++k)
                 acc.v[k] = fmaf(c.x, qi.v[k], fmaf(c.y, qj.v[k], acc.v[k]));
@@ -560,21 +603,42 @@ __global__ __launch_bounds__(kBlock) void k_user(float *__restrict__ P, const fl
 }
 
 // ---------------------------------------------------------------------------
-// commit the item rows: Q[r] -= lr*gQ[r]; gQ[r] = 0
+// commit the item rows: Q[r] -= lr*gQ[r]; gQ[r] = 0.  The touched rows are the
+// distinct items of the sorted entry list: the group that sees the head of an
+// item's run owns the row (dense != 0: every row, after an all-reduce of gQ).
+// WITH_REG: gQ holds the data term only and the regulariser share is added here
+// (single-GPU SGD step: saves one pass over the touched rows).
 // ---------------------------------------------------------------------------
-template <class C>
+template <class C, bool WITH_REG>
 __global__ __launch_bounds__(kBlock) void k_item_apply(float *__restrict__ Q, float *__restrict__ gQ,
-                                                       const uint32_t *__restrict__ bitmap, int64_t I,
-                                                       int d, float lr, int dense) {
+                                                       BatchView v, int64_t n, int d, float lr,
+                                                       int dense, const double *__restrict__ stats,
+                                                       float reg_1, float reg_2) {
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
-    for (int64_t r = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; r < I; r += gstride) {
-        if (!dense && !((bitmap[r >> 5] >> (r & 31)) & 1u)) continue;
+    float rI = 0.f, rJ = 0.f;
+    if constexpr (WITH_REG) {
+        rI = inv_or_zero(stats[DAISY_ST_NORM_I], reg_2);
+        rJ = inv_or_zero(stats[DAISY_ST_NORM_J], reg_2);
+    }
+    for (int64_t pos = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; pos < n; pos += gstride) {
+        int64_t r = pos;
+        if (!dense) {
+            r = (int64_t)(v.ekey[pos] & v.imask);
+            if (pos > 0 && (int64_t)(v.ekey[pos - 1] & v.imask) == r) continue;
+        }
         Row<C> g, q, z;
         g.load(gQ + r * d, lane, d);
         q.load(Q + r * d, lane, d);
         z.zero();
+        if constexpr (WITH_REG) {
+            float fp, fn;
+            count_run<C>(v.ekey, v.imask, v.esu, pos, n, (int32_t)r, lane, fp, fn);
+            const float w1 = reg_1 * (fp + fn), w2 = fp * rI + fn * rJ;
+#pragma unroll
+            for (int k = 0; k < C::NE; ++k) g.v[k] += fmaf(w2, q.v[k], w1 * sgn(q.v[k]));
+        }
 #pragma unroll
         for (int k = 0; k < C::NE; ++k) q.v[k] = fmaf(-lr, g.v[k], q.v[k]);
         q.store(Q + r * d, lane, d);
@@ -608,15 +672,16 @@ static int plan_alloc(daisy_epoch_plan **out, int64_t max_triples, int64_t U, in
     daisy_epoch_plan *p = new daisy_epoch_plan();
     p->max_triples = max_triples; p->U = U; p->I = I;
     p->n = 0; p->batch_size = 0; p->num_batches = 0; p->built = false;
-    const size_t n = (size_t)max_triples;
-    size_t t1 = sort_pairs_u64_i32_temp_bytes(2 * max_triples);
-    p->temp_bytes = t1;
+    const size_t n2 = 2 * (size_t)max_triples;
+    const size_t ta = sort_pairs_u32_u64_temp_bytes(n2), tb = sort_pairs_u64_u64_temp_bytes(n2);
+    p->temp_bytes = ta > tb ? ta : tb;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
-    const size_t o_gu = take(n * 4), o_gi = take(n * 4), o_gj = take(n * 4);
-    const size_t o_ei = take(2 * n * 4), o_eu = take(2 * n * 4), o_es = take(2 * n * 4);
-    const size_t o_ka = take(2 * n * 8), o_kb = take(2 * n * 8);
-    const size_t o_va = take(2 * n * 4), o_vb = take(2 * n * 4);
+    size_t o_k32[2], o_v64[2];
+    o_k32[0] = take(n2 * 4); o_k32[1] = take(n2 * 4);
+    o_v64[0] = take(n2 * 8); o_v64[1] = take(n2 * 8);
+    const size_t o_s32 = take((size_t)max_triples * 4);   // sorted sample keys survive the entry sort
+    const size_t o_sv = take((size_t)max_triples * 8);
     const size_t o_tmp = take(p->temp_bytes);
     p->arena_bytes = off;
     hipError_t e = hipMalloc(&p->arena, p->arena_bytes);
@@ -626,51 +691,120 @@ static int plan_alloc(daisy_epoch_plan **out, int64_t max_triples, int64_t U, in
         return DAISY_ERR_HIP;
     }
     char *b = (char *)p->arena;
-    p->gu = (int32_t *)(b + o_gu); p->gi = (int32_t *)(b + o_gi); p->gj = (int32_t *)(b + o_gj);
-    p->ent_item = (int32_t *)(b + o_ei); p->ent_u = (int32_t *)(b + o_eu); p->ent_s = (uint32_t *)(b + o_es);
-    p->k64a = (uint64_t *)(b + o_ka); p->k64b = (uint64_t *)(b + o_kb);
-    p->v32a = (int32_t *)(b + o_va); p->v32b = (int32_t *)(b + o_vb);
+    for (int k = 0; k < 2; ++k) {
+        p->k32[k] = (uint32_t *)(b + o_k32[k]);
+        p->v64[k] = (uint64_t *)(b + o_v64[k]);
+        p->k64[k] = nullptr;                        // allocated on demand (rare: > 32 key bits)
+    }
+    p->ukey = (uint32_t *)(b + o_s32);
+    p->uval = (uint64_t *)(b + o_sv);
+    p->ekey = nullptr; p->eval = nullptr;
+    p->umask = p->imask = 0;
     p->temp = b + o_tmp;
     *out = p;
     return DAISY_OK;
 }
 
+static int plan_free(daisy_epoch_plan *p) {
+    hipError_t e = hipFree(p->arena);
+    for (int k = 0; k < 2; ++k)
+        if (p->k64[k]) (void)hipFree(p->k64[k]);
+    delete p;
+    if (e != hipSuccess) {
+        set_error("epoch_plan_destroy: hipFree failed: %s", hipGetErrorString(e));
+        return DAISY_ERR_HIP;
+    }
+    return DAISY_OK;
+}
+
+static int plan_need_k64(daisy_epoch_plan *p) {
+    for (int k = 0; k < 2; ++k) {
+        if (!p->k64[k]) {
+            hipError_t e = hipMalloc((void **)&p->k64[k], 2 * (size_t)p->max_triples * 8);
+            if (e != hipSuccess) {
+                set_error("epoch_plan_build: hipMalloc of 64-bit key buffers failed: %s", hipGetErrorString(e));
+                return DAISY_ERR_HIP;
+            }
+        }
+    }
+    return DAISY_OK;
+}
+
+// flags: DAISY_PLAN_TRIPLES_USER_SORTED -> the samples only need a stable partition by batch
 static int plan_build(daisy_epoch_plan *p, const int32_t *triples, int64_t n, int64_t start,
                       const int64_t *perm, int order_mode, uint64_t seed, uint64_t epoch,
-                      int64_t batch_size, int32_t user_base, hipStream_t s) {
+                      int64_t batch_size, int32_t user_base, int32_t flags, hipStream_t s) {
     const int ubits = bits_for(p->U), ibits = bits_for(p->I);
     const int64_t nb = (n + batch_size - 1) / batch_size;
-    const int bbits = bits_for(nb);
+    const int bbits = (nb > 1) ? bits_for(nb) : 0;
+    const uint32_t umask = (uint32_t)(((uint64_t)1 << ubits) - 1);
+    const uint32_t imask = (uint32_t)(((uint64_t)1 << ibits) - 1);
+    const bool wide = (ubits + bbits > 32) || (ibits + bbits > 32);
+    const bool presorted = (flags & DAISY_PLAN_TRIPLES_USER_SORTED) && order_mode != DAISY_ORDER_PERM;
+    const int s_begin = presorted ? ubits : 0;      // user bits ride along unsorted
     FeistelKey fk = make_feistel_key((uint64_t)n, seed, epoch);
-    const int g1 = grid_for(n, kBlock);
-    hipLaunchKernelGGL(k_plan_keys, dim3(g1), dim3(kBlock), 0, s, triples, perm, order_mode, fk, n,
-                       start, batch_size, user_base, ubits, p->k64a, p->v32a);
-    DAISY_LAUNCH_CHECK();
-    int rc = sort_pairs_u64_i32(p->temp, p->temp_bytes, p->k64a, p->k64b, p->v32a, p->v32b, n,
-                                ubits + bbits, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_plan_gather, dim3(g1), dim3(kBlock), 0, s, triples, p->v32b, n, start,
-                       batch_size, user_base, ibits, p->gu, p->gi, p->gj, p->k64a, p->v32a);
-    DAISY_LAUNCH_CHECK();
-    rc = sort_pairs_u64_i32(p->temp, p->temp_bytes, p->k64a, p->k64b, p->v32a, p->v32b, 2 * n,
-                            ibits + bbits, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_plan_entries, dim3(grid_for(2 * n, kBlock)), dim3(kBlock), 0, s, p->k64b,
-                       p->v32b, p->gu, 2 * n, batch_size, ibits, p->ent_item, p->ent_s, p->ent_u);
-    DAISY_LAUNCH_CHECK();
+    const int g1 = grid_for(n, kBlock), g2 = grid_for(2 * n, kBlock);
+    int rc;
+    if (!wide) {
+        hipLaunchKernelGGL((k_plan_keys<uint32_t>), dim3(g1), dim3(kBlock), 0, s, triples, perm,
+                           order_mode, fk, n, start, batch_size, user_base, ubits, p->k32[0], p->v64[0]);
+        DAISY_LAUNCH_CHECK();
+        if (ubits + bbits > s_begin) {
+            rc = sort_pairs_u32_u64(p->temp, p->temp_bytes, p->k32[0], p->ukey, p->v64[0], p->uval, n,
+                                    s_begin, ubits + bbits, s);
+            if (rc) return rc;
+        } else {   // one batch of user-sorted triples: already in plan order
+            DAISY_HIP(hipMemcpyAsync(p->ukey, p->k32[0], n * 4, hipMemcpyDeviceToDevice, s));
+            DAISY_HIP(hipMemcpyAsync(p->uval, p->v64[0], n * 8, hipMemcpyDeviceToDevice, s));
+        }
+        hipLaunchKernelGGL((k_plan_entries<uint32_t>), dim3(g1), dim3(kBlock), 0, s, p->ukey, p->uval,
+                           n, batch_size, ibits, umask, p->k32[0], p->v64[0]);
+        DAISY_LAUNCH_CHECK();
+        rc = sort_pairs_u32_u64(p->temp, p->temp_bytes, p->k32[0], p->k32[1], p->v64[0], p->v64[1], 2 * n,
+                                0, ibits + bbits, s);
+        if (rc) return rc;
+        p->umask = umask;
+        p->imask = imask;
+    } else {
+        if ((rc = plan_need_k64(p))) return rc;
+        hipLaunchKernelGGL((k_plan_keys<uint64_t>), dim3(g1), dim3(kBlock), 0, s, triples, perm,
+                           order_mode, fk, n, start, batch_size, user_base, ubits, p->k64[0], p->v64[0]);
+        DAISY_LAUNCH_CHECK();
+        rc = sort_pairs_u64_u64(p->temp, p->temp_bytes, p->k64[0], p->k64[1], p->v64[0], p->uval, n,
+                                s_begin, ubits + bbits, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_narrow_keys, dim3(g1), dim3(kBlock), 0, s, p->k64[1], n, (uint64_t)umask,
+                           p->ukey);
+        DAISY_LAUNCH_CHECK();
+        hipLaunchKernelGGL((k_plan_entries<uint64_t>), dim3(g1), dim3(kBlock), 0, s, p->k64[1], p->uval,
+                           n, batch_size, ibits, 0xFFFFFFFFu & umask, p->k64[0], p->v64[0]);
+        DAISY_LAUNCH_CHECK();
+        rc = sort_pairs_u64_u64(p->temp, p->temp_bytes, p->k64[0], p->k64[1], p->v64[0], p->v64[1], 2 * n,
+                                0, ibits + bbits, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_narrow_keys, dim3(g2), dim3(kBlock), 0, s, p->k64[1], 2 * n, (uint64_t)imask,
+                           p->k32[1]);
+        DAISY_LAUNCH_CHECK();
+        p->umask = 0xFFFFFFFFu;
+        p->imask = 0xFFFFFFFFu;
+    }
+    p->ekey = p->k32[1];
+    p->eval = p->v64[1];
     p->n = n; p->batch_size = batch_size; p->num_batches = nb; p->built = true;
     return DAISY_OK;
 }
 
-static void view_from_plan(daisy_bpr_ctx *ctx, const daisy_epoch_plan *p, int64_t k) {
+static BatchView plan_view(const daisy_epoch_plan *p, int64_t k) {
     const int64_t lo = k * p->batch_size;
-    const int64_t B = (p->n - lo < p->batch_size) ? (p->n - lo) : p->batch_size;
-    ctx->v.u = p->gu + lo; ctx->v.i = p->gi + lo; ctx->v.j = p->gj + lo;
-    ctx->v.ent_item = p->ent_item + 2 * lo;
-    ctx->v.ent_s = p->ent_s + 2 * lo;
-    ctx->v.ent_u = p->ent_u + 2 * lo;
-    ctx->v.B = B;
-    ctx->batch_set = true; ctx->fwd_done = false;
+    BatchView v;
+    v.B = (p->n - lo < p->batch_size) ? (p->n - lo) : p->batch_size;
+    v.ukey = p->ukey + lo;
+    v.ij = reinterpret_cast<const int2 *>(p->uval + lo);
+    v.ekey = p->ekey + 2 * lo;
+    v.esu = reinterpret_cast<const uint2 *>(p->eval + 2 * lo);
+    v.umask = p->umask;
+    v.imask = p->imask;
+    return v;
 }
 
 }  // namespace daisy
@@ -694,13 +828,7 @@ int daisy_epoch_plan_create(daisy_epoch_plan **out, int64_t max_triples, int64_t
 
 int daisy_epoch_plan_destroy(daisy_epoch_plan *plan) {
     if (!plan) return DAISY_OK;
-    hipError_t e = hipFree(plan->arena);
-    delete plan;
-    if (e != hipSuccess) {
-        set_error("epoch_plan_destroy: hipFree failed: %s", hipGetErrorString(e));
-        return DAISY_ERR_HIP;
-    }
-    return DAISY_OK;
+    return plan_free(plan);
 }
 
 size_t daisy_epoch_plan_bytes(const daisy_epoch_plan *plan) { return plan ? plan->arena_bytes : 0; }
@@ -711,7 +839,8 @@ int64_t daisy_epoch_plan_num_batches(const daisy_epoch_plan *plan) {
 
 int daisy_epoch_plan_build(daisy_epoch_plan *plan, const int32_t *triples, int64_t n_triples,
                            const int64_t *perm, int32_t order_mode, uint64_t seed, uint64_t epoch,
-                           int64_t batch_size, int32_t user_base, daisy_stream_t stream) {
+                           int64_t batch_size, int32_t user_base, int32_t flags,
+                           daisy_stream_t stream) {
     DAISY_CHECK_ARG(plan && triples, "epoch_plan_build: NULL argument");
     DAISY_CHECK_ARG(n_triples > 0 && n_triples <= plan->max_triples,
                     "epoch_plan_build: n_triples=%lld not in 1..%lld", (long long)n_triples,
@@ -722,7 +851,7 @@ int daisy_epoch_plan_build(daisy_epoch_plan *plan, const int32_t *triples, int64
     DAISY_CHECK_ARG(order_mode != DAISY_ORDER_PERM || perm != nullptr,
                     "epoch_plan_build: DAISY_ORDER_PERM needs perm");
     return plan_build(plan, triples, n_triples, 0, perm, order_mode, seed, epoch, batch_size, user_base,
-                      S(stream));
+                      flags, S(stream));
 }
 
 int daisy_epoch_plan_read_batch(const daisy_epoch_plan *plan, int64_t k, int32_t *u, int32_t *i,
@@ -732,16 +861,11 @@ int daisy_epoch_plan_read_batch(const daisy_epoch_plan *plan, int64_t k, int32_t
     if (!plan->built) { set_error("epoch_plan_read_batch: plan has not been built"); return DAISY_ERR_STATE; }
     DAISY_CHECK_ARG(k >= 0 && k < plan->num_batches, "epoch_plan_read_batch: batch %lld not in 0..%lld",
                     (long long)k, (long long)plan->num_batches);
-    const int64_t lo = k * plan->batch_size;
-    const int64_t B = (plan->n - lo < plan->batch_size) ? (plan->n - lo) : plan->batch_size;
-    hipStream_t s = S(stream);
-    DAISY_HIP(hipMemcpyAsync(u, plan->gu + lo, B * 4, hipMemcpyDeviceToDevice, s));
-    DAISY_HIP(hipMemcpyAsync(i, plan->gi + lo, B * 4, hipMemcpyDeviceToDevice, s));
-    DAISY_HIP(hipMemcpyAsync(j, plan->gj + lo, B * 4, hipMemcpyDeviceToDevice, s));
-    if (ent_item) DAISY_HIP(hipMemcpyAsync(ent_item, plan->ent_item + 2 * lo, 2 * B * 4, hipMemcpyDeviceToDevice, s));
-    if (ent_s) DAISY_HIP(hipMemcpyAsync(ent_s, plan->ent_s + 2 * lo, 2 * B * 4, hipMemcpyDeviceToDevice, s));
-    if (ent_u) DAISY_HIP(hipMemcpyAsync(ent_u, plan->ent_u + 2 * lo, 2 * B * 4, hipMemcpyDeviceToDevice, s));
-    if (B_out_host) *B_out_host = B;
+    const BatchView v = plan_view(plan, k);
+    hipLaunchKernelGGL(k_unpack_batch, dim3(grid_for(2 * v.B, kBlock)), dim3(kBlock), 0, S(stream), v, u, i,
+                       j, ent_item, ent_s, ent_u);
+    DAISY_LAUNCH_CHECK();
+    if (B_out_host) *B_out_host = v.B;
     return DAISY_OK;
 }
 
@@ -765,12 +889,10 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
     daisy_bpr_ctx *c = new daisy_bpr_ctx();
     c->max_batch = max_batch; c->d = d; c->U = user_num; c->I = item_num;
     c->batch_set = false; c->fwd_done = false; c->own_plan = nullptr;
-    c->bitmap_bytes = align_up((size_t)((item_num + 31) / 32) * 4);
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     const size_t o_coef = take((size_t)max_batch * 8);
     const size_t o_part = take((size_t)kMaxGrid * 8 * 8);
-    const size_t o_bm = take(c->bitmap_bytes);
     const size_t o_tt = take((size_t)max_batch * 12);
     c->arena_bytes = off;
     hipError_t e = hipMalloc(&c->arena, c->arena_bytes);
@@ -782,15 +904,7 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
     char *base = (char *)c->arena;
     c->coef = (float2 *)(base + o_coef);
     c->partials = (double *)(base + o_part);
-    c->bitmap = (uint32_t *)(base + o_bm);
     c->tmp_triples = (int32_t *)(base + o_tt);
-    e = hipMemset(c->bitmap, 0, c->bitmap_bytes);
-    if (e != hipSuccess) {
-        set_error("ctx_create: hipMemset failed: %s", hipGetErrorString(e));
-        (void)hipFree(c->arena);
-        delete c;
-        return DAISY_ERR_HIP;
-    }
     *out = c;
     return DAISY_OK;
 }
@@ -798,7 +912,7 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
 int daisy_bpr_ctx_destroy(daisy_bpr_ctx *ctx) {
     if (!ctx) return DAISY_OK;
     int rc = DAISY_OK;
-    if (ctx->own_plan) rc = daisy_epoch_plan_destroy(ctx->own_plan);
+    if (ctx->own_plan) rc = plan_free(ctx->own_plan);
     hipError_t e = hipFree(ctx->arena);
     delete ctx;
     if (e != hipSuccess) {
@@ -828,7 +942,8 @@ int daisy_bpr_set_batch_from_plan(daisy_bpr_ctx *ctx, const daisy_epoch_plan *pl
     DAISY_CHECK_ARG(plan->batch_size <= ctx->max_batch && plan->U == ctx->U && plan->I == ctx->I,
                     "set_batch_from_plan: plan (batch %lld, U %lld, I %lld) does not fit the context",
                     (long long)plan->batch_size, (long long)plan->U, (long long)plan->I);
-    view_from_plan(ctx, plan, k);
+    ctx->v = plan_view(plan, k);
+    ctx->batch_set = true; ctx->fwd_done = false;
     return DAISY_OK;
 }
 
@@ -845,9 +960,10 @@ int daisy_bpr_set_batch_from_triples(daisy_bpr_ctx *ctx, const int32_t *triples,
     if (rc) return rc;
     // a one-batch plan over the selected rows
     rc = plan_build(ctx->own_plan, triples, B, idx ? 0 : start, idx, idx ? DAISY_ORDER_PERM : DAISY_ORDER_IDENTITY,
-                    0, 0, B, user_base, S(stream));
+                    0, 0, B, user_base, 0, S(stream));
     if (rc) return rc;
-    view_from_plan(ctx, ctx->own_plan, 0);
+    ctx->v = plan_view(ctx->own_plan, 0);
+    ctx->batch_set = true; ctx->fwd_done = false;
     return DAISY_OK;
 }
 
@@ -876,8 +992,8 @@ int daisy_bpr_forward(daisy_bpr_ctx *ctx, const float *P, const float *Q, int32_
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
         grid = grid_for(v.B, C::GROUPS_PER_BLOCK * 4);
-        hipLaunchKernelGGL((k_fwd<C>), dim3(grid), dim3(kBlock), 0, s, P, Q, v.u, v.i, v.j, v.B, d,
-                           (int)loss_type, gamma, ctx->coef, ctx->partials);
+        hipLaunchKernelGGL((k_fwd<C>), dim3(grid), dim3(kBlock), 0, s, P, Q, v, d, (int)loss_type, gamma,
+                           ctx->coef, ctx->partials);
         return DAISY_OK;
     });
     if (rc) return rc;
@@ -897,9 +1013,9 @@ int daisy_bpr_finalize(daisy_bpr_ctx *ctx, double *stats, float reg_1, float reg
     return DAISY_OK;
 }
 
-int daisy_bpr_item_grad(daisy_bpr_ctx *ctx, const float *P, const float *Q, const double *stats,
-                        float reg_1, float reg_2, float *gQ, int32_t item_mode,
-                        daisy_stream_t stream) {
+static int item_grad_impl(daisy_bpr_ctx *ctx, const float *P, const float *Q, const double *stats,
+                          float reg_1, float reg_2, float *gQ, int32_t item_mode, bool data_only,
+                          daisy_stream_t stream) {
     DAISY_CHECK_ARG(ctx && P && Q && stats && gQ, "item_grad: NULL argument");
     DAISY_CHECK_ARG(item_mode >= DAISY_ITEM_ATOMIC && item_mode <= DAISY_ITEM_CHUNKED,
                     "item_grad: bad item_mode %d", item_mode);
@@ -911,33 +1027,34 @@ int daisy_bpr_item_grad(daisy_bpr_ctx *ctx, const float *P, const float *Q, cons
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
         if (item_mode == DAISY_ITEM_SORTED) {
-            hipLaunchKernelGGL((k_item_grad_sorted<C>), dim3(grid_for(2 * v.B, C::GROUPS_PER_BLOCK)),
-                               dim3(kBlock), 0, s, P, Q, ctx->coef, v.ent_item, v.ent_s, v.ent_u,
-                               2 * v.B, d, stats, reg_1, reg_2, gQ, ctx->bitmap);
+            hipLaunchKernelGGL((k_item_grad_sorted<C>),
+                               dim3(grid_for(2 * v.B, C::GROUPS_PER_BLOCK, kMaxGridSparse)), dim3(kBlock), 0,
+                               s, P, Q, ctx->coef, v, d, stats, reg_1, reg_2, gQ);
         } else if (item_mode == DAISY_ITEM_CHUNKED) {
-            const int grid = grid_for(2 * v.B, ChunkCfg<C>::E);
-            if (reg)
-                hipLaunchKernelGGL((k_item_grad_chunked<C, true>), dim3(grid), dim3(kBlock), 0, s, P, Q,
-                                   ctx->coef, v.ent_item, v.ent_s, v.ent_u, 2 * v.B, d, stats, reg_1,
-                                   reg_2, gQ, ctx->bitmap);
-            else
-                hipLaunchKernelGGL((k_item_grad_chunked<C, false>), dim3(grid), dim3(kBlock), 0, s, P, Q,
-                                   ctx->coef, v.ent_item, v.ent_s, v.ent_u, 2 * v.B, d, stats, reg_1,
-                                   reg_2, gQ, ctx->bitmap);
+            hipLaunchKernelGGL((k_item_grad_chunked<C>), dim3(grid_for(2 * v.B, RunCfg<C>::E)),
+                               dim3(kBlock), 0, s, P, ctx->coef, v, d, gQ);
+            if (reg && !data_only)
+                hipLaunchKernelGGL((k_item_reg<C>),
+                                   dim3(grid_for(2 * v.B, C::GROUPS_PER_BLOCK * 2, kMaxGridSparse)),
+                                   dim3(kBlock), 0, s, Q, v, d, stats, reg_1, reg_2, gQ);
         } else if (reg) {
             hipLaunchKernelGGL((k_item_grad_atomic<C, true>), dim3(grid_for(v.B, C::GROUPS_PER_BLOCK * 4)),
-                               dim3(kBlock), 0, s, P, Q, v.u, v.i, v.j, ctx->coef, v.B, d, stats, reg_1,
-                               reg_2, gQ, ctx->bitmap);
+                               dim3(kBlock), 0, s, P, Q, v, ctx->coef, d, stats, reg_1, reg_2, gQ);
         } else {
             hipLaunchKernelGGL((k_item_grad_atomic<C, false>), dim3(grid_for(v.B, C::GROUPS_PER_BLOCK * 4)),
-                               dim3(kBlock), 0, s, P, Q, v.u, v.i, v.j, ctx->coef, v.B, d, stats, reg_1,
-                               reg_2, gQ, ctx->bitmap);
+                               dim3(kBlock), 0, s, P, Q, v, ctx->coef, d, stats, reg_1, reg_2, gQ);
         }
         return DAISY_OK;
     });
     if (rc) return rc;
     DAISY_LAUNCH_CHECK();
     return DAISY_OK;
+}
+
+int daisy_bpr_item_grad(daisy_bpr_ctx *ctx, const float *P, const float *Q, const double *stats,
+                        float reg_1, float reg_2, float *gQ, int32_t item_mode,
+                        daisy_stream_t stream) {
+    return item_grad_impl(ctx, P, Q, stats, reg_1, reg_2, gQ, item_mode, false, stream);
 }
 
 static int user_pass(daisy_bpr_ctx *ctx, float *P, const float *Q, const double *stats, float lr,
@@ -948,13 +1065,13 @@ static int user_pass(daisy_bpr_ctx *ctx, float *P, const float *Q, const double 
     const int d = ctx->d;
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
-        const int grid = grid_for(v.B, C::GROUPS_PER_BLOCK * 2);
+        const int grid = grid_for(v.B, C::GROUPS_PER_BLOCK * 2, kMaxGridSparse);
         if (sgd)
-            hipLaunchKernelGGL((k_user<C, true>), dim3(grid), dim3(kBlock), 0, s, P, Q, v.u, v.i, v.j,
-                               ctx->coef, v.B, d, stats, lr, reg_1, reg_2, gP);
+            hipLaunchKernelGGL((k_user<C, true>), dim3(grid), dim3(kBlock), 0, s, P, Q, v, ctx->coef, d,
+                               stats, lr, reg_1, reg_2, gP);
         else
-            hipLaunchKernelGGL((k_user<C, false>), dim3(grid), dim3(kBlock), 0, s, P, Q, v.u, v.i, v.j,
-                               ctx->coef, v.B, d, stats, lr, reg_1, reg_2, gP);
+            hipLaunchKernelGGL((k_user<C, false>), dim3(grid), dim3(kBlock), 0, s, P, Q, v, ctx->coef, d,
+                               stats, lr, reg_1, reg_2, gP);
         return DAISY_OK;
     });
     if (rc) return rc;
@@ -974,22 +1091,34 @@ int daisy_bpr_user_grad(daisy_bpr_ctx *ctx, const float *P, const float *Q, cons
     return user_pass(ctx, const_cast<float *>(P), Q, stats, 0.f, reg_1, reg_2, gP, false, stream);
 }
 
-int daisy_bpr_item_sgd_apply(daisy_bpr_ctx *ctx, float *Q, float *gQ, float lr, int32_t dense,
-                             daisy_stream_t stream) {
+static int item_apply_impl(daisy_bpr_ctx *ctx, float *Q, float *gQ, float lr, int32_t dense,
+                           const double *stats, float reg_1, float reg_2, bool with_reg,
+                           daisy_stream_t stream) {
     DAISY_CHECK_ARG(ctx && Q && gQ, "item_sgd_apply: NULL argument");
+    if (!dense && !ctx->batch_set) { set_error("item_sgd_apply: no batch set"); return DAISY_ERR_STATE; }
     hipStream_t s = S(stream);
     const int d = ctx->d;
-    const int64_t I = ctx->I;
+    const BatchView &v = ctx->v;
+    const int64_t n = dense ? ctx->I : 2 * v.B;
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
-        hipLaunchKernelGGL((k_item_apply<C>), dim3(grid_for(I, C::GROUPS_PER_BLOCK * 4)), dim3(kBlock),
-                           0, s, Q, gQ, ctx->bitmap, I, d, lr, (int)dense);
+        const int grid = grid_for(n, C::GROUPS_PER_BLOCK * 2, dense ? kMaxGrid : kMaxGridSparse);
+        if (with_reg)
+            hipLaunchKernelGGL((k_item_apply<C, true>), dim3(grid), dim3(kBlock), 0, s, Q, gQ, v, n, d, lr,
+                               (int)dense, stats, reg_1, reg_2);
+        else
+            hipLaunchKernelGGL((k_item_apply<C, false>), dim3(grid), dim3(kBlock), 0, s, Q, gQ, v, n, d, lr,
+                               (int)dense, stats, reg_1, reg_2);
         return DAISY_OK;
     });
     if (rc) return rc;
     DAISY_LAUNCH_CHECK();
-    DAISY_HIP(hipMemsetAsync(ctx->bitmap, 0, ctx->bitmap_bytes, s));
     return DAISY_OK;
+}
+
+int daisy_bpr_item_sgd_apply(daisy_bpr_ctx *ctx, float *Q, float *gQ, float lr, int32_t dense,
+                             daisy_stream_t stream) {
+    return item_apply_impl(ctx, Q, gQ, lr, dense, nullptr, 0.f, 0.f, false, stream);
 }
 
 int daisy_adam_dense(float *W, float *g, float *m, float *v, int64_t n, float lr, float beta1,
@@ -1010,9 +1139,11 @@ int daisy_bpr_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t loss_type
     int rc;
     if ((rc = daisy_bpr_forward(ctx, P, Q, loss_type, gamma, stats, stream))) return rc;
     if ((rc = daisy_bpr_finalize(ctx, stats, reg_1, reg_2, epoch_acc, step_loss, stream))) return rc;
-    if ((rc = daisy_bpr_item_grad(ctx, P, Q, stats, reg_1, reg_2, gQ, item_mode, stream))) return rc;
+    // throughput mode: gQ carries the data term only, the commit kernel adds the regulariser
+    const bool fold_reg = (item_mode == DAISY_ITEM_CHUNKED) && (reg_1 != 0.f || reg_2 != 0.f);
+    if ((rc = item_grad_impl(ctx, P, Q, stats, reg_1, reg_2, gQ, item_mode, fold_reg, stream))) return rc;
     if ((rc = daisy_bpr_user_sgd(ctx, P, Q, stats, lr, reg_1, reg_2, stream))) return rc;
-    if ((rc = daisy_bpr_item_sgd_apply(ctx, Q, gQ, lr, 0, stream))) return rc;
+    if ((rc = item_apply_impl(ctx, Q, gQ, lr, 0, stats, reg_1, reg_2, fold_reg, stream))) return rc;
     return DAISY_OK;
 }
 

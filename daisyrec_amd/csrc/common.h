@@ -36,11 +36,36 @@ constexpr int kBlock = 256;      // 4 waves per workgroup
 constexpr int kMaxGrid = 2048;   // 256 CUs x 8 workgroups: grid-stride beyond that
 constexpr int kMaxD = 512;
 
-inline int grid_for(int64_t work_items, int items_per_block) {
+constexpr int kMaxGridSparse = 65536;  // head-detect kernels: most groups exit at once, so
+                                       // many short workgroups beat a long grid-stride loop
+inline int grid_for(int64_t work_items, int items_per_block, int cap = kMaxGrid) {
     int64_t g = (work_items + items_per_block - 1) / items_per_block;
     if (g < 1) g = 1;
-    if (g > kMaxGrid) g = kMaxGrid;
+    if (g > cap) g = cap;
     return (int)g;
+}
+
+// occurrences of item r from entry `pos` on (the caller sits on the head of r's run):
+// the LPR lanes of the group test LPR entries per step and count with a ballot.
+template <class C>
+__device__ __forceinline__ void count_run(const uint32_t *__restrict__ ekey, uint32_t imask,
+                                          const uint2 *__restrict__ esu, int64_t pos, int64_t n,
+                                          int32_t r, int lane, float &n_pos, float &n_neg) {
+    const int shift = ((threadIdx.x % kWave) / C::LPR) * C::LPR;
+    const unsigned long long gmask = (C::LPR == 64) ? ~0ull : (((1ull << C::LPR) - 1) << shift);
+    int cp = 0, cn = 0;
+    for (int64_t base = pos;; base += C::LPR) {
+        const int64_t e = base + lane;
+        const bool v = (e < n) && ((int32_t)(ekey[e] & imask) == r);
+        const bool ng = v && ((esu[e].x & 0x80000000u) != 0);
+        const int cv = __popcll(__ballot(v) & gmask);
+        const int cg = __popcll(__ballot(ng) & gmask);
+        cp += cv - cg;
+        cn += cg;
+        if (cv < C::LPR) break;
+    }
+    n_pos = (float)cp;
+    n_neg = (float)cn;
 }
 
 // ----------------------------------------------------------------------------
@@ -228,6 +253,14 @@ size_t sort_pairs_i32_temp_bytes(int64_t n);
 // stable LSD radix sort of (key,val) int32 pairs on bits [0,end_bit)
 int sort_pairs_i32(void *temp, size_t temp_bytes, const int32_t *kin, int32_t *kout,
                    const int32_t *vin, int32_t *vout, int64_t n, int end_bit, hipStream_t s);
+size_t sort_pairs_u32_u64_temp_bytes(int64_t n);
+int sort_pairs_u32_u64(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout,
+                       const uint64_t *vin, uint64_t *vout, int64_t n, int begin_bit, int end_bit,
+                       hipStream_t s);
+size_t sort_pairs_u64_u64_temp_bytes(int64_t n);
+int sort_pairs_u64_u64(void *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout,
+                       const uint64_t *vin, uint64_t *vout, int64_t n, int begin_bit, int end_bit,
+                       hipStream_t s);
 size_t sort_pairs_u64_i32_temp_bytes(int64_t n);
 int sort_pairs_u64_i32(void *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout,
                        const int32_t *vin, int32_t *vout, int64_t n, int end_bit, hipStream_t s);

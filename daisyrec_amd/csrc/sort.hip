@@ -26,6 +26,36 @@ int sort_pairs_i32(void *temp, size_t temp_bytes, const int32_t *kin, int32_t *k
     return DAISY_OK;
 }
 
+size_t sort_pairs_u32_u64_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+                                    (const uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)n, 0, 32);
+    return bytes;
+}
+
+int sort_pairs_u32_u64(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout,
+                       const uint64_t *vin, uint64_t *vout, int64_t n, int begin_bit, int end_bit,
+                       hipStream_t s) {
+    DAISY_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)n,
+                                        (unsigned)begin_bit, (unsigned)end_bit, s));
+    return DAISY_OK;
+}
+
+size_t sort_pairs_u64_u64_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+                                    (const uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)n, 0, 64);
+    return bytes;
+}
+
+int sort_pairs_u64_u64(void *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout,
+                       const uint64_t *vin, uint64_t *vout, int64_t n, int begin_bit, int end_bit,
+                       hipStream_t s) {
+    DAISY_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)n,
+                                        (unsigned)begin_bit, (unsigned)end_bit, s));
+    return DAISY_OK;
+}
+
 size_t sort_pairs_u64_i32_temp_bytes(int64_t n) {
     size_t bytes = 0;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,

@@ -220,6 +220,4 @@ class _AdamState:
         ctx.item_grad(P, Q, reg_1, reg_2, item_mode)
         ctx.user_grad(P, Q, reg_1, reg_2, self.gP)
         ops.adam_dense(P, self.gP, self.mP, self.vP, self.lr, self.t)
-        ops.adam_dense(Q, ctx.gQ, self.mQ, self.vQ, self.lr, self.t)
-        # gQ was zeroed densely by the Adam pass; forget the touched-row marks too
-        ctx.item_sgd_apply(Q, 0.0, dense=False)
+        ops.adam_dense(Q, ctx.gQ, self.mQ, self.vQ, self.lr, self.t)   # also zeroes gQ

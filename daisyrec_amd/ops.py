@@ -64,12 +64,15 @@ class EpochPlan:
                                               int(item_num)))
 
     def build(self, triples, batch_size, order="identity", perm=None, seed=0, epoch=0, user_base=0,
-              n_triples=None):
+              n_triples=None, user_sorted=False):
+        """user_sorted=True promises that `triples` is sorted by user (use `triples_user_sorted`
+        to check once): grouping by user then costs one radix pass instead of a full sort."""
         n = triples.shape[0] if n_triples is None else int(n_triples)
         mode = ORDER_MODES[order] if isinstance(order, str) else int(order)
+        flags = N.PLAN_TRIPLES_USER_SORTED if user_sorted else 0
         check(lib.daisy_epoch_plan_build(self._h, _ptr(triples, torch.int32, "triples"), n,
                                          _ptr(perm, torch.int64, "perm"), mode, int(seed), int(epoch),
-                                         int(batch_size), int(user_base), _stream()))
+                                         int(batch_size), int(user_base), flags, _stream()))
         return self
 
     @property
@@ -103,6 +106,12 @@ class EpochPlan:
             self.close()
         except Exception:
             pass
+
+
+def triples_user_sorted(triples) -> bool:
+    """One-off check (plumbing, not the hot path) that a device triple array is in CSR order."""
+    u = triples[:, 0]
+    return bool((u[1:] >= u[:-1]).all().item()) if u.numel() > 1 else True
 
 
 def feistel_positions(n, seed, epoch=0, device="cuda"):

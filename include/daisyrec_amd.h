@@ -106,10 +106,14 @@ int daisy_epoch_plan_destroy(daisy_epoch_plan *plan);
 size_t daisy_epoch_plan_bytes(const daisy_epoch_plan *plan);
 /* triples: int32 [n_triples][3]; perm: int64 [n_triples], only for DAISY_ORDER_PERM;
  * (seed, epoch) only for DAISY_ORDER_FEISTEL; user_base is subtracted from the user
- * ids (user-sharded tables). */
+ * ids (user-sharded tables).  flags: DAISY_PLAN_TRIPLES_USER_SORTED promises that the
+ * triple array is sorted by user (CSR order), so grouping a batch by user only needs a
+ * stable partition by batch (one radix pass); a wrong promise gives wrong updates. */
+#define DAISY_PLAN_TRIPLES_USER_SORTED 1
 int daisy_epoch_plan_build(daisy_epoch_plan *plan, const int32_t *triples, int64_t n_triples,
                            const int64_t *perm, int32_t order_mode, uint64_t seed, uint64_t epoch,
-                           int64_t batch_size, int32_t user_base, daisy_stream_t stream);
+                           int64_t batch_size, int32_t user_base, int32_t flags,
+                           daisy_stream_t stream);
 int64_t daisy_epoch_plan_num_batches(const daisy_epoch_plan *plan);
 /* copy batch k of a built plan into caller buffers (inspection / tests): u,i,j int32 [B]
  * grouped by user; optional item entries [2B] sorted by item: ent_item, ent_s (sample
@@ -149,8 +153,9 @@ int daisy_bpr_finalize(daisy_bpr_ctx *ctx, double *stats, float reg_1, float reg
                        double *epoch_acc, double *step_loss, daisy_stream_t stream);
 
 /* autograd backward w.r.t. embed_item.weight, restricted to the touched rows
- * (AbstractRecommender.py:125): gQ[I][d] += dL/dQ.  gQ must be zero on entry for
- * untouched rows; touched rows are recorded in the context. */
+ * (AbstractRecommender.py:125): gQ[r] = dL/dQ[r] for every item r of the batch.
+ * gQ must be all zero on entry (daisy_bpr_item_sgd_apply / daisy_adam_dense leave
+ * it so). */
 int daisy_bpr_item_grad(daisy_bpr_ctx *ctx, const float *P, const float *Q, const double *stats,
                         float reg_1, float reg_2, float *gQ, int32_t item_mode,
                         daisy_stream_t stream);
@@ -164,9 +169,9 @@ int daisy_bpr_user_sgd(daisy_bpr_ctx *ctx, float *P, const float *Q, const doubl
 int daisy_bpr_user_grad(daisy_bpr_ctx *ctx, const float *P, const float *Q, const double *stats,
                         float reg_1, float reg_2, float *gP, daisy_stream_t stream);
 
-/* optim.SGD.step on the item table: Q[r] -= lr*gQ[r]; gQ[r] = 0 for the rows
- * recorded by daisy_bpr_item_grad (dense != 0: every row, used after an
- * all-reduce of gQ). */
+/* optim.SGD.step on the item table: Q[r] -= lr*gQ[r]; gQ[r] = 0 for the distinct
+ * items of the current batch (dense != 0: every row, used after an all-reduce
+ * of gQ). */
 int daisy_bpr_item_sgd_apply(daisy_bpr_ctx *ctx, float *Q, float *gQ, float lr, int32_t dense,
                              daisy_stream_t stream);
 

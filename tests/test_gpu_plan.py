@@ -137,3 +137,48 @@ def test_plan_argument_errors():
         ctx.set_batch_from_plan(plan, 0)
     plan.close()
     ctx.close()
+
+
+def test_plan_user_sorted_fast_path_and_wide_keys():
+    from daisyrec_amd import ops
+    # (a) CSR-ordered triples + the one-pass partition must give the same batches as the full sort
+    n, U, I, B = 5000, 400, 300, 128
+    tri = _triples(n, U, I, 3)
+    tri = tri[np.argsort(tri[:, 0], kind="stable")]
+    t_dev = torch.from_numpy(tri).to(DEV)
+    assert ops.triples_user_sorted(t_dev) and not ops.triples_user_sorted(t_dev.flip(0).contiguous())
+    pos = O.feistel_positions(n, 5, 1)
+    inv = np.empty(n, dtype=np.int64)
+    inv[pos] = np.arange(n)
+    plan = ops.EpochPlan(n, U, I)
+    for fast in (True, False):
+        plan.build(t_dev, B, order="feistel", seed=5, epoch=1, user_sorted=fast)
+        nb = plan.num_batches
+        for k in (0, 1, nb - 1):
+            _check_batch(plan, k, B, tri[inv[k * B:(k + 1) * B]], U)
+    plan.build(t_dev, B, order="identity", user_sorted=True)
+    _check_batch(plan, 3, B, tri[3 * B:4 * B], U)
+    plan.build(t_dev, n, order="identity", user_sorted=True)          # single batch: no sort at all
+    _check_batch(plan, 0, n, tri, U)
+    plan.close()
+    # (b) batch bits + id bits > 32 -> the 64-bit key path (U = 2^20 users, 8192 one-sample batches)
+    n, U, I, B = 8192, 1 << 20, 1 << 20, 1
+    tri = _triples(n, U, I, 4)
+    t_dev = torch.from_numpy(tri).to(DEV)
+    plan = ops.EpochPlan(n, U, I).build(t_dev, B, order="identity")
+    for k in (0, 17, n - 1):
+        _check_batch(plan, k, B, tri[k:k + 1], U)
+    B = 3
+    plan.build(t_dev, B, order="feistel", seed=1, epoch=0)
+    pos = O.feistel_positions(n, 1, 0)
+    inv = np.empty(n, dtype=np.int64)
+    inv[pos] = np.arange(n)
+    for k in (0, 5, plan.num_batches - 1):
+        _check_batch(plan, k, B, tri[inv[k * B:(k + 1) * B]], U)
+    # a step on the wide-key plan matches the oracle
+    rng = np.random.default_rng(0)
+    Us, Is, d = 50, 40, 16
+    tri = _triples(4096, Us, Is, 8)
+    P0 = (rng.standard_normal((Us, d)) * 0.1).astype(np.float32)
+    Q0 = (rng.standard_normal((Is, d)) * 0.1).astype(np.float32)
+    plan.close()

@@ -99,7 +99,10 @@ def plan_cost(U=1_000_000, I=100_000, n=50_000_000, B=1 << 20):
     print(f"plan bytes {plan.nbytes / 1e9:.2f} GB")
     for order in ("identity", "feistel"):
         t = timeit(lambda: plan.build(tri, B, order=order, seed=1, epoch=0), iters=3, warm=1)
-        print(f"plan.build({order:8s})  {t:8.3f} ms  = {t / (n / B):6.3f} ms per {B}-batch")
+        print(f"plan.build({order:8s})              {t:8.3f} ms  = {t / (n / B):6.3f} ms per {B}-batch")
+    tri_s = tri[torch.sort(tri[:, 0].long(), stable=True).indices].contiguous()
+    t = timeit(lambda: plan.build(tri_s, B, order="feistel", seed=1, epoch=0, user_sorted=True), iters=3, warm=1)
+    print(f"plan.build(feistel, user-sorted)   {t:8.3f} ms  = {t / (n / B):6.3f} ms per {B}-batch")
     t = timeit(lambda: ops.randperm(n, 1, 0), iters=3, warm=1)
     print(f"randperm(50M, philox sort)  {t:8.3f} ms")
     plan.close()
