@@ -36,13 +36,17 @@ constexpr uint32_t kNegBit = 0x80000000u;
 // What the step kernels see of the current batch (pointers into an epoch plan).
 //   sample s in [0,B):  user = ukey[s] & umask,  (pos item, neg item) = ij[s]
 //                       samples of one user are contiguous (stable order)
-//   entry  q in [0,2B): item = ekey[q] & imask (ascending, stable),
+//   entry  q in [0,2B): item = (ekey[q] & imask) >> 1, negative slot = ekey[q] & 1 (ascending, stable),
 //                       esu[q] = (sample position s | kNegBit for the negative slot, user of s)
 struct BatchView {
     const uint32_t *ukey;
     const int2 *ij;
     const uint32_t *ekey;
     const uint2 *esu;
+    // run-length encoding of the batch's entry keys: run m in [run_off[0], run_off[1]) has
+    // run_key[m] = item << 1 | neg and run_cnt[m] entries (an item owns 1 or 2 adjacent runs)
+    const uint32_t *run_key, *run_cnt;
+    const int32_t *run_off;
     uint32_t umask, imask;
     int64_t B;
 };
@@ -62,6 +66,10 @@ struct daisy_epoch_plan {
     uint64_t *uval;       // [n]  (i, j)
     uint32_t *ekey;       // [2n] sorted entry keys (batch << ibits | item)
     uint64_t *eval;       // [2n] (s | neg, u)
+    uint32_t *run_key;    // [2n]  item << 1 | neg of every run of equal entry keys
+    uint32_t *run_cnt;    // [2n]  its length
+    int32_t *run_off;     // [max_triples+2] first run of every batch; [num_batches] = total
+    uint32_t *run_total;  // [1]   number of runs (device)
     uint32_t umask, imask;
     void *temp;
     int64_t n, batch_size, num_batches;
@@ -118,9 +126,9 @@ __global__ void k_plan_entries(const KeyT *__restrict__ skey, const uint64_t *__
         const uint32_t s = (uint32_t)(p - (int64_t)k * B);
         const uint32_t uu = (uint32_t)skey[p] & umask;
         const uint64_t ij = sval[p];
-        ekey[2 * p] = (KeyT)((k << ibits) | (uint32_t)ij);
+        ekey[2 * p] = (KeyT)((k << (ibits + 1)) | ((uint64_t)(uint32_t)ij << 1));
         eval[2 * p] = ((uint64_t)uu << 32) | s;
-        ekey[2 * p + 1] = (KeyT)((k << ibits) | (uint32_t)(ij >> 32));
+        ekey[2 * p + 1] = (KeyT)((k << (ibits + 1)) | ((uint64_t)(uint32_t)(ij >> 32) << 1) | 1u);
         eval[2 * p + 1] = ((uint64_t)uu << 32) | (s | kNegBit);
     }
 }
@@ -131,6 +139,29 @@ __global__ void k_narrow_keys(const uint64_t *__restrict__ in, int64_t n, uint64
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
          e += (int64_t)gridDim.x * blockDim.x)
         out[e] = (uint32_t)(in[e] & mask);
+}
+
+// runs of equal entry keys -> per-batch run offsets (lower bound of batch k's first key) and
+// the narrowed run keys (item << 1 | neg)
+template <class KeyT>
+__global__ void k_run_finish(const KeyT *__restrict__ full_key, const uint32_t *__restrict__ run_total,
+                             int64_t nb, int ibits1, uint32_t *__restrict__ run_key,
+                             int32_t *__restrict__ run_off) {
+    const int64_t R = *run_total;
+    const uint64_t imask = ((uint64_t)1 << ibits1) - 1;
+    const int64_t tid = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t m = tid; m < R; m += stride) run_key[m] = (uint32_t)((uint64_t)full_key[m] & imask);
+    for (int64_t k = tid; k <= nb; k += stride) {
+        const uint64_t target = (uint64_t)k << ibits1;
+        int64_t lo = 0, hi = R;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((uint64_t)full_key[mid] < target) lo = mid + 1;
+            else hi = mid;
+        }
+        run_off[k] = (int32_t)lo;
+    }
 }
 
 __global__ void k_pack_triples(const int32_t *__restrict__ u, const int32_t *__restrict__ i,
@@ -151,7 +182,7 @@ __global__ void k_unpack_batch(BatchView v, int32_t *__restrict__ u, int32_t *__
             i[e] = v.ij[e].x;
             j[e] = v.ij[e].y;
         }
-        if (ent_item) ent_item[e] = (int32_t)(v.ekey[e] & v.imask);
+        if (ent_item) ent_item[e] = (int32_t)((v.ekey[e] & v.imask) >> 1);
         if (ent_s) ent_s[e] = v.esu[e].x;
         if (ent_u) ent_u[e] = (int32_t)v.esu[e].y;
     }
@@ -351,12 +382,12 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_sorted(
     const float rI = inv_or_zero(stats[DAISY_ST_NORM_I], reg_2);
     const float rJ = inv_or_zero(stats[DAISY_ST_NORM_J], reg_2);
     for (int64_t pos = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; pos < n; pos += gstride) {
-        const uint32_t r = v.ekey[pos] & v.imask;
-        if (pos > 0 && (v.ekey[pos - 1] & v.imask) == r) continue;  // not a segment head
+        const uint32_t r = (v.ekey[pos] & v.imask) >> 1;
+        if (pos > 0 && ((v.ekey[pos - 1] & v.imask) >> 1) == r) continue;  // not a segment head
         Row<C> acc;
         acc.zero();
         float n_pos = 0.f, n_neg = 0.f;
-        for (int64_t q = pos; q < n && (v.ekey[q] & v.imask) == r; ++q) {
+        for (int64_t q = pos; q < n && ((v.ekey[q] & v.imask) >> 1) == r; ++q) {
             const uint2 su = v.esu[q];
             const bool is_neg = (su.x & kNegBit) != 0;
             const float2 c2 = coef[su.x & ~kNegBit];
@@ -430,12 +461,12 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
         int32_t my_item = -1;
         uint2 my_su = make_uint2(0u, 0u);
         if (lane < cnt) {
-            my_item = (int32_t)(v.ekey[t0 + lane] & v.imask);
+            my_item = (int32_t)((v.ekey[t0 + lane] & v.imask) >> 1);
             my_su = v.esu[t0 + lane];
         } else if (lane == RUN && cnt > 0 && t0 > 0) {
-            my_item = (int32_t)(v.ekey[t0 - 1] & v.imask);
+            my_item = (int32_t)((v.ekey[t0 - 1] & v.imask) >> 1);
         } else if (lane == RUN + 1 && cnt > 0 && t1 < n) {
-            my_item = (int32_t)(v.ekey[t1] & v.imask);
+            my_item = (int32_t)((v.ekey[t1] & v.imask) >> 1);
         }
         for (int e = tid; e < (G + 1) * ROWF; e += kBlock) slot_acc[e] = 0.f;
         if (tid <= G) { slot_item[tid] = -1; slot_shared[tid] = 0; }
@@ -474,7 +505,7 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
                     // the segment holds the last entry of run gs; it began there unless run 0 is
                     // all this item and the chunk itself continues the previous chunk
                     const bool inherited = (gs == 0) && (run_first[0] == item_first) && (c0 > 0) &&
-                                           ((int32_t)(v.ekey[c0 - 1] & v.imask) == item_first);
+                                           ((int32_t)((v.ekey[c0 - 1] & v.imask) >> 1) == item_first);
                     cur_slot = inherited ? 0 : gs + 1;
                 }
             }
@@ -530,9 +561,21 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
     }
 }
 
-// regulariser share of the item gradient (MFRecommender.py:88-89): the group that sees the
-// head of an item's run counts its positive / negative occurrences and adds
-//   reg_1*(np+nn)*sign(q) + reg_2*(np/|Q[i]|_F + nn/|Q[j]|_F)*q     to gQ[item]
+// regulariser share of the item gradient (MFRecommender.py:88-89), one lane group per
+// distinct item of the batch (head run of the plan's run list):
+//   gQ[item] += reg_1*(np+nn)*sign(q) + reg_2*(np/|Q[i]|_F + nn/|Q[j]|_F)*q
+__device__ __forceinline__ bool run_head(const BatchView &v, int64_t m, int64_t m0, int64_t m1,
+                                         int64_t &item, float &fp, float &fn) {
+    const uint32_t key = v.run_key[m];
+    if (m > m0 && (v.run_key[m - 1] >> 1) == (key >> 1)) return false;   // the item's second run
+    item = key >> 1;
+    const float c = (float)v.run_cnt[m];
+    fp = (key & 1u) ? 0.f : c;
+    fn = (key & 1u) ? c : 0.f;
+    if (!(key & 1u) && m + 1 < m1 && (v.run_key[m + 1] >> 1) == (key >> 1)) fn = (float)v.run_cnt[m + 1];
+    return true;
+}
+
 template <class C>
 __global__ __launch_bounds__(kBlock) void k_item_reg(const float *__restrict__ Q, BatchView v, int d,
                                                      const double *__restrict__ stats, float reg_1,
@@ -540,21 +583,20 @@ __global__ __launch_bounds__(kBlock) void k_item_reg(const float *__restrict__ Q
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
-    const int64_t n = 2 * v.B;
+    const int64_t m0 = v.run_off[0], m1 = v.run_off[1];
     const float rI = inv_or_zero(stats[DAISY_ST_NORM_I], reg_2);
     const float rJ = inv_or_zero(stats[DAISY_ST_NORM_J], reg_2);
-    for (int64_t pos = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; pos < n; pos += gstride) {
-        const int32_t r = (int32_t)(v.ekey[pos] & v.imask);
-        if (pos > 0 && (int32_t)(v.ekey[pos - 1] & v.imask) == r) continue;
-        Row<C> g, q;
-        g.load(gQ + (int64_t)r * d, lane, d);
-        q.load(Q + (int64_t)r * d, lane, d);
+    for (int64_t m = m0 + (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; m < m1; m += gstride) {
+        int64_t r;
         float fp, fn;
-        count_run<C>(v.ekey, v.imask, v.esu, pos, n, r, lane, fp, fn);
+        if (!run_head(v, m, m0, m1, r, fp, fn)) continue;
+        Row<C> g, q;
+        g.load(gQ + r * d, lane, d);
+        q.load(Q + r * d, lane, d);
         const float w1 = reg_1 * (fp + fn), w2 = fp * rI + fn * rJ;
 #pragma unroll
         for (int k = 0; k < C::NE; ++k) g.v[k] += fmaf(w2, q.v[k], w1 * sgn(q.v[k]));
-        g.store(gQ + (int64_t)r * d, lane, d);
+        g.store(gQ + r * d, lane, d);
     }
 }
 
@@ -603,15 +645,14 @@ __global__ __launch_bounds__(kBlock) void k_user(float *__restrict__ P, const fl
 }
 
 // ---------------------------------------------------------------------------
-// commit the item rows: Q[r] -= lr*gQ[r]; gQ[r] = 0.  The touched rows are the
-// distinct items of the sorted entry list: the group that sees the head of an
-// item's run owns the row (dense != 0: every row, after an all-reduce of gQ).
-// WITH_REG: gQ holds the data term only and the regulariser share is added here
-// (single-GPU SGD step: saves one pass over the touched rows).
+// commit the item rows: Q[r] -= lr*gQ[r]; gQ[r] = 0, one lane group per distinct
+// item of the batch (head run of the plan's run list; dense != 0: every row, after an
+// all-reduce of gQ).  WITH_REG: gQ holds the data term only and the regulariser
+// share is added here (single-GPU SGD step: saves one pass over the touched rows).
 // ---------------------------------------------------------------------------
 template <class C, bool WITH_REG>
 __global__ __launch_bounds__(kBlock) void k_item_apply(float *__restrict__ Q, float *__restrict__ gQ,
-                                                       BatchView v, int64_t n, int d, float lr,
+                                                       BatchView v, int64_t n_dense, int d, float lr,
                                                        int dense, const double *__restrict__ stats,
                                                        float reg_1, float reg_2) {
     const int lane = threadIdx.x % C::LPR;
@@ -622,19 +663,17 @@ __global__ __launch_bounds__(kBlock) void k_item_apply(float *__restrict__ Q, fl
         rI = inv_or_zero(stats[DAISY_ST_NORM_I], reg_2);
         rJ = inv_or_zero(stats[DAISY_ST_NORM_J], reg_2);
     }
-    for (int64_t pos = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; pos < n; pos += gstride) {
-        int64_t r = pos;
-        if (!dense) {
-            r = (int64_t)(v.ekey[pos] & v.imask);
-            if (pos > 0 && (int64_t)(v.ekey[pos - 1] & v.imask) == r) continue;
-        }
+    const int64_t m0 = dense ? 0 : (int64_t)v.run_off[0];
+    const int64_t m1 = dense ? n_dense : (int64_t)v.run_off[1];
+    for (int64_t m = m0 + (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; m < m1; m += gstride) {
+        int64_t r = m;
+        float fp = 0.f, fn = 0.f;
+        if (!dense && !run_head(v, m, m0, m1, r, fp, fn)) continue;
         Row<C> g, q, z;
         g.load(gQ + r * d, lane, d);
         q.load(Q + r * d, lane, d);
         z.zero();
         if constexpr (WITH_REG) {
-            float fp, fn;
-            count_run<C>(v.ekey, v.imask, v.esu, pos, n, (int32_t)r, lane, fp, fn);
             const float w1 = reg_1 * (fp + fn), w2 = fp * rI + fn * rJ;
 #pragma unroll
             for (int k = 0; k < C::NE; ++k) g.v[k] += fmaf(w2, q.v[k], w1 * sgn(q.v[k]));
@@ -674,7 +713,10 @@ static int plan_alloc(daisy_epoch_plan **out, int64_t max_triples, int64_t U, in
     p->n = 0; p->batch_size = 0; p->num_batches = 0; p->built = false;
     const size_t n2 = 2 * (size_t)max_triples;
     const size_t ta = sort_pairs_u32_u64_temp_bytes(n2), tb = sort_pairs_u64_u64_temp_bytes(n2);
+    const size_t tc = rle_u32_temp_bytes(n2), td = rle_u64_temp_bytes(n2);
     p->temp_bytes = ta > tb ? ta : tb;
+    if (tc > p->temp_bytes) p->temp_bytes = tc;
+    if (td > p->temp_bytes) p->temp_bytes = td;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     size_t o_k32[2], o_v64[2];
@@ -682,6 +724,8 @@ static int plan_alloc(daisy_epoch_plan **out, int64_t max_triples, int64_t U, in
     o_v64[0] = take(n2 * 8); o_v64[1] = take(n2 * 8);
     const size_t o_s32 = take((size_t)max_triples * 4);   // sorted sample keys survive the entry sort
     const size_t o_sv = take((size_t)max_triples * 8);
+    const size_t o_ss = take(n2 * 4), o_sn = take(n2 * 4), o_so = take(((size_t)max_triples + 2) * 4);
+    const size_t o_rt = take(256);
     const size_t o_tmp = take(p->temp_bytes);
     p->arena_bytes = off;
     hipError_t e = hipMalloc(&p->arena, p->arena_bytes);
@@ -698,6 +742,10 @@ static int plan_alloc(daisy_epoch_plan **out, int64_t max_triples, int64_t U, in
     }
     p->ukey = (uint32_t *)(b + o_s32);
     p->uval = (uint64_t *)(b + o_sv);
+    p->run_key = (uint32_t *)(b + o_ss);
+    p->run_cnt = (uint32_t *)(b + o_sn);
+    p->run_off = (int32_t *)(b + o_so);
+    p->run_total = (uint32_t *)(b + o_rt);
     p->ekey = nullptr; p->eval = nullptr;
     p->umask = p->imask = 0;
     p->temp = b + o_tmp;
@@ -738,8 +786,9 @@ static int plan_build(daisy_epoch_plan *p, const int32_t *triples, int64_t n, in
     const int64_t nb = (n + batch_size - 1) / batch_size;
     const int bbits = (nb > 1) ? bits_for(nb) : 0;
     const uint32_t umask = (uint32_t)(((uint64_t)1 << ubits) - 1);
-    const uint32_t imask = (uint32_t)(((uint64_t)1 << ibits) - 1);
-    const bool wide = (ubits + bbits > 32) || (ibits + bbits > 32);
+    const int ibits1 = ibits + 1;                    // item << 1 | negative-slot bit
+    const uint32_t imask = (uint32_t)(((uint64_t)1 << ibits1) - 1);
+    const bool wide = (ubits + bbits > 32) || (ibits1 + bbits > 32);
     const bool presorted = (flags & DAISY_PLAN_TRIPLES_USER_SORTED) && order_mode != DAISY_ORDER_PERM;
     const int s_begin = presorted ? ubits : 0;      // user bits ride along unsorted
     FeistelKey fk = make_feistel_key((uint64_t)n, seed, epoch);
@@ -761,8 +810,14 @@ static int plan_build(daisy_epoch_plan *p, const int32_t *triples, int64_t n, in
                            n, batch_size, ibits, umask, p->k32[0], p->v64[0]);
         DAISY_LAUNCH_CHECK();
         rc = sort_pairs_u32_u64(p->temp, p->temp_bytes, p->k32[0], p->k32[1], p->v64[0], p->v64[1], 2 * n,
-                                0, ibits + bbits, s);
+                                0, ibits1 + bbits, s);
         if (rc) return rc;
+        // runs of equal (batch, item, slot) keys: the distinct items of every batch + their counts
+        rc = rle_u32(p->temp, p->temp_bytes, p->k32[1], 2 * n, p->k32[0], p->run_cnt, p->run_total, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_run_finish<uint32_t>), dim3(g2), dim3(kBlock), 0, s, p->k32[0], p->run_total,
+                           nb, ibits1, p->run_key, p->run_off);
+        DAISY_LAUNCH_CHECK();
         p->umask = umask;
         p->imask = imask;
     } else {
@@ -780,8 +835,13 @@ static int plan_build(daisy_epoch_plan *p, const int32_t *triples, int64_t n, in
                            n, batch_size, ibits, 0xFFFFFFFFu & umask, p->k64[0], p->v64[0]);
         DAISY_LAUNCH_CHECK();
         rc = sort_pairs_u64_u64(p->temp, p->temp_bytes, p->k64[0], p->k64[1], p->v64[0], p->v64[1], 2 * n,
-                                0, ibits + bbits, s);
+                                0, ibits1 + bbits, s);
         if (rc) return rc;
+        rc = rle_u64(p->temp, p->temp_bytes, p->k64[1], 2 * n, p->k64[0], p->run_cnt, p->run_total, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL((k_run_finish<uint64_t>), dim3(g2), dim3(kBlock), 0, s, p->k64[0], p->run_total,
+                           nb, ibits1, p->run_key, p->run_off);
+        DAISY_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_narrow_keys, dim3(g2), dim3(kBlock), 0, s, p->k64[1], 2 * n, (uint64_t)imask,
                            p->k32[1]);
         DAISY_LAUNCH_CHECK();
@@ -802,6 +862,9 @@ static BatchView plan_view(const daisy_epoch_plan *p, int64_t k) {
     v.ij = reinterpret_cast<const int2 *>(p->uval + lo);
     v.ekey = p->ekey + 2 * lo;
     v.esu = reinterpret_cast<const uint2 *>(p->eval + 2 * lo);
+    v.run_key = p->run_key;
+    v.run_cnt = p->run_cnt;
+    v.run_off = p->run_off + k;
     v.umask = p->umask;
     v.imask = p->imask;
     return v;
@@ -1035,7 +1098,7 @@ static int item_grad_impl(daisy_bpr_ctx *ctx, const float *P, const float *Q, co
                                dim3(kBlock), 0, s, P, ctx->coef, v, d, gQ);
             if (reg && !data_only)
                 hipLaunchKernelGGL((k_item_reg<C>),
-                                   dim3(grid_for(2 * v.B, C::GROUPS_PER_BLOCK * 2, kMaxGridSparse)),
+                                   dim3(grid_for(2 * v.B < ctx->I ? 2 * v.B : ctx->I, C::GROUPS_PER_BLOCK * 2)),
                                    dim3(kBlock), 0, s, Q, v, d, stats, reg_1, reg_2, gQ);
         } else if (reg) {
             hipLaunchKernelGGL((k_item_grad_atomic<C, true>), dim3(grid_for(v.B, C::GROUPS_PER_BLOCK * 4)),
@@ -1065,7 +1128,7 @@ static int user_pass(daisy_bpr_ctx *ctx, float *P, const float *Q, const double 
     const int d = ctx->d;
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
-        const int grid = grid_for(v.B, C::GROUPS_PER_BLOCK * 2, kMaxGridSparse);
+        const int grid = grid_for(v.B, C::GROUPS_PER_BLOCK * 2);
         if (sgd)
             hipLaunchKernelGGL((k_user<C, true>), dim3(grid), dim3(kBlock), 0, s, P, Q, v, ctx->coef, d,
                                stats, lr, reg_1, reg_2, gP);
@@ -1099,16 +1162,16 @@ static int item_apply_impl(daisy_bpr_ctx *ctx, float *Q, float *gQ, float lr, in
     hipStream_t s = S(stream);
     const int d = ctx->d;
     const BatchView &v = ctx->v;
-    const int64_t n = dense ? ctx->I : 2 * v.B;
+    const int64_t n = dense ? ctx->I : (2 * v.B < ctx->I ? 2 * v.B : ctx->I);   // upper bound of rows
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
-        const int grid = grid_for(n, C::GROUPS_PER_BLOCK * 2, dense ? kMaxGrid : kMaxGridSparse);
+        const int grid = grid_for(n, C::GROUPS_PER_BLOCK * 2);
         if (with_reg)
-            hipLaunchKernelGGL((k_item_apply<C, true>), dim3(grid), dim3(kBlock), 0, s, Q, gQ, v, n, d, lr,
-                               (int)dense, stats, reg_1, reg_2);
+            hipLaunchKernelGGL((k_item_apply<C, true>), dim3(grid), dim3(kBlock), 0, s, Q, gQ, v, ctx->I, d,
+                               lr, (int)dense, stats, reg_1, reg_2);
         else
-            hipLaunchKernelGGL((k_item_apply<C, false>), dim3(grid), dim3(kBlock), 0, s, Q, gQ, v, n, d, lr,
-                               (int)dense, stats, reg_1, reg_2);
+            hipLaunchKernelGGL((k_item_apply<C, false>), dim3(grid), dim3(kBlock), 0, s, Q, gQ, v, ctx->I, d,
+                               lr, (int)dense, stats, reg_1, reg_2);
         return DAISY_OK;
     });
     if (rc) return rc;

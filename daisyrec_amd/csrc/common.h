@@ -56,7 +56,7 @@ __device__ __forceinline__ void count_run(const uint32_t *__restrict__ ekey, uin
     int cp = 0, cn = 0;
     for (int64_t base = pos;; base += C::LPR) {
         const int64_t e = base + lane;
-        const bool v = (e < n) && ((int32_t)(ekey[e] & imask) == r);
+        const bool v = (e < n) && ((int32_t)((ekey[e] & imask) >> 1) == r);
         const bool ng = v && ((esu[e].x & 0x80000000u) != 0);
         const int cv = __popcll(__ballot(v) & gmask);
         const int cg = __popcll(__ballot(ng) & gmask);
@@ -253,6 +253,16 @@ size_t sort_pairs_i32_temp_bytes(int64_t n);
 // stable LSD radix sort of (key,val) int32 pairs on bits [0,end_bit)
 int sort_pairs_i32(void *temp, size_t temp_bytes, const int32_t *kin, int32_t *kout,
                    const int32_t *vin, int32_t *vout, int64_t n, int end_bit, hipStream_t s);
+size_t rle_u32_temp_bytes(int64_t n);
+// run-length encode: unique_out/counts_out get one entry per run, *runs_out the number of runs
+int rle_u32(void *temp, size_t temp_bytes, const uint32_t *in, int64_t n, uint32_t *unique_out,
+            uint32_t *counts_out, uint32_t *runs_out, hipStream_t s);
+size_t rle_u64_temp_bytes(int64_t n);
+int rle_u64(void *temp, size_t temp_bytes, const uint64_t *in, int64_t n, uint64_t *unique_out,
+            uint32_t *counts_out, uint32_t *runs_out, hipStream_t s);
+size_t exclusive_scan_u32_temp_bytes(int64_t n);
+int exclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, int64_t n,
+                       hipStream_t s);
 size_t sort_pairs_u32_u64_temp_bytes(int64_t n);
 int sort_pairs_u32_u64(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout,
                        const uint64_t *vin, uint64_t *vout, int64_t n, int begin_bit, int end_bit,

@@ -26,6 +26,48 @@ int sort_pairs_i32(void *temp, size_t temp_bytes, const int32_t *kin, int32_t *k
     return DAISY_OK;
 }
 
+size_t rle_u32_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    (void)rocprim::run_length_encode(nullptr, bytes, (const uint32_t *)nullptr, (unsigned)n,
+                                     (uint32_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    return bytes;
+}
+
+int rle_u32(void *temp, size_t temp_bytes, const uint32_t *in, int64_t n, uint32_t *unique_out,
+            uint32_t *counts_out, uint32_t *runs_out, hipStream_t s) {
+    DAISY_HIP(rocprim::run_length_encode(temp, temp_bytes, in, (unsigned)n, unique_out, counts_out,
+                                         runs_out, s));
+    return DAISY_OK;
+}
+
+size_t rle_u64_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    (void)rocprim::run_length_encode(nullptr, bytes, (const uint64_t *)nullptr, (unsigned)n,
+                                     (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr);
+    return bytes;
+}
+
+int rle_u64(void *temp, size_t temp_bytes, const uint64_t *in, int64_t n, uint64_t *unique_out,
+            uint32_t *counts_out, uint32_t *runs_out, hipStream_t s) {
+    DAISY_HIP(rocprim::run_length_encode(temp, temp_bytes, in, (unsigned)n, unique_out, counts_out,
+                                         runs_out, s));
+    return DAISY_OK;
+}
+
+size_t exclusive_scan_u32_temp_bytes(int64_t n) {
+    size_t bytes = 0;
+    (void)rocprim::exclusive_scan(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u,
+                                  (size_t)n, rocprim::plus<uint32_t>());
+    return bytes;
+}
+
+int exclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, int64_t n,
+                       hipStream_t s) {
+    DAISY_HIP(rocprim::exclusive_scan(temp, temp_bytes, in, out, 0u, (size_t)n,
+                                      rocprim::plus<uint32_t>(), s));
+    return DAISY_OK;
+}
+
 size_t sort_pairs_u32_u64_temp_bytes(int64_t n) {
     size_t bytes = 0;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,

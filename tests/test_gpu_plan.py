@@ -31,8 +31,8 @@ def _check_batch(plan, k, B, want_rows, U):
     assert np.array_equal(np.sort(s[~neg]), np.arange(b)) and np.array_equal(np.sort(s[neg]), np.arange(b))
     assert np.array_equal(ei[~neg], i[s[~neg]]) and np.array_equal(ei[neg], j[s[neg]])
     assert np.array_equal(eu, u[s])
-    # stable within an item: plan order of creation (pos slot 2p, neg slot 2p+1)
-    order_key = 2 * s + neg
+    # within an item: positive slots first, then negative slots, each in sample order
+    order_key = neg.astype(np.int64) * (1 << 40) + s
     for r in np.unique(ei)[:50]:
         m = ei == r
         assert np.all(np.diff(order_key[m]) > 0)
