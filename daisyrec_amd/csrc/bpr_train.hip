@@ -276,9 +276,18 @@ __global__ __launch_bounds__(kBlock) void k_fwd(const float *__restrict__ P,
     }
 }
 
-// fixed-order reduction of the per-workgroup sums -> stats[0..6]
+__device__ __forceinline__ void finalize_stats(double *__restrict__ stats, float reg_1, float reg_2,
+                                               double *__restrict__ epoch_acc,
+                                               double *__restrict__ step_loss);
+
+// fixed-order reduction of the per-workgroup sums -> stats[0..6]; FINALIZE: also the norms and
+// the loss (single-GPU step: no all-reduce between the two)
+template <bool FINALIZE>
 __global__ __launch_bounds__(kBlock) void k_reduce_partials(const double *__restrict__ partials,
-                                                            int nblocks, double *__restrict__ stats) {
+                                                            int nblocks, double *__restrict__ stats,
+                                                            float reg_1, float reg_2,
+                                                            double *__restrict__ epoch_acc,
+                                                            double *__restrict__ step_loss) {
     __shared__ double sm[kBlock][7];
     double t[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int b = threadIdx.x; b < nblocks; b += kBlock) {
@@ -296,12 +305,16 @@ __global__ __launch_bounds__(kBlock) void k_reduce_partials(const double *__rest
         __syncthreads();
     }
     if (threadIdx.x < 7) stats[threadIdx.x] = sm[0][threadIdx.x];
+    if constexpr (FINALIZE) {
+        __syncthreads();
+        if (threadIdx.x == 0) finalize_stats(stats, reg_1, reg_2, epoch_acc, step_loss);
+    }
 }
 
 // MFRecommender.py:88-89,94-95: loss += reg_1*(L1 terms) + reg_2*(Frobenius terms)
-__global__ void k_finalize(double *__restrict__ stats, float reg_1, float reg_2,
-                           double *__restrict__ epoch_acc, double *__restrict__ step_loss) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ __forceinline__ void finalize_stats(double *__restrict__ stats, float reg_1, float reg_2,
+                                               double *__restrict__ epoch_acc,
+                                               double *__restrict__ step_loss) {
     const double nU = sqrt(stats[DAISY_ST_SQ_U]);
     const double nI = sqrt(stats[DAISY_ST_SQ_I]);
     const double nJ = sqrt(stats[DAISY_ST_SQ_J]);
@@ -318,6 +331,11 @@ __global__ void k_finalize(double *__restrict__ stats, float reg_1, float reg_2,
         if (!(loss == loss) || isinf(loss)) epoch_acc[1] += 1.0;
     }
     if (step_loss) *step_loss = loss;
+}
+
+__global__ void k_finalize(double *__restrict__ stats, float reg_1, float reg_2,
+                           double *__restrict__ epoch_acc, double *__restrict__ step_loss) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) finalize_stats(stats, reg_1, reg_2, epoch_acc, step_loss);
 }
 
 __device__ __forceinline__ float inv_or_zero(double n, float reg_2) {
@@ -1042,8 +1060,9 @@ int daisy_bpr_set_batch(daisy_bpr_ctx *ctx, const int32_t *u, const int32_t *i, 
     return daisy_bpr_set_batch_from_triples(ctx, ctx->tmp_triples, B, nullptr, 0, B, 0, stream);
 }
 
-int daisy_bpr_forward(daisy_bpr_ctx *ctx, const float *P, const float *Q, int32_t loss_type,
-                      float gamma, double *stats, daisy_stream_t stream) {
+static int forward_impl(daisy_bpr_ctx *ctx, const float *P, const float *Q, int32_t loss_type,
+                        float gamma, double *stats, bool finalize, float reg_1, float reg_2,
+                        double *epoch_acc, double *step_loss, daisy_stream_t stream) {
     DAISY_CHECK_ARG(ctx && P && Q && stats, "forward: NULL argument");
     DAISY_CHECK_ARG(loss_type >= DAISY_LOSS_BPR && loss_type <= DAISY_LOSS_TL,
                     "Invalid loss type: %d", loss_type);
@@ -1061,10 +1080,20 @@ int daisy_bpr_forward(daisy_bpr_ctx *ctx, const float *P, const float *Q, int32_
     });
     if (rc) return rc;
     DAISY_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(kBlock), 0, s, ctx->partials, grid, stats);
+    if (finalize)
+        hipLaunchKernelGGL((k_reduce_partials<true>), dim3(1), dim3(kBlock), 0, s, ctx->partials, grid,
+                           stats, reg_1, reg_2, epoch_acc, step_loss);
+    else
+        hipLaunchKernelGGL((k_reduce_partials<false>), dim3(1), dim3(kBlock), 0, s, ctx->partials, grid,
+                           stats, 0.f, 0.f, nullptr, nullptr);
     DAISY_LAUNCH_CHECK();
     ctx->fwd_done = true;
     return DAISY_OK;
+}
+
+int daisy_bpr_forward(daisy_bpr_ctx *ctx, const float *P, const float *Q, int32_t loss_type,
+                      float gamma, double *stats, daisy_stream_t stream) {
+    return forward_impl(ctx, P, Q, loss_type, gamma, stats, false, 0.f, 0.f, nullptr, nullptr, stream);
 }
 
 int daisy_bpr_finalize(daisy_bpr_ctx *ctx, double *stats, float reg_1, float reg_2,
@@ -1200,8 +1229,8 @@ int daisy_bpr_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t loss_type
                        double *epoch_acc, double *step_loss, int32_t item_mode,
                        daisy_stream_t stream) {
     int rc;
-    if ((rc = daisy_bpr_forward(ctx, P, Q, loss_type, gamma, stats, stream))) return rc;
-    if ((rc = daisy_bpr_finalize(ctx, stats, reg_1, reg_2, epoch_acc, step_loss, stream))) return rc;
+    if ((rc = forward_impl(ctx, P, Q, loss_type, gamma, stats, true, reg_1, reg_2, epoch_acc, step_loss,
+                           stream))) return rc;
     // throughput mode: gQ carries the data term only, the commit kernel adds the regulariser
     const bool fold_reg = (item_mode == DAISY_ITEM_CHUNKED) && (reg_1 != 0.f || reg_2 != 0.f);
     if ((rc = item_grad_impl(ctx, P, Q, stats, reg_1, reg_2, gQ, item_mode, fold_reg, stream))) return rc;

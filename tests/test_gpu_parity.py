@@ -370,3 +370,39 @@ def test_c2_scale_step_properties(ops):
         untouched[ul] = False
         assert torch.equal(P1[untouched], P[untouched])
         ctx.close()
+
+
+def test_sharded_trainer_on_rccl_world1(ops):
+    """The multi-GPU step protocol (daisyrec_amd/sharding.py) on the real backend: with one rank
+    the RCCL all-reduces are identities, so the sharded step must equal daisy_bpr_sgd_step."""
+    import os
+    import torch.distributed as dist
+    from daisyrec_amd.sharding import UserShardedBprTrainer
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        rng = np.random.default_rng(11)
+        U, I, d, B = 400, 300, 64, 2048
+        P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+        Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+        tri = np.stack([rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)], 1).astype(np.int32)
+        loss, Pn, Qn = O.mf_sgd_step(P0, Q0, tri[:, 0], tri[:, 1], tri[:, 2], 0.01, 1e-3, 1e-3)
+        for overlap in (True, False):
+            P, Q = _t(P0), _t(Q0)
+            ctx = ops.BprContext(B, d, U, I)
+            tr = UserShardedBprTrainer(ctx, P, Q, 0, 0.01, 1e-3, 1e-3, overlap=overlap)
+            tr.world = 2 if overlap else 1          # force the collective + dense-apply code path
+            stats = tr.step_from_triples(_t(tri))
+            torch.cuda.synchronize()
+            assert abs(float(stats[7].cpu()) - loss) <= 1e-5 * abs(loss)
+            np.testing.assert_allclose(P.cpu().numpy(), Pn, atol=3e-6)
+            np.testing.assert_allclose(Q.cpu().numpy(), Qn, atol=3e-6)
+            assert float(ctx.gQ.abs().max().cpu()) == 0.0
+            ctx.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
