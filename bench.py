@@ -40,10 +40,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=1 << 20, help="interactions per GPU per step")
     ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c3", "tiny"])
-    ap.add_argument("--item-mode", default="chunked", choices=["chunked", "atomic", "sorted"])
+    ap.add_argument("--item-mode", default="chunked", choices=["fused", "chunked", "atomic", "sorted"])
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--reg", type=float, default=0.001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--overlap-plan", type=int, default=0, help="build the next epoch's plan on a side stream")
     ap.add_argument("--cpu-steps", type=int, default=3)
     return ap.parse_args()
 
@@ -147,23 +148,44 @@ def main():
     if a.steps is None:
         a.steps = full_batches                 # one epoch: exactly one plan build inside the timed region
 
-    state = {"epoch": 0, "k": None}
+    # Two plans in ping-pong: while epoch e trains on the main stream, the plan of epoch e+1
+    # (DataLoader(shuffle=True) on the device: a fresh keyed permutation, radix sorts lay the
+    # epoch out batch by batch grouped by user / by item) is built on a side stream.
+    plans = [plan, ops.EpochPlan(n, U_loc, I, device=dev)] if a.overlap_plan else [plan]
+    side = torch.cuda.Stream(device=dev) if a.overlap_plan else None
+    state = {"epoch": 0, "k": None, "cur": 0, "ready": None}
+
+    def build(slot, epoch, stream=None):
+        if stream is None:
+            plans[slot].build(triples, B, order="feistel", seed=2022 + rank, epoch=epoch, user_sorted=user_sorted)
+            return None
+        stream.wait_stream(torch.cuda.current_stream())      # the slot's previous epoch has been consumed
+        with torch.cuda.stream(stream):
+            plans[slot].build(triples, B, order="feistel", seed=2022 + rank, epoch=epoch, user_sorted=user_sorted)
+            return stream.record_event()
 
     def step():
         if state["k"] is None or state["k"] >= full_batches:
-            # DataLoader(shuffle=True) on the device: a fresh keyed permutation per epoch, one
-            # radix-sort pass lays the whole epoch out batch by batch (grouped by user / by item)
-            plan.build(triples, B, order="feistel", seed=2022 + rank, epoch=state["epoch"],
-                       user_sorted=user_sorted)
+            if not a.overlap_plan:
+                build(0, state["epoch"])
+            elif state["k"] is None:                              # cold start
+                build(0, state["epoch"])
+                state["cur"] = 0
+                state["ready"] = build(1, state["epoch"] + 1, side)
+            else:                                                 # steady state: swap, prefetch the next
+                torch.cuda.current_stream().wait_event(state["ready"])
+                state["cur"] ^= 1
+                state["ready"] = build(state["cur"] ^ 1, state["epoch"] + 1, side)
             state["epoch"] += 1
             state["k"] = 0
         k = state["k"]
         state["k"] += 1
+        pl = plans[state["cur"]]
         if trainer is None:
-            ctx.set_batch_from_plan(plan, k)
+            ctx.set_batch_from_plan(pl, k)
             ctx.sgd_step(P, Q, lr, reg, reg, item_mode=item_mode)
         else:
-            trainer.step_from_plan(plan, k)
+            trainer.step_from_plan(pl, k)
 
     def barrier():
         if world > 1:
@@ -172,9 +194,9 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    # start the timed region on an epoch boundary so that exactly the shuffles belonging to the
-    # timed steps are inside it
-    state["k"] = None
+    # start the timed region on an epoch boundary: every timed epoch then contains exactly one
+    # plan build (with --overlap-plan: the build of the NEXT epoch, running beside the steps)
+    state["k"] = full_batches if (a.overlap_plan and state["k"] is not None) else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
     barrier()
     t0 = time.perf_counter()
@@ -196,7 +218,8 @@ def main():
     if rank == 0:
         value = a.steps * B * world / dt
         algo = ALGO_BYTES_PER_INTERACTION_SGD(d) * B                       # bytes per step per GPU
-        achieved = algo / (gpu_ms_mean * 1e-3) / 1e9
+        eff_ms = max(gpu_ms_mean, dt / a.steps * 1e3) if world == 1 else gpu_ms_mean   # never better than wall
+        achieved = algo / (eff_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
@@ -213,11 +236,14 @@ def main():
                        "optimizer": "sgd", "lr": lr, "reg_1": reg, "reg_2": reg, "loss": "BPR",
                        "item_mode": a.item_mode, "id_distribution": a.dist, "interactions_per_gpu": n,
                        "parallelism": f"user-sharded dp{world}" if world > 1 else "single GPU",
-                       "plan_bytes": plan.nbytes,
+                       "plan_bytes": plan.nbytes * len(plans), "plan_overlapped": bool(a.overlap_plan),
                        "semantics": "batch-synchronous (autograd + SGD.step equivalent), shuffle=True (device Feistel permutation per epoch)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "one SGD step = k_fwd + k_reduce + k_finalize + k_item_grad_" + a.item_mode + " + k_user + k_item_apply (+ the epoch plan build amortised over its batches)",
+                         "kernel": ("one SGD step = k_unorm + k_user_fused + k_reduce_partials + k_item_grad_chunked + k_user_commit + k_item_apply"
+                                    if a.item_mode == "fused" else
+                                    "one SGD step = k_fwd + k_reduce_partials + k_item_grad_" + a.item_mode + " + k_user + k_item_apply")
+                                   + " (+ the epoch plan build amortised over its batches)",
                          "algorithmic_bytes_per_interaction": ALGO_BYTES_PER_INTERACTION_SGD(d),
                          "gpu_ms_per_step_events": gpu_ms_mean, "gpu_ms_per_step_median": step_ms[len(step_ms) // 2]},
         }

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libdaisyrec_hip.so")
 
 DAISY_OK, DAISY_ERR_ARG, DAISY_ERR_HIP, DAISY_ERR_STATE = 0, 1, 2, 3
 LOSS_BPR, LOSS_HL, LOSS_TL = 0, 1, 2
-ITEM_ATOMIC, ITEM_SORTED, ITEM_CHUNKED = 0, 1, 2
+ITEM_ATOMIC, ITEM_SORTED, ITEM_CHUNKED, ITEM_FUSED = 0, 1, 2, 3
 ORDER_IDENTITY, ORDER_PERM, ORDER_FEISTEL = 0, 1, 2
 PLAN_TRIPLES_USER_SORTED = 1
 STATS_LEN = 16

@@ -27,6 +27,8 @@
 //
 // HBM/L2 view: a d=64 row is 256 B = 16 lanes x float4, one coalesced request
 // per quarter wave; four rows are in flight per wave instruction.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace daisy {
@@ -84,6 +86,13 @@ struct daisy_bpr_ctx {
     float2 *coef;        // (dL/dpos, dL/dneg) per sample   [max_batch]
     double *partials;    // per-workgroup sums              [kMaxGrid*8]
     int32_t *tmp_triples;  // [max_batch*3] staging for daisy_bpr_set_batch
+    float *edge_vec;     // [2*nchunks][d] partial user gradients of runs that cross a chunk boundary
+    int32_t *edge_user;  // [2*nchunks]    their user (-1: none); [2c] head edge, [2c+1] tail edge
+    float *edge_n;       // [2*nchunks]    their sample counts
+    int32_t *edge_whole; // [nchunks]      the head edge's run also fills the whole chunk
+    float *p_stage;      // [max_batch][d] updated user rows of the fused step, committed after the item pass
+    float *p_sqnorm;     // [U] cache of |P[u]|^2 (fused step: the user-side Frobenius norm before the pass)
+    const float *p_sqnorm_of;   // table the cache describes (NULL = invalid)
     daisy_epoch_plan *own_plan;   // 1-batch plan used by set_batch / set_batch_from_triples
     daisy::BatchView v;
     bool batch_set, fwd_done;
@@ -442,21 +451,23 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_sorted(
 // written once: plain store if the segment lies inside the chunk, fp32 atomics
 // only when it is shared with a neighbouring chunk (<= 2 rows per chunk).
 // ---------------------------------------------------------------------------
-template <class C>
+template <class C, int RUN_OVERRIDE = 0>
 struct RunCfg {
-    // needs RUN + 2 <= LPR; RUN*NE row registers are live at once, keep that <= 32
-    static constexpr int RUN_BY_REGS = (C::NE <= 4) ? 8 : ((C::NE <= 8) ? 4 : 2);
-    static constexpr int RUN = (C::LPR >= 16) ? RUN_BY_REGS : (RUN_BY_REGS < C::LPR / 2 ? RUN_BY_REGS : C::LPR / 2);
+    // needs RUN <= LPR (lane x holds the metadata of entry x); RUN*NE row registers are live at once
+    static constexpr int RUN_BY_REGS = (C::NE <= 4) ? 16 : ((C::NE <= 8) ? 4 : 2);
+    static constexpr int RUN_AUTO = RUN_BY_REGS < C::LPR ? RUN_BY_REGS : C::LPR;
+    static constexpr int RUN = (RUN_OVERRIDE > 0 && RUN_OVERRIDE <= C::LPR) ? RUN_OVERRIDE : RUN_AUTO;
     static constexpr int G = C::GROUPS_PER_BLOCK;
     static constexpr int E = G * RUN;
 };
 
-template <class C>
+template <class C, int RUN_OVERRIDE = 0>
 __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__restrict__ P,
                                                               const float2 *__restrict__ coef,
                                                               BatchView v, int d,
                                                               float *__restrict__ gQ) {
-    constexpr int G = RunCfg<C>::G, RUN = RunCfg<C>::RUN, E = RunCfg<C>::E;
+    constexpr int G = RunCfg<C, RUN_OVERRIDE>::G, RUN = RunCfg<C, RUN_OVERRIDE>::RUN,
+                  E = RunCfg<C, RUN_OVERRIDE>::E;
     constexpr int ROWF = C::NE * C::LPR;
     __shared__ float slot_acc[(G + 1) * ROWF];
     __shared__ int slot_item[G + 1], slot_shared[G + 1];
@@ -474,23 +485,19 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
         const int64_t t1 = (t0 + RUN < n) ? (t0 + RUN) : n;
         const int cnt = (t0 < n) ? (int)(t1 - t0) : 0;       // entries of this run
 
-        // ---- hop 1: the run's metadata, lane x <- entry x; lane RUN <- the entry before
-        // the run, lane RUN+1 <- the entry after it
-        int32_t my_item = -1;
+        // ---- hop 1: the run's metadata, lane x <- entry x; plus the entries just before and
+        // after the run (same address on every lane: one request)
+        int32_t my_item = -1, item_prev = -1, item_next = -1;
         uint2 my_su = make_uint2(0u, 0u);
         if (lane < cnt) {
             my_item = (int32_t)((v.ekey[t0 + lane] & v.imask) >> 1);
             my_su = v.esu[t0 + lane];
-        } else if (lane == RUN && cnt > 0 && t0 > 0) {
-            my_item = (int32_t)((v.ekey[t0 - 1] & v.imask) >> 1);
-        } else if (lane == RUN + 1 && cnt > 0 && t1 < n) {
-            my_item = (int32_t)((v.ekey[t1] & v.imask) >> 1);
         }
+        if (cnt > 0 && t0 > 0) item_prev = (int32_t)((v.ekey[t0 - 1] & v.imask) >> 1);
+        if (cnt > 0 && t1 < n) item_next = (int32_t)((v.ekey[t1] & v.imask) >> 1);
         for (int e = tid; e < (G + 1) * ROWF; e += kBlock) slot_acc[e] = 0.f;
         if (tid <= G) { slot_item[tid] = -1; slot_shared[tid] = 0; }
         const int32_t item_first = __shfl(my_item, 0, C::LPR);
-        const int32_t item_prev = __shfl(my_item, RUN, C::LPR);
-        const int32_t item_next = __shfl(my_item, RUN + 1, C::LPR);
         const int32_t item_last = __shfl(my_item, cnt > 0 ? cnt - 1 : 0, C::LPR);
         if (lane == 0) {
             run_first[group] = cnt > 0 ? item_first : -2;
@@ -504,11 +511,19 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
             my_c = (my_su.x & kNegBit) ? c2.y : c2.x;
         }
         Row<C> p[RUN];
+        if (__all(cnt == RUN)) {        // wave-uniform: every run of this wave is full
 #pragma unroll
-        for (int x = 0; x < RUN; ++x) {
-            const uint32_t ux = __shfl(my_su.y, x, C::LPR);
-            if (x < cnt) p[x].load(P + (int64_t)ux * d, lane, d);
-            else p[x].zero();
+            for (int x = 0; x < RUN; ++x) {
+                const uint32_t ux = __shfl(my_su.y, x, C::LPR);
+                p[x].load(P + (int64_t)ux * d, lane, d);
+            }
+        } else {
+#pragma unroll
+            for (int x = 0; x < RUN; ++x) {
+                const uint32_t ux = __shfl(my_su.y, x, C::LPR);
+                if (x < cnt) p[x].load(P + (int64_t)ux * d, lane, d);
+                else p[x].zero();
+            }
         }
         __syncthreads();
 
@@ -700,6 +715,366 @@ __global__ __launch_bounds__(kBlock) void k_item_apply(float *__restrict__ Q, fl
         for (int k = 0; k < C::NE; ++k) q.v[k] = fmaf(-lr, g.v[k], q.v[k]);
         q.store(Q + r * d, lane, d);
         z.store(gQ + r * d, lane, d);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// user rows, throughput mode: the same run/slot scheme as k_item_grad_chunked over the
+// user-grouped samples, so every lane group streams RUN samples (2 item rows + the user
+// row each, all gathers in flight together) whatever the run lengths are.
+//   in-run user:            its group owns P[u]: P[u] -= lr*(sum + n*reg(p))     in place
+//   run crossing groups:    LDS slot, finished by one group after the barrier
+//   run crossing chunks:    partial (sum, n) to the chunk's head/tail EDGE record; k_user_edges
+//                           walks each chain from the chunk where the run starts and updates P[u]
+//                           (no global atomics, and P[u] is read before anybody writes it)
+// ---------------------------------------------------------------------------
+template <class C>
+struct UserRunCfg {
+    static constexpr int RUN = (C::LPR >= 4) ? 4 : C::LPR;
+    static constexpr int G = C::GROUPS_PER_BLOCK;
+    static constexpr int E = G * RUN;
+};
+
+template <class C>
+__device__ __forceinline__ void user_finish_row(Row<C> &p, const Row<C> &acc, float n, float lr,
+                                                float reg_1, float rU) {
+    const float w1 = reg_1 * n, w2 = rU * n;
+#pragma unroll
+    for (int k = 0; k < C::NE; ++k) {
+        const float g = acc.v[k] + fmaf(w2, p.v[k], w1 * sgn(p.v[k]));
+        p.v[k] = fmaf(-lr, g, p.v[k]);
+    }
+}
+
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_user_chunked(
+    float *__restrict__ P, const float *__restrict__ Q, BatchView v, const float2 *__restrict__ coef,
+    int d, const double *__restrict__ stats, float lr, float reg_1, float reg_2,
+    float *__restrict__ edge_vec, int32_t *__restrict__ edge_user, float *__restrict__ edge_n,
+    int32_t *__restrict__ edge_whole) {
+    constexpr int G = UserRunCfg<C>::G, RUN = UserRunCfg<C>::RUN, E = UserRunCfg<C>::E;
+    constexpr int ROWF = C::NE * C::LPR;
+    __shared__ float slot_acc[(G + 1) * ROWF];
+    __shared__ float slot_n[G + 1];
+    __shared__ int slot_user[G + 1], slot_next[G + 1];
+    __shared__ int run_first[G], run_last[G];
+
+    const int tid = threadIdx.x;
+    const int lane = tid % C::LPR;
+    const int group = tid / C::LPR;
+    const int64_t n = v.B;
+    const int64_t nchunks = (n + E - 1) / E;
+    const float rU = inv_or_zero(stats[DAISY_ST_NORM_U], reg_2);
+
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int64_t c0 = chunk * E;
+        const int64_t t0 = c0 + (int64_t)group * RUN;
+        const int64_t t1 = (t0 + RUN < n) ? (t0 + RUN) : n;
+        const int cnt = (t0 < n) ? (int)(t1 - t0) : 0;
+
+        // ---- hop 1: metadata of the run (lane x <- sample x) and its two neighbours
+        int32_t my_user = -1, user_prev = -1, user_next = -1;
+        int2 my_ij = make_int2(0, 0);
+        float2 my_c = make_float2(0.f, 0.f);
+        if (lane < cnt) {
+            my_user = (int32_t)(v.ukey[t0 + lane] & v.umask);
+            my_ij = v.ij[t0 + lane];
+            my_c = coef[t0 + lane];
+        }
+        if (cnt > 0 && t0 > 0) user_prev = (int32_t)(v.ukey[t0 - 1] & v.umask);
+        if (cnt > 0 && t1 < n) user_next = (int32_t)(v.ukey[t1] & v.umask);
+        for (int e = tid; e < (G + 1) * ROWF; e += kBlock) slot_acc[e] = 0.f;
+        if (tid <= G) { slot_user[tid] = -1; slot_n[tid] = 0.f; slot_next[tid] = 0; }
+        const int32_t user_first = __shfl(my_user, 0, C::LPR);
+        const int32_t user_last = __shfl(my_user, cnt > 0 ? cnt - 1 : 0, C::LPR);
+        if (lane == 0) {
+            run_first[group] = cnt > 0 ? user_first : -2;
+            run_last[group] = cnt > 0 ? user_last : -2;
+        }
+
+        // ---- hop 2: the three rows of every sample of the run
+        Row<C> qi[RUN], qj[RUN], pr[RUN];
+#pragma unroll
+        for (int x = 0; x < RUN; ++x) {
+            const int32_t ux = __shfl(my_user, x, C::LPR);
+            const int ix = __shfl(my_ij.x, x, C::LPR), jx = __shfl(my_ij.y, x, C::LPR);
+            if (x < cnt) {
+                qi[x].load(Q + (int64_t)ix * d, lane, d);
+                qj[x].load(Q + (int64_t)jx * d, lane, d);
+                pr[x].load(P + (int64_t)ux * d, lane, d);
+            } else {
+                qi[x].zero(); qj[x].zero(); pr[x].zero();
+            }
+        }
+        __syncthreads();
+
+        if (cnt > 0) {
+            const bool cont = (t0 > 0) && (user_prev == user_first);
+            int cur_slot = -1;
+            if (cont) {
+                if (group == 0) cur_slot = 0;
+                else {
+                    int gs = group - 1;
+                    while (gs > 0 && run_first[gs] == user_first && run_last[gs - 1] == user_first) --gs;
+                    const bool inherited = (gs == 0) && (run_first[0] == user_first) && (c0 > 0) &&
+                                           ((int32_t)(v.ukey[c0 - 1] & v.umask) == user_first);
+                    cur_slot = inherited ? 0 : gs + 1;
+                }
+            }
+            int32_t cur_user = user_first;
+            Row<C> pcur = pr[0];                     // P row of the current run's user
+            Row<C> acc;
+            acc.zero();
+            float cn_ = 0.f;
+            auto finish = [&](bool ends_here, bool to_next_chunk, const Row<C> &prow) {
+                if (cur_slot < 0 && ends_here) {     // this group owns P[cur_user]
+                    Row<C> pn = prow;
+                    user_finish_row<C>(pn, acc, cn_, lr, reg_1, rU);
+                    pn.store(P + (int64_t)cur_user * d, lane, d);
+                } else {
+                    const int s = (cur_slot >= 0) ? cur_slot : group + 1;
+                    float *dst = slot_acc + s * ROWF;
+#pragma unroll
+                    for (int k = 0; k < C::NE; ++k) atomicAdd(dst + k * C::LPR + lane, acc.v[k]);
+                    if (lane == 0) {
+                        slot_user[s] = cur_user;
+                        atomicAdd(&slot_n[s], cn_);
+                        if (to_next_chunk) slot_next[s] = 1;
+                    }
+                }
+            };
+#pragma unroll
+            for (int x = 0; x < RUN; ++x) {
+                if (x < cnt) {
+                    const int32_t ux = __shfl(my_user, x, C::LPR);
+                    const float cp = __shfl(my_c.x, x, C::LPR), cn = __shfl(my_c.y, x, C::LPR);
+                    if (ux != cur_user) {
+                        finish(true, false, pcur);
+                        cur_user = ux;
+                        cur_slot = -1;
+                        pcur = pr[x];
+                        acc.zero();
+                        cn_ = 0.f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < C::NE; ++k)
+                        acc.v[k] = fmaf(cp, qi[x].v[k], fmaf(cn, qj[x].v[k], acc.v[k]));
+                    cn_ += 1.f;
+                }
+            }
+            const bool continues = (t1 < n) && (user_next == cur_user);
+            finish(!continues, continues && (group == G - 1), pcur);
+        }
+        __syncthreads();
+
+        // ---- one finisher per used slot; runs shared with a neighbouring chunk go to the edges
+        if (tid == 0) { edge_user[2 * chunk] = -1; edge_user[2 * chunk + 1] = -1; edge_whole[chunk] = 0; }
+        __syncthreads();
+        for (int s = group; s <= G; s += G) {
+            const int uu = slot_user[s];
+            if (uu < 0) continue;
+            Row<C> g;
+            const float *src = slot_acc + s * ROWF;
+#pragma unroll
+            for (int k = 0; k < C::NE; ++k) g.v[k] = src[k * C::LPR + lane];
+            const float ns = slot_n[s];
+            const bool from_prev = (s == 0), to_next = slot_next[s] != 0;
+            if (!from_prev && !to_next) {
+                Row<C> p;
+                p.load(P + (int64_t)uu * d, lane, d);
+                user_finish_row<C>(p, g, ns, lr, reg_1, rU);
+                p.store(P + (int64_t)uu * d, lane, d);
+            } else {
+                const int64_t e = 2 * chunk + (from_prev ? 0 : 1);
+                g.store(edge_vec + e * d, lane, d);
+                if (lane == 0) {
+                    edge_user[e] = uu;
+                    edge_n[e] = ns;
+                    if (from_prev && to_next) edge_whole[chunk] = 1;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// chains of edge records: the chunk whose TAIL edge starts a run owns it
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_user_edges(float *__restrict__ P, int64_t nchunks, int d,
+                                                       const double *__restrict__ stats, float lr,
+                                                       float reg_1, float reg_2,
+                                                       const float *__restrict__ edge_vec,
+                                                       const int32_t *__restrict__ edge_user,
+                                                       const float *__restrict__ edge_n,
+                                                       const int32_t *__restrict__ edge_whole) {
+    const int lane = threadIdx.x % C::LPR;
+    const int group = threadIdx.x / C::LPR;
+    const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
+    const float rU = inv_or_zero(stats[DAISY_ST_NORM_U], reg_2);
+    for (int64_t c = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; c < nchunks; c += gstride) {
+        const int uu = edge_user[2 * c + 1];
+        if (uu < 0) continue;
+        Row<C> acc, t;
+        acc.load(edge_vec + (2 * c + 1) * d, lane, d);
+        float ns = edge_n[2 * c + 1];
+        for (int64_t k = c + 1; k < nchunks && edge_user[2 * k] == uu; ++k) {
+            t.load(edge_vec + (2 * k) * d, lane, d);
+#pragma unroll
+            for (int q = 0; q < C::NE; ++q) acc.v[q] += t.v[q];
+            ns += edge_n[2 * k];
+            if (!edge_whole[k]) break;
+        }
+        Row<C> p;
+        p.load(P + (int64_t)uu * d, lane, d);
+        user_finish_row<C>(p, acc, ns, lr, reg_1, rU);
+        p.store(P + (int64_t)uu * d, lane, d);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Fused single-GPU SGD step (throughput mode).  k_fwd and k_user read the same
+// rows; fusing them needs |P[u]|_F (a batch-wide sum) BEFORE the pass, which a
+// per-row cache of squared norms provides (k_unorm: 4 B per sample instead of a
+// 256-B row).  The pass cannot write P in place - the item pass that follows
+// still needs the pre-step rows - so each owner stages its new row and
+// k_user_commit copies it (and refreshes the cache) after the item pass:
+//   k_unorm -> k_user_fused (coef, sums, staged rows) -> k_reduce_partials<true>
+//   -> k_item_grad_chunked -> k_user_commit -> k_item_apply
+// Row traffic per interaction: 2.6 r + 0.6 w | 2 r | 0.6 r + 0.6 w  instead of
+// 3 r | 2 r | 2.6 r + 0.6 w.
+// ---------------------------------------------------------------------------
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_row_sqnorm(const float *__restrict__ W, int64_t rows, int d,
+                                                       float *__restrict__ out) {
+    const int lane = threadIdx.x % C::LPR;
+    const int group = threadIdx.x / C::LPR;
+    const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
+    for (int64_t r = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; r < rows; r += gstride) {
+        Row<C> w;
+        w.load(W + r * d, lane, d);
+        const float s = row_dot<C>(w, w);
+        if (lane == 0) out[r] = s;
+    }
+}
+
+// partials[block] = sum over the block's samples of |P[u_s]|^2 (from the cache)
+__global__ __launch_bounds__(kBlock) void k_unorm(const float *__restrict__ p_sqnorm, BatchView v,
+                                                  double *__restrict__ partials) {
+    double acc = 0.0;
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < v.B;
+         s += (int64_t)gridDim.x * blockDim.x)
+        acc += (double)p_sqnorm[v.ukey[s] & v.umask];
+    __shared__ double sm[kBlock / kWave];
+    const double w = wave_sum_f64(acc);
+    if ((threadIdx.x % kWave) == 0) sm[threadIdx.x / kWave] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < kBlock / kWave; ++k) t += sm[k];
+        partials[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_unorm_reduce(const double *__restrict__ partials, int nblocks,
+                                                         double *__restrict__ stats) {
+    __shared__ double sm[kBlock];
+    double t = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) t += partials[b];
+    sm[threadIdx.x] = t;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) stats[DAISY_ST_NORM_U_PRE] = sqrt(sm[0]);
+}
+
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_user_fused(const float *__restrict__ P,
+                                                       const float *__restrict__ Q, BatchView v, int d,
+                                                       int loss_type, float gamma,
+                                                       const double *__restrict__ stats, float lr,
+                                                       float reg_1, float reg_2,
+                                                       float2 *__restrict__ coef,
+                                                       float *__restrict__ p_stage,
+                                                       double *__restrict__ partials) {
+    const int lane = threadIdx.x % C::LPR;
+    const int group = threadIdx.x / C::LPR;
+    const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
+    const float rU = inv_or_zero(stats[DAISY_ST_NORM_U_PRE], reg_2);
+    float acc7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int64_t pos = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; pos < v.B; pos += gstride) {
+        const uint32_t uu = v.ukey[pos] & v.umask;
+        if (pos > 0 && (v.ukey[pos - 1] & v.umask) == uu) continue;  // not the head of this user's run
+        Row<C> p, acc;
+        p.load(P + (int64_t)uu * d, lane, d);
+        acc.zero();
+        float n = 0.f;
+        for (int64_t q = pos; q < v.B && (v.ukey[q] & v.umask) == uu; ++q) {
+            const int2 ij = v.ij[q];
+            Row<C> qi, qj;
+            qi.load(Q + (int64_t)ij.x * d, lane, d);
+            qj.load(Q + (int64_t)ij.y * d, lane, d);
+            const float sp = row_dot<C>(p, qi);
+            const float sn = row_dot<C>(p, qj);
+            float term, cp, cn;
+            pair_coef(loss_type, sp, sn, gamma, term, cp, cn);   // every lane of the group: same values
+#pragma unroll
+            for (int k = 0; k < C::NE; ++k) {
+                acc.v[k] = fmaf(cp, qi.v[k], fmaf(cn, qj.v[k], acc.v[k]));
+                acc7[2] += fabsf(qi.v[k]);
+                acc7[3] += fabsf(qj.v[k]);
+                acc7[5] = fmaf(qi.v[k], qi.v[k], acc7[5]);
+                acc7[6] = fmaf(qj.v[k], qj.v[k], acc7[6]);
+            }
+            if (lane == 0) {
+                coef[q] = make_float2(cp, cn);
+                acc7[0] += term;
+            }
+            n += 1.f;
+        }
+        const float w1 = reg_1 * n, w2 = rU * n;
+#pragma unroll
+        for (int k = 0; k < C::NE; ++k) {
+            acc7[1] = fmaf(n, fabsf(p.v[k]), acc7[1]);
+            acc7[4] = fmaf(n * p.v[k], p.v[k], acc7[4]);
+            const float g = acc.v[k] + fmaf(w2, p.v[k], w1 * sgn(p.v[k]));
+            p.v[k] = fmaf(-lr, g, p.v[k]);
+        }
+        p.store(p_stage + pos * d, lane, d);
+    }
+    __shared__ double sm[kBlock / kWave][8];
+    const int wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const double w = wave_sum_f64((double)acc7[k]);
+        if ((threadIdx.x % kWave) == 0) sm[wave][k] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBlock / kWave; ++w) t += sm[w][threadIdx.x];
+        partials[(int64_t)blockIdx.x * 8 + threadIdx.x] = t;
+    }
+}
+
+// staged rows -> P (single owner per user run); refresh the squared-norm cache
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_user_commit(float *__restrict__ P, BatchView v, int d,
+                                                        const float *__restrict__ p_stage,
+                                                        float *__restrict__ p_sqnorm) {
+    const int lane = threadIdx.x % C::LPR;
+    const int group = threadIdx.x / C::LPR;
+    const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
+    for (int64_t pos = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; pos < v.B; pos += gstride) {
+        const uint32_t uu = v.ukey[pos] & v.umask;
+        if (pos > 0 && (v.ukey[pos - 1] & v.umask) == uu) continue;
+        Row<C> p;
+        p.load(p_stage + pos * d, lane, d);
+        p.store(P + (int64_t)uu * d, lane, d);
+        const float s = row_dot<C>(p, p);
+        if (lane == 0) p_sqnorm[uu] = s;
     }
 }
 
@@ -975,6 +1350,11 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
     const size_t o_coef = take((size_t)max_batch * 8);
     const size_t o_part = take((size_t)kMaxGrid * 8 * 8);
     const size_t o_tt = take((size_t)max_batch * 12);
+    const size_t n_edge = 2 * ((size_t)max_batch / 32 + 2);   // chunks hold >= 32 samples
+    const size_t o_ev = take(n_edge * (size_t)d * 4), o_eu = take(n_edge * 4), o_en = take(n_edge * 4);
+    const size_t o_ew = take(n_edge * 4);
+    const size_t o_ps = take((size_t)max_batch * (size_t)d * 4);
+    const size_t o_pn = take((size_t)user_num * 4);
     c->arena_bytes = off;
     hipError_t e = hipMalloc(&c->arena, c->arena_bytes);
     if (e != hipSuccess) {
@@ -986,6 +1366,13 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
     c->coef = (float2 *)(base + o_coef);
     c->partials = (double *)(base + o_part);
     c->tmp_triples = (int32_t *)(base + o_tt);
+    c->edge_vec = (float *)(base + o_ev);
+    c->edge_user = (int32_t *)(base + o_eu);
+    c->edge_n = (float *)(base + o_en);
+    c->edge_whole = (int32_t *)(base + o_ew);
+    c->p_stage = (float *)(base + o_ps);
+    c->p_sqnorm = (float *)(base + o_pn);
+    c->p_sqnorm_of = nullptr;
     *out = c;
     return DAISY_OK;
 }
@@ -1109,6 +1496,7 @@ static int item_grad_impl(daisy_bpr_ctx *ctx, const float *P, const float *Q, co
                           float reg_1, float reg_2, float *gQ, int32_t item_mode, bool data_only,
                           daisy_stream_t stream) {
     DAISY_CHECK_ARG(ctx && P && Q && stats && gQ, "item_grad: NULL argument");
+    if (item_mode == DAISY_ITEM_FUSED) item_mode = DAISY_ITEM_CHUNKED;   // phase API: same item kernel
     DAISY_CHECK_ARG(item_mode >= DAISY_ITEM_ATOMIC && item_mode <= DAISY_ITEM_CHUNKED,
                     "item_grad: bad item_mode %d", item_mode);
     if (!ctx->fwd_done) { set_error("item_grad: forward has not run for this batch"); return DAISY_ERR_STATE; }
@@ -1123,8 +1511,20 @@ static int item_grad_impl(daisy_bpr_ctx *ctx, const float *P, const float *Q, co
                                dim3(grid_for(2 * v.B, C::GROUPS_PER_BLOCK, kMaxGridSparse)), dim3(kBlock), 0,
                                s, P, Q, ctx->coef, v, d, stats, reg_1, reg_2, gQ);
         } else if (item_mode == DAISY_ITEM_CHUNKED) {
-            hipLaunchKernelGGL((k_item_grad_chunked<C>), dim3(grid_for(2 * v.B, RunCfg<C>::E)),
-                               dim3(kBlock), 0, s, P, ctx->coef, v, d, gQ);
+            static const int tune_run = getenv("DAISY_CHUNK_RUN") ? atoi(getenv("DAISY_CHUNK_RUN")) : 0;
+            static const int tune_cap = getenv("DAISY_CHUNK_GRID") ? atoi(getenv("DAISY_CHUNK_GRID")) : 16384;
+            if (tune_run == 4)
+                hipLaunchKernelGGL((k_item_grad_chunked<C, 4>), dim3(grid_for(2 * v.B, RunCfg<C, 4>::E, tune_cap)),
+                                   dim3(kBlock), 0, s, P, ctx->coef, v, d, gQ);
+            else if (tune_run == 16)
+                hipLaunchKernelGGL((k_item_grad_chunked<C, 16>), dim3(grid_for(2 * v.B, RunCfg<C, 16>::E, tune_cap)),
+                                   dim3(kBlock), 0, s, P, ctx->coef, v, d, gQ);
+            else if (tune_run == 12)
+                hipLaunchKernelGGL((k_item_grad_chunked<C, 12>), dim3(grid_for(2 * v.B, RunCfg<C, 12>::E, tune_cap)),
+                                   dim3(kBlock), 0, s, P, ctx->coef, v, d, gQ);
+            else
+                hipLaunchKernelGGL((k_item_grad_chunked<C>), dim3(grid_for(2 * v.B, RunCfg<C>::E, tune_cap)),
+                                   dim3(kBlock), 0, s, P, ctx->coef, v, d, gQ);
             if (reg && !data_only)
                 hipLaunchKernelGGL((k_item_reg<C>),
                                    dim3(grid_for(2 * v.B < ctx->I ? 2 * v.B : ctx->I, C::GROUPS_PER_BLOCK * 2)),
@@ -1150,15 +1550,26 @@ int daisy_bpr_item_grad(daisy_bpr_ctx *ctx, const float *P, const float *Q, cons
 }
 
 static int user_pass(daisy_bpr_ctx *ctx, float *P, const float *Q, const double *stats, float lr,
-                     float reg_1, float reg_2, float *gP, bool sgd, daisy_stream_t stream) {
+                     float reg_1, float reg_2, float *gP, bool sgd, daisy_stream_t stream,
+                     bool chunked = false) {
+    ctx->p_sqnorm_of = nullptr;   // P rows change (or an optimiser outside will change them)
     if (!ctx->fwd_done) { set_error("user update: forward has not run for this batch"); return DAISY_ERR_STATE; }
     hipStream_t s = S(stream);
     const BatchView &v = ctx->v;
     const int d = ctx->d;
+    static const int user_kernel = getenv("DAISY_USER_KERNEL") ? atoi(getenv("DAISY_USER_KERNEL")) : 1;
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
         const int grid = grid_for(v.B, C::GROUPS_PER_BLOCK * 2);
-        if (sgd)
+        if (sgd && chunked && user_kernel == 1 && C::NE <= 4) {
+            const int64_t nchunks = (v.B + UserRunCfg<C>::E - 1) / UserRunCfg<C>::E;
+            hipLaunchKernelGGL((k_user_chunked<C>), dim3(grid_for(nchunks, 1, 16384)), dim3(kBlock), 0, s, P, Q,
+                               v, ctx->coef, d, stats, lr, reg_1, reg_2, ctx->edge_vec, ctx->edge_user,
+                               ctx->edge_n, ctx->edge_whole);
+            hipLaunchKernelGGL((k_user_edges<C>), dim3(grid_for(nchunks, C::GROUPS_PER_BLOCK)), dim3(kBlock),
+                               0, s, P, nchunks, d, stats, lr, reg_1, reg_2, ctx->edge_vec, ctx->edge_user,
+                               ctx->edge_n, ctx->edge_whole);
+        } else if (sgd)
             hipLaunchKernelGGL((k_user<C, true>), dim3(grid), dim3(kBlock), 0, s, P, Q, v, ctx->coef, d,
                                stats, lr, reg_1, reg_2, gP);
         else
@@ -1224,17 +1635,60 @@ int daisy_adam_dense(float *W, float *g, float *m, float *v, int64_t n, float lr
     return DAISY_OK;
 }
 
+// throughput mode of one whole step (see the comment above k_row_sqnorm)
+static int sgd_step_fused(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t loss_type, float gamma, float lr,
+                          float reg_1, float reg_2, float *gQ, double *stats, double *epoch_acc,
+                          double *step_loss, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(ctx && P && Q && gQ && stats, "sgd_step: NULL argument");
+    DAISY_CHECK_ARG(loss_type >= DAISY_LOSS_BPR && loss_type <= DAISY_LOSS_TL, "Invalid loss type: %d",
+                    loss_type);
+    if (!ctx->batch_set) { set_error("sgd_step: no batch set"); return DAISY_ERR_STATE; }
+    hipStream_t s = S(stream);
+    const BatchView &v = ctx->v;
+    const int d = ctx->d;
+    const bool reg = (reg_1 != 0.f) || (reg_2 != 0.f);
+    int rc = dispatch_d(d, [&](auto cfg) {
+        using C = decltype(cfg);
+        if (ctx->p_sqnorm_of != P) {   // (re)build the squared-norm cache: one dense pass over P
+            hipLaunchKernelGGL((k_row_sqnorm<C>), dim3(grid_for(ctx->U, C::GROUPS_PER_BLOCK * 4)),
+                               dim3(kBlock), 0, s, P, ctx->U, d, ctx->p_sqnorm);
+            ctx->p_sqnorm_of = P;
+        }
+        const int gn = grid_for(v.B, kBlock * 4);
+        hipLaunchKernelGGL(k_unorm, dim3(gn), dim3(kBlock), 0, s, ctx->p_sqnorm, v, ctx->partials);
+        hipLaunchKernelGGL(k_unorm_reduce, dim3(1), dim3(kBlock), 0, s, ctx->partials, gn, stats);
+        const int gu = grid_for(v.B, C::GROUPS_PER_BLOCK * 2);
+        hipLaunchKernelGGL((k_user_fused<C>), dim3(gu), dim3(kBlock), 0, s, P, Q, v, d, (int)loss_type,
+                           gamma, stats, lr, reg_1, reg_2, ctx->coef, ctx->p_stage, ctx->partials);
+        hipLaunchKernelGGL((k_reduce_partials<true>), dim3(1), dim3(kBlock), 0, s, ctx->partials, gu, stats,
+                           reg_1, reg_2, epoch_acc, step_loss);
+        hipLaunchKernelGGL((k_item_grad_chunked<C>), dim3(grid_for(2 * v.B, RunCfg<C>::E)), dim3(kBlock), 0,
+                           s, P, ctx->coef, v, d, gQ);
+        hipLaunchKernelGGL((k_user_commit<C>), dim3(gu), dim3(kBlock), 0, s, P, v, d, ctx->p_stage,
+                           ctx->p_sqnorm);
+        return DAISY_OK;
+    });
+    if (rc) return rc;
+    DAISY_LAUNCH_CHECK();
+    ctx->fwd_done = true;
+    return item_apply_impl(ctx, Q, gQ, lr, 0, stats, reg_1, reg_2, reg, stream);
+}
+
 int daisy_bpr_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t loss_type, float gamma,
                        float lr, float reg_1, float reg_2, float *gQ, double *stats,
                        double *epoch_acc, double *step_loss, int32_t item_mode,
                        daisy_stream_t stream) {
+    if (item_mode == DAISY_ITEM_FUSED)
+        return sgd_step_fused(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, gQ, stats, epoch_acc,
+                              step_loss, stream);
     int rc;
     if ((rc = forward_impl(ctx, P, Q, loss_type, gamma, stats, true, reg_1, reg_2, epoch_acc, step_loss,
                            stream))) return rc;
     // throughput mode: gQ carries the data term only, the commit kernel adds the regulariser
     const bool fold_reg = (item_mode == DAISY_ITEM_CHUNKED) && (reg_1 != 0.f || reg_2 != 0.f);
     if ((rc = item_grad_impl(ctx, P, Q, stats, reg_1, reg_2, gQ, item_mode, fold_reg, stream))) return rc;
-    if ((rc = daisy_bpr_user_sgd(ctx, P, Q, stats, lr, reg_1, reg_2, stream))) return rc;
+    if ((rc = user_pass(ctx, P, Q, stats, lr, reg_1, reg_2, nullptr, true, stream,
+                        item_mode == DAISY_ITEM_CHUNKED))) return rc;
     if ((rc = item_apply_impl(ctx, Q, gQ, lr, 0, stats, reg_1, reg_2, fold_reg, stream))) return rc;
     return DAISY_OK;
 }

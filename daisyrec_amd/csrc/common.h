@@ -75,11 +75,14 @@ __device__ __forceinline__ void count_run(const uint32_t *__restrict__ ekey, uin
 // global_load_dwordx4 and LPR lanes read LPR*16 contiguous bytes: d=64 -> 16
 // lanes x 16 B = one 256-B row per quarter wave, fully coalesced.
 // ----------------------------------------------------------------------------
-template <int LPR_, int VEC_, int NV_>
+// EXACT: d == LPR*VEC*NV, so no per-chunk bounds test (each test costs an exec-mask branch
+// around the load; the common d = 32/64/128/256 take this path).
+template <int LPR_, int VEC_, int NV_, bool EXACT_ = false>
 struct RowCfg {
     static constexpr int LPR = LPR_;
     static constexpr int VEC = VEC_;
     static constexpr int NV = NV_;
+    static constexpr bool EXACT = EXACT_;
     static constexpr int NE = VEC_ * NV_;            // floats per lane
     static constexpr int GROUPS_PER_WAVE = kWave / LPR_;
     static constexpr int GROUPS_PER_BLOCK = kBlock / LPR_;
@@ -100,10 +103,10 @@ struct Row {
             const int e = (c * C::LPR + lane) * C::VEC;
             if constexpr (C::VEC == 4) {
                 float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (e < d) t = *reinterpret_cast<const float4 *>(row + e);
+                if (C::EXACT || e < d) t = *reinterpret_cast<const float4 *>(row + e);
                 v[c * 4 + 0] = t.x; v[c * 4 + 1] = t.y; v[c * 4 + 2] = t.z; v[c * 4 + 3] = t.w;
             } else {
-                v[c] = (e < d) ? row[e] : 0.f;
+                v[c] = (C::EXACT || e < d) ? row[e] : 0.f;
             }
         }
     }
@@ -111,7 +114,7 @@ struct Row {
 #pragma unroll
         for (int c = 0; c < C::NV; ++c) {
             const int e = (c * C::LPR + lane) * C::VEC;
-            if (e < d) {
+            if (C::EXACT || e < d) {
                 if constexpr (C::VEC == 4) {
                     *reinterpret_cast<float4 *>(row + e) =
                         make_float4(v[c * 4 + 0], v[c * 4 + 1], v[c * 4 + 2], v[c * 4 + 3]);
@@ -126,7 +129,7 @@ struct Row {
 #pragma unroll
         for (int c = 0; c < C::NV; ++c) {
             const int e = (c * C::LPR + lane) * C::VEC;
-            if (e < d) {
+            if (C::EXACT || e < d) {
 #pragma unroll
                 for (int k = 0; k < C::VEC; ++k) unsafeAtomicAdd(row + e + k, v[c * C::VEC + k]);
             }
@@ -164,6 +167,10 @@ inline int dispatch_d(int d, F &&f) {
         set_error("unsupported factor count d=%d (1..%d)", d, kMaxD);
         return DAISY_ERR_ARG;
     }
+    if (d == 32) return f(RowCfg<8, 4, 1, true>{});
+    if (d == 64) return f(RowCfg<16, 4, 1, true>{});
+    if (d == 128) return f(RowCfg<16, 4, 2, true>{});
+    if (d == 256) return f(RowCfg<16, 4, 4, true>{});
     if (d % 4 == 0) {
         if (d <= 32) return f(RowCfg<8, 4, 1>{});
         if (d <= 64) return f(RowCfg<16, 4, 1>{});

@@ -14,7 +14,8 @@ from . import _native as N
 from ._native import check, lib
 
 LOSS_IDS = {"BPR": N.LOSS_BPR, "HL": N.LOSS_HL, "TL": N.LOSS_TL}
-ITEM_MODES = {"atomic": N.ITEM_ATOMIC, "sorted": N.ITEM_SORTED, "chunked": N.ITEM_CHUNKED}
+ITEM_MODES = {"atomic": N.ITEM_ATOMIC, "sorted": N.ITEM_SORTED, "chunked": N.ITEM_CHUNKED,
+              "fused": N.ITEM_FUSED}
 ORDER_MODES = {"identity": N.ORDER_IDENTITY, "perm": N.ORDER_PERM, "feistel": N.ORDER_FEISTEL}
 
 

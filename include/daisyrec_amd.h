@@ -49,7 +49,9 @@ enum daisy_loss {
 enum daisy_item_mode {
     DAISY_ITEM_ATOMIC = 0,  /* one fp32 atomic row per entry (kept for A/B measurements only) */
     DAISY_ITEM_SORTED = 1,  /* one owner per row, entries summed in plan order: bitwise reproducible */
-    DAISY_ITEM_CHUNKED = 2  /* segmented reduction through LDS accumulators (throughput mode) */
+    DAISY_ITEM_CHUNKED = 2, /* segmented reduction through LDS accumulators (throughput mode) */
+    DAISY_ITEM_FUSED = 3    /* daisy_bpr_sgd_step only: CHUNKED item kernel + forward fused into the
+                               user pass (per-row norm cache, staged user rows); elsewhere = CHUNKED */
 };
 
 /* order of an epoch (what DataLoader(shuffle=...) decides, dataset.py:5-7) */
@@ -72,6 +74,7 @@ enum daisy_stats_slot {
     DAISY_ST_NORM_U = 8,    /* |P[u]|_F (written by finalize)                  */
     DAISY_ST_NORM_I = 9,
     DAISY_ST_NORM_J = 10,
+    DAISY_ST_NORM_U_PRE = 11, /* |P[u]|_F from the row-norm cache (fused step only)   */
     DAISY_STATS_LEN = 16
 };
 

@@ -28,7 +28,7 @@ def ops():
 
 
 # ------------------------------------------------------------------ per-step KATs
-@pytest.mark.parametrize("item_mode", ["sorted", "atomic", "chunked"])
+@pytest.mark.parametrize("item_mode", ["sorted", "atomic", "chunked", "fused"])
 def test_kat_steps_sgd(ops, kat_steps, item_mode):
     g = kat_steps
     for name in g["names"]:
@@ -89,7 +89,7 @@ def test_step_vs_oracle_shapes(ops, d):
     lr, r1, r2 = 0.05, 0.01, 0.02
     for lt_name in ("BPR", "HL", "TL"):
         loss, Pn, Qn = O.mf_sgd_step(P0, Q0, u, i, j, lr, r1, r2, O.LOSS_IDS[lt_name])
-        for mode in ("sorted", "atomic", "chunked"):
+        for mode in ("sorted", "atomic", "chunked", "fused"):
             P, Q = _t(P0), _t(Q0)
             ctx = ops.BprContext(B, d, U, I)
             sl = torch.zeros(1, dtype=torch.float64, device=DEV)
@@ -112,7 +112,7 @@ def test_step_vs_oracle_batch_sizes(ops, B):
     i = rng.integers(0, I, B).astype(np.int32)
     j = rng.integers(0, I, B).astype(np.int32)
     loss, Pn, Qn = O.mf_sgd_step(P0, Q0, u, i, j, 0.01, 1e-3, 1e-3)
-    for mode in ("sorted", "atomic", "chunked"):
+    for mode in ("sorted", "atomic", "chunked", "fused"):
         P, Q = _t(P0), _t(Q0)
         ctx = ops.BprContext(max(B, 8), d, U, I)
         sl = torch.zeros(1, dtype=torch.float64, device=DEV)
@@ -311,7 +311,7 @@ def test_ml100k_atomic_mode_and_adam_run(ml100k):
     from daisyrec_amd.model.MFRecommender import MF
     from daisyrec_amd.utils.dataset import BasicDataset, get_dataloader
     g = ml100k
-    cfg = mf_config(user_num=int(g["user_num"]), item_num=int(g["item_num"]), epochs=2, item_mode="atomic")
+    cfg = mf_config(user_num=int(g["user_num"]), item_num=int(g["item_num"]), epochs=2, item_mode="fused")
     torch.manual_seed(int(g["seed"]))
     model = MF(cfg)
     loader = get_dataloader(BasicDataset(g["samples"]), batch_size=256, shuffle=True, num_workers=0)
@@ -354,7 +354,7 @@ def test_c2_scale_step_properties(ops):
     Pn.index_add_(0, ul, -lr * (c * (qi - qj) + r1 * pu.sign() + r2 * pu / nU.float()))
     Qn.index_add_(0, il, -lr * (c * pu + r1 * qi.sign() + r2 * qi / nI.float()))
     Qn.index_add_(0, jl, -lr * (-c * pu + r1 * qj.sign() + r2 * qj / nJ.float()))
-    for mode in ("chunked", "atomic", "sorted"):
+    for mode in ("fused", "chunked", "atomic", "sorted"):
         P1, Q1 = P.clone(), Q.clone()
         ctx = ops.BprContext(B, d, U, I)
         sl = torch.zeros(1, dtype=torch.float64, device=DEV)
@@ -406,3 +406,25 @@ def test_sharded_trainer_on_rccl_world1(ops):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("U,B", [(7, 3000), (40, 3000), (300, 3000), (100000, 2500), (3, 64)])
+def test_user_chunked_long_and_short_runs(ops, U, B):
+    """k_user_chunked / k_user_edges: user runs inside a lane group, across groups, across
+    chunks (a user filling several whole chunks when U is tiny) must all reduce to the same
+    update as the oracle."""
+    rng = np.random.default_rng(U + B)
+    I, d = 50, 64
+    P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    u = rng.integers(0, U, B).astype(np.int32)
+    i = rng.integers(0, I, B).astype(np.int32)
+    j = rng.integers(0, I, B).astype(np.int32)
+    loss, Pn, Qn = O.mf_sgd_step(P0, Q0, u, i, j, 0.003, 1e-3, 1e-3)
+    P, Q = _t(P0), _t(Q0)
+    ctx = ops.BprContext(B, d, U, I)
+    ctx.set_batch(_t(u), _t(i), _t(j))
+    ctx.sgd_step(P, Q, 0.003, 1e-3, 1e-3, item_mode=ops.ITEM_MODES["chunked"])
+    np.testing.assert_allclose(P.cpu().numpy(), Pn, rtol=0, atol=5e-6)
+    np.testing.assert_allclose(Q.cpu().numpy(), Qn, rtol=0, atol=5e-6)
+    ctx.close()

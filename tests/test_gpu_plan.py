@@ -104,7 +104,7 @@ def test_fit_epoch_over_plan_matches_oracle_order():
         rows = tri[inv[s:s + B]]
         loss, P, Q = O.mf_sgd_step(P, Q, rows[:, 0], rows[:, 1], rows[:, 2], 0.02, 1e-3, 1e-3)
         losses.append(loss)
-    for mode in ("sorted", "chunked"):
+    for mode in ("sorted", "chunked", "fused"):
         Pd, Qd = torch.from_numpy(P0).to(DEV), torch.from_numpy(Q0).to(DEV)
         ctx = ops.BprContext(B, d, U, I)
         plan = ops.EpochPlan(n, U, I).build(torch.from_numpy(tri).to(DEV), B, order="feistel", seed=9, epoch=0)

@@ -83,6 +83,7 @@ def phases(U=1_000_000, I=100_000, B=1 << 20, d=64, reg=1e-3):
     res["sgd_step atomic  (batch preset)"] = timeit(lambda: ctx.sgd_step(P, Q, 1e-9, reg, reg, item_mode=0))
     res["sgd_step sorted  (batch preset)"] = timeit(lambda: ctx.sgd_step(P, Q, 1e-9, reg, reg, item_mode=1))
     res["sgd_step chunked (batch preset)"] = timeit(lambda: ctx.sgd_step(P, Q, 1e-9, reg, reg, item_mode=2))
+    res["sgd_step fused   (batch preset)"] = timeit(lambda: ctx.sgd_step(P, Q, 1e-9, reg, reg, item_mode=3))
     for k, v in res.items():
         print(f"{k:34s} {v:8.3f} ms   {B / v / 1e6:8.3f} G inter/s   algo {algo / v / 1e6:8.1f} GB/s ({algo / v / 1e6 / 8000:5.1%} of 8 TB/s)")
     ctx.close()
@@ -118,6 +119,8 @@ if __name__ == "__main__":
         phases()
         phases(B=1 << 16)
         phases(I=1_000_000)
+    if "small" in which:
+        phases(U=100_000)                   # P table cache resident: memory- or structure-bound?
     if "plan" in which:
         plan_cost()
     print("probe wall", time.time() - t0)
