@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap-plan", type=int, default=0, help="build the next epoch's plan on a side stream")
     ap.add_argument("--cpu-steps", type=int, default=3)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 code path on one GPU)")
     return ap.parse_args()
 
 
@@ -105,11 +107,15 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from daisyrec_amd import ops
     from daisyrec_amd.sharding import UserShardedBprTrainer

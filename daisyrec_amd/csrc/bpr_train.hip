@@ -95,6 +95,7 @@ struct daisy_bpr_ctx {
     const float *p_sqnorm_of;   // table the cache describes (NULL = invalid)
     daisy_epoch_plan *own_plan;   // 1-batch plan used by set_batch / set_batch_from_triples
     daisy::BatchView v;
+    int last_item_mode;  // mode of the last daisy_bpr_item_grad: the user pass of the same step follows it
     bool batch_set, fwd_done;
 };
 
@@ -461,7 +462,9 @@ struct RunCfg {
     static constexpr int E = G * RUN;
 };
 
-template <class C, int RUN_OVERRIDE = 0>
+// FROM_STAGE: P is the per-sample stage of pre-step user rows written by the fused user pass
+// (row of entry e = stage[sample position]) instead of the user table (row = P[user]).
+template <class C, int RUN_OVERRIDE = 0, bool FROM_STAGE = false>
 __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__restrict__ P,
                                                               const float2 *__restrict__ coef,
                                                               BatchView v, int d,
@@ -514,13 +517,13 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
         if (__all(cnt == RUN)) {        // wave-uniform: every run of this wave is full
 #pragma unroll
             for (int x = 0; x < RUN; ++x) {
-                const uint32_t ux = __shfl(my_su.y, x, C::LPR);
+                const uint32_t ux = __shfl(FROM_STAGE ? (my_su.x & ~kNegBit) : my_su.y, x, C::LPR);
                 p[x].load(P + (int64_t)ux * d, lane, d);
             }
         } else {
 #pragma unroll
             for (int x = 0; x < RUN; ++x) {
-                const uint32_t ux = __shfl(my_su.y, x, C::LPR);
+                const uint32_t ux = __shfl(FROM_STAGE ? (my_su.x & ~kNegBit) : my_su.y, x, C::LPR);
                 if (x < cnt) p[x].load(P + (int64_t)ux * d, lane, d);
                 else p[x].zero();
             }
@@ -746,12 +749,19 @@ __device__ __forceinline__ void user_finish_row(Row<C> &p, const Row<C> &acc, fl
     }
 }
 
-template <class C>
+// FUSED (single-GPU throughput step): the forward pass rides along - the group already holds
+// p_u, q_i, q_j of every sample, so it also forms the scores, the loss term and (dL/dpos, dL/dneg),
+// writes them to coef[] for the item pass, accumulates the seven batch sums, and saves the
+// PRE-STEP user row of every sample to stage[s]: P is updated in place here, and the item pass
+// that follows reads the user rows from the stage instead of P.  |P[u]|_F for the regulariser
+// comes from the row-norm cache (stats[NORM_U_PRE]), which every writer keeps current.
+template <class C, bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_user_chunked(
-    float *__restrict__ P, const float *__restrict__ Q, BatchView v, const float2 *__restrict__ coef,
+    float *__restrict__ P, const float *__restrict__ Q, BatchView v, float2 *__restrict__ coef,
     int d, const double *__restrict__ stats, float lr, float reg_1, float reg_2,
     float *__restrict__ edge_vec, int32_t *__restrict__ edge_user, float *__restrict__ edge_n,
-    int32_t *__restrict__ edge_whole) {
+    int32_t *__restrict__ edge_whole, int loss_type, float gamma, float *__restrict__ stage,
+    float *__restrict__ p_sqnorm, double *__restrict__ partials) {
     constexpr int G = UserRunCfg<C>::G, RUN = UserRunCfg<C>::RUN, E = UserRunCfg<C>::E;
     constexpr int ROWF = C::NE * C::LPR;
     __shared__ float slot_acc[(G + 1) * ROWF];
@@ -764,7 +774,8 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
     const int group = tid / C::LPR;
     const int64_t n = v.B;
     const int64_t nchunks = (n + E - 1) / E;
-    const float rU = inv_or_zero(stats[DAISY_ST_NORM_U], reg_2);
+    const float rU = inv_or_zero(stats[FUSED ? DAISY_ST_NORM_U_PRE : DAISY_ST_NORM_U], reg_2);
+    float acc7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const int64_t c0 = chunk * E;
@@ -779,7 +790,7 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
         if (lane < cnt) {
             my_user = (int32_t)(v.ukey[t0 + lane] & v.umask);
             my_ij = v.ij[t0 + lane];
-            my_c = coef[t0 + lane];
+            if constexpr (!FUSED) my_c = coef[t0 + lane];
         }
         if (cnt > 0 && t0 > 0) user_prev = (int32_t)(v.ukey[t0 - 1] & v.umask);
         if (cnt > 0 && t1 < n) user_next = (int32_t)(v.ukey[t1] & v.umask);
@@ -831,6 +842,10 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
                     Row<C> pn = prow;
                     user_finish_row<C>(pn, acc, cn_, lr, reg_1, rU);
                     pn.store(P + (int64_t)cur_user * d, lane, d);
+                    if constexpr (FUSED) {
+                        const float sq = row_dot<C>(pn, pn);
+                        if (lane == 0) p_sqnorm[cur_user] = sq;
+                    }
                 } else {
                     const int s = (cur_slot >= 0) ? cur_slot : group + 1;
                     float *dst = slot_acc + s * ROWF;
@@ -847,7 +862,33 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
             for (int x = 0; x < RUN; ++x) {
                 if (x < cnt) {
                     const int32_t ux = __shfl(my_user, x, C::LPR);
-                    const float cp = __shfl(my_c.x, x, C::LPR), cn = __shfl(my_c.y, x, C::LPR);
+                    float cp, cn;
+                    if constexpr (FUSED) {
+                        const float sp = row_dot<C>(pr[x], qi[x]);
+                        const float sn = row_dot<C>(pr[x], qj[x]);
+                        float term = 0.f;
+                        cp = 0.f; cn = 0.f;
+                        if (lane == 0) {
+                            pair_coef(loss_type, sp, sn, gamma, term, cp, cn);
+                            coef[t0 + x] = make_float2(cp, cn);
+                            acc7[0] += term;
+                        }
+                        cp = __shfl(cp, 0, C::LPR);
+                        cn = __shfl(cn, 0, C::LPR);
+#pragma unroll
+                        for (int k = 0; k < C::NE; ++k) {
+                            acc7[1] += fabsf(pr[x].v[k]);
+                            acc7[2] += fabsf(qi[x].v[k]);
+                            acc7[3] += fabsf(qj[x].v[k]);
+                            acc7[4] = fmaf(pr[x].v[k], pr[x].v[k], acc7[4]);
+                            acc7[5] = fmaf(qi[x].v[k], qi[x].v[k], acc7[5]);
+                            acc7[6] = fmaf(qj[x].v[k], qj[x].v[k], acc7[6]);
+                        }
+                        pr[x].store(stage + (t0 + x) * d, lane, d);     // pre-step row for the item pass
+                    } else {
+                        cp = __shfl(my_c.x, x, C::LPR);
+                        cn = __shfl(my_c.y, x, C::LPR);
+                    }
                     if (ux != cur_user) {
                         finish(true, false, pcur);
                         cur_user = ux;
@@ -884,6 +925,10 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
                 p.load(P + (int64_t)uu * d, lane, d);
                 user_finish_row<C>(p, g, ns, lr, reg_1, rU);
                 p.store(P + (int64_t)uu * d, lane, d);
+                if constexpr (FUSED) {
+                    const float sq = row_dot<C>(p, p);
+                    if (lane == 0) p_sqnorm[uu] = sq;
+                }
             } else {
                 const int64_t e = 2 * chunk + (from_prev ? 0 : 1);
                 g.store(edge_vec + e * d, lane, d);
@@ -896,21 +941,38 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
         }
         __syncthreads();
     }
+    if constexpr (FUSED) {
+        __shared__ double sm7[kBlock / kWave][8];
+        const int wave = tid / kWave;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+            const double w = wave_sum_f64((double)acc7[k]);
+            if ((tid % kWave) == 0) sm7[wave][k] = w;
+        }
+        __syncthreads();
+        if (tid < 7) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < kBlock / kWave; ++w) t += sm7[w][tid];
+            partials[(int64_t)blockIdx.x * 8 + tid] = t;
+        }
+    }
 }
 
 // chains of edge records: the chunk whose TAIL edge starts a run owns it
-template <class C>
+template <class C, bool FUSED>
 __global__ __launch_bounds__(kBlock) void k_user_edges(float *__restrict__ P, int64_t nchunks, int d,
                                                        const double *__restrict__ stats, float lr,
                                                        float reg_1, float reg_2,
                                                        const float *__restrict__ edge_vec,
                                                        const int32_t *__restrict__ edge_user,
                                                        const float *__restrict__ edge_n,
-                                                       const int32_t *__restrict__ edge_whole) {
+                                                       const int32_t *__restrict__ edge_whole,
+                                                       float *__restrict__ p_sqnorm) {
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
-    const float rU = inv_or_zero(stats[DAISY_ST_NORM_U], reg_2);
+    const float rU = inv_or_zero(stats[FUSED ? DAISY_ST_NORM_U_PRE : DAISY_ST_NORM_U], reg_2);
     for (int64_t c = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; c < nchunks; c += gstride) {
         const int uu = edge_user[2 * c + 1];
         if (uu < 0) continue;
@@ -928,20 +990,21 @@ __global__ __launch_bounds__(kBlock) void k_user_edges(float *__restrict__ P, in
         p.load(P + (int64_t)uu * d, lane, d);
         user_finish_row<C>(p, acc, ns, lr, reg_1, rU);
         p.store(P + (int64_t)uu * d, lane, d);
+        if constexpr (FUSED) {
+            const float sq = row_dot<C>(p, p);
+            if (lane == 0) p_sqnorm[uu] = sq;
+        }
     }
 }
 
 // ---------------------------------------------------------------------------
-// Fused single-GPU SGD step (throughput mode).  k_fwd and k_user read the same
-// rows; fusing them needs |P[u]|_F (a batch-wide sum) BEFORE the pass, which a
-// per-row cache of squared norms provides (k_unorm: 4 B per sample instead of a
-// 256-B row).  The pass cannot write P in place - the item pass that follows
-// still needs the pre-step rows - so each owner stages its new row and
-// k_user_commit copies it (and refreshes the cache) after the item pass:
-//   k_unorm -> k_user_fused (coef, sums, staged rows) -> k_reduce_partials<true>
-//   -> k_item_grad_chunked -> k_user_commit -> k_item_apply
-// Row traffic per interaction: 2.6 r + 0.6 w | 2 r | 0.6 r + 0.6 w  instead of
-// 3 r | 2 r | 2.6 r + 0.6 w.
+// Fused single-GPU SGD step (throughput mode).  k_fwd and the user pass read the
+// same rows; fusing them (k_user_chunked<FUSED>) needs |P[u]|_F - a batch-wide
+// sum - BEFORE the pass, which a per-row cache of squared norms provides
+// (k_unorm: 4 B per sample instead of a 256-B row):
+//   k_unorm -> k_user_chunked<FUSED> (coef, sums, pre-step rows to the stage, P in place)
+//   -> k_user_edges -> k_reduce_partials<true> -> k_item_grad_chunked<FROM_STAGE> -> k_item_apply
+// Row traffic per interaction: 2.6 r + 1.6 w | 2 r   instead of   3 r | 2 r | 2.6 r + 0.6 w.
 // ---------------------------------------------------------------------------
 template <class C>
 __global__ __launch_bounds__(kBlock) void k_row_sqnorm(const float *__restrict__ W, int64_t rows, int d,
@@ -987,95 +1050,6 @@ __global__ __launch_bounds__(kBlock) void k_unorm_reduce(const double *__restric
         __syncthreads();
     }
     if (threadIdx.x == 0) stats[DAISY_ST_NORM_U_PRE] = sqrt(sm[0]);
-}
-
-template <class C>
-__global__ __launch_bounds__(kBlock) void k_user_fused(const float *__restrict__ P,
-                                                       const float *__restrict__ Q, BatchView v, int d,
-                                                       int loss_type, float gamma,
-                                                       const double *__restrict__ stats, float lr,
-                                                       float reg_1, float reg_2,
-                                                       float2 *__restrict__ coef,
-                                                       float *__restrict__ p_stage,
-                                                       double *__restrict__ partials) {
-    const int lane = threadIdx.x % C::LPR;
-    const int group = threadIdx.x / C::LPR;
-    const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
-    const float rU = inv_or_zero(stats[DAISY_ST_NORM_U_PRE], reg_2);
-    float acc7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int64_t pos = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; pos < v.B; pos += gstride) {
-        const uint32_t uu = v.ukey[pos] & v.umask;
-        if (pos > 0 && (v.ukey[pos - 1] & v.umask) == uu) continue;  // not the head of this user's run
-        Row<C> p, acc;
-        p.load(P + (int64_t)uu * d, lane, d);
-        acc.zero();
-        float n = 0.f;
-        for (int64_t q = pos; q < v.B && (v.ukey[q] & v.umask) == uu; ++q) {
-            const int2 ij = v.ij[q];
-            Row<C> qi, qj;
-            qi.load(Q + (int64_t)ij.x * d, lane, d);
-            qj.load(Q + (int64_t)ij.y * d, lane, d);
-            const float sp = row_dot<C>(p, qi);
-            const float sn = row_dot<C>(p, qj);
-            float term, cp, cn;
-            pair_coef(loss_type, sp, sn, gamma, term, cp, cn);   // every lane of the group: same values
-#pragma unroll
-            for (int k = 0; k < C::NE; ++k) {
-                acc.v[k] = fmaf(cp, qi.v[k], fmaf(cn, qj.v[k], acc.v[k]));
-                acc7[2] += fabsf(qi.v[k]);
-                acc7[3] += fabsf(qj.v[k]);
-                acc7[5] = fmaf(qi.v[k], qi.v[k], acc7[5]);
-                acc7[6] = fmaf(qj.v[k], qj.v[k], acc7[6]);
-            }
-            if (lane == 0) {
-                coef[q] = make_float2(cp, cn);
-                acc7[0] += term;
-            }
-            n += 1.f;
-        }
-        const float w1 = reg_1 * n, w2 = rU * n;
-#pragma unroll
-        for (int k = 0; k < C::NE; ++k) {
-            acc7[1] = fmaf(n, fabsf(p.v[k]), acc7[1]);
-            acc7[4] = fmaf(n * p.v[k], p.v[k], acc7[4]);
-            const float g = acc.v[k] + fmaf(w2, p.v[k], w1 * sgn(p.v[k]));
-            p.v[k] = fmaf(-lr, g, p.v[k]);
-        }
-        p.store(p_stage + pos * d, lane, d);
-    }
-    __shared__ double sm[kBlock / kWave][8];
-    const int wave = threadIdx.x / kWave;
-#pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        const double w = wave_sum_f64((double)acc7[k]);
-        if ((threadIdx.x % kWave) == 0) sm[wave][k] = w;
-    }
-    __syncthreads();
-    if (threadIdx.x < 7) {
-        double t = 0.0;
-#pragma unroll
-        for (int w = 0; w < kBlock / kWave; ++w) t += sm[w][threadIdx.x];
-        partials[(int64_t)blockIdx.x * 8 + threadIdx.x] = t;
-    }
-}
-
-// staged rows -> P (single owner per user run); refresh the squared-norm cache
-template <class C>
-__global__ __launch_bounds__(kBlock) void k_user_commit(float *__restrict__ P, BatchView v, int d,
-                                                        const float *__restrict__ p_stage,
-                                                        float *__restrict__ p_sqnorm) {
-    const int lane = threadIdx.x % C::LPR;
-    const int group = threadIdx.x / C::LPR;
-    const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
-    for (int64_t pos = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; pos < v.B; pos += gstride) {
-        const uint32_t uu = v.ukey[pos] & v.umask;
-        if (pos > 0 && (v.ukey[pos - 1] & v.umask) == uu) continue;
-        Row<C> p;
-        p.load(p_stage + pos * d, lane, d);
-        p.store(P + (int64_t)uu * d, lane, d);
-        const float s = row_dot<C>(p, p);
-        if (lane == 0) p_sqnorm[uu] = s;
-    }
 }
 
 // torch.optim.Adam single-tensor math (exp_avg.lerp_, addcmul_, addcdiv_), dense
@@ -1345,6 +1319,7 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
     daisy_bpr_ctx *c = new daisy_bpr_ctx();
     c->max_batch = max_batch; c->d = d; c->U = user_num; c->I = item_num;
     c->batch_set = false; c->fwd_done = false; c->own_plan = nullptr;
+    c->last_item_mode = DAISY_ITEM_SORTED;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     const size_t o_coef = take((size_t)max_batch * 8);
@@ -1499,6 +1474,7 @@ static int item_grad_impl(daisy_bpr_ctx *ctx, const float *P, const float *Q, co
     if (item_mode == DAISY_ITEM_FUSED) item_mode = DAISY_ITEM_CHUNKED;   // phase API: same item kernel
     DAISY_CHECK_ARG(item_mode >= DAISY_ITEM_ATOMIC && item_mode <= DAISY_ITEM_CHUNKED,
                     "item_grad: bad item_mode %d", item_mode);
+    ctx->last_item_mode = item_mode;
     if (!ctx->fwd_done) { set_error("item_grad: forward has not run for this batch"); return DAISY_ERR_STATE; }
     hipStream_t s = S(stream);
     const BatchView &v = ctx->v;
@@ -1563,12 +1539,12 @@ static int user_pass(daisy_bpr_ctx *ctx, float *P, const float *Q, const double 
         const int grid = grid_for(v.B, C::GROUPS_PER_BLOCK * 2);
         if (sgd && chunked && user_kernel == 1 && C::NE <= 4) {
             const int64_t nchunks = (v.B + UserRunCfg<C>::E - 1) / UserRunCfg<C>::E;
-            hipLaunchKernelGGL((k_user_chunked<C>), dim3(grid_for(nchunks, 1, 16384)), dim3(kBlock), 0, s, P, Q,
-                               v, ctx->coef, d, stats, lr, reg_1, reg_2, ctx->edge_vec, ctx->edge_user,
-                               ctx->edge_n, ctx->edge_whole);
-            hipLaunchKernelGGL((k_user_edges<C>), dim3(grid_for(nchunks, C::GROUPS_PER_BLOCK)), dim3(kBlock),
-                               0, s, P, nchunks, d, stats, lr, reg_1, reg_2, ctx->edge_vec, ctx->edge_user,
-                               ctx->edge_n, ctx->edge_whole);
+            hipLaunchKernelGGL((k_user_chunked<C, false>), dim3(grid_for(nchunks, 1, 16384)), dim3(kBlock), 0,
+                               s, P, Q, v, ctx->coef, d, stats, lr, reg_1, reg_2, ctx->edge_vec,
+                               ctx->edge_user, ctx->edge_n, ctx->edge_whole, 0, 0.f, nullptr, nullptr, nullptr);
+            hipLaunchKernelGGL((k_user_edges<C, false>), dim3(grid_for(nchunks, C::GROUPS_PER_BLOCK)),
+                               dim3(kBlock), 0, s, P, nchunks, d, stats, lr, reg_1, reg_2, ctx->edge_vec,
+                               ctx->edge_user, ctx->edge_n, ctx->edge_whole, nullptr);
         } else if (sgd)
             hipLaunchKernelGGL((k_user<C, true>), dim3(grid), dim3(kBlock), 0, s, P, Q, v, ctx->coef, d,
                                stats, lr, reg_1, reg_2, gP);
@@ -1585,7 +1561,10 @@ static int user_pass(daisy_bpr_ctx *ctx, float *P, const float *Q, const double 
 int daisy_bpr_user_sgd(daisy_bpr_ctx *ctx, float *P, const float *Q, const double *stats, float lr,
                        float reg_1, float reg_2, daisy_stream_t stream) {
     DAISY_CHECK_ARG(ctx && P && Q && stats, "user_sgd: NULL argument");
-    return user_pass(ctx, P, Q, stats, lr, reg_1, reg_2, nullptr, true, stream);
+    // throughput kernel when the step's item gradient was formed in throughput mode,
+    // the reproducible run-owner kernel otherwise
+    return user_pass(ctx, P, Q, stats, lr, reg_1, reg_2, nullptr, true, stream,
+                     ctx->last_item_mode == DAISY_ITEM_CHUNKED);
 }
 
 int daisy_bpr_user_grad(daisy_bpr_ctx *ctx, const float *P, const float *Q, const double *stats,
@@ -1657,15 +1636,21 @@ static int sgd_step_fused(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t loss_t
         const int gn = grid_for(v.B, kBlock * 4);
         hipLaunchKernelGGL(k_unorm, dim3(gn), dim3(kBlock), 0, s, ctx->p_sqnorm, v, ctx->partials);
         hipLaunchKernelGGL(k_unorm_reduce, dim3(1), dim3(kBlock), 0, s, ctx->partials, gn, stats);
-        const int gu = grid_for(v.B, C::GROUPS_PER_BLOCK * 2);
-        hipLaunchKernelGGL((k_user_fused<C>), dim3(gu), dim3(kBlock), 0, s, P, Q, v, d, (int)loss_type,
-                           gamma, stats, lr, reg_1, reg_2, ctx->coef, ctx->p_stage, ctx->partials);
-        hipLaunchKernelGGL((k_reduce_partials<true>), dim3(1), dim3(kBlock), 0, s, ctx->partials, gu, stats,
-                           reg_1, reg_2, epoch_acc, step_loss);
-        hipLaunchKernelGGL((k_item_grad_chunked<C>), dim3(grid_for(2 * v.B, RunCfg<C>::E)), dim3(kBlock), 0,
-                           s, P, ctx->coef, v, d, gQ);
-        hipLaunchKernelGGL((k_user_commit<C>), dim3(gu), dim3(kBlock), 0, s, P, v, d, ctx->p_stage,
-                           ctx->p_sqnorm);
+        if constexpr (C::NE <= 4) {
+            const int64_t nchunks = (v.B + UserRunCfg<C>::E - 1) / UserRunCfg<C>::E;
+            const int gu = grid_for(nchunks, 1, kMaxGrid);
+            hipLaunchKernelGGL((k_user_chunked<C, true>), dim3(gu), dim3(kBlock), 0, s, P, Q, v, ctx->coef, d,
+                               stats, lr, reg_1, reg_2, ctx->edge_vec, ctx->edge_user, ctx->edge_n,
+                               ctx->edge_whole, (int)loss_type, gamma, ctx->p_stage, ctx->p_sqnorm,
+                               ctx->partials);
+            hipLaunchKernelGGL((k_user_edges<C, true>), dim3(grid_for(nchunks, C::GROUPS_PER_BLOCK)),
+                               dim3(kBlock), 0, s, P, nchunks, d, stats, lr, reg_1, reg_2, ctx->edge_vec,
+                               ctx->edge_user, ctx->edge_n, ctx->edge_whole, ctx->p_sqnorm);
+            hipLaunchKernelGGL((k_reduce_partials<true>), dim3(1), dim3(kBlock), 0, s, ctx->partials, gu,
+                               stats, reg_1, reg_2, epoch_acc, step_loss);
+            hipLaunchKernelGGL((k_item_grad_chunked<C, 0, true>), dim3(grid_for(2 * v.B, RunCfg<C>::E, 16384)),
+                               dim3(kBlock), 0, s, ctx->p_stage, ctx->coef, v, d, gQ);
+        }
         return DAISY_OK;
     });
     if (rc) return rc;
@@ -1678,9 +1663,12 @@ int daisy_bpr_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t loss_type
                        float lr, float reg_1, float reg_2, float *gQ, double *stats,
                        double *epoch_acc, double *step_loss, int32_t item_mode,
                        daisy_stream_t stream) {
-    if (item_mode == DAISY_ITEM_FUSED)
-        return sgd_step_fused(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, gQ, stats, epoch_acc,
-                              step_loss, stream);
+    if (item_mode == DAISY_ITEM_FUSED) {
+        if (ctx->d <= 64)   // rows of <= 4 floats per lane: the fused kernel fits the register budget
+            return sgd_step_fused(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, gQ, stats, epoch_acc,
+                                  step_loss, stream);
+        item_mode = DAISY_ITEM_CHUNKED;
+    }
     int rc;
     if ((rc = forward_impl(ctx, P, Q, loss_type, gamma, stats, true, reg_1, reg_2, epoch_acc, step_loss,
                            stream))) return rc;
