@@ -69,6 +69,7 @@ SIGNATURES = {
     "daisy_sample_neg_per_user": (C.c_int, [_p, _p, _i64, _i64, _i32, _u64, _u64, _p, _p]),
     "daisy_expand_triples": (C.c_int, [_p, _p, _i64, _p, _i32, _p, _p]),
     "daisy_resample_neg_per_interaction": (C.c_int, [_p, _p, _i64, _p, _i64, _u64, _u64, _p]),
+    "daisy_build_candidates": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i64, _i32, _u64, _p, _p]),
     "daisy_randperm_workspace_bytes": (_sz, [_i64]),
     "daisy_randperm": (C.c_int, [_i64, _u64, _u64, _p, _p, _sz, _p]),
     "daisy_membench": (C.c_int, [_i32, _p, _i64, _i32, _p, _i64, _p, _p]),

@@ -203,3 +203,81 @@ int daisy_randperm(int64_t n, uint64_t seed, uint64_t epoch, int64_t *perm, void
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// Candidate sets for ranking (reference: daisy/utils/utils.py:53-85,
+// build_candidates_set): per test user `cand_num` items = uniform negatives
+// drawn WITH replacement from the items in neither the user's test row nor
+// train row, followed by the test (ground-truth) items; a user with more than
+// cand_num truths gets cand_num draws from the truths instead.
+// The reference loops over users with np.setdiff1d (O(U*I)); here one thread per
+// candidate: the r-th free item is found by a binary search on the item id with
+// two rank queries (test row, train row; the rows are disjoint by construction
+// of the split).  Truth items are appended in ascending id order.
+// ---------------------------------------------------------------------------
+namespace daisy {
+
+__device__ __forceinline__ int64_t count_le(const int32_t *__restrict__ row, int64_t deg, int64_t x) {
+    int64_t lo = 0, hi = deg;       // number of row elements <= x
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if ((int64_t)row[mid] <= x) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void k_build_candidates(const int64_t *__restrict__ ip_te, const int32_t *__restrict__ it_te,
+                                   const int64_t *__restrict__ ip_tr, const int32_t *__restrict__ it_tr,
+                                   const int64_t *__restrict__ users, int64_t n_users, int64_t I,
+                                   int cand_num, uint64_t seed, int64_t *__restrict__ out) {
+    const int64_t total = n_users * cand_num;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total;
+         e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = e / cand_num;
+        const int k = (int)(e % cand_num);
+        const int64_t u = users[row];
+        const int32_t *te = it_te + ip_te[u];
+        const int64_t dte = ip_te[u + 1] - ip_te[u];
+        const uint64_t x = philox_u64(seed, 1ull << 60, (uint64_t)e);
+        if (dte > cand_num) {                       // utils.py:72-73: draws from the truths
+            out[e] = te[(int64_t)__umul64hi(x, (uint64_t)dte)];
+            continue;
+        }
+        const int64_t n_neg = cand_num - dte;
+        if (k >= n_neg) {                           // utils.py:79: ... followed by the truths
+            out[e] = te[k - n_neg];
+            continue;
+        }
+        const int32_t *tr = it_tr + ip_tr[u];
+        const int64_t dtr = ip_tr[u + 1] - ip_tr[u];
+        const int64_t free_ = I - dte - dtr;
+        if (free_ <= 0) { out[e] = -1; continue; }
+        const int64_t r = (int64_t)__umul64hi(x, (uint64_t)free_);   // r-th free item, 0-based
+        int64_t lo = 0, hi = I - 1;                 // smallest id with (#free ids <= id) >= r+1
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            const int64_t free_le = mid + 1 - count_le(te, dte, mid) - count_le(tr, dtr, mid);
+            if (free_le >= r + 1) hi = mid;
+            else lo = mid + 1;
+        }
+        out[e] = lo;
+    }
+}
+
+}  // namespace daisy
+
+extern "C" int daisy_build_candidates(const int64_t *indptr_test, const int32_t *items_test,
+                                      const int64_t *indptr_train, const int32_t *items_train,
+                                      const int64_t *users, int64_t n_users, int64_t item_num,
+                                      int32_t cand_num, uint64_t seed, int64_t *out,
+                                      daisy_stream_t stream) {
+    DAISY_CHECK_ARG(indptr_test && items_test && indptr_train && items_train && users && out &&
+                        n_users > 0 && item_num > 0 && cand_num > 0,
+                    "build_candidates: bad argument");
+    hipLaunchKernelGGL(daisy::k_build_candidates, dim3(daisy::grid_for(n_users * cand_num, daisy::kBlock)),
+                       dim3(daisy::kBlock), 0, reinterpret_cast<hipStream_t>(stream), indptr_test, items_test,
+                       indptr_train, items_train, users, n_users, item_num, (int)cand_num, seed, out);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}

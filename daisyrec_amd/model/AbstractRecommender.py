@@ -113,6 +113,11 @@ class GeneralRecommender(AbstractRecommender):
         # knobs of the native path (absent from the reference config: defaults keep its behaviour)
         self.item_mode = str(config.get("item_mode", "sorted")).lower()   # 'sorted' = reproducible
         self.show_progress = bool(config.get("progress", True))
+        # 'loader' (default): replay the DataLoader's torch RNG order (what the reference run does);
+        # 'device': shuffle=True as a keyed permutation computed on the GPU (no host permutation,
+        # no upload: the scalable choice, same distribution, different stream)
+        self.shuffle_mode = str(config.get("shuffle_mode", "loader")).lower()
+        self.seed = int(config.get("seed", 2022))
         self.epoch_losses = []
 
     # -- helpers ---------------------------------------------------------------
@@ -162,6 +167,7 @@ class GeneralRecommender(AbstractRecommender):
         ctx = ops.BprContext(min(B, max(n, 1)), P.shape[1], P.shape[0], Q.shape[0], device=P.device)
         plan = ops.EpochPlan(n, P.shape[0], Q.shape[0], device=P.device)
         adam = _AdamState(P, Q, self.lr) if opt == "adam" else None
+        user_sorted = ops.triples_user_sorted(triples[:n])
         self.epoch_losses = []
         last_loss = 0.0
         try:
@@ -169,12 +175,17 @@ class GeneralRecommender(AbstractRecommender):
             bar = _tqdm(epochs) if (_tqdm is not None and self.show_progress) else None
             for epoch in (bar if bar is not None else epochs):
                 self.train()
-                perm = self._epoch_order(train_loader, triples.shape[0])
-                if perm is not None:
-                    perm = perm[:n].contiguous().to(self.device)
-                # one radix-sort pass lays the epoch out batch by batch, in the DataLoader's order
-                plan.build(triples, B, order="identity" if perm is None else "perm", perm=perm,
-                           n_triples=n)
+                from torch.utils.data import SequentialSampler
+                if self.shuffle_mode == "device" and not isinstance(train_loader.sampler, SequentialSampler):
+                    plan.build(triples, B, order="feistel", seed=self.seed, epoch=epoch, n_triples=n,
+                               user_sorted=user_sorted)
+                else:
+                    perm = self._epoch_order(train_loader, triples.shape[0])
+                    if perm is not None:
+                        perm = perm[:n].contiguous().to(self.device)
+                    # radix sorts lay the epoch out batch by batch, in the DataLoader's order
+                    plan.build(triples, B, order="identity" if perm is None else "perm", perm=perm,
+                               n_triples=n, user_sorted=user_sorted)
                 ctx.epoch_acc.zero_()
                 if adam is None:
                     ctx.fit_epoch_sgd(plan, P, Q, self.lr, self.reg_1, self.reg_2, loss_type=loss_id,

@@ -312,6 +312,19 @@ def resample_neg_per_interaction(indptr, csr_items, item_num, triples, seed, epo
     return triples
 
 
+def build_candidates(indptr_test, items_test, indptr_train, items_train, users, item_num, cand_num, seed):
+    """build_candidates_set (utils.py:53-85) on the device -> int64 [n_users, cand_num]."""
+    users = users.to(torch.int64).contiguous()
+    out = torch.empty(users.numel(), cand_num, dtype=torch.int64, device=users.device)
+    check(lib.daisy_build_candidates(_ptr(indptr_test, torch.int64, "indptr_test"),
+                                     _ptr(items_test, torch.int32, "items_test"),
+                                     _ptr(indptr_train, torch.int64, "indptr_train"),
+                                     _ptr(items_train, torch.int32, "items_train"),
+                                     _ptr(users, torch.int64, "users"), users.numel(), int(item_num),
+                                     int(cand_num), int(seed), _ptr(out, torch.int64, "out"), _stream()))
+    return out
+
+
 def randperm(n, seed, epoch=0, device="cuda"):
     perm = torch.empty(n, dtype=torch.int64, device=device)
     ws = _ws(lib.daisy_randperm_workspace_bytes(n), perm.device)

@@ -245,6 +245,16 @@ int daisy_resample_neg_per_interaction(const int64_t *indptr, const int32_t *csr
                                        int64_t item_num, int32_t *triples, int64_t n,
                                        uint64_t seed, uint64_t epoch, daisy_stream_t stream);
 
+/* build_candidates_set (utils.py:53-85): for each of n_users test users (ids in `users`)
+ * cand_num candidates int64 [n_users][cand_num]: uniform negatives (with replacement) from
+ * the items in neither the user's test CSR row nor train CSR row, then the test items in
+ * ascending order; a user with more than cand_num test items gets cand_num draws from them.
+ * The two rows of a user must be disjoint (they are, by construction of the split). */
+int daisy_build_candidates(const int64_t *indptr_test, const int32_t *items_test,
+                           const int64_t *indptr_train, const int32_t *items_train,
+                           const int64_t *users, int64_t n_users, int64_t item_num,
+                           int32_t cand_num, uint64_t seed, int64_t *out, daisy_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Device-side epoch order (replaces RandomSampler's torch.randperm for the
  * throughput loader; dataset.py:5-7 shuffle=True): perm = a uniformly random

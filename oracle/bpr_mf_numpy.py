@@ -297,3 +297,30 @@ def feistel_positions(n, seed, epoch=0):
         x[todo] = v
         todo[todo] = v >= np.uint64(n)
     return x.astype(np.int64)
+
+
+def build_candidates(indptr_te, items_te, indptr_tr, items_tr, users, item_num, cand_num, seed):
+    """utils.py:53-85 with the device generator: negatives (with replacement, uniform over the items
+    in neither the test nor the train row) first, then the test items ascending; more than cand_num
+    truths -> cand_num draws from the truths.  stream = 1<<60, index = row*cand_num + k."""
+    out = np.empty((len(users), cand_num), dtype=np.int64)
+    for row, u in enumerate(users):
+        te = items_te[indptr_te[u]:indptr_te[u + 1]]
+        tr = items_tr[indptr_tr[u]:indptr_tr[u + 1]]
+        dte = len(te)
+        for k in range(cand_num):
+            x = _draw_u64(seed, 1 << 60, row * cand_num + k)
+            if dte > cand_num:
+                out[row, k] = te[(x * dte) >> 64]
+                continue
+            n_neg = cand_num - dte
+            if k >= n_neg:
+                out[row, k] = te[k - n_neg]
+                continue
+            taken = np.union1d(te, tr)
+            free = item_num - len(taken)
+            if free <= 0:
+                out[row, k] = -1
+                continue
+            out[row, k] = kth_in_complement(taken, (x * free) >> 64)
+    return out

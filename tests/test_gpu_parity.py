@@ -428,3 +428,69 @@ def test_user_chunked_long_and_short_runs(ops, U, B):
     np.testing.assert_allclose(P.cpu().numpy(), Pn, rtol=0, atol=5e-6)
     np.testing.assert_allclose(Q.cpu().numpy(), Qn, rtol=0, atol=5e-6)
     ctx.close()
+
+
+def test_build_candidates_bit_exact_and_semantics(ops, ml100k):
+    """build_candidates_set (utils.py:53-85) on the device: bit-exact vs the oracle, and the
+    reference's semantics (negatives never in test or train rows, truths at the tail, the
+    >cand_num-truths branch)."""
+    from daisyrec_amd.utils.utils import build_candidates_set
+    g = ml100k
+    U, I = int(g["user_num"]), int(g["item_num"])
+    tr_u, tr_i = g["train_users"], g["train_items"]
+    test_u = g["test_u"]
+    # a synthetic test split: for every test user the reference's truths are the tail of its candidates
+    truths = {}
+    rng = np.random.default_rng(0)
+    train_sets = {}
+    for a, b in zip(tr_u, tr_i):
+        train_sets.setdefault(int(a), set()).add(int(b))
+    for u in test_u[:60]:
+        free = np.setdiff1d(np.arange(I), list(train_sets.get(int(u), ())))
+        truths[int(u)] = set(rng.choice(free, size=int(rng.integers(1, 30)), replace=False).tolist())
+    big = int(test_u[60])
+    free = np.setdiff1d(np.arange(I), list(train_sets.get(big, ())))
+    truths[big] = set(free[:40].tolist())                       # more truths than cand_num=25 below
+    te_u = np.array([u for u, s in truths.items() for _ in s], dtype=np.int32)
+    te_i = np.array([i for _, s in truths.items() for i in s], dtype=np.int32)
+    ip_te_o, it_te_o = _csr(te_u, te_i, U)
+    ip_tr_o, it_tr_o = _csr(tr_u, tr_i, U)
+    ip_te, it_te = ops.build_user_csr(_t(te_u), _t(te_i), U)
+    ip_tr, it_tr = ops.build_user_csr(_t(tr_u), _t(tr_i), U)
+    users = np.array(list(truths.keys()), dtype=np.int64)
+    for cand_num in (25, 100):
+        got = ops.build_candidates(ip_te, it_te, ip_tr, it_tr, _t(users), I, cand_num, 7).cpu().numpy()
+        want = O.build_candidates(ip_te_o, it_te_o, ip_tr_o, it_tr_o, users, I, cand_num, 7)
+        np.testing.assert_array_equal(got, want)
+        for row, u in enumerate(users):
+            t = sorted(truths[int(u)])
+            if len(t) > cand_num:
+                assert set(got[row].tolist()) <= set(t)
+                continue
+            n_neg = cand_num - len(t)
+            assert got[row, n_neg:].tolist() == t
+            negs = set(got[row, :n_neg].tolist())
+            assert not (negs & set(t)) and not (negs & train_sets.get(int(u), set()))
+    cfg = mf_config(user_num=U, item_num=I, cand_num=100)
+    tu, tc = build_candidates_set(truths, train_sets, cfg)
+    assert tu == list(truths.keys()) and len(tc) == len(tu) and tc[3][1].shape == (100,)
+    assert tc[0][0] == tu[0] and tc[0][1][-1] == max(truths[tu[0]])
+
+
+def test_fit_device_shuffle_trains(ml100k):
+    """config['shuffle_mode']='device' (Feistel order, throughput kernels): not the reference's batch
+    stream, so no golden to match, but the same optimisation: the epoch losses must fall and land
+    close to the reference's first epochs."""
+    from daisyrec_amd.model.MFRecommender import MF
+    from daisyrec_amd.utils.dataset import BasicDataset, get_dataloader
+    g = ml100k
+    cfg = mf_config(user_num=int(g["user_num"]), item_num=int(g["item_num"]), epochs=3,
+                    item_mode="chunked", shuffle_mode="device")
+    torch.manual_seed(int(g["seed"]))
+    model = MF(cfg)
+    loader = get_dataloader(BasicDataset(g["samples"]), batch_size=256, shuffle=True, num_workers=0)
+    model.fit(loader)
+    L = model.epoch_losses
+    assert L[0] > L[1] > L[2]
+    for got, ref in zip(L, g["epoch_losses"]):
+        assert abs(got - ref) <= 0.02 * ref            # different shuffles of the same data

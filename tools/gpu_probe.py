@@ -109,6 +109,36 @@ def plan_cost(U=1_000_000, I=100_000, n=50_000_000, B=1 << 20):
     plan.close()
 
 
+def frontend(U=1_000_000, I=100_000, n=50_000_000):
+    """Front-end rows of SURVEY 8f rank 1 at C2 scale: get_ur -> CSR, BasicNegtiveSampler, candidates."""
+    print(f"== front end at U={U} I={I} nnz={n} ==")
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    key = torch.unique((torch.randint(0, U, (n,), device=dev, generator=g, dtype=torch.int64) << 32)
+                       | torch.randint(0, I, (n,), device=dev, generator=g, dtype=torch.int64))
+    users, items = (key >> 32).to(torch.int32), (key & 0xFFFFFFFF).to(torch.int32)
+    n = users.numel()
+    t = timeit(lambda: ops.build_user_csr(users, items, U), iters=3, warm=1)
+    print(f"build_user_csr (get_ur)            {t:8.3f} ms   {n / t / 1e6:8.2f} G pairs/s")
+    indptr, csr = ops.build_user_csr(users, items, U)
+    for num_ng in (1, 4):
+        t = timeit(lambda: ops.sample_neg_per_user(indptr, csr, I, num_ng, 1, 0), iters=5, warm=1)
+        print(f"sample_neg_per_user num_ng={num_ng}      {t:8.3f} ms   {U * num_ng / t / 1e6:8.2f} G negatives/s")
+    js = ops.sample_neg_per_user(indptr, csr, I, 1, 1, 0)
+    t = timeit(lambda: ops.expand_triples(users, items, js), iters=3, warm=1)
+    print(f"expand_triples                     {t:8.3f} ms   {n / t / 1e6:8.2f} G triples/s")
+    tri = ops.expand_triples(users, items, js)
+    t = timeit(lambda: ops.resample_neg_per_interaction(indptr, csr, I, tri, 1, 0), iters=3, warm=1)
+    print(f"resample_neg_per_interaction       {t:8.3f} ms   {n / t / 1e6:8.2f} G negatives/s")
+    # candidates: 100k test users x 1000 candidates, a 10-item test row per user
+    tu = torch.arange(0, 100_000, device=dev, dtype=torch.int64)
+    te_items = torch.randint(0, I, (100_000, 10), device=dev, generator=g, dtype=torch.int64)
+    te_key = torch.unique((tu.repeat_interleave(10) << 32) | te_items.reshape(-1))
+    ip_te, it_te = ops.build_user_csr((te_key >> 32).to(torch.int32), (te_key & 0xFFFFFFFF).to(torch.int32), U)
+    t = timeit(lambda: ops.build_candidates(ip_te, it_te, indptr, csr, tu, I, 1000, 3), iters=3, warm=1)
+    print(f"build_candidates 100k x 1000       {t:8.3f} ms   {1e8 / t / 1e6:8.2f} G candidates/s")
+
+
 if __name__ == "__main__":
     print(torch.cuda.get_device_name(0), torch.version.hip)
     t0 = time.time()
@@ -123,4 +153,6 @@ if __name__ == "__main__":
         phases(U=100_000)                   # P table cache resident: memory- or structure-bound?
     if "plan" in which:
         plan_cost()
+    if "frontend" in which:
+        frontend()
     print("probe wall", time.time() - t0)
