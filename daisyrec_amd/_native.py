@@ -19,10 +19,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdaisyrec_hip.so")
 
 DAISY_OK, DAISY_ERR_ARG, DAISY_ERR_HIP, DAISY_ERR_STATE = 0, 1, 2, 3
-LOSS_BPR, LOSS_HL, LOSS_TL = 0, 1, 2
+LOSS_BPR, LOSS_HL, LOSS_TL, LOSS_CL, LOSS_SL = 0, 1, 2, 3, 4
 ITEM_ATOMIC, ITEM_SORTED, ITEM_CHUNKED, ITEM_FUSED = 0, 1, 2, 3
 ORDER_IDENTITY, ORDER_PERM, ORDER_FEISTEL = 0, 1, 2
 PLAN_TRIPLES_USER_SORTED = 1
+PLAN_POINTWISE = 2
 STATS_LEN = 16
 ST_LOSS_DATA, ST_L1_U, ST_L1_I, ST_L1_J, ST_SQ_U, ST_SQ_I, ST_SQ_J = range(7)
 ST_LOSS, ST_NORM_U, ST_NORM_I, ST_NORM_J = 7, 8, 9, 10
@@ -41,6 +42,7 @@ SIGNATURES = {
     "daisy_bpr_set_batch_from_triples": (C.c_int, [_p, _p, _i64, _p, _i64, _i64, _i32, _p]),
     "daisy_bpr_set_batch": (C.c_int, [_p, _p, _p, _p, _i64, _p]),
     "daisy_bpr_set_batch_from_plan": (C.c_int, [_p, _p, _i64, _p]),
+    "daisy_bpr_ctx_set_pointwise": (C.c_int, [_p, _i32]),
     "daisy_epoch_plan_create": (C.c_int, [C.POINTER(_p), _i64, _i64, _i64]),
     "daisy_epoch_plan_destroy": (C.c_int, [_p]),
     "daisy_epoch_plan_bytes": (_sz, [_p]),

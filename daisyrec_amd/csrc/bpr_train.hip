@@ -50,6 +50,9 @@ struct BatchView {
     const uint32_t *run_key, *run_cnt;
     const int32_t *run_off;
     uint32_t umask, imask;
+    // point-wise losses (CL / SL, MFRecommender.py:75-81): ij[s] = (item, label); the "negative"
+    // slot of a sample is an inert copy of its item (coefficient 0, not counted by the regulariser)
+    int32_t pointwise;
     int64_t B;
 };
 
@@ -75,6 +78,7 @@ struct daisy_epoch_plan {
     uint32_t umask, imask;
     void *temp;
     int64_t n, batch_size, num_batches;
+    int32_t pointwise;
     bool built;
 };
 
@@ -95,6 +99,7 @@ struct daisy_bpr_ctx {
     const float *p_sqnorm_of;   // table the cache describes (NULL = invalid)
     daisy_epoch_plan *own_plan;   // 1-batch plan used by set_batch / set_batch_from_triples
     daisy::BatchView v;
+    int32_t pointwise;   // batches set through set_batch* hold (user, item, label) rows
     int last_item_mode;  // mode of the last daisy_bpr_item_grad: the user pass of the same step follows it
     bool batch_set, fwd_done;
 };
@@ -128,7 +133,7 @@ __global__ void k_plan_keys(const int32_t *__restrict__ triples, const int64_t *
 // from the user-grouped samples: the two item entries of every sample
 template <class KeyT>
 __global__ void k_plan_entries(const KeyT *__restrict__ skey, const uint64_t *__restrict__ sval,
-                               int64_t n, int64_t B, int ibits, uint32_t umask,
+                               int64_t n, int64_t B, int ibits, uint32_t umask, int pointwise,
                                KeyT *__restrict__ ekey, uint64_t *__restrict__ eval) {
     for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n;
          p += (int64_t)gridDim.x * blockDim.x) {
@@ -138,7 +143,8 @@ __global__ void k_plan_entries(const KeyT *__restrict__ skey, const uint64_t *__
         const uint64_t ij = sval[p];
         ekey[2 * p] = (KeyT)((k << (ibits + 1)) | ((uint64_t)(uint32_t)ij << 1));
         eval[2 * p] = ((uint64_t)uu << 32) | s;
-        ekey[2 * p + 1] = (KeyT)((k << (ibits + 1)) | ((uint64_t)(uint32_t)(ij >> 32) << 1) | 1u);
+        const uint32_t jn = pointwise ? (uint32_t)ij : (uint32_t)(ij >> 32);
+        ekey[2 * p + 1] = (KeyT)((k << (ibits + 1)) | ((uint64_t)jn << 1) | 1u);
         eval[2 * p + 1] = ((uint64_t)uu << 32) | (s | kNegBit);
     }
 }
@@ -222,6 +228,16 @@ __device__ __forceinline__ void pair_coef(int loss_type, float pos, float neg, f
         term = fmaxf(m, 0.f);
         cp = (m >= 0.f) ? -1.f : 0.f;
         cn = -cp;
+    } else if (loss_type == DAISY_LOSS_CL) {  // BCEWithLogitsLoss(sum)(pos, label); neg carries the label
+        const float y = neg;
+        term = fmaxf(pos, 0.f) - pos * y + log1pf(expf(-fabsf(pos)));
+        cp = sigmoidf_(pos) - y;
+        cn = 0.f;
+    } else if (loss_type == DAISY_LOSS_SL) {  // MSELoss(sum)(pos, label)
+        const float e = pos - neg;
+        term = e * e;
+        cp = 2.f * e;
+        cn = 0.f;
     } else {  // TOP1, loss.py:30-33
         const float s1 = sigmoidf_(neg - pos);
         const float s2 = sigmoidf_(neg * neg);
@@ -251,17 +267,18 @@ __global__ __launch_bounds__(kBlock) void k_fwd(const float *__restrict__ P,
         Row<C> p, qi, qj;
         p.load(P + uu * d, lane, d);
         qi.load(Q + (int64_t)ij.x * d, lane, d);
-        qj.load(Q + (int64_t)ij.y * d, lane, d);
+        qj.load(Q + (int64_t)(v.pointwise ? ij.x : ij.y) * d, lane, d);
         const float pos = row_dot<C>(p, qi);
-        const float neg = row_dot<C>(p, qj);
+        const float neg = v.pointwise ? (float)ij.y : row_dot<C>(p, qj);   // point-wise: the label
+        const float wj = v.pointwise ? 0.f : 1.f;                          // no negative item to regularise
 #pragma unroll
         for (int k = 0; k < C::NE; ++k) {
             acc[1] += fabsf(p.v[k]);
             acc[2] += fabsf(qi.v[k]);
-            acc[3] += fabsf(qj.v[k]);
+            acc[3] = fmaf(wj, fabsf(qj.v[k]), acc[3]);
             acc[4] = fmaf(p.v[k], p.v[k], acc[4]);
             acc[5] = fmaf(qi.v[k], qi.v[k], acc[5]);
-            acc[6] = fmaf(qj.v[k], qj.v[k], acc[6]);
+            acc[6] = fmaf(wj * qj.v[k], qj.v[k], acc[6]);
         }
         if (lane == 0) {
             float term, cp, cn;
@@ -375,7 +392,7 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_atomic(
         if constexpr (REG) {
             Row<C> qi, qj;
             qi.load(Q + (int64_t)ij.x * d, lane, d);
-            qj.load(Q + (int64_t)ij.y * d, lane, d);
+            qj.load(Q + (int64_t)(v.pointwise ? ij.x : ij.y) * d, lane, d);
 #pragma unroll
             for (int k = 0; k < C::NE; ++k) {
                 gi.v[k] = fmaf(c.x, p.v[k], fmaf(rI, qi.v[k], reg_1 * sgn(qi.v[k])));
@@ -389,7 +406,7 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_atomic(
             }
         }
         gi.atomic_add_to(gQ + (int64_t)ij.x * d, lane, d);
-        gj.atomic_add_to(gQ + (int64_t)ij.y * d, lane, d);
+        if (!v.pointwise) gj.atomic_add_to(gQ + (int64_t)ij.y * d, lane, d);
     }
 }
 
@@ -421,7 +438,7 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_sorted(
             const float2 c2 = coef[su.x & ~kNegBit];
             const float c = is_neg ? c2.y : c2.x;
             n_pos += is_neg ? 0.f : 1.f;
-            n_neg += is_neg ? 1.f : 0.f;
+            n_neg += (is_neg && !v.pointwise) ? 1.f : 0.f;
             Row<C> p;
             p.load(P + (int64_t)su.y * d, lane, d);
 #pragma unroll
@@ -609,6 +626,7 @@ __device__ __forceinline__ bool run_head(const BatchView &v, int64_t m, int64_t 
     fp = (key & 1u) ? 0.f : c;
     fn = (key & 1u) ? c : 0.f;
     if (!(key & 1u) && m + 1 < m1 && (v.run_key[m + 1] >> 1) == (key >> 1)) fn = (float)v.run_cnt[m + 1];
+    if (v.pointwise) fn = 0.f;      // the negative slots are inert copies
     return true;
 }
 
@@ -662,7 +680,7 @@ __global__ __launch_bounds__(kBlock) void k_user(float *__restrict__ P, const fl
             const int2 ij = v.ij[q];
             Row<C> qi, qj;
             qi.load(Q + (int64_t)ij.x * d, lane, d);
-            qj.load(Q + (int64_t)ij.y * d, lane, d);
+            qj.load(Q + (int64_t)(v.pointwise ? ij.x : ij.y) * d, lane, d);
 #pragma unroll
             for (int k = 0; k < C::NE; ++k)
                 acc.v[k] = fmaf(c.x, qi.v[k], fmaf(c.y, qj.v[k], acc.v[k]));
@@ -808,7 +826,8 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
 #pragma unroll
         for (int x = 0; x < RUN; ++x) {
             const int32_t ux = __shfl(my_user, x, C::LPR);
-            const int ix = __shfl(my_ij.x, x, C::LPR), jx = __shfl(my_ij.y, x, C::LPR);
+            const int ix = __shfl(my_ij.x, x, C::LPR);
+            const int jx = v.pointwise ? ix : __shfl(my_ij.y, x, C::LPR);
             if (x < cnt) {
                 qi[x].load(Q + (int64_t)ix * d, lane, d);
                 qj[x].load(Q + (int64_t)jx * d, lane, d);
@@ -1157,6 +1176,7 @@ static int plan_build(daisy_epoch_plan *p, const int32_t *triples, int64_t n, in
     const uint32_t imask = (uint32_t)(((uint64_t)1 << ibits1) - 1);
     const bool wide = (ubits + bbits > 32) || (ibits1 + bbits > 32);
     const bool presorted = (flags & DAISY_PLAN_TRIPLES_USER_SORTED) && order_mode != DAISY_ORDER_PERM;
+    const int pointwise = (flags & DAISY_PLAN_POINTWISE) ? 1 : 0;
     const int s_begin = presorted ? ubits : 0;      // user bits ride along unsorted
     FeistelKey fk = make_feistel_key((uint64_t)n, seed, epoch);
     const int g1 = grid_for(n, kBlock), g2 = grid_for(2 * n, kBlock);
@@ -1174,7 +1194,7 @@ static int plan_build(daisy_epoch_plan *p, const int32_t *triples, int64_t n, in
             DAISY_HIP(hipMemcpyAsync(p->uval, p->v64[0], n * 8, hipMemcpyDeviceToDevice, s));
         }
         hipLaunchKernelGGL((k_plan_entries<uint32_t>), dim3(g1), dim3(kBlock), 0, s, p->ukey, p->uval,
-                           n, batch_size, ibits, umask, p->k32[0], p->v64[0]);
+                           n, batch_size, ibits, umask, pointwise, p->k32[0], p->v64[0]);
         DAISY_LAUNCH_CHECK();
         rc = sort_pairs_u32_u64(p->temp, p->temp_bytes, p->k32[0], p->k32[1], p->v64[0], p->v64[1], 2 * n,
                                 0, ibits1 + bbits, s);
@@ -1199,7 +1219,7 @@ static int plan_build(daisy_epoch_plan *p, const int32_t *triples, int64_t n, in
                            p->ukey);
         DAISY_LAUNCH_CHECK();
         hipLaunchKernelGGL((k_plan_entries<uint64_t>), dim3(g1), dim3(kBlock), 0, s, p->k64[1], p->uval,
-                           n, batch_size, ibits, 0xFFFFFFFFu & umask, p->k64[0], p->v64[0]);
+                           n, batch_size, ibits, 0xFFFFFFFFu & umask, pointwise, p->k64[0], p->v64[0]);
         DAISY_LAUNCH_CHECK();
         rc = sort_pairs_u64_u64(p->temp, p->temp_bytes, p->k64[0], p->k64[1], p->v64[0], p->v64[1], 2 * n,
                                 0, ibits1 + bbits, s);
@@ -1218,6 +1238,7 @@ static int plan_build(daisy_epoch_plan *p, const int32_t *triples, int64_t n, in
     p->ekey = p->k32[1];
     p->eval = p->v64[1];
     p->n = n; p->batch_size = batch_size; p->num_batches = nb; p->built = true;
+    p->pointwise = pointwise;
     return DAISY_OK;
 }
 
@@ -1234,6 +1255,7 @@ static BatchView plan_view(const daisy_epoch_plan *p, int64_t k) {
     v.run_off = p->run_off + k;
     v.umask = p->umask;
     v.imask = p->imask;
+    v.pointwise = p->pointwise;
     return v;
 }
 
@@ -1320,6 +1342,7 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
     c->max_batch = max_batch; c->d = d; c->U = user_num; c->I = item_num;
     c->batch_set = false; c->fwd_done = false; c->own_plan = nullptr;
     c->last_item_mode = DAISY_ITEM_SORTED;
+    c->pointwise = 0;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     const size_t o_coef = take((size_t)max_batch * 8);
@@ -1375,6 +1398,12 @@ static int ensure_own_plan(daisy_bpr_ctx *ctx) {
     return plan_alloc(&ctx->own_plan, ctx->max_batch, ctx->U, ctx->I);
 }
 
+int daisy_bpr_ctx_set_pointwise(daisy_bpr_ctx *ctx, int32_t pointwise) {
+    DAISY_CHECK_ARG(ctx != nullptr, "ctx_set_pointwise: NULL argument");
+    ctx->pointwise = pointwise ? 1 : 0;
+    return DAISY_OK;
+}
+
 int daisy_bpr_set_batch_from_plan(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, int64_t k,
                                   daisy_stream_t stream) {
     (void)stream;
@@ -1403,7 +1432,7 @@ int daisy_bpr_set_batch_from_triples(daisy_bpr_ctx *ctx, const int32_t *triples,
     if (rc) return rc;
     // a one-batch plan over the selected rows
     rc = plan_build(ctx->own_plan, triples, B, idx ? 0 : start, idx, idx ? DAISY_ORDER_PERM : DAISY_ORDER_IDENTITY,
-                    0, 0, B, user_base, 0, S(stream));
+                    0, 0, B, user_base, ctx->pointwise ? DAISY_PLAN_POINTWISE : 0, S(stream));
     if (rc) return rc;
     ctx->v = plan_view(ctx->own_plan, 0);
     ctx->batch_set = true; ctx->fwd_done = false;
@@ -1426,9 +1455,12 @@ static int forward_impl(daisy_bpr_ctx *ctx, const float *P, const float *Q, int3
                         float gamma, double *stats, bool finalize, float reg_1, float reg_2,
                         double *epoch_acc, double *step_loss, daisy_stream_t stream) {
     DAISY_CHECK_ARG(ctx && P && Q && stats, "forward: NULL argument");
-    DAISY_CHECK_ARG(loss_type >= DAISY_LOSS_BPR && loss_type <= DAISY_LOSS_TL,
+    DAISY_CHECK_ARG(loss_type >= DAISY_LOSS_BPR && loss_type <= DAISY_LOSS_SL,
                     "Invalid loss type: %d", loss_type);
     if (!ctx->batch_set) { set_error("forward: no batch set"); return DAISY_ERR_STATE; }
+    DAISY_CHECK_ARG((loss_type >= DAISY_LOSS_CL) == (ctx->v.pointwise != 0),
+                    "forward: loss type %d does not match the batch layout (point-wise=%d)", loss_type,
+                    ctx->v.pointwise);
     hipStream_t s = S(stream);
     const BatchView &v = ctx->v;
     const int d = ctx->d;
@@ -1664,7 +1696,7 @@ int daisy_bpr_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t loss_type
                        double *epoch_acc, double *step_loss, int32_t item_mode,
                        daisy_stream_t stream) {
     if (item_mode == DAISY_ITEM_FUSED) {
-        if (ctx->d <= 64)   // rows of <= 4 floats per lane: the fused kernel fits the register budget
+        if (ctx->d <= 64 && !ctx->v.pointwise)   // rows of <= 4 floats per lane: the fused kernel fits the register budget
             return sgd_step_fused(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, gQ, stats, epoch_acc,
                                   step_loss, stream);
         item_mode = DAISY_ITEM_CHUNKED;

@@ -94,9 +94,6 @@ class AbstractRecommender(nn.Module):
         """AbstractRecommender.py:79-93.  Pairwise losses are an epilogue of the
         forward kernel; the returned value is the native loss id."""
         key = str(loss_type).upper()
-        if key in ("CL", "SL"):
-            raise NotImplementedError(
-                f"point-wise loss {key} is outside the BPR hot path (SURVEY.md section 8f, next rows)")
         if key not in ops.LOSS_IDS:
             raise NotImplementedError(f"Invalid loss type: {self.loss_type}...")
         return ops.LOSS_IDS[key]
@@ -168,6 +165,7 @@ class GeneralRecommender(AbstractRecommender):
         plan = ops.EpochPlan(n, P.shape[0], Q.shape[0], device=P.device)
         adam = _AdamState(P, Q, self.lr) if opt == "adam" else None
         user_sorted = ops.triples_user_sorted(triples[:n])
+        pointwise = loss_id in ops.POINTWISE_LOSSES      # rows are (user, item, label), sampler.py:93-98
         self.epoch_losses = []
         last_loss = 0.0
         try:
@@ -178,14 +176,14 @@ class GeneralRecommender(AbstractRecommender):
                 from torch.utils.data import SequentialSampler
                 if self.shuffle_mode == "device" and not isinstance(train_loader.sampler, SequentialSampler):
                     plan.build(triples, B, order="feistel", seed=self.seed, epoch=epoch, n_triples=n,
-                               user_sorted=user_sorted)
+                               user_sorted=user_sorted, pointwise=pointwise)
                 else:
                     perm = self._epoch_order(train_loader, triples.shape[0])
                     if perm is not None:
                         perm = perm[:n].contiguous().to(self.device)
                     # radix sorts lay the epoch out batch by batch, in the DataLoader's order
                     plan.build(triples, B, order="identity" if perm is None else "perm", perm=perm,
-                               n_triples=n, user_sorted=user_sorted)
+                               n_triples=n, user_sorted=user_sorted, pointwise=pointwise)
                 ctx.epoch_acc.zero_()
                 if adam is None:
                     ctx.fit_epoch_sgd(plan, P, Q, self.lr, self.reg_1, self.reg_2, loss_type=loss_id,

@@ -57,14 +57,12 @@ class MF(GeneralRecommender):
         """MFRecommender.py:70-97 for the pairwise losses: returns the batch loss
         (0-dim float64 tensor on the device; no autograd graph — the gradient is
         produced by the update kernels, not by backward())."""
-        key = str(self.loss_type).upper()
-        if key in ("CL", "SL"):
-            raise NotImplementedError(f"point-wise loss {key} is outside the BPR hot path")
         loss_id = self._build_criterion(self.loss_type)          # raises on invalid types
         P, Q = self._tables()
         u, i, j = (torch.as_tensor(x).to(torch.int32).to(P.device).contiguous() for x in batch[:3])
         ctx = ops.BprContext(u.numel(), P.shape[1], P.shape[0], Q.shape[0], device=P.device)
         try:
+            ctx.set_pointwise(loss_id in ops.POINTWISE_LOSSES)   # batch[2] is the label (MFRecommender.py:76)
             ctx.set_batch(u, i, j)
             ctx.forward(P, Q, loss_id)
             out = torch.zeros((), dtype=torch.float64, device=P.device)

@@ -13,7 +13,8 @@ import torch
 from . import _native as N
 from ._native import check, lib
 
-LOSS_IDS = {"BPR": N.LOSS_BPR, "HL": N.LOSS_HL, "TL": N.LOSS_TL}
+LOSS_IDS = {"BPR": N.LOSS_BPR, "HL": N.LOSS_HL, "TL": N.LOSS_TL, "CL": N.LOSS_CL, "SL": N.LOSS_SL}
+POINTWISE_LOSSES = (N.LOSS_CL, N.LOSS_SL)
 ITEM_MODES = {"atomic": N.ITEM_ATOMIC, "sorted": N.ITEM_SORTED, "chunked": N.ITEM_CHUNKED,
               "fused": N.ITEM_FUSED}
 ORDER_MODES = {"identity": N.ORDER_IDENTITY, "perm": N.ORDER_PERM, "feistel": N.ORDER_FEISTEL}
@@ -65,12 +66,12 @@ class EpochPlan:
                                               int(item_num)))
 
     def build(self, triples, batch_size, order="identity", perm=None, seed=0, epoch=0, user_base=0,
-              n_triples=None, user_sorted=False):
+              n_triples=None, user_sorted=False, pointwise=False):
         """user_sorted=True promises that `triples` is sorted by user (use `triples_user_sorted`
         to check once): grouping by user then costs one radix pass instead of a full sort."""
         n = triples.shape[0] if n_triples is None else int(n_triples)
         mode = ORDER_MODES[order] if isinstance(order, str) else int(order)
-        flags = N.PLAN_TRIPLES_USER_SORTED if user_sorted else 0
+        flags = (N.PLAN_TRIPLES_USER_SORTED if user_sorted else 0) | (N.PLAN_POINTWISE if pointwise else 0)
         check(lib.daisy_epoch_plan_build(self._h, _ptr(triples, torch.int32, "triples"), n,
                                          _ptr(perm, torch.int64, "perm"), mode, int(seed), int(epoch),
                                          int(batch_size), int(user_base), flags, _stream()))
@@ -154,6 +155,10 @@ class BprContext:
     @property
     def scratch_bytes(self):
         return int(lib.daisy_bpr_ctx_scratch_bytes(self._h))
+
+    def set_pointwise(self, flag):
+        """Rows given to set_batch* are (user, item, label) - the CL / SL layout (sampler.py:93-98)."""
+        check(lib.daisy_bpr_ctx_set_pointwise(self._h, int(bool(flag))))
 
     # -- batch -------------------------------------------------------------
     def set_batch_from_triples(self, triples, idx=None, start=0, B=None, user_base=0):

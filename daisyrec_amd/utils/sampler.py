@@ -61,9 +61,12 @@ class BasicNegtiveSampler(AbstractSampler):
     def sampling_device(self):
         """Triples as an int32 [N*num_ng, 3] DEVICE tensor."""
         if self.num_ng == 0:
+            if self.loss_type in ("CL", "SL"):                                          # sampler.py:58-59
+                cols = [self.uid_name, self.iid_name, self.inter_name]
+                return torch.from_numpy(self.df[cols].to_numpy().astype(np.int32)).to(self.device)
             raise NotImplementedError("loss function (BPR, TL, HL) need num_ng > 0")   # sampler.py:61
-        if self.loss_type not in ("BPR", "HL", "TL"):
-            raise NotImplementedError(f"{self.loss_type}: point-wise sample layout is outside the BPR hot path")
+        if self.loss_type not in ("BPR", "HL", "TL", "CL", "SL"):
+            raise NotImplementedError(f"Invalid loss type: {self.loss_type}")
         if not torch.cuda.is_available():
             raise RuntimeError("daisyrec_amd sampler needs a HIP device (no CPU fallback)")
         pu, pi = self._train_pairs()
@@ -72,7 +75,14 @@ class BasicNegtiveSampler(AbstractSampler):
         js = ops.sample_neg_per_user(indptr, csr, self.item_num, self.num_ng, self.seed, self.epoch)
         users = torch.from_numpy(self.df[self.uid_name].to_numpy().astype(np.int32)).to(self.device)
         items = torch.from_numpy(self.df[self.iid_name].to_numpy().astype(np.int32)).to(self.device)
-        return ops.expand_triples(users, items, js)
+        triples = ops.expand_triples(users, items, js)
+        if self.loss_type in ("CL", "SL"):
+            # sampler.py:93-98: positives (u, i, rating) stacked on negatives (u, neg, 0)
+            rating = torch.from_numpy(self.df[self.inter_name].to_numpy().astype(np.int32)).to(self.device)
+            pos = torch.stack([users, items, rating], 1)
+            neg = torch.stack([triples[:, 0], triples[:, 2], torch.zeros_like(triples[:, 2])], 1)
+            return torch.cat([pos, neg], 0).contiguous()
+        return triples
 
     def sampling(self):
         """np.int32 (N*num_ng, 3) like sampler.py:100-101."""

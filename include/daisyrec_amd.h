@@ -42,7 +42,10 @@ enum daisy_status {
 enum daisy_loss {
     DAISY_LOSS_BPR = 0, /* -(gamma + sigmoid(pos-neg)).log().sum()          loss.py:10-13 */
     DAISY_LOSS_HL = 1,  /* clamp(1-(pos-neg), min=0).sum()                  loss.py:20-23 */
-    DAISY_LOSS_TL = 2   /* sigmoid(neg-pos).sum()+sigmoid(neg**2).sum()     loss.py:30-33 */
+    DAISY_LOSS_TL = 2,  /* sigmoid(neg-pos).sum()+sigmoid(neg**2).sum()     loss.py:30-33 */
+    /* point-wise (AbstractRecommender.py:80-83, MFRecommender.py:75-81): rows are (user, item, label) */
+    DAISY_LOSS_CL = 3,  /* nn.BCEWithLogitsLoss(reduction='sum')(pred, label)               */
+    DAISY_LOSS_SL = 4   /* nn.MSELoss(reduction='sum')(pred, label)                         */
 };
 
 /* how the item-side gradient is accumulated (entries of a batch are always sorted by item) */
@@ -113,6 +116,7 @@ size_t daisy_epoch_plan_bytes(const daisy_epoch_plan *plan);
  * triple array is sorted by user (CSR order), so grouping a batch by user only needs a
  * stable partition by batch (one radix pass); a wrong promise gives wrong updates. */
 #define DAISY_PLAN_TRIPLES_USER_SORTED 1
+#define DAISY_PLAN_POINTWISE 2 /* rows are (user, item, label): CL / SL losses */
 int daisy_epoch_plan_build(daisy_epoch_plan *plan, const int32_t *triples, int64_t n_triples,
                            const int64_t *perm, int32_t order_mode, uint64_t seed, uint64_t epoch,
                            int64_t batch_size, int32_t user_base, int32_t flags,
@@ -129,6 +133,8 @@ int daisy_epoch_plan_read_batch(const daisy_epoch_plan *plan, int64_t k, int32_t
 int daisy_feistel_positions(int64_t n, uint64_t seed, uint64_t epoch, int64_t *out,
                             daisy_stream_t stream);
 
+/* batches set with daisy_bpr_set_batch / _from_triples are (user, item, label) rows (CL / SL) */
+int daisy_bpr_ctx_set_pointwise(daisy_bpr_ctx *ctx, int32_t pointwise);
 /* make batch k of a built plan current (no copy) */
 int daisy_bpr_set_batch_from_plan(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, int64_t k,
                                   daisy_stream_t stream);

@@ -24,8 +24,8 @@ from __future__ import annotations
 
 import numpy as np
 
-LOSS_BPR, LOSS_HL, LOSS_TL = 0, 1, 2
-LOSS_IDS = {"BPR": LOSS_BPR, "HL": LOSS_HL, "TL": LOSS_TL}
+LOSS_BPR, LOSS_HL, LOSS_TL, LOSS_CL, LOSS_SL = 0, 1, 2, 3, 4
+LOSS_IDS = {"BPR": LOSS_BPR, "HL": LOSS_HL, "TL": LOSS_TL, "CL": LOSS_CL, "SL": LOSS_SL}
 
 
 def _sigmoid(x):
@@ -105,6 +105,40 @@ def mf_pair_grad(P, Q, u, i, j, reg_1, reg_2, loss_type=LOSS_BPR, gamma=1e-10,
     return loss, gP, gQ
 
 
+def mf_point_grad(P, Q, u, i, label, reg_1, reg_2, loss_type=LOSS_CL, dtype=np.float64):
+    """Point-wise branch of MF.calc_loss (MFRecommender.py:75-81,93-95): rows (user, item, label),
+    criterion = BCEWithLogitsLoss(sum) [CL] or MSELoss(sum) [SL] (AbstractRecommender.py:80-83),
+    regularisers on Q[item] and P[user] only."""
+    P = np.asarray(P, dtype=dtype)
+    Q = np.asarray(Q, dtype=dtype)
+    u = np.asarray(u, dtype=np.int64)
+    i = np.asarray(i, dtype=np.int64)
+    y = np.asarray(label, dtype=dtype)
+    pu, qi = P[u], Q[i]
+    x = np.einsum("bk,bk->b", pu, qi)
+    if loss_type == LOSS_CL:
+        terms = np.maximum(x, 0) - x * y + np.log1p(np.exp(-np.abs(x)))
+        c = _sigmoid(x) - y
+    elif loss_type == LOSS_SL:
+        terms = (x - y) ** 2
+        c = 2.0 * (x - y)
+    else:
+        raise NotImplementedError(f"Invalid point-wise loss type: {loss_type}")
+    nU = np.sqrt((pu * pu).sum(dtype=dtype))
+    nI = np.sqrt((qi * qi).sum(dtype=dtype))
+    loss = terms.sum(dtype=dtype) + reg_1 * np.abs(qi).sum(dtype=dtype) + reg_2 * nI \
+        + reg_1 * np.abs(pu).sum(dtype=dtype) + reg_2 * nU
+
+    def _fro(v, n):
+        return v / n if n > 0 else np.zeros_like(v)
+
+    gP = np.zeros_like(P)
+    gQ = np.zeros_like(Q)
+    np.add.at(gP, u, c[:, None] * qi + reg_1 * np.sign(pu) + reg_2 * _fro(pu, nU))
+    np.add.at(gQ, i, c[:, None] * pu + reg_1 * np.sign(qi) + reg_2 * _fro(qi, nI))
+    return loss, gP, gQ
+
+
 def mf_sgd_step(P, Q, u, i, j, lr, reg_1, reg_2, loss_type=LOSS_BPR, gamma=1e-10,
                 dtype=np.float64):
     """One `zero_grad / calc_loss / backward / SGD.step` (AbstractRecommender.py:119-126).
@@ -113,7 +147,10 @@ def mf_sgd_step(P, Q, u, i, j, lr, reg_1, reg_2, loss_type=LOSS_BPR, gamma=1e-10
     reference's parameters.  With dtype=float64 this is the "exact" batch
     synchronous result rounded once.
     """
-    loss, gP, gQ = mf_pair_grad(P, Q, u, i, j, reg_1, reg_2, loss_type, gamma, dtype)
+    if loss_type in (LOSS_CL, LOSS_SL):       # j holds the labels
+        loss, gP, gQ = mf_point_grad(P, Q, u, i, j, reg_1, reg_2, loss_type, dtype)
+    else:
+        loss, gP, gQ = mf_pair_grad(P, Q, u, i, j, reg_1, reg_2, loss_type, gamma, dtype)
     Pn = (np.asarray(P, dtype=dtype) - dtype(lr) * gP).astype(np.float32)
     Qn = (np.asarray(Q, dtype=dtype) - dtype(lr) * gQ).astype(np.float32)
     return float(loss), Pn, Qn

@@ -88,10 +88,13 @@ def kat_case(name, U, I, d, B, loss_type, optimizer, reg_1, reg_2, lr, n_steps, 
         u = rng.integers(0, U, size=B).astype(np.int32)
         i = rng.integers(0, I, size=B).astype(np.int32)
         j = rng.integers(0, I, size=B).astype(np.int32)
+        if loss_type in ("CL", "SL"):    # point-wise rows are (user, item, label)  (sampler.py:93-98)
+            j = rng.integers(0, 2, size=B).astype(np.int32)
         if B >= 4:                       # force the hard cases
             u[1] = u[0]                  # duplicate user
             i[2] = i[0]                  # duplicate positive
-            j[3] = i[0]                  # same item positive and negative in one batch
+            if loss_type not in ("CL", "SL"):
+                j[3] = i[0]              # same item positive and negative in one batch
         if zero_rows:
             u[0] = 0
             i[0] = 0
@@ -132,6 +135,9 @@ def make_kat_steps():
         ("hl_d32",      50,  40,  32, 64,  "HL",  "sgd",  1e-3,  1e-3,  0.01, 2, {"scale": 0.5}),
         ("tl_d32",      50,  40,  32, 64,  "TL",  "sgd",  1e-3,  1e-3,  0.01, 2, {"scale": 0.5}),
         ("bpr_adam",    50,  40,  32, 64,  "BPR", "adam", 1e-3,  1e-3,  0.01, 4, {}),
+        ("cl_d32",      50,  40,  32, 64,  "CL",  "sgd",  1e-3,  1e-3,  0.01, 3, {"scale": 0.5}),
+        ("sl_d64",      50,  40,  64, 96,  "SL",  "sgd",  1e-3,  1e-3,  0.01, 3, {"scale": 0.5}),
+        ("cl_zero",     50,  40,  32, 64,  "CL",  "sgd",  1e-3,  1e-3,  0.01, 2, {"zero_rows": True}),
     ]
     for (name, U, I, d, B, lt, opt, r1, r2, lr, ns, kw) in cases:
         out.update(kat_case(name, U, I, d, B, lt, opt, r1, r2, lr, ns, rng, **kw))

@@ -40,6 +40,7 @@ def test_kat_steps_sgd(ops, kat_steps, item_mode):
         lt = ops.loss_id(str(g[f"{name}/loss_type"]))
         P, Q = _t(g[f"{name}/P0"]), _t(g[f"{name}/Q0"])
         ctx = ops.BprContext(B, d, U, I)
+        ctx.set_pointwise(lt in ops.POINTWISE_LOSSES)          # CL / SL rows are (user, item, label)
         step_loss = torch.zeros(1, dtype=torch.float64, device=DEV)
         scale = max(1.0, float(np.abs(g[f"{name}/P0"]).max()))
         for s in range(ns):
@@ -87,13 +88,16 @@ def test_step_vs_oracle_shapes(ops, d):
     i = rng.integers(0, I, B).astype(np.int32)
     j = rng.integers(0, I, B).astype(np.int32)
     lr, r1, r2 = 0.05, 0.01, 0.02
-    for lt_name in ("BPR", "HL", "TL"):
-        loss, Pn, Qn = O.mf_sgd_step(P0, Q0, u, i, j, lr, r1, r2, O.LOSS_IDS[lt_name])
+    lab = rng.integers(0, 2, B).astype(np.int32)
+    for lt_name in ("BPR", "HL", "TL", "CL", "SL"):
+        third = lab if lt_name in ("CL", "SL") else j
+        loss, Pn, Qn = O.mf_sgd_step(P0, Q0, u, i, third, lr, r1, r2, O.LOSS_IDS[lt_name])
         for mode in ("sorted", "atomic", "chunked", "fused"):
             P, Q = _t(P0), _t(Q0)
             ctx = ops.BprContext(B, d, U, I)
+            ctx.set_pointwise(lt_name in ("CL", "SL"))
             sl = torch.zeros(1, dtype=torch.float64, device=DEV)
-            ctx.set_batch(_t(u), _t(i), _t(j))
+            ctx.set_batch(_t(u), _t(i), _t(third))
             ctx.sgd_step(P, Q, lr, r1, r2, loss_type=ops.LOSS_IDS[lt_name],
                          item_mode=ops.ITEM_MODES[mode], step_loss=sl)
             assert abs(float(sl.cpu()) - loss) <= 1e-5 * abs(loss), (d, lt_name, mode)
@@ -494,3 +498,42 @@ def test_fit_device_shuffle_trains(ml100k):
     assert L[0] > L[1] > L[2]
     for got, ref in zip(L, g["epoch_losses"]):
         assert abs(got - ref) <= 0.02 * ref            # different shuffles of the same data
+
+
+def test_pointwise_cl_through_sampler_and_fit(ops, ml100k):
+    """CL loss end to end through the mirrors (sampler.py:93-98 layout, MFRecommender.py:75-81):
+    the device sampler emits (u, i, 1) rows followed by (u, neg, 0) rows; MF.fit trains on them and
+    one collated batch gives the oracle's point-wise loss."""
+    import pandas as pd
+    from daisyrec_amd.model.MFRecommender import MF
+    from daisyrec_amd.utils.dataset import BasicDataset, get_dataloader
+    from daisyrec_amd.utils.sampler import BasicNegtiveSampler
+    g = ml100k
+    U, I = int(g["user_num"]), int(g["item_num"])
+    df = pd.DataFrame({"user": g["train_users"], "item": g["train_items"], "rating": 1})
+    cfg = mf_config(user_num=U, item_num=I, num_ng=2, loss_type="CL", epochs=2, item_mode="chunked")
+    rows = BasicNegtiveSampler(df, cfg).sampling()
+    n = len(df)
+    assert rows.shape == (3 * n, 3) and rows.dtype == np.int32
+    np.testing.assert_array_equal(rows[:n], np.stack([g["train_users"], g["train_items"], np.ones(n, np.int32)], 1))
+    assert (rows[n:, 2] == 0).all()
+    np.testing.assert_array_equal(rows[n::1][::2, 0][:n], g["train_users"])
+    pos = {(int(a), int(b)) for a, b in zip(g["train_users"], g["train_items"])}
+    assert not any((int(a), int(b)) in pos for a, b in rows[n:n + 5000, :2])
+    torch.manual_seed(3)
+    model = MF(cfg)
+    P0 = model.embed_user.weight.detach().numpy().copy()
+    Q0 = model.embed_item.weight.detach().numpy().copy()
+    b = rows[np.random.default_rng(0).permutation(len(rows))[:512]]
+    want = O.mf_point_grad(P0, Q0, b[:, 0], b[:, 1], b[:, 2], cfg["reg_1"], cfg["reg_2"], O.LOSS_CL)[0]
+    got = float(model.calc_loss([torch.from_numpy(b[:, k].copy()) for k in range(3)]).cpu())
+    assert abs(got - want) <= 1e-5 * abs(want)
+    loader = get_dataloader(BasicDataset(rows), batch_size=1024, shuffle=True, num_workers=0)
+    model.fit(loader)
+    assert model.epoch_losses[1] < model.epoch_losses[0] and np.isfinite(model.epoch_losses).all()
+    with pytest.raises(ValueError):                 # pair-wise loss on a point-wise batch layout
+        ctx = ops.BprContext(8, 32, U, I)
+        ctx.set_pointwise(True)
+        z = _t(np.zeros(8, np.int32))
+        ctx.set_batch(z, z, z)
+        ctx.forward(model.embed_user.weight.data, model.embed_item.weight.data, ops.LOSS_IDS["BPR"])
