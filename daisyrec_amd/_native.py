@@ -53,6 +53,8 @@ SIGNATURES = {
     "daisy_bpr_forward": (C.c_int, [_p, _p, _p, _i32, _f32, _p, _p]),
     "daisy_bpr_finalize": (C.c_int, [_p, _p, _f32, _f32, _p, _p, _p]),
     "daisy_bpr_item_grad": (C.c_int, [_p, _p, _p, _p, _f32, _f32, _p, _i32, _p]),
+    "daisy_bpr_item_grad_data": (C.c_int, [_p, _p, _p, _p, _p, _i32, _p]),
+    "daisy_bpr_item_grad_reg": (C.c_int, [_p, _p, _p, _f32, _f32, _p, _p]),
     "daisy_bpr_user_sgd": (C.c_int, [_p, _p, _p, _p, _f32, _f32, _f32, _p]),
     "daisy_bpr_user_grad": (C.c_int, [_p, _p, _p, _p, _f32, _f32, _p, _p]),
     "daisy_bpr_item_sgd_apply": (C.c_int, [_p, _p, _p, _f32, _i32, _p]),

@@ -251,39 +251,71 @@ __device__ __forceinline__ void pair_coef(int loss_type, float pos, float neg, f
 // ---------------------------------------------------------------------------
 // forward: scores, coefficients, the seven batch sums
 // ---------------------------------------------------------------------------
+// A lane group takes a run of LPR consecutive samples: lane x loads the ids of sample x (one
+// coalesced read), the rows of FWD_SUB samples are in flight together, their two scores land in
+// lane x, and the loss epilogue (exp/log) is evaluated once per run with one sample per lane
+// instead of once per sample on a single lane.
 template <class C>
+struct FwdCfg {
+    static constexpr int RUN = C::LPR;
+    static constexpr int SUB = (C::NE <= 4) ? 4 : ((C::NE <= 8) ? 2 : 1);
+};
+
+template <class C, bool POINTWISE>
 __global__ __launch_bounds__(kBlock) void k_fwd(const float *__restrict__ P,
                                                 const float *__restrict__ Q, BatchView v, int d,
                                                 int loss_type, float gamma,
                                                 float2 *__restrict__ coef,
                                                 double *__restrict__ partials) {
+    constexpr int RUN = FwdCfg<C>::RUN, SUB = FwdCfg<C>::SUB;
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
+    const int64_t nruns = (v.B + RUN - 1) / RUN;
     float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int64_t s = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; s < v.B; s += gstride) {
-        const int64_t uu = v.ukey[s] & v.umask;
-        const int2 ij = v.ij[s];
-        Row<C> p, qi, qj;
-        p.load(P + uu * d, lane, d);
-        qi.load(Q + (int64_t)ij.x * d, lane, d);
-        qj.load(Q + (int64_t)(v.pointwise ? ij.x : ij.y) * d, lane, d);
-        const float pos = row_dot<C>(p, qi);
-        const float neg = v.pointwise ? (float)ij.y : row_dot<C>(p, qj);   // point-wise: the label
-        const float wj = v.pointwise ? 0.f : 1.f;                          // no negative item to regularise
+    for (int64_t r = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; r < nruns; r += gstride) {
+        const int64_t t0 = r * RUN;
+        const int cnt = (v.B - t0 < RUN) ? (int)(v.B - t0) : RUN;
+        // the ids of a tail run are clamped to its last sample, so no load sits behind a branch
+        // (a guarded load makes the compiler drain vmcnt first); the duplicates are masked below
+        const int64_t il = t0 + ((lane < cnt) ? lane : cnt - 1);
+        const int32_t my_u = (int32_t)(v.ukey[il] & v.umask);
+        const int2 my_ij = v.ij[il];
+        float my_pos = 0.f, my_neg = 0.f;
 #pragma unroll
-        for (int k = 0; k < C::NE; ++k) {
-            acc[1] += fabsf(p.v[k]);
-            acc[2] += fabsf(qi.v[k]);
-            acc[3] = fmaf(wj, fabsf(qj.v[k]), acc[3]);
-            acc[4] = fmaf(p.v[k], p.v[k], acc[4]);
-            acc[5] = fmaf(qi.v[k], qi.v[k], acc[5]);
-            acc[6] = fmaf(wj * qj.v[k], qj.v[k], acc[6]);
+        for (int x0 = 0; x0 < RUN; x0 += SUB) {
+            Row<C> p[SUB], qi[SUB], qj[SUB];
+#pragma unroll
+            for (int y = 0; y < SUB; ++y) {
+                const int x = x0 + y;
+                p[y].load(P + (int64_t)group_bcast<C>(my_u, x) * d, lane, d);
+                qi[y].load(Q + (int64_t)group_bcast<C>(my_ij.x, x) * d, lane, d);
+                if constexpr (!POINTWISE) qj[y].load(Q + (int64_t)group_bcast<C>(my_ij.y, x) * d, lane, d);
+                else qj[y].zero();                       // point-wise: j is the label, no second row
+            }
+#pragma unroll
+            for (int y = 0; y < SUB; ++y) {
+                const float pos = row_dot<C>(p[y], qi[y]);
+                const float neg = row_dot<C>(p[y], qj[y]);
+                if (lane == x0 + y) { my_pos = pos; my_neg = neg; }
+                const float w = (x0 + y < cnt) ? 1.f : 0.f;     // 0 for the clamped duplicates
+#pragma unroll
+                for (int k = 0; k < C::NE; ++k) {
+                    acc[1] = fmaf(w, fabsf(p[y].v[k]), acc[1]);
+                    acc[2] = fmaf(w, fabsf(qi[y].v[k]), acc[2]);
+                    acc[4] = fmaf(w * p[y].v[k], p[y].v[k], acc[4]);
+                    acc[5] = fmaf(w * qi[y].v[k], qi[y].v[k], acc[5]);
+                    if constexpr (!POINTWISE) {
+                        acc[3] = fmaf(w, fabsf(qj[y].v[k]), acc[3]);
+                        acc[6] = fmaf(w * qj[y].v[k], qj[y].v[k], acc[6]);
+                    }
+                }
+            }
         }
-        if (lane == 0) {
+        if (lane < cnt) {
             float term, cp, cn;
-            pair_coef(loss_type, pos, neg, gamma, term, cp, cn);
-            coef[s] = make_float2(cp, cn);
+            pair_coef(loss_type, my_pos, POINTWISE ? (float)my_ij.y : my_neg, gamma, term, cp, cn);
+            coef[t0 + lane] = make_float2(cp, cn);
             acc[0] += term;
         }
     }
@@ -507,17 +539,24 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
 
         // ---- hop 1: the run's metadata, lane x <- entry x; plus the entries just before and
         // after the run (same address on every lane: one request)
-        int32_t my_item = -1, item_prev = -1, item_next = -1;
-        uint2 my_su = make_uint2(0u, 0u);
-        if (lane < cnt) {
-            my_item = (int32_t)((v.ekey[t0 + lane] & v.imask) >> 1);
-            my_su = v.esu[t0 + lane];
-        }
-        if (cnt > 0 && t0 > 0) item_prev = (int32_t)((v.ekey[t0 - 1] & v.imask) >> 1);
-        if (cnt > 0 && t1 < n) item_next = (int32_t)((v.ekey[t1] & v.imask) >> 1);
+        // Every load is unconditional on a clamped address (n >= 1 here): a branch around a
+        // load makes the compiler drain vmcnt before it, which would serialise these requests
+        // into one memory round trip each.
+        const int64_t last = n - 1;
+        const int64_t il = (t0 + lane < n) ? (t0 + lane) : last;
+        const uint32_t k_me = v.ekey[il];
+        const uint2 su_me = v.esu[il];
+        const uint32_t k_prev = v.ekey[(t0 > 0) ? ((t0 - 1 < n) ? t0 - 1 : last) : 0];
+        const uint32_t k_next = v.ekey[(t1 < n) ? t1 : last];
+        const uint32_t k_cprev = v.ekey[(c0 > 0) ? c0 - 1 : 0];
+        const int32_t my_item = (lane < cnt) ? (int32_t)((k_me & v.imask) >> 1) : -1;
+        const uint2 my_su = (lane < cnt) ? su_me : make_uint2(0u, 0u);
+        const int32_t item_prev = (cnt > 0 && t0 > 0) ? (int32_t)((k_prev & v.imask) >> 1) : -1;
+        const int32_t item_next = (cnt > 0 && t1 < n) ? (int32_t)((k_next & v.imask) >> 1) : -1;
+        const int32_t chunk_prev_item = (c0 > 0) ? (int32_t)((k_cprev & v.imask) >> 1) : -1;
         for (int e = tid; e < (G + 1) * ROWF; e += kBlock) slot_acc[e] = 0.f;
         if (tid <= G) { slot_item[tid] = -1; slot_shared[tid] = 0; }
-        const int32_t item_first = __shfl(my_item, 0, C::LPR);
+        const int32_t item_first = group_bcast<C>(my_item, 0);
         const int32_t item_last = __shfl(my_item, cnt > 0 ? cnt - 1 : 0, C::LPR);
         if (lane == 0) {
             run_first[group] = cnt > 0 ? item_first : -2;
@@ -525,22 +564,19 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
         }
 
         // ---- hop 2: coefficient of entry `lane`, and all row gathers of the run
-        float my_c = 0.f;
-        if (lane < cnt) {
-            const float2 c2 = coef[my_su.x & ~kNegBit];
-            my_c = (my_su.x & kNegBit) ? c2.y : c2.x;
-        }
+        const float2 c2 = coef[su_me.x & ~kNegBit];
+        const float my_c = (lane < cnt) ? ((su_me.x & kNegBit) ? c2.y : c2.x) : 0.f;
         Row<C> p[RUN];
         if (__all(cnt == RUN)) {        // wave-uniform: every run of this wave is full
 #pragma unroll
             for (int x = 0; x < RUN; ++x) {
-                const uint32_t ux = __shfl(FROM_STAGE ? (my_su.x & ~kNegBit) : my_su.y, x, C::LPR);
+                const uint32_t ux = group_bcast<C>(FROM_STAGE ? (my_su.x & ~kNegBit) : my_su.y, x);
                 p[x].load(P + (int64_t)ux * d, lane, d);
             }
         } else {
 #pragma unroll
             for (int x = 0; x < RUN; ++x) {
-                const uint32_t ux = __shfl(FROM_STAGE ? (my_su.x & ~kNegBit) : my_su.y, x, C::LPR);
+                const uint32_t ux = group_bcast<C>(FROM_STAGE ? (my_su.x & ~kNegBit) : my_su.y, x);
                 if (x < cnt) p[x].load(P + (int64_t)ux * d, lane, d);
                 else p[x].zero();
             }
@@ -558,7 +594,7 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
                     // the segment holds the last entry of run gs; it began there unless run 0 is
                     // all this item and the chunk itself continues the previous chunk
                     const bool inherited = (gs == 0) && (run_first[0] == item_first) && (c0 > 0) &&
-                                           ((int32_t)((v.ekey[c0 - 1] & v.imask) >> 1) == item_first);
+                                           (chunk_prev_item == item_first);
                     cur_slot = inherited ? 0 : gs + 1;
                 }
             }
@@ -582,8 +618,8 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
 #pragma unroll
             for (int x = 0; x < RUN; ++x) {
                 if (x < cnt) {
-                    const int32_t it = __shfl(my_item, x, C::LPR);
-                    const float cx = __shfl(my_c, x, C::LPR);
+                    const int32_t it = group_bcast<C>(my_item, x);
+                    const float cx = group_bcast<C>(my_c, x);
                     if (it != cur_item) {           // previous segment ended inside this run
                         finish(true, false);
                         cur_item = it;
@@ -802,19 +838,27 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
         const int cnt = (t0 < n) ? (int)(t1 - t0) : 0;
 
         // ---- hop 1: metadata of the run (lane x <- sample x) and its two neighbours
-        int32_t my_user = -1, user_prev = -1, user_next = -1;
-        int2 my_ij = make_int2(0, 0);
+        // (unconditional loads on clamped addresses: see k_item_grad_chunked)
+        const int64_t last = n - 1;
+        const int64_t il = (t0 + lane < n) ? (t0 + lane) : last;
+        const uint32_t k_me = v.ukey[il];
+        const int2 ij_me = v.ij[il];
         float2 my_c = make_float2(0.f, 0.f);
-        if (lane < cnt) {
-            my_user = (int32_t)(v.ukey[t0 + lane] & v.umask);
-            my_ij = v.ij[t0 + lane];
-            if constexpr (!FUSED) my_c = coef[t0 + lane];
+        if constexpr (!FUSED) {
+            const float2 c_me = coef[il];
+            if (lane < cnt) my_c = c_me;
         }
-        if (cnt > 0 && t0 > 0) user_prev = (int32_t)(v.ukey[t0 - 1] & v.umask);
-        if (cnt > 0 && t1 < n) user_next = (int32_t)(v.ukey[t1] & v.umask);
+        const uint32_t k_prev = v.ukey[(t0 > 0) ? ((t0 - 1 < n) ? t0 - 1 : last) : 0];
+        const uint32_t k_next = v.ukey[(t1 < n) ? t1 : last];
+        const uint32_t k_cprev = v.ukey[(c0 > 0) ? c0 - 1 : 0];
+        const int32_t my_user = (lane < cnt) ? (int32_t)(k_me & v.umask) : -1;
+        const int2 my_ij = (lane < cnt) ? ij_me : make_int2(0, 0);
+        const int32_t user_prev = (cnt > 0 && t0 > 0) ? (int32_t)(k_prev & v.umask) : -1;
+        const int32_t user_next = (cnt > 0 && t1 < n) ? (int32_t)(k_next & v.umask) : -1;
+        const int32_t chunk_prev_user = (c0 > 0) ? (int32_t)(k_cprev & v.umask) : -1;
         for (int e = tid; e < (G + 1) * ROWF; e += kBlock) slot_acc[e] = 0.f;
         if (tid <= G) { slot_user[tid] = -1; slot_n[tid] = 0.f; slot_next[tid] = 0; }
-        const int32_t user_first = __shfl(my_user, 0, C::LPR);
+        const int32_t user_first = group_bcast<C>(my_user, 0);
         const int32_t user_last = __shfl(my_user, cnt > 0 ? cnt - 1 : 0, C::LPR);
         if (lane == 0) {
             run_first[group] = cnt > 0 ? user_first : -2;
@@ -823,17 +867,29 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
 
         // ---- hop 2: the three rows of every sample of the run
         Row<C> qi[RUN], qj[RUN], pr[RUN];
+        if (__all(cnt == RUN)) {        // wave-uniform: no branch between the 3*RUN gathers
 #pragma unroll
-        for (int x = 0; x < RUN; ++x) {
-            const int32_t ux = __shfl(my_user, x, C::LPR);
-            const int ix = __shfl(my_ij.x, x, C::LPR);
-            const int jx = v.pointwise ? ix : __shfl(my_ij.y, x, C::LPR);
-            if (x < cnt) {
+            for (int x = 0; x < RUN; ++x) {
+                const int32_t ux = group_bcast<C>(my_user, x);
+                const int ix = group_bcast<C>(my_ij.x, x);
+                const int jx = v.pointwise ? ix : group_bcast<C>(my_ij.y, x);
                 qi[x].load(Q + (int64_t)ix * d, lane, d);
                 qj[x].load(Q + (int64_t)jx * d, lane, d);
                 pr[x].load(P + (int64_t)ux * d, lane, d);
-            } else {
-                qi[x].zero(); qj[x].zero(); pr[x].zero();
+            }
+        } else {
+#pragma unroll
+            for (int x = 0; x < RUN; ++x) {
+                const int32_t ux = group_bcast<C>(my_user, x);
+                const int ix = group_bcast<C>(my_ij.x, x);
+                const int jx = v.pointwise ? ix : group_bcast<C>(my_ij.y, x);
+                if (x < cnt) {
+                    qi[x].load(Q + (int64_t)ix * d, lane, d);
+                    qj[x].load(Q + (int64_t)jx * d, lane, d);
+                    pr[x].load(P + (int64_t)ux * d, lane, d);
+                } else {
+                    qi[x].zero(); qj[x].zero(); pr[x].zero();
+                }
             }
         }
         __syncthreads();
@@ -847,7 +903,7 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
                     int gs = group - 1;
                     while (gs > 0 && run_first[gs] == user_first && run_last[gs - 1] == user_first) --gs;
                     const bool inherited = (gs == 0) && (run_first[0] == user_first) && (c0 > 0) &&
-                                           ((int32_t)(v.ukey[c0 - 1] & v.umask) == user_first);
+                                           (chunk_prev_user == user_first);
                     cur_slot = inherited ? 0 : gs + 1;
                 }
             }
@@ -877,23 +933,15 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
                     }
                 }
             };
+            if constexpr (FUSED) {
+                // scores of the run's samples -> lane x; one loss epilogue per run, a sample per lane
+                float my_sp = 0.f, my_sn = 0.f;
 #pragma unroll
-            for (int x = 0; x < RUN; ++x) {
-                if (x < cnt) {
-                    const int32_t ux = __shfl(my_user, x, C::LPR);
-                    float cp, cn;
-                    if constexpr (FUSED) {
+                for (int x = 0; x < RUN; ++x) {
+                    if (x < cnt) {
                         const float sp = row_dot<C>(pr[x], qi[x]);
                         const float sn = row_dot<C>(pr[x], qj[x]);
-                        float term = 0.f;
-                        cp = 0.f; cn = 0.f;
-                        if (lane == 0) {
-                            pair_coef(loss_type, sp, sn, gamma, term, cp, cn);
-                            coef[t0 + x] = make_float2(cp, cn);
-                            acc7[0] += term;
-                        }
-                        cp = __shfl(cp, 0, C::LPR);
-                        cn = __shfl(cn, 0, C::LPR);
+                        if (lane == x) { my_sp = sp; my_sn = sn; }
 #pragma unroll
                         for (int k = 0; k < C::NE; ++k) {
                             acc7[1] += fabsf(pr[x].v[k]);
@@ -903,11 +951,22 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
                             acc7[5] = fmaf(qi[x].v[k], qi[x].v[k], acc7[5]);
                             acc7[6] = fmaf(qj[x].v[k], qj[x].v[k], acc7[6]);
                         }
-                        pr[x].store(stage + (t0 + x) * d, lane, d);     // pre-step row for the item pass
-                    } else {
-                        cp = __shfl(my_c.x, x, C::LPR);
-                        cn = __shfl(my_c.y, x, C::LPR);
+                        pr[x].store(stage + (t0 + x) * d, lane, d);   // pre-step row for the item pass
                     }
+                }
+                if (lane < cnt) {
+                    float term;
+                    pair_coef(loss_type, my_sp, my_sn, gamma, term, my_c.x, my_c.y);
+                    coef[t0 + lane] = my_c;
+                    acc7[0] += term;
+                }
+            }
+#pragma unroll
+            for (int x = 0; x < RUN; ++x) {
+                if (x < cnt) {
+                    const int32_t ux = group_bcast<C>(my_user, x);
+                    const float cp = group_bcast<C>(my_c.x, x);
+                    const float cn = group_bcast<C>(my_c.y, x);
                     if (ux != cur_user) {
                         finish(true, false, pcur);
                         cur_user = ux;
@@ -1467,9 +1526,13 @@ static int forward_impl(daisy_bpr_ctx *ctx, const float *P, const float *Q, int3
     int grid = 0;
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
-        grid = grid_for(v.B, C::GROUPS_PER_BLOCK * 4);
-        hipLaunchKernelGGL((k_fwd<C>), dim3(grid), dim3(kBlock), 0, s, P, Q, v, d, (int)loss_type, gamma,
-                           ctx->coef, ctx->partials);
+        grid = grid_for(v.B, C::GROUPS_PER_BLOCK * FwdCfg<C>::RUN);
+        if (v.pointwise)
+            hipLaunchKernelGGL((k_fwd<C, true>), dim3(grid), dim3(kBlock), 0, s, P, Q, v, d, (int)loss_type,
+                               gamma, ctx->coef, ctx->partials);
+        else
+            hipLaunchKernelGGL((k_fwd<C, false>), dim3(grid), dim3(kBlock), 0, s, P, Q, v, d, (int)loss_type,
+                               gamma, ctx->coef, ctx->partials);
         return DAISY_OK;
     });
     if (rc) return rc;
@@ -1555,6 +1618,33 @@ int daisy_bpr_item_grad(daisy_bpr_ctx *ctx, const float *P, const float *Q, cons
                         float reg_1, float reg_2, float *gQ, int32_t item_mode,
                         daisy_stream_t stream) {
     return item_grad_impl(ctx, P, Q, stats, reg_1, reg_2, gQ, item_mode, false, stream);
+}
+
+int daisy_bpr_item_grad_data(daisy_bpr_ctx *ctx, const float *P, const float *Q, const double *stats,
+                             float *gQ, int32_t item_mode, daisy_stream_t stream) {
+    if (item_mode == DAISY_ITEM_FUSED) item_mode = DAISY_ITEM_CHUNKED;
+    DAISY_CHECK_ARG(item_mode == DAISY_ITEM_CHUNKED,
+                    "item_grad_data: only the chunked mode splits data term and regulariser (mode %d)", item_mode);
+    return item_grad_impl(ctx, P, Q, stats, 0.f, 0.f, gQ, item_mode, true, stream);
+}
+
+int daisy_bpr_item_grad_reg(daisy_bpr_ctx *ctx, const float *Q, const double *stats, float reg_1,
+                            float reg_2, float *gQ, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(ctx && Q && stats && gQ, "item_grad_reg: NULL argument");
+    if (!ctx->batch_set) { set_error("item_grad_reg: no batch set"); return DAISY_ERR_STATE; }
+    if (reg_1 == 0.f && reg_2 == 0.f) return DAISY_OK;
+    const BatchView &v = ctx->v;
+    const int d = ctx->d;
+    int rc = dispatch_d(d, [&](auto cfg) {
+        using C = decltype(cfg);
+        hipLaunchKernelGGL((k_item_reg<C>),
+                           dim3(grid_for(2 * v.B < ctx->I ? 2 * v.B : ctx->I, C::GROUPS_PER_BLOCK * 2)),
+                           dim3(kBlock), 0, S(stream), Q, v, d, stats, reg_1, reg_2, gQ);
+        return DAISY_OK;
+    });
+    if (rc) return rc;
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
 }
 
 static int user_pass(daisy_bpr_ctx *ctx, float *P, const float *Q, const double *stats, float lr,

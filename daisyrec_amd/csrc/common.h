@@ -137,11 +137,61 @@ struct Row {
     }
 };
 
+// ---- cross-lane moves inside a 16-lane DPP row (a lane group never spans rows for LPR <= 16).
+// DPP modifiers ride on the consuming VALU instruction; ds_bpermute (what __shfl lowers to)
+// costs an LDS-crossbar round trip plus address math per use.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, 0xF, 0xF, true);
+}
+constexpr int kDppQuadXor1 = 0xB1;       // quad_perm:[1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;       // quad_perm:[2,3,0,1]
+constexpr int kDppHalfMirror = 0x141;    // row_half_mirror (lane i <- 7-i inside 8)
+constexpr int kDppMirror = 0x140;        // row_mirror      (lane i <- 15-i inside 16)
+constexpr int kDppRowBcast0 = 0x150;     // row_newbcast:k  (every lane of the row <- lane k)
+
+// value of lane (group base + x) for every lane of the group; x is uniform.  LPR == 16 -> one DPP
+// broadcast (the switch folds once the caller's loop is unrolled); other shapes: ds_bpermute.
+template <class C>
+__device__ __forceinline__ int group_bcast(int v, int x) {
+    if constexpr (C::LPR == 16) {
+        switch (x & 15) {
+#define DAISY_BC(k) case k: return dpp_i32<kDppRowBcast0 + k>(v);
+            DAISY_BC(0) DAISY_BC(1) DAISY_BC(2) DAISY_BC(3) DAISY_BC(4) DAISY_BC(5) DAISY_BC(6) DAISY_BC(7)
+            DAISY_BC(8) DAISY_BC(9) DAISY_BC(10) DAISY_BC(11) DAISY_BC(12) DAISY_BC(13) DAISY_BC(14)
+            default: return dpp_i32<kDppRowBcast0 + 15>(v);
+#undef DAISY_BC
+        }
+    } else {
+        return __shfl(v, x, C::LPR);
+    }
+}
+template <class C>
+__device__ __forceinline__ uint32_t group_bcast(uint32_t v, int x) { return (uint32_t)group_bcast<C>((int)v, x); }
+template <class C>
+__device__ __forceinline__ float group_bcast(float v, int x) {
+    return __builtin_bit_cast(float, group_bcast<C>(__builtin_bit_cast(int, v), x));
+}
+
+// sum over the lanes of a group, result in every lane (bitwise identical across lanes: each
+// step adds the same two partial sums on both sides)
 template <class C>
 __device__ __forceinline__ float group_sum(float x) {
+    if constexpr (C::LPR <= 16) {
+        if constexpr (C::LPR >= 2) x += dpp_f32<kDppQuadXor1>(x);
+        if constexpr (C::LPR >= 4) x += dpp_f32<kDppQuadXor2>(x);
+        if constexpr (C::LPR >= 8) x += dpp_f32<kDppHalfMirror>(x);
+        if constexpr (C::LPR >= 16) x += dpp_f32<kDppMirror>(x);
+        return x;
+    } else {
 #pragma unroll
-    for (int off = C::LPR / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
-    return x;
+        for (int off = C::LPR / 2; off > 0; off >>= 1) x += __shfl_xor(x, off, kWave);
+        return x;
+    }
 }
 
 template <class C>

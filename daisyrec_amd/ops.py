@@ -195,6 +195,18 @@ class BprContext:
                                       float(reg_2), _ptr(gQ, torch.float32, "gQ"), int(item_mode),
                                       _stream()))
 
+    def item_grad_data(self, P, Q, item_mode=N.ITEM_CHUNKED, gQ=None):
+        gQ = self.gQ if gQ is None else gQ
+        check(lib.daisy_bpr_item_grad_data(self._h, _ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"),
+                                           _ptr(self.stats, torch.float64, "stats"),
+                                           _ptr(gQ, torch.float32, "gQ"), int(item_mode), _stream()))
+
+    def item_grad_reg(self, Q, reg_1, reg_2, gQ=None):
+        gQ = self.gQ if gQ is None else gQ
+        check(lib.daisy_bpr_item_grad_reg(self._h, _ptr(Q, torch.float32, "Q"),
+                                          _ptr(self.stats, torch.float64, "stats"), float(reg_1),
+                                          float(reg_2), _ptr(gQ, torch.float32, "gQ"), _stream()))
+
     def user_sgd(self, P, Q, lr, reg_1, reg_2):
         check(lib.daisy_bpr_user_sgd(self._h, _ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"),
                                      _ptr(self.stats, torch.float64, "stats"), float(lr), float(reg_1),

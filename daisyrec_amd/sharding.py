@@ -15,10 +15,14 @@ The union of the per-rank batches is one global batch: the result equals the sin
 step on that union up to fp32 summation order.
 
 Per step and rank (compute stream | collective):
-    forward -> stats[0:7]          | all_reduce(stats[0:7])      (tiny, latency bound)
-    finalize, item_grad -> gQ      | all_reduce(gQ) async  --+
-    user_sgd (reads Q pre-step)    |   overlapped           <+
-    wait; item_sgd_apply(dense)    |
+    forward -> stats[0:7]              | all_reduce(stats[0:7]) async --+  (56 B, latency bound)
+    item_grad_data -> gQ (no norms)    |   overlapped                 <+
+    wait; finalize; item_grad_reg      |
+                                       | all_reduce(gQ) async  --+
+    user_sgd (reads Q pre-step)        |   overlapped           <+
+    wait; item_sgd_apply(dense)        |
+(the reproducible item modes form data term and regulariser in one kernel, so there the first
+ all-reduce is waited for before item_grad)
 """
 from __future__ import annotations
 
@@ -81,9 +85,18 @@ class UserShardedBprTrainer:
     def _step(self):
         c = self.ctx
         c.forward(self.P, self.Q, self.loss_type, self.gamma)
-        self._all_reduce(c.stats[:7])
-        c.finalize(self.reg_1, self.reg_2)                 # every rank: the GLOBAL loss and norms
-        c.item_grad(self.P, self.Q, self.reg_1, self.reg_2, self.item_mode)
+        split = self.item_mode in (N.ITEM_CHUNKED, N.ITEM_FUSED) and hasattr(c, "item_grad_data")
+        if split:
+            w0 = self._all_reduce(c.stats[:7], async_op=self.overlap)
+            c.item_grad_data(self.P, self.Q, self.item_mode)      # overlaps the 56-byte all-reduce
+            if w0 is not None:
+                w0.wait()
+            c.finalize(self.reg_1, self.reg_2)             # every rank: the GLOBAL loss and norms
+            c.item_grad_reg(self.Q, self.reg_1, self.reg_2)
+        else:
+            self._all_reduce(c.stats[:7])
+            c.finalize(self.reg_1, self.reg_2)
+            c.item_grad(self.P, self.Q, self.reg_1, self.reg_2, self.item_mode)
         work = self._all_reduce(c.gQ, async_op=self.overlap)
         c.user_sgd(self.P, self.Q, self.lr, self.reg_1, self.reg_2)   # overlaps the all-reduce
         if work is not None:

@@ -169,6 +169,14 @@ int daisy_bpr_item_grad(daisy_bpr_ctx *ctx, const float *P, const float *Q, cons
                         float reg_1, float reg_2, float *gQ, int32_t item_mode,
                         daisy_stream_t stream);
 
+/* The same gradient in two parts (chunked mode only), so that a multi-GPU step can form the
+ * data term  sum_e c_e * p_u(e)  while the all-reduce of the batch sums is still in flight, and
+ * add the regulariser share (which needs the global norms in stats[8..10]) afterwards. */
+int daisy_bpr_item_grad_data(daisy_bpr_ctx *ctx, const float *P, const float *Q, const double *stats,
+                             float *gQ, int32_t item_mode, daisy_stream_t stream);
+int daisy_bpr_item_grad_reg(daisy_bpr_ctx *ctx, const float *Q, const double *stats, float reg_1,
+                            float reg_2, float *gQ, daisy_stream_t stream);
+
 /* backward w.r.t. embed_user.weight + optim.SGD.step on the touched user rows
  * (AbstractRecommender.py:125-126).  Reads Q, so it must run BEFORE the item
  * rows are committed. */

@@ -52,6 +52,23 @@ class OracleContext:
         np.add.at(g, self.j, self.cn[:, None] * pu + reg_1 * np.sign(qj) + reg_2 * self._fro(qj, nJ))
         self.gQ += torch.from_numpy(g.astype(np.float32))
 
+    def item_grad_data(self, P, Q, item_mode=2, gQ=None):
+        P64 = P.numpy().astype(np.float64)
+        pu = P64[self.u]
+        g = np.zeros((self.item_num, self.d))
+        np.add.at(g, self.i, self.cp[:, None] * pu)
+        np.add.at(g, self.j, self.cn[:, None] * pu)
+        self.gQ += torch.from_numpy(g.astype(np.float32))
+
+    def item_grad_reg(self, Q, reg_1, reg_2, gQ=None):
+        Q64 = Q.numpy().astype(np.float64)
+        qi, qj = Q64[self.i], Q64[self.j]
+        nI, nJ = float(self.stats[9]), float(self.stats[10])
+        g = np.zeros((self.item_num, self.d))
+        np.add.at(g, self.i, reg_1 * np.sign(qi) + reg_2 * self._fro(qi, nI))
+        np.add.at(g, self.j, reg_1 * np.sign(qj) + reg_2 * self._fro(qj, nJ))
+        self.gQ += torch.from_numpy(g.astype(np.float32))
+
     def user_sgd(self, P, Q, lr, reg_1, reg_2):
         P64, Q64 = P.numpy().astype(np.float64), Q.numpy().astype(np.float64)
         pu, qi, qj = P64[self.u], Q64[self.i], Q64[self.j]
