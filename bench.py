@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None, help="default: one epoch of full batches")
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=1 << 20, help="interactions per GPU per step")
+    ap.add_argument("--batch", type=int, default=1 << 21, help="interactions per GPU per step")
     ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c3", "tiny"])
     ap.add_argument("--item-mode", default="chunked", choices=["fused", "chunked", "atomic", "sorted"])
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
