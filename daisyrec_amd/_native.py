@@ -43,6 +43,7 @@ SIGNATURES = {
     "daisy_bpr_set_batch": (C.c_int, [_p, _p, _p, _p, _i64, _p]),
     "daisy_bpr_set_batch_from_plan": (C.c_int, [_p, _p, _i64, _p]),
     "daisy_bpr_ctx_set_pointwise": (C.c_int, [_p, _i32]),
+    "daisy_bpr_ctx_set_bias": (C.c_int, [_p, _p, _p, _p, _p, _p, _p]),
     "daisy_epoch_plan_create": (C.c_int, [C.POINTER(_p), _i64, _i64, _i64]),
     "daisy_epoch_plan_destroy": (C.c_int, [_p]),
     "daisy_epoch_plan_bytes": (_sz, [_p]),
@@ -68,6 +69,9 @@ SIGNATURES = {
     "daisy_mf_rank_topk": (C.c_int, [_p, _p, _i32, _p, _p, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),
     "daisy_mf_full_rank_workspace_bytes": (_sz, [_i64]),
     "daisy_mf_full_rank": (C.c_int, [_p, _p, _i32, _i64, _i64, _i32, _p, _p, _sz, _p]),
+    "daisy_fm_predict": (C.c_int, [_p, _p, _p, _p, _p, _i32, _p, _p, _i64, _p, _p]),
+    "daisy_fm_rank_topk": (C.c_int, [_p, _p, _p, _p, _p, _i32, _p, _p, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),
+    "daisy_fm_full_rank": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i64, _i64, _i32, _p, _p, _sz, _p]),
     "daisy_csr_workspace_bytes": (_sz, [_i64]),
     "daisy_build_user_csr": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _sz, _p]),
     "daisy_sample_neg_per_user": (C.c_int, [_p, _p, _i64, _i64, _i32, _u64, _u64, _p, _p]),

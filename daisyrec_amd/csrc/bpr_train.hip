@@ -54,6 +54,11 @@ struct BatchView {
     // slot of a sample is an inert copy of its item (coefficient 0, not counted by the regulariser)
     int32_t pointwise;
     int64_t B;
+    // FM (FMRecommender.py:61-68): score += u_bias[u] + i_bias[item] + bias_; bu == nullptr -> plain MF.
+    // g_bi accumulates like gQ (zero between steps, consumed by k_item_apply); g_bu / g_b0 are only
+    // written by the gradient-output user pass (Adam); the SGD user pass updates bu and b0 in place.
+    float *bu, *bi, *b0;
+    float *g_bu, *g_bi, *g_b0;
 };
 
 }  // namespace daisy
@@ -92,7 +97,7 @@ struct daisy_bpr_ctx {
     int32_t *tmp_triples;  // [max_batch*3] staging for daisy_bpr_set_batch
     float *edge_vec;     // [2*nchunks][d] partial user gradients of runs that cross a chunk boundary
     int32_t *edge_user;  // [2*nchunks]    their user (-1: none); [2c] head edge, [2c+1] tail edge
-    float *edge_n;       // [2*nchunks]    their sample counts
+    float *edge_n;       // [2*nchunks][2] their sample counts and (FM) coefficient sums
     int32_t *edge_whole; // [nchunks]      the head edge's run also fills the whole chunk
     float *p_stage;      // [max_batch][d] updated user rows of the fused step, committed after the item pass
     float *p_sqnorm;     // [U] cache of |P[u]|^2 (fused step: the user-side Frobenius norm before the pass)
@@ -101,6 +106,7 @@ struct daisy_bpr_ctx {
     daisy::BatchView v;
     int32_t pointwise;   // batches set through set_batch* hold (user, item, label) rows
     int last_item_mode;  // mode of the last daisy_bpr_item_grad: the user pass of the same step follows it
+    float *bu, *bi, *b0, *g_bu, *g_bi, *g_b0;   // FM bias parameters (daisy_bpr_ctx_set_bias); bu == nullptr: MF
     bool batch_set, fwd_done;
 };
 
@@ -272,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void k_fwd(const float *__restrict__ P,
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
     const int64_t nruns = (v.B + RUN - 1) / RUN;
-    float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int64_t r = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; r < nruns; r += gstride) {
         const int64_t t0 = r * RUN;
         const int cnt = (v.B - t0 < RUN) ? (int)(v.B - t0) : RUN;
@@ -313,21 +319,27 @@ __global__ __launch_bounds__(kBlock) void k_fwd(const float *__restrict__ P,
             }
         }
         if (lane < cnt) {
+            if (v.bu) {                                   // FMRecommender.py:65-66
+                const float b0 = v.b0[0], ub = v.bu[my_u];
+                my_pos += (ub + v.bi[my_ij.x]) + b0;
+                if constexpr (!POINTWISE) my_neg += (ub + v.bi[my_ij.y]) + b0;
+            }
             float term, cp, cn;
             pair_coef(loss_type, my_pos, POINTWISE ? (float)my_ij.y : my_neg, gamma, term, cp, cn);
             coef[t0 + lane] = make_float2(cp, cn);
             acc[0] += term;
+            acc[7] += cp + cn;                            // d loss / d bias_
         }
     }
     __shared__ double sm[kBlock / kWave][8];
     const int wave = threadIdx.x / kWave;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
+    for (int k = 0; k < 8; ++k) {
         const double w = wave_sum_f64((double)acc[k]);
         if ((threadIdx.x % kWave) == 0) sm[wave][k] = w;
     }
     __syncthreads();
-    if (threadIdx.x < 7) {
+    if (threadIdx.x < 8) {
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < kBlock / kWave; ++w) t += sm[w][threadIdx.x];
@@ -347,23 +359,24 @@ __global__ __launch_bounds__(kBlock) void k_reduce_partials(const double *__rest
                                                             float reg_1, float reg_2,
                                                             double *__restrict__ epoch_acc,
                                                             double *__restrict__ step_loss) {
-    __shared__ double sm[kBlock][7];
-    double t[7] = {0, 0, 0, 0, 0, 0, 0};
+    __shared__ double sm[kBlock][8];
+    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (int b = threadIdx.x; b < nblocks; b += kBlock) {
 #pragma unroll
-        for (int k = 0; k < 7; ++k) t[k] += partials[(int64_t)b * 8 + k];
+        for (int k = 0; k < 8; ++k) t[k] += partials[(int64_t)b * 8 + k];
     }
 #pragma unroll
-    for (int k = 0; k < 7; ++k) sm[threadIdx.x][k] = t[k];
+    for (int k = 0; k < 8; ++k) sm[threadIdx.x][k] = t[k];
     __syncthreads();
     for (int off = kBlock / 2; off > 0; off >>= 1) {
         if (threadIdx.x < off) {
 #pragma unroll
-            for (int k = 0; k < 7; ++k) sm[threadIdx.x][k] += sm[threadIdx.x + off][k];
+            for (int k = 0; k < 8; ++k) sm[threadIdx.x][k] += sm[threadIdx.x + off][k];
         }
         __syncthreads();
     }
     if (threadIdx.x < 7) stats[threadIdx.x] = sm[0][threadIdx.x];
+    if (threadIdx.x == 7) stats[DAISY_ST_SUM_COEF] = sm[0][7];
     if constexpr (FINALIZE) {
         __syncthreads();
         if (threadIdx.x == 0) finalize_stats(stats, reg_1, reg_2, epoch_acc, step_loss);
@@ -439,6 +452,10 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_atomic(
         }
         gi.atomic_add_to(gQ + (int64_t)ij.x * d, lane, d);
         if (!v.pointwise) gj.atomic_add_to(gQ + (int64_t)ij.y * d, lane, d);
+        if (v.g_bi && lane == 0) {
+            unsafeAtomicAdd(v.g_bi + ij.x, c.x);
+            if (!v.pointwise) unsafeAtomicAdd(v.g_bi + ij.y, c.y);
+        }
     }
 }
 
@@ -463,12 +480,13 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_sorted(
         if (pos > 0 && ((v.ekey[pos - 1] & v.imask) >> 1) == r) continue;  // not a segment head
         Row<C> acc;
         acc.zero();
-        float n_pos = 0.f, n_neg = 0.f;
+        float n_pos = 0.f, n_neg = 0.f, csum = 0.f;
         for (int64_t q = pos; q < n && ((v.ekey[q] & v.imask) >> 1) == r; ++q) {
             const uint2 su = v.esu[q];
             const bool is_neg = (su.x & kNegBit) != 0;
             const float2 c2 = coef[su.x & ~kNegBit];
             const float c = is_neg ? c2.y : c2.x;
+            csum += c;
             n_pos += is_neg ? 0.f : 1.f;
             n_neg += (is_neg && !v.pointwise) ? 1.f : 0.f;
             Row<C> p;
@@ -483,6 +501,7 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_sorted(
 #pragma unroll
         for (int k = 0; k < C::NE; ++k) acc.v[k] += fmaf(w2, qr.v[k], w1 * sgn(qr.v[k]));
         acc.store(gQ + (int64_t)r * d, lane, d);
+        if (v.g_bi && lane == 0) v.g_bi[r] = csum;
     }
 }
 
@@ -522,6 +541,7 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
                   E = RunCfg<C, RUN_OVERRIDE>::E;
     constexpr int ROWF = C::NE * C::LPR;
     __shared__ float slot_acc[(G + 1) * ROWF];
+    __shared__ float slot_b[G + 1];              // FM: sum of the coefficients (d loss / d i_bias)
     __shared__ int slot_item[G + 1], slot_shared[G + 1];
     __shared__ int run_first[G], run_last[G];
 
@@ -555,7 +575,7 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
         const int32_t item_next = (cnt > 0 && t1 < n) ? (int32_t)((k_next & v.imask) >> 1) : -1;
         const int32_t chunk_prev_item = (c0 > 0) ? (int32_t)((k_cprev & v.imask) >> 1) : -1;
         for (int e = tid; e < (G + 1) * ROWF; e += kBlock) slot_acc[e] = 0.f;
-        if (tid <= G) { slot_item[tid] = -1; slot_shared[tid] = 0; }
+        if (tid <= G) { slot_item[tid] = -1; slot_shared[tid] = 0; slot_b[tid] = 0.f; }
         const int32_t item_first = group_bcast<C>(my_item, 0);
         const int32_t item_last = __shfl(my_item, cnt > 0 ? cnt - 1 : 0, C::LPR);
         if (lane == 0) {
@@ -601,9 +621,11 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
             int32_t cur_item = item_first;
             Row<C> acc;
             acc.zero();
+            float accb = 0.f;
             auto finish = [&](bool ends_here, bool to_next_chunk) {
                 if (cur_slot < 0 && ends_here) {    // interior: this group owns gQ[cur_item]
                     acc.store(gQ + (int64_t)cur_item * d, lane, d);
+                    if (v.g_bi && lane == 0) v.g_bi[cur_item] = accb;
                 } else {                            // crosses a run boundary: LDS slot
                     const int s = (cur_slot >= 0) ? cur_slot : group + 1;
                     float *dst = slot_acc + s * ROWF;
@@ -611,6 +633,7 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
                     for (int k = 0; k < C::NE; ++k) atomicAdd(dst + k * C::LPR + lane, acc.v[k]);
                     if (lane == 0) {
                         slot_item[s] = cur_item;
+                        atomicAdd(&slot_b[s], accb);
                         if (to_next_chunk) slot_shared[s] = 1;
                     }
                 }
@@ -625,9 +648,11 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
                         cur_item = it;
                         cur_slot = -1;
                         acc.zero();
+                        accb = 0.f;
                     }
 #pragma unroll
                     for (int k = 0; k < C::NE; ++k) acc.v[k] = fmaf(cx, p[x].v[k], acc.v[k]);
+                    accb += cx;
                 }
             }
             const bool continues = (t1 < n) && (item_next == cur_item);
@@ -643,8 +668,13 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
             const float *src = slot_acc + s * ROWF;
 #pragma unroll
             for (int k = 0; k < C::NE; ++k) g.v[k] = src[k * C::LPR + lane];
-            if (s == 0 || slot_shared[s]) g.atomic_add_to(gQ + (int64_t)r * d, lane, d);
-            else g.store(gQ + (int64_t)r * d, lane, d);
+            if (s == 0 || slot_shared[s]) {
+                g.atomic_add_to(gQ + (int64_t)r * d, lane, d);
+                if (v.g_bi && lane == 0) unsafeAtomicAdd(v.g_bi + r, slot_b[s]);
+            } else {
+                g.store(gQ + (int64_t)r * d, lane, d);
+                if (v.g_bi && lane == 0) v.g_bi[r] = slot_b[s];
+            }
         }
         __syncthreads();   // the slots are reused by the next chunk
     }
@@ -710,9 +740,10 @@ __global__ __launch_bounds__(kBlock) void k_user(float *__restrict__ P, const fl
         Row<C> p, acc;
         p.load(P + (int64_t)uu * d, lane, d);
         acc.zero();
-        float n = 0.f;
+        float n = 0.f, csum = 0.f;
         for (int64_t q = pos; q < v.B && (v.ukey[q] & v.umask) == uu; ++q) {
             const float2 c = coef[q];
+            csum += c.x + c.y;
             const int2 ij = v.ij[q];
             Row<C> qi, qj;
             qi.load(Q + (int64_t)ij.x * d, lane, d);
@@ -731,6 +762,15 @@ __global__ __launch_bounds__(kBlock) void k_user(float *__restrict__ P, const fl
         }
         if constexpr (SGD) p.store(P + (int64_t)uu * d, lane, d);
         else p.store(gP + (int64_t)uu * d, lane, d);
+        if (v.bu && lane == 0) {                           // d loss / d u_bias[u] = sum (cp + cn)
+            if constexpr (SGD) v.bu[uu] = fmaf(-lr, csum, v.bu[uu]);
+            else v.g_bu[uu] = csum;
+        }
+    }
+    if (v.bu && blockIdx.x == 0 && threadIdx.x == 0) {     // the global bias (FMRecommender.py:59)
+        const float g0 = (float)stats[DAISY_ST_SUM_COEF];
+        if constexpr (SGD) v.b0[0] = fmaf(-lr, g0, v.b0[0]);
+        else v.g_b0[0] = g0;
     }
 }
 
@@ -772,6 +812,10 @@ __global__ __launch_bounds__(kBlock) void k_item_apply(float *__restrict__ Q, fl
         for (int k = 0; k < C::NE; ++k) q.v[k] = fmaf(-lr, g.v[k], q.v[k]);
         q.store(Q + r * d, lane, d);
         z.store(gQ + r * d, lane, d);
+        if (v.bi && lane == 0) {
+            v.bi[r] = fmaf(-lr, v.g_bi[r], v.bi[r]);
+            v.g_bi[r] = 0.f;
+        }
     }
 }
 
@@ -819,7 +863,7 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
     constexpr int G = UserRunCfg<C>::G, RUN = UserRunCfg<C>::RUN, E = UserRunCfg<C>::E;
     constexpr int ROWF = C::NE * C::LPR;
     __shared__ float slot_acc[(G + 1) * ROWF];
-    __shared__ float slot_n[G + 1];
+    __shared__ float slot_n[G + 1], slot_b[G + 1];   // slot_b: FM, sum of (cp + cn) = d loss / d u_bias
     __shared__ int slot_user[G + 1], slot_next[G + 1];
     __shared__ int run_first[G], run_last[G];
 
@@ -857,7 +901,7 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
         const int32_t user_next = (cnt > 0 && t1 < n) ? (int32_t)(k_next & v.umask) : -1;
         const int32_t chunk_prev_user = (c0 > 0) ? (int32_t)(k_cprev & v.umask) : -1;
         for (int e = tid; e < (G + 1) * ROWF; e += kBlock) slot_acc[e] = 0.f;
-        if (tid <= G) { slot_user[tid] = -1; slot_n[tid] = 0.f; slot_next[tid] = 0; }
+        if (tid <= G) { slot_user[tid] = -1; slot_n[tid] = 0.f; slot_b[tid] = 0.f; slot_next[tid] = 0; }
         const int32_t user_first = group_bcast<C>(my_user, 0);
         const int32_t user_last = __shfl(my_user, cnt > 0 ? cnt - 1 : 0, C::LPR);
         if (lane == 0) {
@@ -911,12 +955,13 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
             Row<C> pcur = pr[0];                     // P row of the current run's user
             Row<C> acc;
             acc.zero();
-            float cn_ = 0.f;
+            float cn_ = 0.f, cb_ = 0.f;
             auto finish = [&](bool ends_here, bool to_next_chunk, const Row<C> &prow) {
                 if (cur_slot < 0 && ends_here) {     // this group owns P[cur_user]
                     Row<C> pn = prow;
                     user_finish_row<C>(pn, acc, cn_, lr, reg_1, rU);
                     pn.store(P + (int64_t)cur_user * d, lane, d);
+                    if (v.bu && lane == 0) v.bu[cur_user] = fmaf(-lr, cb_, v.bu[cur_user]);
                     if constexpr (FUSED) {
                         const float sq = row_dot<C>(pn, pn);
                         if (lane == 0) p_sqnorm[cur_user] = sq;
@@ -929,6 +974,7 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
                     if (lane == 0) {
                         slot_user[s] = cur_user;
                         atomicAdd(&slot_n[s], cn_);
+                        atomicAdd(&slot_b[s], cb_);
                         if (to_next_chunk) slot_next[s] = 1;
                     }
                 }
@@ -974,11 +1020,13 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
                         pcur = pr[x];
                         acc.zero();
                         cn_ = 0.f;
+                        cb_ = 0.f;
                     }
 #pragma unroll
                     for (int k = 0; k < C::NE; ++k)
                         acc.v[k] = fmaf(cp, qi[x].v[k], fmaf(cn, qj[x].v[k], acc.v[k]));
                     cn_ += 1.f;
+                    cb_ += cp + cn;
                 }
             }
             const bool continues = (t1 < n) && (user_next == cur_user);
@@ -1003,6 +1051,7 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
                 p.load(P + (int64_t)uu * d, lane, d);
                 user_finish_row<C>(p, g, ns, lr, reg_1, rU);
                 p.store(P + (int64_t)uu * d, lane, d);
+                if (v.bu && lane == 0) v.bu[uu] = fmaf(-lr, slot_b[s], v.bu[uu]);
                 if constexpr (FUSED) {
                     const float sq = row_dot<C>(p, p);
                     if (lane == 0) p_sqnorm[uu] = sq;
@@ -1012,12 +1061,17 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
                 g.store(edge_vec + e * d, lane, d);
                 if (lane == 0) {
                     edge_user[e] = uu;
-                    edge_n[e] = ns;
+                    edge_n[2 * e] = ns;
+                    edge_n[2 * e + 1] = slot_b[s];
                     if (from_prev && to_next) edge_whole[chunk] = 1;
                 }
             }
         }
         __syncthreads();
+    }
+    if constexpr (!FUSED) {
+        if (v.bu && blockIdx.x == 0 && tid == 0)           // the global bias (FMRecommender.py:59)
+            v.b0[0] = fmaf(-lr, (float)stats[DAISY_ST_SUM_COEF], v.b0[0]);
     }
     if constexpr (FUSED) {
         __shared__ double sm7[kBlock / kWave][8];
@@ -1034,6 +1088,7 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
             for (int w = 0; w < kBlock / kWave; ++w) t += sm7[w][tid];
             partials[(int64_t)blockIdx.x * 8 + tid] = t;
         }
+        if (tid == 7) partials[(int64_t)blockIdx.x * 8 + 7] = 0.0;   // (no biases on the fused path)
     }
 }
 
@@ -1046,7 +1101,8 @@ __global__ __launch_bounds__(kBlock) void k_user_edges(float *__restrict__ P, in
                                                        const int32_t *__restrict__ edge_user,
                                                        const float *__restrict__ edge_n,
                                                        const int32_t *__restrict__ edge_whole,
-                                                       float *__restrict__ p_sqnorm) {
+                                                       float *__restrict__ p_sqnorm,
+                                                       float *__restrict__ u_bias) {
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
@@ -1056,18 +1112,20 @@ __global__ __launch_bounds__(kBlock) void k_user_edges(float *__restrict__ P, in
         if (uu < 0) continue;
         Row<C> acc, t;
         acc.load(edge_vec + (2 * c + 1) * d, lane, d);
-        float ns = edge_n[2 * c + 1];
+        float ns = edge_n[2 * (2 * c + 1)], sb = edge_n[2 * (2 * c + 1) + 1];
         for (int64_t k = c + 1; k < nchunks && edge_user[2 * k] == uu; ++k) {
             t.load(edge_vec + (2 * k) * d, lane, d);
 #pragma unroll
             for (int q = 0; q < C::NE; ++q) acc.v[q] += t.v[q];
-            ns += edge_n[2 * k];
+            ns += edge_n[2 * (2 * k)];
+            sb += edge_n[2 * (2 * k) + 1];
             if (!edge_whole[k]) break;
         }
         Row<C> p;
         p.load(P + (int64_t)uu * d, lane, d);
         user_finish_row<C>(p, acc, ns, lr, reg_1, rU);
         p.store(P + (int64_t)uu * d, lane, d);
+        if (u_bias && lane == 0) u_bias[uu] = fmaf(-lr, sb, u_bias[uu]);
         if constexpr (FUSED) {
             const float sq = row_dot<C>(p, p);
             if (lane == 0) p_sqnorm[uu] = sq;
@@ -1315,12 +1373,19 @@ static BatchView plan_view(const daisy_epoch_plan *p, int64_t k) {
     v.umask = p->umask;
     v.imask = p->imask;
     v.pointwise = p->pointwise;
+    v.bu = v.bi = v.b0 = v.g_bu = v.g_bi = v.g_b0 = nullptr;
     return v;
 }
 
 }  // namespace daisy
 
 using namespace daisy;
+
+static void view_bias(daisy_bpr_ctx *ctx) {
+    BatchView &v = ctx->v;
+    v.bu = ctx->bu; v.bi = ctx->bi; v.b0 = ctx->b0;
+    v.g_bu = ctx->g_bu; v.g_bi = ctx->g_bi; v.g_b0 = ctx->g_b0;
+}
 
 // =============================================================================
 // C ABI
@@ -1402,13 +1467,14 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
     c->batch_set = false; c->fwd_done = false; c->own_plan = nullptr;
     c->last_item_mode = DAISY_ITEM_SORTED;
     c->pointwise = 0;
+    c->bu = c->bi = c->b0 = c->g_bu = c->g_bi = c->g_b0 = nullptr;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     const size_t o_coef = take((size_t)max_batch * 8);
     const size_t o_part = take((size_t)kMaxGrid * 8 * 8);
     const size_t o_tt = take((size_t)max_batch * 12);
     const size_t n_edge = 2 * ((size_t)max_batch / 32 + 2);   // chunks hold >= 32 samples
-    const size_t o_ev = take(n_edge * (size_t)d * 4), o_eu = take(n_edge * 4), o_en = take(n_edge * 4);
+    const size_t o_ev = take(n_edge * (size_t)d * 4), o_eu = take(n_edge * 4), o_en = take(n_edge * 8);
     const size_t o_ew = take(n_edge * 4);
     const size_t o_ps = take((size_t)max_batch * (size_t)d * 4);
     const size_t o_pn = take((size_t)user_num * 4);
@@ -1463,6 +1529,21 @@ int daisy_bpr_ctx_set_pointwise(daisy_bpr_ctx *ctx, int32_t pointwise) {
     return DAISY_OK;
 }
 
+int daisy_bpr_ctx_set_bias(daisy_bpr_ctx *ctx, float *u_bias, float *i_bias, float *bias,
+                           float *g_u_bias, float *g_i_bias, float *g_bias) {
+    DAISY_CHECK_ARG(ctx != nullptr, "ctx_set_bias: NULL context");
+    if (u_bias == nullptr) {                  // detach: plain MF again
+        ctx->bu = ctx->bi = ctx->b0 = ctx->g_bu = ctx->g_bi = ctx->g_b0 = nullptr;
+    } else {
+        DAISY_CHECK_ARG(i_bias && bias && g_i_bias,
+                        "ctx_set_bias: u_bias, i_bias, bias and g_i_bias must all be given");
+        ctx->bu = u_bias; ctx->bi = i_bias; ctx->b0 = bias;
+        ctx->g_bu = g_u_bias; ctx->g_bi = g_i_bias; ctx->g_b0 = g_bias;
+    }
+    if (ctx->batch_set) view_bias(ctx);
+    return DAISY_OK;
+}
+
 int daisy_bpr_set_batch_from_plan(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, int64_t k,
                                   daisy_stream_t stream) {
     (void)stream;
@@ -1474,6 +1555,7 @@ int daisy_bpr_set_batch_from_plan(daisy_bpr_ctx *ctx, const daisy_epoch_plan *pl
                     "set_batch_from_plan: plan (batch %lld, U %lld, I %lld) does not fit the context",
                     (long long)plan->batch_size, (long long)plan->U, (long long)plan->I);
     ctx->v = plan_view(plan, k);
+    view_bias(ctx);
     ctx->batch_set = true; ctx->fwd_done = false;
     return DAISY_OK;
 }
@@ -1494,6 +1576,7 @@ int daisy_bpr_set_batch_from_triples(daisy_bpr_ctx *ctx, const int32_t *triples,
                     0, 0, B, user_base, ctx->pointwise ? DAISY_PLAN_POINTWISE : 0, S(stream));
     if (rc) return rc;
     ctx->v = plan_view(ctx->own_plan, 0);
+    view_bias(ctx);
     ctx->batch_set = true; ctx->fwd_done = false;
     return DAISY_OK;
 }
@@ -1666,13 +1749,18 @@ static int user_pass(daisy_bpr_ctx *ctx, float *P, const float *Q, const double 
                                ctx->edge_user, ctx->edge_n, ctx->edge_whole, 0, 0.f, nullptr, nullptr, nullptr);
             hipLaunchKernelGGL((k_user_edges<C, false>), dim3(grid_for(nchunks, C::GROUPS_PER_BLOCK)),
                                dim3(kBlock), 0, s, P, nchunks, d, stats, lr, reg_1, reg_2, ctx->edge_vec,
-                               ctx->edge_user, ctx->edge_n, ctx->edge_whole, nullptr);
+                               ctx->edge_user, ctx->edge_n, ctx->edge_whole, nullptr, v.bu);
         } else if (sgd)
             hipLaunchKernelGGL((k_user<C, true>), dim3(grid), dim3(kBlock), 0, s, P, Q, v, ctx->coef, d,
                                stats, lr, reg_1, reg_2, gP);
-        else
+        else {
+            if (v.bu && !(v.g_bu && v.g_b0)) {
+                set_error("user_grad: the context has biases but no g_u_bias / g_bias outputs");
+                return DAISY_ERR_ARG;
+            }
             hipLaunchKernelGGL((k_user<C, false>), dim3(grid), dim3(kBlock), 0, s, P, Q, v, ctx->coef, d,
                                stats, lr, reg_1, reg_2, gP);
+        }
         return DAISY_OK;
     });
     if (rc) return rc;
@@ -1767,7 +1855,7 @@ static int sgd_step_fused(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t loss_t
                                ctx->partials);
             hipLaunchKernelGGL((k_user_edges<C, true>), dim3(grid_for(nchunks, C::GROUPS_PER_BLOCK)),
                                dim3(kBlock), 0, s, P, nchunks, d, stats, lr, reg_1, reg_2, ctx->edge_vec,
-                               ctx->edge_user, ctx->edge_n, ctx->edge_whole, ctx->p_sqnorm);
+                               ctx->edge_user, ctx->edge_n, ctx->edge_whole, ctx->p_sqnorm, nullptr);
             hipLaunchKernelGGL((k_reduce_partials<true>), dim3(1), dim3(kBlock), 0, s, ctx->partials, gu,
                                stats, reg_1, reg_2, epoch_acc, step_loss);
             hipLaunchKernelGGL((k_item_grad_chunked<C, 0, true>), dim3(grid_for(2 * v.B, RunCfg<C>::E, 16384)),
@@ -1786,7 +1874,7 @@ int daisy_bpr_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t loss_type
                        double *epoch_acc, double *step_loss, int32_t item_mode,
                        daisy_stream_t stream) {
     if (item_mode == DAISY_ITEM_FUSED) {
-        if (ctx->d <= 64 && !ctx->v.pointwise)   // rows of <= 4 floats per lane: the fused kernel fits the register budget
+        if (ctx->d <= 64 && !ctx->v.pointwise && !ctx->bu)   // rows of <= 4 floats per lane: the fused kernel fits the register budget
             return sgd_step_fused(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, gQ, stats, epoch_acc,
                                   step_loss, stream);
         item_mode = DAISY_ITEM_CHUNKED;

@@ -10,7 +10,10 @@ __global__ __launch_bounds__(kBlock) void k_predict(const float *__restrict__ P,
                                                     const float *__restrict__ Q, int d,
                                                     const int64_t *__restrict__ u,
                                                     const int64_t *__restrict__ i, int64_t B,
-                                                    float *__restrict__ out) {
+                                                    float *__restrict__ out,
+                                                    const float *__restrict__ bu,
+                                                    const float *__restrict__ bi,
+                                                    const float *__restrict__ b0) {
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
@@ -18,7 +21,8 @@ __global__ __launch_bounds__(kBlock) void k_predict(const float *__restrict__ P,
         Row<C> p, q;
         p.load(P + u[s] * d, lane, d);
         q.load(Q + i[s] * d, lane, d);
-        const float x = row_dot<C>(p, q);
+        float x = row_dot<C>(p, q);
+        if (bu) x += (bu[u[s]] + bi[i[s]]) + b0[0];        // FMRecommender.py:65-66
         if (lane == 0) out[s] = x;
     }
 }
@@ -30,7 +34,10 @@ __global__ __launch_bounds__(kBlock) void k_rank_scores(const float *__restrict_
                                                         const int64_t *__restrict__ us,
                                                         const int64_t *__restrict__ cands,
                                                         int64_t B, int64_t Cn,
-                                                        float *__restrict__ scores) {
+                                                        float *__restrict__ scores,
+                                                        const float *__restrict__ bu,
+                                                        const float *__restrict__ bi,
+                                                        const float *__restrict__ b0) {
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
@@ -40,7 +47,8 @@ __global__ __launch_bounds__(kBlock) void k_rank_scores(const float *__restrict_
         Row<C> p, q;
         p.load(P + us[b] * d, lane, d);
         q.load(Q + cands[e] * d, lane, d);
-        const float x = row_dot<C>(p, q);
+        float x = row_dot<C>(p, q);
+        if (bu) x += (bu[us[b]] + bi[cands[e]]) + b0[0];   // FMRecommender.py:115
         if (lane == 0) scores[e] = x;
     }
 }
@@ -50,7 +58,10 @@ template <class C>
 __global__ __launch_bounds__(kBlock) void k_scores_all(const float *__restrict__ P,
                                                        const float *__restrict__ Q, int d, int64_t u,
                                                        int64_t I, float *__restrict__ scores,
-                                                       int64_t *__restrict__ ids) {
+                                                       int64_t *__restrict__ ids,
+                                                       const float *__restrict__ bu,
+                                                       const float *__restrict__ bi,
+                                                       const float *__restrict__ b0) {
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
@@ -59,7 +70,8 @@ __global__ __launch_bounds__(kBlock) void k_scores_all(const float *__restrict__
     for (int64_t r = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; r < I; r += gstride) {
         Row<C> q;
         q.load(Q + r * d, lane, d);
-        const float x = row_dot<C>(p, q);
+        float x = row_dot<C>(p, q);
+        if (bu) x += (bu[u] + bi[r]) + b0[0];              // FMRecommender.py:131
         if (lane == 0) {
             scores[r] = x;
             ids[r] = r;
@@ -86,11 +98,18 @@ extern "C" {
 
 int daisy_mf_predict(const float *P, const float *Q, int32_t d, const int64_t *u, const int64_t *i,
                      int64_t B, float *out, daisy_stream_t stream) {
+    return daisy_fm_predict(P, Q, nullptr, nullptr, nullptr, d, u, i, B, out, stream);
+}
+
+int daisy_fm_predict(const float *P, const float *Q, const float *u_bias, const float *i_bias,
+                     const float *bias, int32_t d, const int64_t *u, const int64_t *i, int64_t B,
+                     float *out, daisy_stream_t stream) {
     DAISY_CHECK_ARG(P && Q && u && i && out && B > 0, "mf_predict: bad argument");
+    DAISY_CHECK_ARG(!u_bias || (i_bias && bias), "fm_predict: u_bias without i_bias / bias");
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
         hipLaunchKernelGGL((k_predict<C>), dim3(grid_for(B, C::GROUPS_PER_BLOCK)), dim3(kBlock), 0,
-                           S(stream), P, Q, (int)d, u, i, B, out);
+                           S(stream), P, Q, (int)d, u, i, B, out, u_bias, i_bias, bias);
         return DAISY_OK;
     });
     if (rc) return rc;
@@ -108,6 +127,15 @@ int daisy_mf_rank_topk(const float *P, const float *Q, int32_t d, const int64_t 
                        const int64_t *cands, int64_t B, int64_t C, int32_t topk, int64_t *out_ids,
                        float *scores_out, void *workspace, size_t workspace_bytes,
                        daisy_stream_t stream) {
+    return daisy_fm_rank_topk(P, Q, nullptr, nullptr, nullptr, d, us, cands, B, C, topk, out_ids,
+                              scores_out, workspace, workspace_bytes, stream);
+}
+
+int daisy_fm_rank_topk(const float *P, const float *Q, const float *u_bias, const float *i_bias,
+                       const float *bias, int32_t d, const int64_t *us, const int64_t *cands,
+                       int64_t B, int64_t C, int32_t topk, int64_t *out_ids, float *scores_out,
+                       void *workspace, size_t workspace_bytes, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(!u_bias || (i_bias && bias), "fm_rank_topk: u_bias without i_bias / bias");
     DAISY_CHECK_ARG(P && Q && us && cands && out_ids && workspace, "mf_rank_topk: NULL argument");
     DAISY_CHECK_ARG(B > 0 && C > 0 && topk > 0 && topk <= C && B * C < ((int64_t)1 << 31),
                     "mf_rank_topk: bad sizes B=%lld C=%lld topk=%d", (long long)B, (long long)C, topk);
@@ -124,7 +152,7 @@ int daisy_mf_rank_topk(const float *P, const float *Q, int32_t d, const int64_t 
     int rc = dispatch_d(d, [&](auto cfg) {
         using Cf = decltype(cfg);
         hipLaunchKernelGGL((k_rank_scores<Cf>), dim3(grid_for(B * C, Cf::GROUPS_PER_BLOCK * 4)),
-                           dim3(kBlock), 0, s, P, Q, (int)d, us, cands, B, C, scores);
+                           dim3(kBlock), 0, s, P, Q, (int)d, us, cands, B, C, scores, u_bias, i_bias, bias);
         return DAISY_OK;
     });
     if (rc) return rc;
@@ -147,6 +175,15 @@ size_t daisy_mf_full_rank_workspace_bytes(int64_t item_num) {
 int daisy_mf_full_rank(const float *P, const float *Q, int32_t d, int64_t item_num, int64_t u,
                        int32_t topk, int64_t *out_ids, void *workspace, size_t workspace_bytes,
                        daisy_stream_t stream) {
+    return daisy_fm_full_rank(P, Q, nullptr, nullptr, nullptr, d, item_num, u, topk, out_ids, workspace,
+                              workspace_bytes, stream);
+}
+
+int daisy_fm_full_rank(const float *P, const float *Q, const float *u_bias, const float *i_bias,
+                       const float *bias, int32_t d, int64_t item_num, int64_t u, int32_t topk,
+                       int64_t *out_ids, void *workspace, size_t workspace_bytes,
+                       daisy_stream_t stream) {
+    DAISY_CHECK_ARG(!u_bias || (i_bias && bias), "fm_full_rank: u_bias without i_bias / bias");
     DAISY_CHECK_ARG(P && Q && out_ids && workspace && item_num > 0 && u >= 0 && topk > 0 &&
                         topk <= item_num,
                     "mf_full_rank: bad argument");
@@ -163,7 +200,7 @@ int daisy_mf_full_rank(const float *P, const float *Q, int32_t d, int64_t item_n
     int rc = dispatch_d(d, [&](auto cfg) {
         using Cf = decltype(cfg);
         hipLaunchKernelGGL((k_scores_all<Cf>), dim3(grid_for(item_num, Cf::GROUPS_PER_BLOCK * 4)),
-                           dim3(kBlock), 0, s, P, Q, (int)d, u, item_num, scores, ids);
+                           dim3(kBlock), 0, s, P, Q, (int)d, u, item_num, scores, ids, u_bias, i_bias, bias);
         return DAISY_OK;
     });
     if (rc) return rc;

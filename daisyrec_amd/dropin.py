@@ -13,9 +13,12 @@ import importlib
 def install(sampler=False):
     """Patch `daisy.model.MFRecommender.MF` (and optionally the sampler) in place."""
     from .model.MFRecommender import MF
+    from .model.FMRecommender import FM
 
     ref_mf = importlib.import_module("daisy.model.MFRecommender")
     ref_mf.MF = MF
+    ref_fm = importlib.import_module("daisy.model.FMRecommender")
+    ref_fm.FM = FM
     if sampler:
         from .utils.sampler import BasicNegtiveSampler
 

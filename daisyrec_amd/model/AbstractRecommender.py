@@ -163,7 +163,12 @@ class GeneralRecommender(AbstractRecommender):
         P, Q = self.embed_user.weight.data, self.embed_item.weight.data
         ctx = ops.BprContext(min(B, max(n, 1)), P.shape[1], P.shape[0], Q.shape[0], device=P.device)
         plan = ops.EpochPlan(n, P.shape[0], Q.shape[0], device=P.device)
-        adam = _AdamState(P, Q, self.lr) if opt == "adam" else None
+        biases = self._biases() if hasattr(self, "_biases") else None     # FM: (u_bias, i_bias, bias_)
+        adam = _AdamState(P, Q, self.lr, biases) if opt == "adam" else None
+        if biases is not None:
+            g_i_bias = adam.g[1] if adam is not None else torch.zeros(Q.shape[0], device=P.device)
+            ctx.set_bias(*biases, g_u_bias=adam.g[0] if adam is not None else None, g_i_bias=g_i_bias,
+                         g_bias=adam.g[2] if adam is not None else None)
         user_sorted = ops.triples_user_sorted(triples[:n])
         pointwise = loss_id in ops.POINTWISE_LOSSES      # rows are (user, item, label), sampler.py:93-98
         self.epoch_losses = []
@@ -216,11 +221,16 @@ class GeneralRecommender(AbstractRecommender):
 class _AdamState:
     """Dense torch.optim.Adam state for the two tables (AbstractRecommender.py:54)."""
 
-    def __init__(self, P, Q, lr):
+    def __init__(self, P, Q, lr, biases=None):
         self.lr, self.t = lr, 0
         self.gP = torch.zeros_like(P)
         self.mP, self.vP = torch.zeros_like(P), torch.zeros_like(P)
         self.mQ, self.vQ = torch.zeros_like(Q), torch.zeros_like(Q)
+        # FM: dense Adam state and gradient buffers of (u_bias, i_bias, bias_)
+        self.w = [] if biases is None else [b.view(-1) for b in biases]
+        self.g = [torch.zeros_like(b) for b in self.w]
+        self.m = [torch.zeros_like(b) for b in self.w]
+        self.v = [torch.zeros_like(b) for b in self.w]
 
     def step(self, ctx, P, Q, reg_1, reg_2, loss_id, item_mode):
         self.t += 1
@@ -230,3 +240,5 @@ class _AdamState:
         ctx.user_grad(P, Q, reg_1, reg_2, self.gP)
         ops.adam_dense(P, self.gP, self.mP, self.vP, self.lr, self.t)
         ops.adam_dense(Q, ctx.gQ, self.mQ, self.vQ, self.lr, self.t)   # also zeroes gQ
+        for w, g, m, v in zip(self.w, self.g, self.m, self.v):
+            ops.adam_dense(w, g, m, v, self.lr, self.t)

@@ -46,12 +46,16 @@ class MF(GeneralRecommender):
             self.to(self.device)
         return self.embed_user.weight.data, self.embed_item.weight.data
 
+    def _biases(self):
+        """None for MF; FM returns (u_bias, i_bias, bias_) device tensors (FMRecommender.py:49-53)."""
+        return None
+
     def forward(self, user, item):
         """MFRecommender.py:63-68: pred = (P[user] * Q[item]).sum(-1)."""
         P, Q = self._tables()
         user = torch.as_tensor(user).to(P.device)
         item = torch.as_tensor(item).to(P.device)
-        return ops.mf_predict(P, Q, user.reshape(-1), item.reshape(-1)).view(user.shape)
+        return ops.mf_predict(P, Q, user.reshape(-1), item.reshape(-1), biases=self._biases()).view(user.shape)
 
     def calc_loss(self, batch):
         """MFRecommender.py:70-97 for the pairwise losses: returns the batch loss
@@ -63,6 +67,9 @@ class MF(GeneralRecommender):
         ctx = ops.BprContext(u.numel(), P.shape[1], P.shape[0], Q.shape[0], device=P.device)
         try:
             ctx.set_pointwise(loss_id in ops.POINTWISE_LOSSES)   # batch[2] is the label (MFRecommender.py:76)
+            b = self._biases()
+            if b is not None:
+                ctx.set_bias(*b, g_i_bias=torch.zeros(Q.shape[0], device=P.device))
             ctx.set_batch(u, i, j)
             ctx.forward(P, Q, loss_id)
             out = torch.zeros((), dtype=torch.float64, device=P.device)
@@ -77,7 +84,7 @@ class MF(GeneralRecommender):
         P, Q = self._tables()
         u = torch.tensor([u], device=P.device)
         i = torch.tensor([i], device=P.device)
-        return float(ops.mf_predict(P, Q, u, i).cpu().item())
+        return float(ops.mf_predict(P, Q, u, i, biases=self._biases()).cpu().item())
 
     def rank(self, test_loader):
         """MFRecommender.py:106-123.  Returns float32 [n_users, topk] like the reference
@@ -89,7 +96,7 @@ class MF(GeneralRecommender):
             cands_ids = torch.as_tensor(cands_ids).to(P.device)
             if cands_ids.dim() == 1:
                 cands_ids = cands_ids.unsqueeze(0)
-            out.append(ops.mf_rank_topk(P, Q, us.reshape(-1), cands_ids, self.topk))
+            out.append(ops.mf_rank_topk(P, Q, us.reshape(-1), cands_ids, self.topk, biases=self._biases()))
         if not out:
             return np.zeros((0,), dtype=np.float32)
         return torch.cat(out, 0).to(torch.float32).cpu().numpy()
@@ -97,4 +104,4 @@ class MF(GeneralRecommender):
     def full_rank(self, u):
         """MFRecommender.py:126-133 -> int64 [topk]."""
         P, Q = self._tables()
-        return ops.mf_full_rank(P, Q, int(u), self.topk).cpu().numpy()
+        return ops.mf_full_rank(P, Q, int(u), self.topk, biases=self._biases()).cpu().numpy()

@@ -1,2 +1,3 @@
 from .AbstractRecommender import AbstractRecommender, GeneralRecommender  # noqa: F401
 from .MFRecommender import MF  # noqa: F401
+from .FMRecommender import FM  # noqa: F401

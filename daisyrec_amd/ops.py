@@ -160,6 +160,19 @@ class BprContext:
         """Rows given to set_batch* are (user, item, label) - the CL / SL layout (sampler.py:93-98)."""
         check(lib.daisy_bpr_ctx_set_pointwise(self._h, int(bool(flag))))
 
+    def set_bias(self, u_bias=None, i_bias=None, bias=None, g_u_bias=None, g_i_bias=None, g_bias=None):
+        """Attach FM's bias parameters (FMRecommender.py:46-50); `set_bias()` detaches them.
+        g_i_bias [I] is mandatory (zeroed scratch like gQ); g_u_bias [U] / g_bias [1] only for user_grad."""
+        if u_bias is None:
+            check(lib.daisy_bpr_ctx_set_bias(self._h, None, None, None, None, None, None))
+            self._bias = None
+            return
+        f = torch.float32
+        check(lib.daisy_bpr_ctx_set_bias(self._h, _ptr(u_bias.view(-1), f, "u_bias"), _ptr(i_bias.view(-1), f, "i_bias"),
+                                         _ptr(bias.view(-1), f, "bias"), _ptr(g_u_bias, f, "g_u_bias"),
+                                         _ptr(g_i_bias, f, "g_i_bias"), _ptr(g_bias, f, "g_bias")))
+        self._bias = (u_bias, i_bias, bias, g_u_bias, g_i_bias, g_bias)     # keep the storage alive
+
     # -- batch -------------------------------------------------------------
     def set_batch_from_triples(self, triples, idx=None, start=0, B=None, user_base=0):
         n = triples.shape[0]
@@ -249,21 +262,31 @@ def adam_dense(W, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
                                float(lr), float(beta1), float(beta2), float(eps), int(step), _stream()))
 
 
-def mf_predict(P, Q, u, i):
-    """MF.forward (MFRecommender.py:63-68)."""
+def _bias_ptrs(biases):
+    if biases is None:
+        return None, None, None
+    bu, bi, b0 = biases
+    f = torch.float32
+    return _ptr(bu.view(-1), f, "u_bias"), _ptr(bi.view(-1), f, "i_bias"), _ptr(b0.view(-1), f, "bias")
+
+
+def mf_predict(P, Q, u, i, biases=None):
+    """MF.forward (MFRecommender.py:63-68); biases=(u_bias, i_bias, bias_): FM.forward (FMRecommender.py:61-68)."""
     u = u.to(torch.int64).contiguous()
     i = i.to(torch.int64).contiguous()
     out = torch.empty(u.numel(), dtype=torch.float32, device=P.device)
     if u.numel() == 0:
         return out
-    check(lib.daisy_mf_predict(_ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"), P.shape[1],
+    bu, bi, b0 = _bias_ptrs(biases)
+    check(lib.daisy_fm_predict(_ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"), bu, bi, b0, P.shape[1],
                                _ptr(u, torch.int64, "u"), _ptr(i, torch.int64, "i"), u.numel(),
                                _ptr(out, torch.float32, "out"), _stream()))
     return out.view(u.shape)
 
 
-def mf_rank_topk(P, Q, us, cands, topk, return_scores=False):
-    """One batch of MF.rank (MFRecommender.py:109-121) -> int64 [B, topk]."""
+def mf_rank_topk(P, Q, us, cands, topk, return_scores=False, biases=None):
+    """One batch of MF.rank (MFRecommender.py:109-121) -> int64 [B, topk]; biases: FM.rank
+    (FMRecommender.py:105-123)."""
     us = us.to(torch.int64).contiguous()
     cands = cands.to(torch.int64).contiguous()
     B, Cn = cands.shape
@@ -271,7 +294,8 @@ def mf_rank_topk(P, Q, us, cands, topk, return_scores=False):
     scores = torch.empty(B, Cn, dtype=torch.float32, device=P.device) if return_scores else None
     nbytes = lib.daisy_mf_rank_workspace_bytes(B, Cn)
     ws = _ws(nbytes, P.device)
-    check(lib.daisy_mf_rank_topk(_ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"), P.shape[1],
+    bu, bi, b0 = _bias_ptrs(biases)
+    check(lib.daisy_fm_rank_topk(_ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"), bu, bi, b0, P.shape[1],
                                  _ptr(us, torch.int64, "us"), _ptr(cands, torch.int64, "cands"), B, Cn,
                                  int(topk), _ptr(out, torch.int64, "out"),
                                  _ptr(scores, torch.float32, "scores"), _ptr(ws, torch.uint8, "ws"),
@@ -279,12 +303,13 @@ def mf_rank_topk(P, Q, us, cands, topk, return_scores=False):
     return (out, scores) if return_scores else out
 
 
-def mf_full_rank(P, Q, u, topk):
-    """MF.full_rank (MFRecommender.py:126-133) -> int64 [topk]."""
+def mf_full_rank(P, Q, u, topk, biases=None):
+    """MF.full_rank (MFRecommender.py:126-133) -> int64 [topk]; biases: FM.full_rank (FMRecommender.py:125-133)."""
     I = Q.shape[0]
     out = torch.empty(topk, dtype=torch.int64, device=P.device)
     ws = _ws(lib.daisy_mf_full_rank_workspace_bytes(I), P.device)
-    check(lib.daisy_mf_full_rank(_ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"), P.shape[1], I,
+    bu, bi, b0 = _bias_ptrs(biases)
+    check(lib.daisy_fm_full_rank(_ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"), bu, bi, b0, P.shape[1], I,
                                  int(u), int(topk), _ptr(out, torch.int64, "out"),
                                  _ptr(ws, torch.uint8, "ws"), ws.numel(), _stream()))
     return out

@@ -78,6 +78,8 @@ enum daisy_stats_slot {
     DAISY_ST_NORM_I = 9,
     DAISY_ST_NORM_J = 10,
     DAISY_ST_NORM_U_PRE = 11, /* |P[u]|_F from the row-norm cache (fused step only)   */
+    DAISY_ST_SUM_COEF = 12,   /* sum_b (dL/dpos + dL/dneg) = dL/d bias_ (FM); a batch sum like 0..6:
+                                 multi-GPU callers all-reduce it with them before finalize       */
     DAISY_STATS_LEN = 16
 };
 
@@ -135,6 +137,20 @@ int daisy_feistel_positions(int64_t n, uint64_t seed, uint64_t epoch, int64_t *o
 
 /* batches set with daisy_bpr_set_batch / _from_triples are (user, item, label) rows (CL / SL) */
 int daisy_bpr_ctx_set_pointwise(daisy_bpr_ctx *ctx, int32_t pointwise);
+/* FM (FMRecommender.py:46-68): score(u,item) = <P[u],Q[item]> + u_bias[u] + i_bias[item] + bias_.
+ * Attaches the bias parameters (device, caller-owned: u_bias f32[U], i_bias f32[I], bias f32[1]) to
+ * the context; u_bias == NULL detaches them (plain MF).  From then on
+ *   daisy_bpr_forward        adds them to both scores and reduces stats[DAISY_ST_SUM_COEF];
+ *   daisy_bpr_item_grad*     accumulates g_i_bias[item] = sum of the item's coefficients (f32[I],
+ *                            zero between steps like gQ; mandatory);
+ *   daisy_bpr_item_sgd_apply does i_bias -= lr*g_i_bias and clears g_i_bias;
+ *   daisy_bpr_user_sgd       does u_bias[u] -= lr*sum(cp+cn) and bias -= lr*stats[SUM_COEF];
+ *   daisy_bpr_user_grad      writes g_u_bias[u] (f32[U]) and g_bias[0] instead (needed only for this
+ *                            call; may be NULL otherwise) - dense Adam then runs daisy_adam_dense on them.
+ * The regularisers of FM.calc_loss (FMRecommender.py:77-93) are those of MF: embeddings only.
+ * DAISY_ITEM_FUSED falls back to DAISY_ITEM_CHUNKED while biases are attached. */
+int daisy_bpr_ctx_set_bias(daisy_bpr_ctx *ctx, float *u_bias, float *i_bias, float *bias,
+                           float *g_u_bias, float *g_i_bias, float *g_bias);
 /* make batch k of a built plan current (no copy) */
 int daisy_bpr_set_batch_from_plan(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, int64_t k,
                                   daisy_stream_t stream);
@@ -228,6 +244,20 @@ int daisy_mf_rank_topk(const float *P, const float *Q, int32_t d, const int64_t 
                        float *scores_out, void *workspace, size_t workspace_bytes,
                        daisy_stream_t stream);
 size_t daisy_mf_full_rank_workspace_bytes(int64_t item_num);
+/* FM.predict / rank / full_rank (FMRecommender.py:95-133): the MF entry points plus
+ * `+ (u_bias[u] + i_bias[item]) + bias[0]` on every score, in the reference's order of additions;
+ * same workspaces; u_bias == NULL gives the MF result. */
+int daisy_fm_predict(const float *P, const float *Q, const float *u_bias, const float *i_bias,
+                     const float *bias, int32_t d, const int64_t *u, const int64_t *i, int64_t B,
+                     float *out, daisy_stream_t stream);
+int daisy_fm_rank_topk(const float *P, const float *Q, const float *u_bias, const float *i_bias,
+                       const float *bias, int32_t d, const int64_t *us, const int64_t *cands,
+                       int64_t B, int64_t C, int32_t topk, int64_t *out_ids, float *scores_out,
+                       void *workspace, size_t workspace_bytes, daisy_stream_t stream);
+int daisy_fm_full_rank(const float *P, const float *Q, const float *u_bias, const float *i_bias,
+                       const float *bias, int32_t d, int64_t item_num, int64_t u, int32_t topk,
+                       int64_t *out_ids, void *workspace, size_t workspace_bytes,
+                       daisy_stream_t stream);
 /* MF.full_rank (MFRecommender.py:126-133): argsort(P[u] @ Q^T, descending)[:topk] */
 int daisy_mf_full_rank(const float *P, const float *Q, int32_t d, int64_t item_num, int64_t u,
                        int32_t topk, int64_t *out_ids, void *workspace, size_t workspace_bytes,

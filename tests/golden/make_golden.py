@@ -249,7 +249,7 @@ def make_rank_kat():
     print("rank_kat.npz: preds", preds.shape, "full", full.shape)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__":  # pragma: no cover
     make_kat_steps()
     make_rank_kat()
     make_ml100k()
