@@ -1,0 +1,111 @@
+"""oracle/neumf_numpy.py against the golden vectors the REAL reference NeuMF produced
+(tests/golden/make_golden_neumf.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bpr_mf_numpy as O
+from oracle import neumf_numpy as N
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def kat_neumf():
+    return np.load(os.path.join(HERE, "golden", "kat_neumf.npz"))
+
+
+def assert_params_close(got, ref, names, tag, atol, adam_lr=None, steps=1, frac=0.999):
+    """SGD: every element within atol.  Adam: m/sqrt(v) is sign-like where a gradient is ~0, so a
+    last-ulp difference in such a gradient moves the weight by up to lr per step: require `frac`
+    of the elements within atol and all of them within 2*lr*steps."""
+    for k in names:
+        a, b = np.asarray(got[k], np.float64).reshape(-1), np.asarray(ref[k], np.float64).reshape(-1)
+        diff = np.abs(a - b)
+        if adam_lr is None:
+            assert diff.max() <= atol, f"{tag} {k}: max diff {diff.max():.3e}"
+        else:
+            assert (diff <= atol).mean() >= frac and diff.max() <= 2 * adam_lr * steps + atol, \
+                f"{tag} {k}: {(diff > atol).sum()} of {diff.size} beyond {atol}, max {diff.max():.3e}"
+
+
+def load_params(g, prefix, L, suffix=""):
+    return {k: g[f"{prefix}/{k}{suffix}"] for k in N.param_names(L)}
+
+
+def oracle_steps(g, name, dtype=np.float64):
+    U, I, d, L, B, ns = (int(x) for x in g[f"{name}/meta"])
+    lr, r1, r2 = (float(x) for x in g[f"{name}/hyper"])
+    lt = O.LOSS_IDS[str(g[f"{name}/loss_type"])]
+    model = str(g[f"{name}/model"])
+    p = load_params(g, name, L, "0")
+    names = N.param_names(L)
+    adam = O.DenseAdam([p[k].shape for k in names], lr, dtype=dtype) if str(g[f"{name}/optimizer"]) == "adam" else None
+    for s in range(ns):
+        loss, grads = N.neumf_grad(p, g[f"{name}/u"][s], g[f"{name}/i"][s], g[f"{name}/j"][s], r1, r2, L, lt,
+                                   model, dtype=dtype)
+        if adam is None:
+            p = {k: (np.asarray(p[k], dtype) - lr * grads[k]).astype(np.float32) for k in names}
+        else:
+            p = dict(zip(names, adam.step([p[k] for k in names], [grads[k] for k in names])))
+        yield s, loss, p
+
+
+def test_neumf_kat_steps(kat_neumf):
+    g = kat_neumf
+    for name in g["names"]:
+        name = str(name)
+        L = int(g[f"{name}/meta"][3])
+        for s, loss, p in oracle_steps(g, name):
+            ref = g[f"{name}/loss"][s]
+            assert abs(loss - ref) <= 5e-6 * abs(ref), (name, s, loss, ref)
+        is_adam = str(g[f"{name}/optimizer"]) == "adam"
+        assert_params_close(p, {k: g[f"{name}/{k}"] for k in N.param_names(L)}, N.param_names(L), name, 3e-6,
+                            adam_lr=float(g[f"{name}/hyper"][0]) if is_adam else None,
+                            steps=int(g[f"{name}/meta"][5]))
+
+
+def test_neumf_rank_kat(kat_neumf):
+    g = kat_neumf
+    U, I, d, L = (int(x) for x in g["rank/meta"])
+    p = load_params(g, "rank", L)
+    pred, _ = N.neumf_rank(p, g["rank/us"], g["rank/cands"], int(g["rank/topk"]), L)
+    assert (pred == g["rank/preds"]).mean() > 0.99      # fp32 sum order of torch's GEMMs differs in the last ulp
+    full = np.stack([N.neumf_full_rank(p, int(u), int(g["rank/topk"]), L) for u in g["rank/us"]])
+    assert (full == g["rank/full"]).mean() > 0.99
+    pp, _ = N.neumf_forward(p, g["rank/us"], g["rank/cands"][:, 0], L)
+    np.testing.assert_allclose(pp, g["rank/predict"], rtol=1e-5, atol=1e-6)
+
+
+def test_neumf_ml100k_end_to_end(kat_neumf):
+    """run_examples/test.py --algo_name neumf (dropout 0) on ml-100k: epoch losses within 1e-5."""
+    g = kat_neumf
+    U, I, d, L = (int(x) for x in g["ml/meta"])
+    samples, B = g["ml/samples"], int(g["ml/batch_size"])
+    lr, r1, r2 = (float(x) for x in g["ml/hyper"])
+    names = N.param_names(L)
+    p = load_params(g, "ml", L, "0")
+    adam = O.DenseAdam([p[k].shape for k in names], lr)
+    n = len(samples)
+    torch.set_rng_state(torch.from_numpy(g["ml/rng_state_before_fit"]))
+    for ep in range(int(g["ml/epochs"])):
+        torch.empty((), dtype=torch.int64).random_()
+        gen = torch.Generator()
+        gen.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+        perm = torch.randperm(n, generator=gen).numpy()
+        tot = 0.0
+        for s in range(0, n, B):
+            idx = perm[s:s + B]
+            loss, grads = N.neumf_grad(p, samples[idx, 0], samples[idx, 1], samples[idx, 2], r1, r2, L)
+            p = dict(zip(names, adam.step([p[k] for k in names], [grads[k] for k in names])))
+            tot += loss
+        ref = g["ml/epoch_losses"][ep]
+        # epoch 1 within 1e-5; after ~300 Adam steps fp32 (reference) and fp64 (oracle) trajectories
+        # drift apart at the 1e-5 level (Adam's sign-like update amplifies last-ulp differences)
+        assert abs(tot - ref) <= (1e-5 if ep == 0 else 1e-4) * abs(ref), (ep, tot, ref)
+    assert_params_close(p, {k: g[f"ml/{k}1"] for k in names}, names, "ml-100k", 5e-4, adam_lr=lr, steps=20, frac=0.99)
+    pred, _ = N.neumf_rank(p, g["ml/test_u"], g["ml/cands"], int(g["ml/topk"]), L)
+    same = (pred == g["ml/preds"]).all(axis=1).mean()
+    assert same > 0.9, f"top-N lists identical for {same:.3f} of the users"
