@@ -121,11 +121,11 @@ def rank_case(rng):
     return out
 
 
-def ml100k_case(epochs=2):
+def ml100k_case(epochs=2, prefix="ml", **over):
     cwd = os.getcwd()
     os.chdir(G.REF)
     try:
-        cfg = neumf_config(num_ng=1, epochs=epochs, early_stop=False, algo_name="neumf", dataset="ml-100k")
+        cfg = neumf_config(num_ng=1, epochs=epochs, early_stop=False, algo_name="neumf", dataset="ml-100k", **over)
         G.seed_all(cfg["seed"])
         df = RawDataReader(cfg).get_data()
         pre = Preprocessor(cfg)
@@ -151,18 +151,20 @@ def ml100k_case(epochs=2):
                                           num_workers=0))
     finally:
         os.chdir(cwd)
-    out = {"ml/meta": np.array([cfg["user_num"], cfg["item_num"], cfg["factors"], cfg["num_layers"]], dtype=np.int64),
-           "ml/hyper": np.array([cfg["lr"], cfg["reg_1"], cfg["reg_2"]], dtype=np.float64),
-           "ml/batch_size": np.int64(cfg["batch_size"]), "ml/epochs": np.int64(epochs),
-           "ml/topk": np.int64(cfg["topk"]), "ml/seed": np.int64(cfg["seed"]),
-           "ml/samples": samples.astype(np.int32), "ml/rng_state_before_fit": rng_state,
-           "ml/epoch_losses": epoch_losses, "ml/test_u": np.array(test_u, dtype=np.int64), "ml/cands": cands,
-           "ml/preds": preds.astype(np.float32)}
+    out = {"meta": np.array([cfg["user_num"], cfg["item_num"], cfg["factors"], cfg["num_layers"]], dtype=np.int64),
+           "hyper": np.array([cfg["lr"], cfg["reg_1"], cfg["reg_2"]], dtype=np.float64),
+           "optimizer": np.array(model.optimizer),
+           "batch_size": np.int64(cfg["batch_size"]), "epochs": np.int64(epochs),
+           "topk": np.int64(cfg["topk"]), "seed": np.int64(cfg["seed"]),
+           "samples": samples.astype(np.int32), "rng_state_before_fit": rng_state,
+           "epoch_losses": epoch_losses, "test_u": np.array(test_u, dtype=np.int64), "cands": cands,
+           "preds": preds.astype(np.float32)}
     for k in init:
-        out[f"ml/{k}0"] = init[k]
-        out[f"ml/{k}1"] = final[k]
-    print("ml-100k NeuMF: samples", samples.shape, "epoch losses", epoch_losses, "preds", preds.shape)
-    return out
+        out[f"{k}0"] = init[k]
+        out[f"{k}1"] = final[k]
+    print(f"ml-100k NeuMF ({model.optimizer}): samples", samples.shape, "epoch losses", epoch_losses, "preds",
+          preds.shape)
+    return {f"{prefix}/{k}": v for k, v in out.items()}
 
 
 def main():
@@ -182,7 +184,12 @@ def main():
         names.append(name)
     out["names"] = np.array(names)
     out.update(rank_case(rng))
-    out.update(ml100k_case())
+    out.update(ml100k_case())                                                  # neumf.yaml: Adam, lr 0.001
+    sgd = ml100k_case(epochs=1, prefix="mlsgd", optimizer="sgd", lr=0.01)        # smooth optimiser: top-N identity
+    for k in ("samples", "cands", "test_u"):                                     # same data as ml/*
+        assert np.array_equal(sgd[f"mlsgd/{k}"], out[f"ml/{k}"])
+        del sgd[f"mlsgd/{k}"]
+    out.update(sgd)
     np.savez_compressed(os.path.join(HERE, "kat_neumf.npz"), **out)
     print("kat_neumf.npz:", names)
 
