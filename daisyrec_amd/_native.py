@@ -32,6 +32,19 @@ ABI_VERSION = 2
 _p = C.c_void_p
 _i32, _i64, _u64, _f32, _sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
 
+NEUMF_MAX_LAYERS = 8
+NEUMF_FULL, NEUMF_GMF, NEUMF_MLP = 0, 1, 2
+NST_LOSS_DATA, NST_L1, NST_SQ, NST_LOSS, NST_NORM, NEUMF_STATS_LEN = 0, 1, 6, 11, 12, 24
+
+
+class NeumfParams(C.Structure):
+    """daisy_neumf_params: table of device pointers (include/daisyrec_amd.h)."""
+    _fields_ = [("uG", _p), ("iG", _p), ("uM", _p), ("iM", _p),
+                ("W", _p * NEUMF_MAX_LAYERS), ("b", _p * NEUMF_MAX_LAYERS), ("Wp", _p), ("bp", _p)]
+
+
+_pp = C.POINTER(NeumfParams)
+
 # name -> (restype, argtypes); every symbol include/daisyrec_amd.h declares
 SIGNATURES = {
     "daisy_last_error": (C.c_char_p, []),
@@ -72,6 +85,15 @@ SIGNATURES = {
     "daisy_fm_predict": (C.c_int, [_p, _p, _p, _p, _p, _i32, _p, _p, _i64, _p, _p]),
     "daisy_fm_rank_topk": (C.c_int, [_p, _p, _p, _p, _p, _i32, _p, _p, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),
     "daisy_fm_full_rank": (C.c_int, [_p, _p, _p, _p, _p, _i32, _i64, _i64, _i32, _p, _p, _sz, _p]),
+    "daisy_neumf_ctx_create": (C.c_int, [C.POINTER(_p), _i64, _i32, _i32, _i32, _i64, _i64]),
+    "daisy_neumf_ctx_destroy": (C.c_int, [_p]),
+    "daisy_neumf_ctx_bytes": (_sz, [_p]),
+    "daisy_neumf_scores": (C.c_int, [_p, _pp, _p, _p, _i64, _i64, _p, _p]),
+    "daisy_neumf_step_grads": (C.c_int, [_p, _pp, _pp, _p, _p, _p, _i64, _i32, _f32, _f32, _f32, _f32, _u64, _p, _p]),
+    "daisy_sgd_dense": (C.c_int, [_p, _p, _i64, _f32, _p]),
+    "daisy_topk_from_scores": (C.c_int, [_p, _p, _i64, _i64, _i32, _p, _p, _sz, _p]),
+    "daisy_full_topk_from_scores": (C.c_int, [_p, _i64, _i32, _p, _p, _sz, _p]),
+    "daisy_gemm_nt_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _p]),
     "daisy_csr_workspace_bytes": (_sz, [_i64]),
     "daisy_build_user_csr": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _sz, _p]),
     "daisy_sample_neg_per_user": (C.c_int, [_p, _p, _i64, _i64, _i32, _u64, _u64, _p, _p]),

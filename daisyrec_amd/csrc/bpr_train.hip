@@ -217,44 +217,6 @@ __global__ void k_feistel_perm(int64_t n, FeistelKey fk, int64_t *__restrict__ o
 }
 
 // ---------------------------------------------------------------------------
-// loss coefficient (daisy/utils/loss.py)
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
-
-__device__ __forceinline__ void pair_coef(int loss_type, float pos, float neg, float gamma,
-                                          float &term, float &cp, float &cn) {
-    if (loss_type == DAISY_LOSS_BPR) {  // loss.py:10-13
-        const float s = sigmoidf_(pos - neg);
-        const float t = gamma + s;
-        term = -logf(t);
-        cp = -(s * (1.f - s)) / t;
-        cn = -cp;
-    } else if (loss_type == DAISY_LOSS_HL) {  // loss.py:20-23 (clamp passes grad at equality)
-        const float m = 1.f - (pos - neg);
-        term = fmaxf(m, 0.f);
-        cp = (m >= 0.f) ? -1.f : 0.f;
-        cn = -cp;
-    } else if (loss_type == DAISY_LOSS_CL) {  // BCEWithLogitsLoss(sum)(pos, label); neg carries the label
-        const float y = neg;
-        term = fmaxf(pos, 0.f) - pos * y + log1pf(expf(-fabsf(pos)));
-        cp = sigmoidf_(pos) - y;
-        cn = 0.f;
-    } else if (loss_type == DAISY_LOSS_SL) {  // MSELoss(sum)(pos, label)
-        const float e = pos - neg;
-        term = e * e;
-        cp = 2.f * e;
-        cn = 0.f;
-    } else {  // TOP1, loss.py:30-33
-        const float s1 = sigmoidf_(neg - pos);
-        const float s2 = sigmoidf_(neg * neg);
-        term = s1 + s2;
-        const float d1 = s1 * (1.f - s1);
-        cp = -d1;
-        cn = d1 + 2.f * neg * s2 * (1.f - s2);
-    }
-}
-
-// ---------------------------------------------------------------------------
 // forward: scores, coefficients, the seven batch sums
 // ---------------------------------------------------------------------------
 // A lane group takes a run of LPR consecutive samples: lane x loads the ids of sample x (one

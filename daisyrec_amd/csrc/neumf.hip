@@ -1,0 +1,646 @@
+// NeuMF (daisy/model/NeuMFRecommender.py) on gfx950.
+//
+//   forward   k_nmf_gather      x0 = [uM[u] | iM[item]] (dropout of layer 1 applied), g = uG[u]*iG[item],
+//                               regulariser sums of the gathered rows (training only)
+//             k_gemm<EPI_BIAS_RELU>   x_l = ReLU(x_{l-1} W_l^T + b_l) (* dropout mask of layer l+1):
+//                               fp32 MFMA 32x32x2 tiles, LDS-staged, register-prefetched
+//             k_nmf_predict     pred = <Wp, [g | x_L]> + bp
+//   loss      k_nmf_loss        criterion epilogue shared with MF (pair_coef) -> d loss / d pred
+//             k_nmf_finalize    norms + NeuMF.calc_loss value
+//   backward  k_nmf_pred_bwd    dZ_L = dpred * Wp[mlp part] gated by x_L > 0;  gWp, gbp
+//             k_gemm<EPI_ATOMIC>      gW_l += dZ_l^T x_{l-1}   (reduction over the batch rows, split over blocks)
+//             k_colsum          gb_l += column sums of dZ_l
+//             k_gemm<EPI_GATE>  dZ_{l-1} = (dZ_l W_l) gated by x_{l-1} > 0 (layer 1: dropout mask of x0)
+//             k_nmf_scatter     embedding gradients (fp32 atomics into the dense gradient tables) +
+//                               the regulariser gradients exactly as NeuMFRecommender.py:149-167 lists them
+// Dropout: x_{l-1} is stored already masked and scaled, so "x > 0" carries mask and ReLU gate at once.
+#include "common.h"
+
+namespace daisy {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kBK = 16;        // k depth of an LDS tile
+constexpr int kGemmBM = 128;   // block tile rows (2 x 2 waves, each 64 rows)
+constexpr int kLdsPad = 4;
+
+enum { EPI_STORE = 0, EPI_BIAS_RELU = 1, EPI_GATE = 2, EPI_ATOMIC = 3 };
+
+// keep mask of element `idx` of dropout stream `stream` (one stream per MLP layer input)
+__host__ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint32_t stream, uint64_t idx,
+                                                   uint32_t thresh) {
+    uint32_t h = mix32((uint32_t)idx ^ (uint32_t)seed);
+    h = mix32(h + (uint32_t)(idx >> 32) * 0x9E3779B9u + (uint32_t)(seed >> 32) + stream * 0x85EBCA6Bu);
+    return h >= thresh;
+}
+
+struct GemmOp {
+    const float *A; int64_t sam, sak;     // A(m,k) = A[m*sam + k*sak]
+    const float *B; int64_t sbn, sbk;     // B(n,k) = B[n*sbn + k*sbk]
+    float *C; int64_t ldc;                // C(m,n) = C[m*ldc + n]
+    int64_t M; int N; int64_t K;
+    const float *bias;                    // EPI_BIAS_RELU
+    const float *gate; int64_t ldg;       // EPI_GATE: out = acc * (gate(m,n) > 0 ? gate_scale : 0)
+    float gate_scale;
+    uint32_t drop_thresh, drop_stream;    // dropout on output element (m,n), idx = m*N + n; thresh 0: off
+    float drop_scale;
+    uint64_t drop_seed;
+    int64_t k_chunk;                      // reduction range per blockIdx.z
+};
+
+// C = A * B^T-style contraction over k with arbitrary strides.  WN: 32-column MFMA blocks per wave
+// (block tile = 128 x 64*WN).  Operand tiles go global -> registers -> LDS (k-major, so the MFMA
+// fragment reads are conflict free) with the next tile's loads in flight during the MFMAs.
+template <int WN, int EPI>
+__global__ __launch_bounds__(kBlock) void k_gemm(GemmOp op) {
+    constexpr int BM = kGemmBM, BN = 64 * WN;
+    constexpr int EA = BM * kBK / kBlock, EB = BN * kBK / kBlock;     // elements per thread per tile
+    __shared__ float As[kBK][BM + kLdsPad];
+    __shared__ float Bs[kBK][BN + kLdsPad];
+    const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+    const int wm = wave / 2, wn = wave % 2;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int64_t k_lo = (int64_t)blockIdx.z * op.k_chunk;
+    const int64_t k_hi = (k_lo + op.k_chunk < op.K) ? (k_lo + op.k_chunk) : op.K;
+    const bool a_kfast = (op.sak == 1), b_kfast = (op.sbk == 1);
+
+    floatx16 acc[2][WN];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+
+    float ra[EA], rb[EB];
+    auto load_tile = [&](int64_t kt) {
+#pragma unroll
+        for (int q = 0; q < EA; ++q) {
+            const int e = tid + q * kBlock;
+            const int kk = a_kfast ? (e % kBK) : (e / BM);
+            const int mm = a_kfast ? (e / kBK) : (e % BM);
+            const int64_t m = m0 + mm, k = kt + kk;
+            ra[q] = (m < op.M && k < k_hi) ? op.A[m * op.sam + k * op.sak] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < EB; ++q) {
+            const int e = tid + q * kBlock;
+            const int kk = b_kfast ? (e % kBK) : (e / BN);
+            const int nn = b_kfast ? (e / kBK) : (e % BN);
+            const int64_t n = n0 + nn, k = kt + kk;
+            rb[q] = (n < op.N && k < k_hi) ? op.B[n * op.sbn + k * op.sbk] : 0.f;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int q = 0; q < EA; ++q) {
+            const int e = tid + q * kBlock;
+            const int kk = a_kfast ? (e % kBK) : (e / BM);
+            const int mm = a_kfast ? (e / kBK) : (e % BM);
+            As[kk][mm] = ra[q];
+        }
+#pragma unroll
+        for (int q = 0; q < EB; ++q) {
+            const int e = tid + q * kBlock;
+            const int kk = b_kfast ? (e % kBK) : (e / BN);
+            const int nn = b_kfast ? (e / kBK) : (e % BN);
+            Bs[kk][nn] = rb[q];
+        }
+    };
+
+    if (k_lo < k_hi) {
+        load_tile(k_lo);
+        store_tile();
+        __syncthreads();
+        for (int64_t kt = k_lo; kt < k_hi; kt += kBK) {
+            const bool more = kt + kBK < k_hi;
+            if (more) load_tile(kt + kBK);
+#pragma unroll
+            for (int kk = 0; kk < kBK; kk += 2) {
+                const int kr = kk + lane / 32, c = lane % 32;
+                float a[2], b[WN];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) a[mi] = As[kr][wm * 64 + mi * 32 + c];
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni) b[ni] = Bs[kr][wn * 32 * WN + ni * 32 + c];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            }
+            __syncthreads();
+            if (more) {
+                store_tile();
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue: lane holds column (lane % 32), rows (i/4)*8 + (lane/32)*4 + i%4 of each 32x32 block
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) {
+            const int n = n0 + wn * 32 * WN + ni * 32 + lane % 32;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t m = m0 + wm * 64 + mi * 32 + (i / 4) * 8 + (lane / 32) * 4 + (i % 4);
+                if (m >= op.M || n >= op.N) continue;
+                float v = acc[mi][ni][i];
+                if constexpr (EPI == EPI_BIAS_RELU) v = fmaxf(v + op.bias[n], 0.f);
+                if constexpr (EPI == EPI_GATE)
+                    if (op.gate) v = (op.gate[m * op.ldg + n] > 0.f) ? v * op.gate_scale : 0.f;
+                if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_GATE)
+                    if (op.drop_thresh)
+                        v = drop_keep(op.drop_seed, op.drop_stream, (uint64_t)m * (uint64_t)op.N + n, op.drop_thresh)
+                                ? v * op.drop_scale : 0.f;
+                if constexpr (EPI == EPI_ATOMIC) unsafeAtomicAdd(op.C + m * op.ldc + n, v);
+                else op.C[m * op.ldc + n] = v;
+            }
+        }
+}
+
+template <int EPI>
+static void launch_gemm(GemmOp op, hipStream_t s) {
+    const int64_t splits = (op.k_chunk < op.K) ? (op.K + op.k_chunk - 1) / op.k_chunk : 1;
+    if (op.k_chunk >= op.K) op.k_chunk = op.K;
+    if (op.N > 64) {
+        dim3 grid((unsigned)((op.M + kGemmBM - 1) / kGemmBM), (unsigned)((op.N + 127) / 128), (unsigned)splits);
+        hipLaunchKernelGGL((k_gemm<2, EPI>), grid, dim3(kBlock), 0, s, op);
+    } else {
+        dim3 grid((unsigned)((op.M + kGemmBM - 1) / kGemmBM), (unsigned)((op.N + 63) / 64), (unsigned)splits);
+        hipLaunchKernelGGL((k_gemm<1, EPI>), grid, dim3(kBlock), 0, s, op);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the three pair layouts of daisy_neumf_scores plus the training batch
+// ---------------------------------------------------------------------------------------------
+struct PairSrc {
+    const int32_t *u, *i, *j;     // training: row r < B -> (u[r], i[r]); r >= B -> (u[r-B], j[r-B])
+    int64_t B;
+    const int64_t *users, *items; // scoring
+    int64_t C;                    // > 0: user of pair e = users[e / C];  0 with items == NULL: (users[0], e)
+    int64_t base;                 // first pair of this chunk
+};
+__device__ __forceinline__ void pair_ids(const PairSrc &s, int64_t r, int64_t &user, int64_t &item) {
+    if (s.u) {
+        const int64_t b = (r < s.B) ? r : r - s.B;
+        user = s.u[b];
+        item = (r < s.B) ? s.i[b] : s.j[b];
+    } else {
+        const int64_t e = s.base + r;
+        if (!s.items) { user = s.users[0]; item = e; }
+        else if (s.C > 0) { user = s.users[e / s.C]; item = s.items[e]; }
+        else { user = s.users[e]; item = s.items[e]; }
+    }
+}
+
+struct L16 { static constexpr int LPR = 16; };
+
+// x0[r] = [uM[user] | iM[item]] (* dropout), g[r] = uG[user]*iG[item]; TRAIN: the ten regulariser sums.
+template <bool TRAIN>
+__global__ __launch_bounds__(kBlock) void k_nmf_gather(daisy_neumf_params p, PairSrc src, int64_t R, int d,
+                                                       int dm, int pointwise, float *__restrict__ X0,
+                                                       float *__restrict__ G, uint32_t thresh,
+                                                       float scale, uint64_t seed,
+                                                       double *__restrict__ stats) {
+    const int lane = threadIdx.x % 16, group = threadIdx.x / 16;
+    const int64_t gstride = (int64_t)gridDim.x * (kBlock / 16);
+    float s1[5] = {0, 0, 0, 0, 0}, s2[5] = {0, 0, 0, 0, 0};
+    for (int64_t r = (int64_t)blockIdx.x * (kBlock / 16) + group; r < R; r += gstride) {
+        int64_t user, item;
+        pair_ids(src, r, user, item);
+        const bool first = !TRAIN || r < src.B;            // rows r >= B repeat the users with the negatives
+        const float *um = p.uM + user * dm, *im = p.iM + item * dm;
+        float *x = X0 + r * (int64_t)(2 * dm);
+        for (int c = lane; c < dm; c += 16) {
+            float a = um[c], b = im[c];
+            if (TRAIN) {
+                if (first) { s1[1] += fabsf(a); s2[1] = fmaf(a, a, s2[1]); s1[3] += fabsf(b); s2[3] = fmaf(b, b, s2[3]); }
+                if (thresh) {
+                    a = drop_keep(seed, 1, (uint64_t)r * (2 * dm) + c, thresh) ? a * scale : 0.f;
+                    b = drop_keep(seed, 1, (uint64_t)r * (2 * dm) + dm + c, thresh) ? b * scale : 0.f;
+                }
+            }
+            x[c] = a;
+            x[dm + c] = b;
+        }
+        const float *ug = p.uG + user * d, *ig = p.iG + item * d;
+        for (int c = lane; c < d; c += 16) {
+            const float a = ug[c], b = ig[c];
+            G[r * (int64_t)d + c] = a * b;
+            if (TRAIN) {
+                if (first) { s1[0] += fabsf(a); s2[0] = fmaf(a, a, s2[0]); s1[2] += fabsf(b); s2[2] = fmaf(b, b, s2[2]); }
+                else if (!pointwise) { s1[4] += fabsf(b); s2[4] = fmaf(b, b, s2[4]); }
+            }
+        }
+    }
+    if constexpr (TRAIN) {
+        __shared__ double sm[kBlock / kWave][10];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const double a = wave_sum_f64((double)s1[k]), b = wave_sum_f64((double)s2[k]);
+            if (threadIdx.x % kWave == 0) { sm[threadIdx.x / kWave][k] = a; sm[threadIdx.x / kWave][5 + k] = b; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 10) {
+            double t = 0.0;
+            for (int w = 0; w < kBlock / kWave; ++w) t += sm[w][threadIdx.x];
+            atomicAdd(stats + DAISY_NST_L1 + threadIdx.x, t);        // L1[5] then SQ[5] are adjacent
+        }
+    }
+}
+
+// pred[r] = <Wp[:dg], g[r]> + <Wp[dg:], x_L[r]> + bp      (dg = 0 for model MLP, nl = 0 for model GMF)
+__global__ __launch_bounds__(kBlock) void k_nmf_predict(const float *__restrict__ G, int dg,
+                                                        const float *__restrict__ XL, int nl,
+                                                        const float *__restrict__ Wp,
+                                                        const float *__restrict__ bp, int64_t R,
+                                                        float *__restrict__ pred) {
+    const int lane = threadIdx.x % 16, group = threadIdx.x / 16;
+    const int64_t gstride = (int64_t)gridDim.x * (kBlock / 16);
+    for (int64_t r = (int64_t)blockIdx.x * (kBlock / 16) + group; r < R; r += gstride) {
+        float s = 0.f;
+        for (int c = lane; c < dg; c += 16) s = fmaf(Wp[c], G[r * (int64_t)dg + c], s);
+        for (int c = lane; c < nl; c += 16) s = fmaf(Wp[dg + c], XL[r * (int64_t)nl + c], s);
+        s = group_sum<L16>(s);
+        if (lane == 0) pred[r] = s + bp[0];
+    }
+}
+
+// criterion epilogue (AbstractRecommender.py:79-93, daisy/utils/loss.py): d loss / d pred for both rows of a sample
+__global__ __launch_bounds__(kBlock) void k_nmf_loss(const float *__restrict__ pred,
+                                                     const int32_t *__restrict__ j, int64_t B,
+                                                     int loss_type, float gamma, int pointwise,
+                                                     float *__restrict__ dpred,
+                                                     double *__restrict__ stats,
+                                                     float *__restrict__ gbp) {
+    // gbp = sum_b (cp_b + cn_b), paired per sample: under BPR / HL every pair is exactly 0, as it is in
+    // the reference's autograd (a rounding residue here would be blown up to +-lr by Adam)
+    double acc = 0.0;
+    float accb = 0.f;
+    for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x) {
+        float term, cp, cn;
+        pair_coef(loss_type, pred[b], pointwise ? (float)j[b] : pred[B + b], gamma, term, cp, cn);
+        dpred[b] = cp;
+        if (!pointwise) dpred[B + b] = cn;
+        acc += (double)term;
+        accb += cp + cn;
+    }
+    acc = wave_sum_f64(acc);
+    const double sb = wave_sum_f64((double)accb);
+    if (threadIdx.x % kWave == 0) {
+        atomicAdd(stats + DAISY_NST_LOSS_DATA, acc);
+        if (sb != 0.0) unsafeAtomicAdd(gbp, (float)sb);
+    }
+}
+
+// NeuMFRecommender.py:149-167 summed up: the negative item's GMF rows enter twice, its MLP rows never
+__global__ void k_nmf_finalize(double *__restrict__ stats, float reg_1, float reg_2, int pointwise) {
+    if (threadIdx.x || blockIdx.x) return;
+    double l1 = 0.0, fro = 0.0;
+    for (int k = 0; k < 5; ++k) {
+        const double n = sqrt(stats[DAISY_NST_SQ + k]);
+        stats[DAISY_NST_NORM + k] = n;
+        const double w = (k == 4) ? (pointwise ? 0.0 : 2.0) : 1.0;
+        l1 += w * stats[DAISY_NST_L1 + k];
+        fro += w * n;
+    }
+    stats[DAISY_NST_LOSS] = stats[DAISY_NST_LOSS_DATA] + (double)reg_1 * l1 + (double)reg_2 * fro;
+}
+
+// dZ_L[r] = dpred[r] * Wp[dg:] gated by x_L[r] > 0;  gWp += sum_r dpred[r]*[g[r] | x_L[r]];  gbp += sum dpred
+__global__ __launch_bounds__(kBlock) void k_nmf_pred_bwd(const float *__restrict__ dpred,
+                                                         const float *__restrict__ G, int dg,
+                                                         const float *__restrict__ XL, int nl,
+                                                         const float *__restrict__ Wp, int64_t R,
+                                                         float *__restrict__ DZ, float *__restrict__ gWp) {
+    __shared__ float col[512];                       // dg + nl <= 2 * kMaxD
+    for (int c = threadIdx.x; c < dg + nl; c += kBlock) col[c] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x % 16, group = threadIdx.x / 16;
+    const int64_t gstride = (int64_t)gridDim.x * (kBlock / 16);
+    for (int c0 = 0; c0 < dg + nl; c0 += 16 * 8) {   // 8 column registers per lane per sweep
+        float part[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int64_t r = (int64_t)blockIdx.x * (kBlock / 16) + group; r < R; r += gstride) {
+            const float dp = dpred[r];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int c = c0 + q * 16 + lane;
+                if (c < dg) part[q] = fmaf(dp, G[r * (int64_t)dg + c], part[q]);
+                else if (c < dg + nl) {
+                    const float x = XL[r * (int64_t)nl + (c - dg)];
+                    part[q] = fmaf(dp, x, part[q]);
+                    DZ[r * (int64_t)nl + (c - dg)] = (x > 0.f) ? dp * Wp[c] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int c = c0 + q * 16 + lane;
+            if (c < dg + nl) atomicAdd(&col[c], part[q]);
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < dg + nl; c += kBlock) unsafeAtomicAdd(gWp + c, col[c]);
+}
+
+// out[n] += sum_r X[r*ld + n]
+__global__ __launch_bounds__(kBlock) void k_colsum(const float *__restrict__ X, int64_t R, int N, int64_t ld,
+                                                   float *__restrict__ out) {
+    __shared__ float sm[4][64];
+    const int c = threadIdx.x % 64, rr = threadIdx.x / 64;
+    const int64_t rows_per_block = 1024;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = (r0 + rows_per_block < R) ? r0 + rows_per_block : R;
+    for (int n0 = 0; n0 < N; n0 += 64) {
+        float s = 0.f;
+        if (n0 + c < N)
+            for (int64_t r = r0 + rr; r < r1; r += 4) s += X[r * ld + n0 + c];
+        sm[rr][c] = s;
+        __syncthreads();
+        if (rr == 0 && n0 + c < N) unsafeAtomicAdd(out + n0 + c, sm[0][c] + sm[1][c] + sm[2][c] + sm[3][c]);
+        __syncthreads();
+    }
+}
+
+// embedding gradients of one row r (dense tables, fp32 atomics) + the regulariser gradients
+__global__ __launch_bounds__(kBlock) void k_nmf_scatter(daisy_neumf_params p, daisy_neumf_params g, PairSrc src,
+                                                        int64_t R, int d, int dm, int model, int pointwise,
+                                                        const float *__restrict__ dpred,
+                                                        const float *__restrict__ DX0,
+                                                        const double *__restrict__ stats, float reg_1,
+                                                        float reg_2) {
+    const int lane = threadIdx.x % 16, group = threadIdx.x / 16;
+    const int64_t gstride = (int64_t)gridDim.x * (kBlock / 16);
+    float inv[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const double n = stats[DAISY_NST_NORM + k];
+        inv[k] = (n > 0.0) ? (float)((double)reg_2 / n) : 0.f;
+    }
+    const bool reg = (reg_1 != 0.f) || (reg_2 != 0.f);
+    for (int64_t r = (int64_t)blockIdx.x * (kBlock / 16) + group; r < R; r += gstride) {
+        int64_t user, item;
+        pair_ids(src, r, user, item);
+        const bool first = r < src.B;
+        const float dp = dpred[r];
+        // MLP tables
+        for (int c = lane; c < dm; c += 16) {
+            float gu = 0.f, gi = 0.f;
+            if (model != DAISY_NEUMF_GMF) {
+                gu = DX0[r * (int64_t)(2 * dm) + c];
+                gi = DX0[r * (int64_t)(2 * dm) + dm + c];
+            }
+            if (reg && first) {
+                const float a = p.uM[user * dm + c], b = p.iM[item * dm + c];
+                gu += fmaf(inv[1], a, reg_1 * sgn(a));
+                gi += fmaf(inv[3], b, reg_1 * sgn(b));
+            }
+            if (gu != 0.f) unsafeAtomicAdd(g.uM + user * dm + c, gu);
+            if (gi != 0.f) unsafeAtomicAdd(g.iM + item * dm + c, gi);
+        }
+        // GMF tables
+        for (int c = lane; c < d; c += 16) {
+            const float a = p.uG[user * d + c], b = p.iG[item * d + c];
+            float gu = 0.f, gi = 0.f;
+            if (model != DAISY_NEUMF_MLP) {
+                const float w = dp * p.Wp[c];
+                gu = w * b;
+                gi = w * a;
+            }
+            if (reg) {
+                if (first) {
+                    gu += fmaf(inv[0], a, reg_1 * sgn(a));
+                    gi += fmaf(inv[2], b, reg_1 * sgn(b));
+                } else if (!pointwise) {
+                    gi += 2.f * fmaf(inv[4], b, reg_1 * sgn(b));
+                }
+            }
+            if (gu != 0.f) unsafeAtomicAdd(g.uG + user * d + c, gu);
+            if (gi != 0.f) unsafeAtomicAdd(g.iG + item * d + c, gi);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_sgd_dense(float *__restrict__ W, float *__restrict__ g, int64_t n,
+                                                      float lr) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        W[e] = fmaf(-lr, g[e], W[e]);
+        g[e] = 0.f;
+    }
+}
+
+}  // namespace daisy
+
+using namespace daisy;
+
+struct daisy_neumf_ctx {
+    int64_t max_rows, U, I;
+    int d, L, dm, model;
+    int width[DAISY_NEUMF_MAX_LAYERS + 1];   // width[0] = 2*dm, width[l] = width[l-1]/2
+    void *arena;
+    size_t arena_bytes;
+    float *X[DAISY_NEUMF_MAX_LAYERS + 1];    // X[0] = (dropped) concat input, X[l] = layer outputs
+    float *G, *pred, *dpred, *DZ[2];
+};
+
+static inline hipStream_t NS(daisy_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static uint32_t drop_threshold(float p) {
+    if (!(p > 0.f)) return 0u;
+    const double t = (double)p * 4294967296.0;
+    return (t >= 4294967295.0) ? 4294967295u : (uint32_t)t;
+}
+
+// x_L and pred for R pairs starting at src.base (eval: thresh == 0)
+static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p, const PairSrc &src, int64_t R,
+                              bool train, int pointwise, uint32_t thresh, float scale, uint64_t seed,
+                              double *stats, hipStream_t s) {
+    const int d = ctx->d, dm = ctx->dm, L = ctx->L;
+    const int grid = grid_for(R, kBlock / 16 * 2);
+    if (train)
+        hipLaunchKernelGGL((k_nmf_gather<true>), dim3(grid), dim3(kBlock), 0, s, *p, src, R, d, dm, pointwise,
+                           ctx->X[0], ctx->G, thresh, scale, seed, stats);
+    else
+        hipLaunchKernelGGL((k_nmf_gather<false>), dim3(grid), dim3(kBlock), 0, s, *p, src, R, d, dm, 0, ctx->X[0],
+                           ctx->G, 0u, 1.f, (uint64_t)0, nullptr);
+    DAISY_LAUNCH_CHECK();
+    if (ctx->model != DAISY_NEUMF_GMF) {
+        for (int l = 1; l <= L; ++l) {
+            GemmOp op{};
+            op.A = ctx->X[l - 1]; op.sam = ctx->width[l - 1]; op.sak = 1;
+            op.B = p->W[l - 1]; op.sbn = ctx->width[l - 1]; op.sbk = 1;
+            op.C = ctx->X[l]; op.ldc = ctx->width[l];
+            op.M = R; op.N = ctx->width[l]; op.K = ctx->width[l - 1];
+            op.bias = p->b[l - 1];
+            op.k_chunk = op.K;
+            if (l < L && thresh) {       // the Dropout in front of Linear l+1 acts on this output
+                op.drop_thresh = thresh; op.drop_scale = scale; op.drop_seed = seed; op.drop_stream = (uint32_t)(l + 1);
+            }
+            launch_gemm<EPI_BIAS_RELU>(op, s);
+            DAISY_LAUNCH_CHECK();
+        }
+    }
+    const int dg = (ctx->model == DAISY_NEUMF_MLP) ? 0 : d;
+    const int nl = (ctx->model == DAISY_NEUMF_GMF) ? 0 : ctx->width[L];
+    hipLaunchKernelGGL(k_nmf_predict, dim3(grid), dim3(kBlock), 0, s, ctx->G, dg, ctx->X[L], nl, p->Wp, p->bp, R,
+                       ctx->pred);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+extern "C" {
+
+int daisy_neumf_ctx_create(daisy_neumf_ctx **out, int64_t max_rows, int32_t factors, int32_t num_layers,
+                           int32_t model, int64_t user_num, int64_t item_num) {
+    DAISY_CHECK_ARG(out != nullptr, "neumf_ctx_create: out is NULL");
+    *out = nullptr;
+    DAISY_CHECK_ARG(max_rows > 0 && user_num > 0 && item_num > 0, "neumf_ctx_create: bad sizes");
+    DAISY_CHECK_ARG(factors > 0 && factors % 4 == 0 && factors <= 256,
+                    "neumf_ctx_create: factors=%d must be a multiple of 4 in 4..256", factors);
+    DAISY_CHECK_ARG(num_layers >= 1 && num_layers <= DAISY_NEUMF_MAX_LAYERS, "neumf_ctx_create: num_layers=%d",
+                    num_layers);
+    DAISY_CHECK_ARG(model >= DAISY_NEUMF_FULL && model <= DAISY_NEUMF_MLP, "neumf_ctx_create: model=%d", model);
+    daisy_neumf_ctx *c = new daisy_neumf_ctx();
+    c->max_rows = max_rows; c->U = user_num; c->I = item_num;
+    c->d = factors; c->L = num_layers; c->model = model;
+    c->dm = factors << (num_layers - 1);
+    c->width[0] = 2 * c->dm;
+    for (int l = 1; l <= num_layers; ++l) c->width[l] = c->width[l - 1] / 2;
+    size_t off = 0, ox[DAISY_NEUMF_MAX_LAYERS + 1];
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+    for (int l = 0; l <= num_layers; ++l) ox[l] = take((size_t)max_rows * c->width[l] * 4);
+    const size_t og = take((size_t)max_rows * factors * 4), op = take((size_t)max_rows * 4),
+                 od = take((size_t)max_rows * 4);
+    const size_t oz0 = take((size_t)max_rows * c->width[0] * 4), oz1 = take((size_t)max_rows * c->width[0] * 4);
+    c->arena_bytes = off;
+    hipError_t e = hipMalloc(&c->arena, off);
+    if (e != hipSuccess) {
+        set_error("neumf_ctx_create: hipMalloc(%zu) failed: %s", off, hipGetErrorString(e));
+        delete c;
+        return DAISY_ERR_HIP;
+    }
+    char *base = (char *)c->arena;
+    for (int l = 0; l <= num_layers; ++l) c->X[l] = (float *)(base + ox[l]);
+    c->G = (float *)(base + og); c->pred = (float *)(base + op); c->dpred = (float *)(base + od);
+    c->DZ[0] = (float *)(base + oz0); c->DZ[1] = (float *)(base + oz1);
+    *out = c;
+    return DAISY_OK;
+}
+
+int daisy_neumf_ctx_destroy(daisy_neumf_ctx *ctx) {
+    if (!ctx) return DAISY_OK;
+    if (ctx->arena) (void)hipFree(ctx->arena);
+    delete ctx;
+    return DAISY_OK;
+}
+
+size_t daisy_neumf_ctx_bytes(const daisy_neumf_ctx *ctx) { return ctx ? ctx->arena_bytes : 0; }
+
+int daisy_neumf_scores(daisy_neumf_ctx *ctx, const daisy_neumf_params *params, const int64_t *users,
+                       const int64_t *items, int64_t n, int64_t C, float *out, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(ctx && params && users && out && n > 0 && C >= 0, "neumf_scores: bad argument");
+    DAISY_CHECK_ARG(items || C == 0, "neumf_scores: items is NULL but C != 0");
+    hipStream_t s = NS(stream);
+    for (int64_t base = 0; base < n; base += ctx->max_rows) {
+        const int64_t R = (n - base < ctx->max_rows) ? (n - base) : ctx->max_rows;
+        PairSrc src{};
+        src.users = users; src.items = items; src.C = C; src.base = base;
+        int rc = neumf_forward_rows(ctx, params, src, R, false, 0, 0u, 1.f, 0, nullptr, s);
+        if (rc) return rc;
+        DAISY_HIP(hipMemcpyAsync(out + base, ctx->pred, (size_t)R * 4, hipMemcpyDeviceToDevice, s));
+    }
+    return DAISY_OK;
+}
+
+int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *params,
+                           const daisy_neumf_params *grads, const int32_t *u, const int32_t *i,
+                           const int32_t *j, int64_t B, int32_t loss_type, float gamma, float reg_1,
+                           float reg_2, float dropout_p, uint64_t seed, double *stats,
+                           daisy_stream_t stream) {
+    DAISY_CHECK_ARG(ctx && params && grads && u && i && j && stats && B > 0, "neumf_step_grads: bad argument");
+    DAISY_CHECK_ARG(loss_type >= DAISY_LOSS_BPR && loss_type <= DAISY_LOSS_SL, "Invalid loss type: %d", loss_type);
+    DAISY_CHECK_ARG(dropout_p >= 0.f && dropout_p < 1.f, "neumf_step_grads: dropout_p=%g not in [0,1)", dropout_p);
+    const int pointwise = loss_type >= DAISY_LOSS_CL;
+    const int64_t R = pointwise ? B : 2 * B;
+    DAISY_CHECK_ARG(R <= ctx->max_rows, "neumf_step_grads: %lld rows exceed the context's %lld",
+                    (long long)R, (long long)ctx->max_rows);
+    hipStream_t s = NS(stream);
+    const daisy_neumf_params &p = *params, &g = *grads;
+    const int d = ctx->d, dm = ctx->dm, L = ctx->L, model = ctx->model;
+    const uint32_t thresh = (model == DAISY_NEUMF_GMF) ? 0u : drop_threshold(dropout_p);
+    const float scale = thresh ? 1.f / (1.f - dropout_p) : 1.f;
+    DAISY_HIP(hipMemsetAsync(stats, 0, DAISY_NEUMF_STATS_LEN * sizeof(double), s));
+    PairSrc src{};
+    src.u = u; src.i = i; src.j = pointwise ? i : j; src.B = B;
+    int rc = neumf_forward_rows(ctx, params, src, R, true, pointwise, thresh, scale, seed, stats, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_nmf_loss, dim3(grid_for(B, kBlock * 2)), dim3(kBlock), 0, s, ctx->pred, j, B,
+                       (int)loss_type, gamma, pointwise, ctx->dpred, stats, g.bp);
+    hipLaunchKernelGGL(k_nmf_finalize, dim3(1), dim3(64), 0, s, stats, reg_1, reg_2, pointwise);
+    DAISY_LAUNCH_CHECK();
+    // ---- backward
+    const int dg = (model == DAISY_NEUMF_MLP) ? 0 : d;
+    const int nl = (model == DAISY_NEUMF_GMF) ? 0 : ctx->width[L];
+    float *dz = ctx->DZ[0], *dz_next = ctx->DZ[1];
+    hipLaunchKernelGGL(k_nmf_pred_bwd, dim3(grid_for(R, kBlock / 16 * 16, 1024)), dim3(kBlock), 0, s, ctx->dpred,
+                       ctx->G, dg, ctx->X[L], nl, p.Wp, R, dz, g.Wp);
+    DAISY_LAUNCH_CHECK();
+    if (model != DAISY_NEUMF_GMF) {
+        for (int l = L; l >= 1; --l) {
+            const int n_out = ctx->width[l], n_in = ctx->width[l - 1];
+            GemmOp w{};                                   // gW_l[n_out, n_in] += dZ^T x_{l-1}
+            w.A = dz; w.sam = 1; w.sak = n_out;
+            w.B = ctx->X[l - 1]; w.sbn = 1; w.sbk = n_in;
+            w.C = g.W[l - 1]; w.ldc = n_in;
+            w.M = n_out; w.N = n_in; w.K = R;
+            w.k_chunk = 2048;
+            launch_gemm<EPI_ATOMIC>(w, s);
+            hipLaunchKernelGGL(k_colsum, dim3((unsigned)((R + 1023) / 1024)), dim3(kBlock), 0, s, dz, R, n_out,
+                               (int64_t)n_out, g.b[l - 1]);
+            GemmOp x{};                                   // dZ_{l-1}[R, n_in] = (dZ W_l) gated
+            x.A = dz; x.sam = n_out; x.sak = 1;
+            x.B = p.W[l - 1]; x.sbn = 1; x.sbk = n_in;
+            x.C = dz_next; x.ldc = n_in;
+            x.M = R; x.N = n_in; x.K = n_out;
+            x.k_chunk = x.K;
+            if (l > 1) {                                  // ReLU (and dropout) gate of x_{l-1}
+                x.gate = ctx->X[l - 1]; x.ldg = n_in; x.gate_scale = scale;
+            } else if (thresh) {                          // dropout mask of the concat input
+                x.drop_thresh = thresh; x.drop_scale = scale; x.drop_seed = seed; x.drop_stream = 1u;
+            }
+            launch_gemm<EPI_GATE>(x, s);
+            DAISY_LAUNCH_CHECK();
+            float *t = dz; dz = dz_next; dz_next = t;
+        }
+    }
+    hipLaunchKernelGGL(k_nmf_scatter, dim3(grid_for(R, kBlock / 16 * 2)), dim3(kBlock), 0, s, p, g, src, R, d, dm,
+                       model, pointwise, ctx->dpred, dz, stats, reg_1, reg_2);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int daisy_sgd_dense(float *W, float *g, int64_t n, float lr, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(W && g && n > 0, "sgd_dense: bad argument");
+    hipLaunchKernelGGL(k_sgd_dense, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, NS(stream), W, g, n, lr);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int daisy_gemm_nt_f32(const float *A, const float *B, float *C, int64_t M, int32_t N, int32_t K,
+                      daisy_stream_t stream) {
+    DAISY_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "gemm_nt_f32: bad argument");
+    GemmOp op{};
+    op.A = A; op.sam = K; op.sak = 1;
+    op.B = B; op.sbn = K; op.sbk = 1;
+    op.C = C; op.ldc = N; op.M = M; op.N = N; op.K = K; op.k_chunk = K;
+    launch_gemm<EPI_STORE>(op, NS(stream));
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+}  // extern "C"

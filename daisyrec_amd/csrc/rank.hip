@@ -90,6 +90,11 @@ __global__ void k_take_topk(const int64_t *__restrict__ sorted_ids, int64_t B, i
 
 static inline hipStream_t S(daisy_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+__global__ void k_iota_i64(int64_t n, int64_t *__restrict__ out) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        out[e] = e;
+}
+
 }  // namespace daisy
 
 using namespace daisy;
@@ -207,6 +212,50 @@ int daisy_fm_full_rank(const float *P, const float *Q, const float *u_bias, cons
     DAISY_LAUNCH_CHECK();
     rc = sort_pairs_desc_f32_i64(temp, sort_pairs_desc_f32_i64_temp_bytes(n), scores, sorted_scores,
                                  ids, sorted_ids, item_num, s);
+    if (rc) return rc;
+    DAISY_HIP(hipMemcpyAsync(out_ids, sorted_ids, (size_t)topk * 8, hipMemcpyDeviceToDevice, s));
+    return DAISY_OK;
+}
+
+int daisy_topk_from_scores(const float *scores, const int64_t *cands, int64_t B, int64_t C, int32_t topk,
+                           int64_t *out_ids, void *workspace, size_t workspace_bytes,
+                           daisy_stream_t stream) {
+    DAISY_CHECK_ARG(scores && cands && out_ids && workspace, "topk_from_scores: NULL argument");
+    DAISY_CHECK_ARG(B > 0 && C > 0 && topk > 0 && topk <= C && B * C < ((int64_t)1 << 31),
+                    "topk_from_scores: bad sizes B=%lld C=%lld topk=%d", (long long)B, (long long)C, topk);
+    DAISY_CHECK_ARG(workspace_bytes >= daisy_mf_rank_workspace_bytes(B, C), "topk_from_scores: workspace too small");
+    hipStream_t s = S(stream);
+    const size_t n = (size_t)B * (size_t)C;
+    char *w = (char *)workspace;
+    w += align_up(n * 4);                                 // (the slot the MF path keeps its scores in)
+    float *sorted_scores = (float *)w;      w += align_up(n * 4);
+    int64_t *sorted_ids = (int64_t *)w;     w += align_up(n * 8);
+    int rc = seg_sort_desc_f32_i64(w, seg_sort_desc_f32_i64_temp_bytes(n, B), scores, sorted_scores, cands,
+                                   sorted_ids, B, C, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_take_topk, dim3(grid_for(B * topk, kBlock)), dim3(kBlock), 0, s, sorted_ids, B, C,
+                       (int)topk, out_ids);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int daisy_full_topk_from_scores(const float *scores, int64_t item_num, int32_t topk, int64_t *out_ids,
+                                void *workspace, size_t workspace_bytes, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(scores && out_ids && workspace && item_num > 0 && topk > 0 && topk <= item_num,
+                    "full_topk_from_scores: bad argument");
+    DAISY_CHECK_ARG(workspace_bytes >= daisy_mf_full_rank_workspace_bytes(item_num),
+                    "full_topk_from_scores: workspace too small");
+    hipStream_t s = S(stream);
+    const size_t n = (size_t)item_num;
+    char *w = (char *)workspace;
+    w += align_up(n * 4);
+    float *sorted_scores = (float *)w;   w += align_up(n * 4);
+    int64_t *ids = (int64_t *)w;         w += align_up(n * 8);
+    int64_t *sorted_ids = (int64_t *)w;  w += align_up(n * 8);
+    hipLaunchKernelGGL(k_iota_i64, dim3(grid_for(item_num, kBlock)), dim3(kBlock), 0, s, item_num, ids);
+    DAISY_LAUNCH_CHECK();
+    int rc = sort_pairs_desc_f32_i64(w, sort_pairs_desc_f32_i64_temp_bytes(n), scores, sorted_scores, ids,
+                                     sorted_ids, item_num, s);
     if (rc) return rc;
     DAISY_HIP(hipMemcpyAsync(out_ids, sorted_ids, (size_t)topk * 8, hipMemcpyDeviceToDevice, s));
     return DAISY_OK;

@@ -379,3 +379,115 @@ def membench(what, table, idx, out):
     check(lib.daisy_membench(int(what), _ptr(table, torch.float32, "table"), table.shape[0],
                              table.shape[1], _ptr(idx, torch.int32, "idx"), idx.numel(),
                              _ptr(out, torch.float32, "out"), _stream()))
+
+
+# ------------------------------------------------------------------------------------------------
+# NeuMF (NeuMFRecommender.py) - see include/daisyrec_amd.h
+# ------------------------------------------------------------------------------------------------
+NEUMF_MODELS = {"NeuMF": N.NEUMF_FULL, "NeuMF-end": N.NEUMF_FULL, "GMF": N.NEUMF_GMF, "MLP": N.NEUMF_MLP}
+
+
+def neumf_param_names(num_layers):
+    names = ["uG", "iG", "uM", "iM"]
+    for l in range(1, num_layers + 1):
+        names += [f"W{l}", f"b{l}"]
+    return names + ["Wp", "bp"]
+
+
+def _neumf_table(tensors, num_layers):
+    """dict name -> float32 device tensor  =>  daisy_neumf_params"""
+    t = N.NeumfParams()
+    f = torch.float32
+    for k in ("uG", "iG", "uM", "iM", "Wp", "bp"):
+        setattr(t, k, _ptr(tensors[k], f, k))
+    for l in range(1, num_layers + 1):
+        t.W[l - 1] = _ptr(tensors[f"W{l}"], f, f"W{l}")
+        t.b[l - 1] = _ptr(tensors[f"b{l}"], f, f"b{l}")
+    return t
+
+
+class NeumfContext:
+    """Activation workspace + entry points of the NeuMF path (daisy_neumf_*)."""
+
+    def __init__(self, max_rows, factors, num_layers, user_num, item_num, model="NeuMF", device=None):
+        if model not in NEUMF_MODELS:
+            raise NotImplementedError(f"NeuMF model_name '{model}' (native: {sorted(NEUMF_MODELS)})")
+        self.device = torch.device(device if device is not None else "cuda")
+        self.L, self.d = int(num_layers), int(factors)
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib.daisy_neumf_ctx_create(C.byref(self._h), int(max_rows), int(factors), int(num_layers),
+                                             NEUMF_MODELS[model], int(user_num), int(item_num)))
+        self.max_rows = int(max_rows)
+        self.stats = torch.zeros(N.NEUMF_STATS_LEN, dtype=torch.float64, device=self.device)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib.daisy_neumf_ctx_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def nbytes(self):
+        return int(lib.daisy_neumf_ctx_bytes(self._h))
+
+    def scores(self, params, users, items=None, C_=0, n=None):
+        """NeuMF.forward in eval mode: see daisy_neumf_scores for the three pair layouts."""
+        users = users.to(torch.int64).contiguous()
+        if items is not None:
+            items = items.to(torch.int64).contiguous()
+            n = items.numel()
+        out = torch.empty(int(n), dtype=torch.float32, device=self.device)
+        tab = _neumf_table(params, self.L)
+        check(lib.daisy_neumf_scores(self._h, C.byref(tab), _ptr(users, torch.int64, "users"),
+                                     _ptr(items, torch.int64, "items"), int(n), int(C_),
+                                     _ptr(out, torch.float32, "out"), _stream()))
+        return out
+
+    def step_grads(self, params, grads, u, i, j, loss_type=N.LOSS_BPR, reg_1=0.0, reg_2=0.0, dropout=0.0,
+                   seed=0, gamma=1e-10):
+        """NeuMF.calc_loss + backward for one batch: accumulates into `grads`, loss in stats[NST_LOSS]."""
+        pt, gt = _neumf_table(params, self.L), _neumf_table(grads, self.L)
+        check(lib.daisy_neumf_step_grads(self._h, C.byref(pt), C.byref(gt), _ptr(u, torch.int32, "u"),
+                                         _ptr(i, torch.int32, "i"), _ptr(j, torch.int32, "j"), u.numel(),
+                                         int(loss_type), float(gamma), float(reg_1), float(reg_2), float(dropout),
+                                         int(seed), _ptr(self.stats, torch.float64, "stats"), _stream()))
+
+
+def sgd_dense(W, g, lr):
+    check(lib.daisy_sgd_dense(_ptr(W, torch.float32, "W"), _ptr(g, torch.float32, "g"), W.numel(), float(lr),
+                              _stream()))
+
+
+def topk_from_scores(scores, cands, topk):
+    """argsort(descending, stable) + gather + [:topk] of every rank() (e.g. NeuMFRecommender.py:203-206)."""
+    cands = cands.to(torch.int64).contiguous()
+    B, Cn = cands.shape
+    out = torch.empty(B, topk, dtype=torch.int64, device=scores.device)
+    ws = _ws(lib.daisy_mf_rank_workspace_bytes(B, Cn), scores.device)
+    check(lib.daisy_topk_from_scores(_ptr(scores.contiguous(), torch.float32, "scores"),
+                                     _ptr(cands, torch.int64, "cands"), B, Cn, int(topk),
+                                     _ptr(out, torch.int64, "out"), _ptr(ws, torch.uint8, "ws"), ws.numel(),
+                                     _stream()))
+    return out
+
+
+def full_topk_from_scores(scores, topk):
+    I = scores.numel()
+    out = torch.empty(topk, dtype=torch.int64, device=scores.device)
+    ws = _ws(lib.daisy_mf_full_rank_workspace_bytes(I), scores.device)
+    check(lib.daisy_full_topk_from_scores(_ptr(scores.contiguous(), torch.float32, "scores"), I, int(topk),
+                                          _ptr(out, torch.int64, "out"), _ptr(ws, torch.uint8, "ws"), ws.numel(),
+                                          _stream()))
+    return out
+
+
+def gemm_nt(A, B):
+    """C = A @ B.T on the fp32 MFMA tile kernel of the NeuMF tower (test / bench hook)."""
+    M, K = A.shape
+    Nn = B.shape[0]
+    out = torch.empty(M, Nn, dtype=torch.float32, device=A.device)
+    check(lib.daisy_gemm_nt_f32(_ptr(A, torch.float32, "A"), _ptr(B, torch.float32, "B"),
+                                _ptr(out, torch.float32, "C"), M, Nn, K, _stream()))
+    return out

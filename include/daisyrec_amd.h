@@ -308,6 +308,73 @@ size_t daisy_randperm_workspace_bytes(int64_t n);
 int daisy_randperm(int64_t n, uint64_t seed, uint64_t epoch, int64_t *perm, void *workspace,
                    size_t workspace_bytes, daisy_stream_t stream);
 
+/* -------------------------------------------------------------------------
+ * NeuMF (daisy/model/NeuMFRecommender.py:15-233)
+ *   GMF branch  g = uG[u] * iG[item]                                  (:119-122)
+ *   MLP branch  x0 = [uM[u] | iM[item]];  x_l = ReLU(Linear_l(Dropout(x_{l-1}))), l = 1..L   (:60-66,123-127)
+ *   pred = predict_layer(concat(g, x_L))            (model GMF / MLP: one branch only)  (:129-137)
+ * The MLP tower runs on the matrix cores (fp32 MFMA tiles, bias+ReLU+dropout fused into the
+ * epilogue; backward data/weight GEMMs with the ReLU gate fused); gathers, the loss epilogue
+ * (shared with MF: daisy_loss ids) and the embedding-gradient scatter are HBM-bound kernels.
+ * Parameters stay caller-owned (the nn.Module's tensors), passed as a table of device pointers.
+ * ---------------------------------------------------------------------- */
+#define DAISY_NEUMF_MAX_LAYERS 8
+typedef enum { DAISY_NEUMF_FULL = 0, DAISY_NEUMF_GMF = 1, DAISY_NEUMF_MLP = 2 } daisy_neumf_model;
+typedef struct {
+    float *uG, *iG;                       /* embed_user_GMF [U,d], embed_item_GMF [I,d]            */
+    float *uM, *iM;                       /* embed_user_MLP [U,dm], embed_item_MLP [I,dm], dm = d*2^(L-1) */
+    float *W[DAISY_NEUMF_MAX_LAYERS];     /* Linear l weight [n_l/2, n_l] row-major, n_1 = 2*dm (:61-65) */
+    float *b[DAISY_NEUMF_MAX_LAYERS];     /* Linear l bias   [n_l/2]                                */
+    float *Wp, *bp;                       /* predict_layer weight [1, d or 2d], bias [1]   (:68-73) */
+} daisy_neumf_params;
+/* stats vector of a training step (device, double[DAISY_NEUMF_STATS_LEN]) */
+enum {
+    DAISY_NST_LOSS_DATA = 0,                         /* sum of the criterion terms                  */
+    DAISY_NST_L1 = 1,  /* +0 uG[u], +1 uM[u], +2 iG[i], +3 iM[i], +4 iG[j]: sum |x| over the batch */
+    DAISY_NST_SQ = 6,  /* same five, sum x^2                                                        */
+    DAISY_NST_LOSS = 11,                             /* NeuMF.calc_loss value (:139-169)             */
+    DAISY_NST_NORM = 12,                             /* same five, Frobenius norms                   */
+    DAISY_NEUMF_STATS_LEN = 24
+};
+typedef struct daisy_neumf_ctx daisy_neumf_ctx;
+/* activation workspace for up to max_rows (user,item) pairs per call (a training batch of B
+ * pairwise samples forwards 2B rows).  factors % 4 == 0, 1 <= num_layers <= DAISY_NEUMF_MAX_LAYERS. */
+int daisy_neumf_ctx_create(daisy_neumf_ctx **out, int64_t max_rows, int32_t factors, int32_t num_layers,
+                           int32_t model, int64_t user_num, int64_t item_num);
+int daisy_neumf_ctx_destroy(daisy_neumf_ctx *ctx);
+size_t daisy_neumf_ctx_bytes(const daisy_neumf_ctx *ctx);
+/* NeuMF.forward in eval mode (:118-137) on n pairs -> out f32[n]; processed in chunks of max_rows.
+ * Pairs are given in one of three layouts (the three callers of the reference):
+ *   users/items i64[n]                                   predict (:171-176), forward
+ *   users i64[B], items = cands i64[B*C], C > 0          rank  (:178-209): user of pair e = users[e / C]
+ *   users i64[1], items == NULL, C == 0                  full_rank (:211-233): item of pair e = e   */
+int daisy_neumf_scores(daisy_neumf_ctx *ctx, const daisy_neumf_params *params, const int64_t *users,
+                       const int64_t *items, int64_t n, int64_t C, float *out, daisy_stream_t stream);
+/* One training batch of NeuMF.calc_loss + backward (:139-169): rows (u, i, j) int32[B] (point-wise
+ * losses: j = label).  ACCUMULATES the dense gradients into `grads` (same table layout; zero before
+ * the first step, the optimiser kernels below clear what they consume) and writes stats.
+ * dropout_p in [0,1): keep masks come from a counter hash of (seed, layer, row, column) - a fresh
+ * `seed` per step gives fresh masks; p == 0 is the deterministic path the golden vectors pin. */
+int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *params,
+                           const daisy_neumf_params *grads, const int32_t *u, const int32_t *i,
+                           const int32_t *j, int64_t B, int32_t loss_type, float gamma, float reg_1,
+                           float reg_2, float dropout_p, uint64_t seed, double *stats,
+                           daisy_stream_t stream);
+/* optim.SGD step on one dense tensor: W -= lr*g; g = 0   (AbstractRecommender.py:56) */
+int daisy_sgd_dense(float *W, float *g, int64_t n, float lr, daisy_stream_t stream);
+/* the argsort / top-k tail of every rank(): scores f32[B,C] (+ candidate ids i64[B,C]) -> ids of the
+ * topk best per row, stable descending like torch.argsort(descending=True); workspace as
+ * daisy_mf_rank_workspace_bytes(B, C).  full-rank variant: scores f32[I] -> item ids i64[topk],
+ * workspace as daisy_mf_full_rank_workspace_bytes(I). */
+int daisy_topk_from_scores(const float *scores, const int64_t *cands, int64_t B, int64_t C, int32_t topk,
+                           int64_t *out_ids, void *workspace, size_t workspace_bytes,
+                           daisy_stream_t stream);
+int daisy_full_topk_from_scores(const float *scores, int64_t item_num, int32_t topk, int64_t *out_ids,
+                                void *workspace, size_t workspace_bytes, daisy_stream_t stream);
+/* C[M,N] = A[M,K] * B[N,K]^T on the fp32 MFMA tile kernel the MLP tower uses (test / bench hook) */
+int daisy_gemm_nt_f32(const float *A, const float *B, float *C, int64_t M, int32_t N, int32_t K,
+                      daisy_stream_t stream);
+
 /* micro-benchmarks of the memory system used to place the kernels on the
  * roofline (tools/membench.py); not part of the reference surface. */
 int daisy_membench(int32_t what, float *table, int64_t rows, int32_t d, const int32_t *idx,

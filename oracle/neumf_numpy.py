@@ -19,7 +19,7 @@ Pinned by tests/golden/kat_neumf.npz (tests/golden/make_golden_neumf.py).
 """
 import numpy as np
 
-from .bpr_mf_numpy import LOSS_CL, LOSS_SL, LOSS_BPR, _sigmoid, pair_loss_coef  # noqa: F401
+from .bpr_mf_numpy import LOSS_CL, LOSS_SL, LOSS_BPR, _mix32, _sigmoid, pair_loss_coef  # noqa: F401
 
 PARAM_ORDER = ("uG", "iG", "uM", "iM")          # embedding tables; then W1,b1,...,WL,bL, Wp, bp
 
@@ -155,3 +155,32 @@ def neumf_full_rank(p, u, topk, num_layers, model="NeuMF"):
     I = np.asarray(p["iG"]).shape[0]
     pred, _ = neumf_forward(p, np.full(I, u, np.int64), np.arange(I), num_layers, model, None, np.float32)
     return np.argsort(-pred, kind="stable")[:topk].astype(np.int64)
+
+
+# --------------------------------------------------------------------------------------------------
+# Dropout masks of the HIP path (csrc/neumf.hip: drop_keep): a counter hash of (seed, layer, element),
+# restated here so that training steps WITH dropout can be compared bit for bit in the mask.
+# --------------------------------------------------------------------------------------------------
+def drop_keep(seed, stream, idx, p):
+    m32 = np.uint64(0xFFFFFFFF)
+    thresh = np.uint64(min(int(np.float32(p).astype(np.float64) * 4294967296.0), 4294967295))
+    idx = np.asarray(idx, np.uint64)
+    seed = np.uint64(seed)
+    h = _mix32((idx & m32) ^ (seed & m32))
+    h = _mix32((h + (idx >> np.uint64(32)) * np.uint64(0x9E3779B9) + (seed >> np.uint64(32))
+                + np.uint64(stream) * np.uint64(0x85EBCA6B)) & m32)
+    return h >= thresh
+
+
+def dropout_masks(seed, rows, d, num_layers, p, dtype=np.float64):
+    """masks[l-1][r, c] for the input of Linear l (width 2*dm / 2^(l-1)), rows = global row ids of
+    the step (positives 0..B-1, negatives B..2B-1), already scaled by 1/(1-p)."""
+    rows = np.asarray(rows, np.uint64)
+    w = 2 * d * (1 << (num_layers - 1))
+    scale = dtype(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
+    out = []
+    for l in range(1, num_layers + 1):
+        idx = rows[:, None] * np.uint64(w) + np.arange(w, dtype=np.uint64)[None, :]
+        out.append(drop_keep(seed, l, idx, p).astype(dtype) * scale)
+        w //= 2
+    return out

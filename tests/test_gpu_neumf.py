@@ -1,0 +1,135 @@
+"""NeuMF widening on the GPU: the HIP path through the C ABI against the golden
+vectors of the REAL reference NeuMF (tests/golden/kat_neumf.npz) and the CPU oracle.
+Tolerances: loss within 1e-5 relative per step; parameters at fp32 round-off (SGD) or, under Adam,
+round-off for all but the few elements whose gradient is ~0 (see tests/test_oracle_neumf.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bpr_mf_numpy as O
+from oracle import neumf_numpy as NO
+from test_oracle_neumf import assert_params_close, load_params
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def kat_neumf():
+    return np.load(os.path.join(HERE, "golden", "kat_neumf.npz"))
+
+
+def _dev(p):
+    return {k: torch.as_tensor(np.ascontiguousarray(v)).to(DEV) for k, v in p.items()}
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 16), (1, 1, 1), (257, 96, 48), (1000, 24, 48), (333, 256, 512),
+                                   (4096, 64, 128), (70, 130, 9)])
+def test_mfma_gemm_nt(M, N, K):
+    """The fp32 MFMA tile kernel of the MLP tower against torch (fp64 reference)."""
+    from daisyrec_amd import ops
+    g = torch.Generator(device=DEV)
+    g.manual_seed(M * 7 + N)
+    A = torch.randn(M, K, device=DEV, generator=g)
+    B = torch.randn(N, K, device=DEV, generator=g)
+    got = ops.gemm_nt(A, B)
+    want = (A.double() @ B.double().T)
+    assert float((got.double() - want).abs().max()) <= 2e-6 * K * float(want.abs().max() + 1)
+
+
+def _run_case(g, name, ops, dropout=0.0):
+    U, I, d, L, B, ns = (int(x) for x in g[f"{name}/meta"])
+    lr, r1, r2 = (float(x) for x in g[f"{name}/hyper"])
+    lt = ops.loss_id(str(g[f"{name}/loss_type"]))
+    model = str(g[f"{name}/model"])
+    names = ops.neumf_param_names(L)
+    p = _dev(load_params(g, name, L, "0"))
+    grads = {k: torch.zeros_like(v) for k, v in p.items()}
+    is_adam = str(g[f"{name}/optimizer"]) == "adam"
+    m = {k: torch.zeros_like(v) for k, v in p.items()}
+    v = {k: torch.zeros_like(v) for k, v in p.items()}
+    ctx = ops.NeumfContext(2 * B, d, L, U, I, model=model)
+    losses = []
+    for s in range(ns):
+        u, i, j = (torch.as_tensor(g[f"{name}/{k}"][s]).to(DEV) for k in "uij")
+        ctx.step_grads(p, grads, u, i, j, lt, r1, r2, dropout=dropout, seed=1000 + s)
+        losses.append(float(ctx.stats[11].cpu()))
+        for k in names:
+            if is_adam:
+                ops.adam_dense(p[k], grads[k], m[k], v[k], lr, s + 1)
+            else:
+                ops.sgd_dense(p[k], grads[k], lr)
+    ctx.close()
+    return {k: t.cpu().numpy() for k, t in p.items()}, losses, is_adam, lr, ns, names
+
+
+def test_neumf_kat_steps(kat_neumf):
+    from daisyrec_amd import ops
+    g = kat_neumf
+    for name in g["names"]:
+        name = str(name)
+        p, losses, is_adam, lr, ns, names = _run_case(g, name, ops)
+        for s, loss in enumerate(losses):
+            ref = float(g[f"{name}/loss"][s])
+            assert abs(loss - ref) <= 1e-5 * abs(ref), (name, s, loss, ref)
+        # Adam: gradients that cancel pairwise under BPR (a bias of a unit that is active on both rows of
+        # every sample) are pure rounding residue in BOTH implementations and Adam turns their sign into
+        # a +-lr step, so up to ~10 % of a small bias vector may legitimately differ by <= 2*lr*steps
+        assert_params_close(p, {k: g[f"{name}/{k}"] for k in names}, names, name, 5e-6,
+                            adam_lr=lr if is_adam else None, steps=ns, frac=0.9)
+
+
+def test_neumf_rank_kat(kat_neumf):
+    from daisyrec_amd import ops
+    g = kat_neumf
+    U, I, d, L = (int(x) for x in g["rank/meta"])
+    p_np = load_params(g, "rank", L)
+    p = _dev(p_np)
+    us, cands, topk = g["rank/us"], g["rank/cands"], int(g["rank/topk"])
+    B, C = cands.shape
+    ctx = ops.NeumfContext(300, d, L, U, I)          # smaller than B*C: exercises the chunked scoring
+    scores = ctx.scores(p, torch.as_tensor(us).to(DEV), torch.as_tensor(cands).reshape(-1).to(DEV), C_=C)
+    _, want = NO.neumf_rank(p_np, us, cands, topk, L)
+    np.testing.assert_allclose(scores.cpu().numpy().reshape(B, C), want, rtol=1e-5, atol=2e-6)
+    out = ops.topk_from_scores(scores.view(B, C), torch.as_tensor(cands).to(DEV), topk).cpu().numpy()
+    assert (out.astype(np.float32) == g["rank/preds"]).mean() > 0.99
+    full_scores = ctx.scores(p, torch.as_tensor(us[:1]).to(DEV), None, C_=0, n=I)
+    full = ops.full_topk_from_scores(full_scores, topk).cpu().numpy()
+    assert (full == g["rank/full"][0]).mean() >= 0.9
+    pp = ctx.scores(p, torch.as_tensor(us).to(DEV), torch.as_tensor(cands[:, 0].copy()).to(DEV))
+    np.testing.assert_allclose(pp.cpu().numpy(), g["rank/predict"], rtol=1e-5, atol=2e-6)
+    ctx.close()
+
+
+@pytest.mark.parametrize("model,loss", [("NeuMF", "BPR"), ("MLP", "CL")])
+def test_neumf_dropout_step_matches_oracle_with_the_same_masks(model, loss):
+    """Training mode: the device's dropout masks (counter hash) restated by the oracle."""
+    from daisyrec_amd import ops
+    rng = np.random.default_rng(3)
+    U, I, d, L, B, pdrop, seed = 40, 30, 8, 3, 50, 0.5, 77
+    dm = d << (L - 1)
+    shapes = {"uG": (U, d), "iG": (I, d), "uM": (U, dm), "iM": (I, dm), "Wp": (1, d if model == "MLP" else 2 * d),
+              "bp": (1,)}
+    w = 2 * dm
+    for l in range(1, L + 1):
+        shapes[f"W{l}"], shapes[f"b{l}"] = (w // 2, w), (w // 2,)
+        w //= 2
+    p_np = {k: (rng.standard_normal(s) * 0.3).astype(np.float32) for k, s in shapes.items()}
+    u, i = rng.integers(0, U, B).astype(np.int32), rng.integers(0, I, B).astype(np.int32)
+    lt = O.LOSS_IDS[loss]
+    j = (rng.integers(0, 2, B) if loss == "CL" else rng.integers(0, I, B)).astype(np.int32)
+    mp = NO.dropout_masks(seed, np.arange(B), d, L, pdrop)
+    mn = NO.dropout_masks(seed, np.arange(B, 2 * B), d, L, pdrop)
+    assert 0.4 < np.mean(mp[0] > 0) < 0.6
+    want_loss, want = NO.neumf_grad(p_np, u, i, j, 1e-3, 1e-3, L, lt, model, masks_pos=mp, masks_neg=mn)
+    p = _dev(p_np)
+    grads = {k: torch.zeros_like(v) for k, v in p.items()}
+    ctx = ops.NeumfContext(2 * B, d, L, U, I, model=model)
+    ctx.step_grads(p, grads, *(torch.as_tensor(x).to(DEV) for x in (u, i, j)), lt, 1e-3, 1e-3, dropout=pdrop, seed=seed)
+    assert abs(float(ctx.stats[11].cpu()) - want_loss) <= 1e-5 * abs(want_loss)
+    for k in shapes:
+        np.testing.assert_allclose(grads[k].cpu().numpy(), want[k], rtol=2e-4, atol=2e-5, err_msg=k)
+    ctx.close()
