@@ -19,6 +19,9 @@ def install(sampler=False):
     ref_mf.MF = MF
     ref_fm = importlib.import_module("daisy.model.FMRecommender")
     ref_fm.FM = FM
+    from .model.NeuMFRecommender import NeuMF
+    ref_nm = importlib.import_module("daisy.model.NeuMFRecommender")
+    ref_nm.NeuMF = NeuMF
     if sampler:
         from .utils.sampler import BasicNegtiveSampler
 

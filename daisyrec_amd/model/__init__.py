@@ -1,3 +1,4 @@
 from .AbstractRecommender import AbstractRecommender, GeneralRecommender  # noqa: F401
 from .MFRecommender import MF  # noqa: F401
 from .FMRecommender import FM  # noqa: F401
+from .NeuMFRecommender import NeuMF  # noqa: F401

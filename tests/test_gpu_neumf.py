@@ -133,3 +133,88 @@ def test_neumf_dropout_step_matches_oracle_with_the_same_masks(model, loss):
     for k in shapes:
         np.testing.assert_allclose(grads[k].cpu().numpy(), want[k], rtol=2e-4, atol=2e-5, err_msg=k)
     ctx.close()
+
+
+def _neumf_cfg(g, prefix, **over):
+    from conftest import mf_config
+    U, I, d, L = (int(x) for x in g[f"{prefix}/meta"])
+    lr, r1, r2 = (float(x) for x in g[f"{prefix}/hyper"])
+    cfg = mf_config(user_num=U, item_num=I, factors=d, num_layers=L, lr=lr, reg_1=r1, reg_2=r2, dropout=0.0,
+                    model_name="NeuMF", GMF_model=None, MLP_model=None, algo_name="neumf",
+                    epochs=int(g[f"{prefix}/epochs"]), optimizer=str(g[f"{prefix}/optimizer"]))
+    cfg.update(over)
+    return cfg, L
+
+
+def _fit_like_the_reference(g, prefix):
+    from daisyrec_amd.model.NeuMFRecommender import NeuMF
+    from daisyrec_amd.utils.dataset import BasicDataset, CandidatesDataset, get_dataloader
+    cfg, L = _neumf_cfg(g, prefix)
+    torch.manual_seed(int(g[f"{prefix}/seed"]))
+    model = NeuMF(cfg)
+    for k, p in model._named().items():               # same module order + RNG stream => same init
+        np.testing.assert_array_equal(p.detach().numpy(), g[f"{prefix}/{k}0"], err_msg=k)
+    loader = get_dataloader(BasicDataset(g["ml/samples"]), batch_size=int(g[f"{prefix}/batch_size"]), shuffle=True,
+                            num_workers=4)
+    torch.set_rng_state(torch.from_numpy(g[f"{prefix}/rng_state_before_fit"]))
+    model.fit(loader)
+    ucands = [[int(u), c] for u, c in zip(g["ml/test_u"], g["ml/cands"])]
+    preds = model.rank(get_dataloader(CandidatesDataset(ucands), batch_size=128, shuffle=False, num_workers=0))
+    return model, preds, L
+
+
+def test_neumf_ml100k_sgd_through_the_dropin(kat_neumf):
+    """run_examples/test.py --algo_name neumf --optimizer sgd (dropout 0) on ml-100k (first 100 batches: see
+    tests/golden/make_golden_neumf.py) through NeuMF.fit / NeuMF.rank with the reference's triples, init
+    and DataLoader order: epoch loss within 1e-5, parameters at round-off, ranked top-N identical."""
+    g = kat_neumf
+    model, preds, L = _fit_like_the_reference(g, "mlsgd")
+    ref = float(g["mlsgd/epoch_losses"][0])
+    assert abs(model.epoch_losses[0] - ref) <= 1e-5 * abs(ref), (model.epoch_losses, ref)
+    for k, p in model._named().items():
+        np.testing.assert_allclose(p.detach().cpu().numpy(), g[f"mlsgd/{k}1"], atol=3e-5, err_msg=k)
+    assert preds.dtype == np.float32 and preds.shape == g["mlsgd/preds"].shape
+    same = (preds == g["mlsgd/preds"]).all(axis=1).mean()
+    assert same > 0.98, f"top-N lists identical for {same:.3f} of the users"
+    # predict / full_rank / calc_loss agree with the oracle on the trained parameters
+    p_np = {k: p.detach().cpu().numpy() for k, p in model._named().items()}
+    want, _ = NO.neumf_forward(p_np, [3], [5], L)
+    assert abs(model.predict(3, 5) - float(want[0])) < 1e-5
+    full = model.full_rank(int(g["ml/test_u"][0]))
+    assert (full == NO.neumf_full_rank(p_np, int(g["ml/test_u"][0]), model.topk, L)).mean() > 0.9
+    b = g["ml/samples"][:256]
+    model.eval()
+    loss = float(model.calc_loss([torch.from_numpy(b[:, k].copy()) for k in range(3)]).cpu())
+    want_loss, _ = NO.neumf_grad(p_np, b[:, 0], b[:, 1], b[:, 2], model.reg_1, model.reg_2, L)
+    assert abs(loss - want_loss) <= 1e-5 * abs(want_loss)
+
+
+def test_neumf_ml100k_adam_defaults(kat_neumf):
+    """neumf.yaml defaults (Adam lr 0.001; dropout 0), 100 batches: epoch loss within 1e-5, ranked lists
+    identical for >= 90 % of the users (Adam's sign-like first steps amplify round-off in a few rows)."""
+    g = kat_neumf
+    model, preds, L = _fit_like_the_reference(g, "ml")
+    ref = float(g["ml/epoch_losses"][0])
+    assert abs(model.epoch_losses[0] - ref) <= 1e-5 * abs(ref), (model.epoch_losses, ref)
+    same = (preds == g["ml/preds"]).all(axis=1).mean()
+    assert same > 0.9, f"top-N lists identical for {same:.3f} of the users"
+
+
+def test_neumf_dropout_training_runs_and_learns(kat_neumf):
+    """neumf.yaml's dropout 0.5 with the device masks: the loss goes down, eval-mode scoring is deterministic."""
+    from daisyrec_amd.model.NeuMFRecommender import NeuMF
+    from daisyrec_amd.utils.dataset import BasicDataset, get_dataloader
+    g = kat_neumf
+    cfg, L = _neumf_cfg(g, "ml", dropout=0.5, epochs=2)
+    torch.manual_seed(0)
+    model = NeuMF(cfg)
+    loader = get_dataloader(BasicDataset(g["ml/samples"]), batch_size=1024, shuffle=True, num_workers=0)
+    model.fit(loader)
+    assert model.epoch_losses[1] < model.epoch_losses[0]
+    a = model.forward(torch.arange(50), torch.arange(50)).cpu()
+    b = model.forward(torch.arange(50), torch.arange(50)).cpu()
+    assert torch.equal(a, b)
+    for name in ("GMF", "MLP"):
+        m2 = NeuMF({**cfg, "model_name": name, "epochs": 1, "dropout": 0.0})
+        m2.fit(loader)
+        assert np.isfinite(m2.epoch_losses[0])

@@ -122,18 +122,15 @@ def test_neumf_ml100k_sgd_end_to_end(kat_neumf):
 
 
 def test_neumf_ml100k_adam_end_to_end(kat_neumf):
-    """neumf.yaml defaults (Adam, lr 0.001; dropout 0), 2 epochs."""
+    """neumf.yaml defaults (Adam, lr 0.001; dropout 0), 100 batches."""
     g = kat_neumf
     p, losses, L = _replay_ml100k(g, "ml")
-    for ep, tot in enumerate(losses):
-        ref = g["ml/epoch_losses"][ep]
-        # epoch 1 within 1e-5; after ~300 Adam steps fp32 (reference) and fp64 (oracle) trajectories
-        # drift apart at the 1e-5 level (Adam's sign-like update amplifies last-ulp differences)
-        assert abs(tot - ref) <= (1e-5 if ep == 0 else 1e-4) * abs(ref), (ep, tot, ref)
+    ref = g["ml/epoch_losses"][0]
+    assert abs(losses[0] - ref) <= 1e-5 * abs(ref), (losses, ref)
     for k in N.param_names(L):
         ref = g[f"ml/{k}1"].astype(np.float64)
         err = np.linalg.norm(np.asarray(p[k], np.float64) - ref)
-        assert err <= 0.02 * np.linalg.norm(ref) + 1e-6, (k, err)      # (bp stays exactly 0 under BPR)
+        assert err <= 1e-3 * np.linalg.norm(ref) + 1e-6, (k, err)      # (bp stays exactly 0 under BPR)
     pred, _ = N.neumf_rank(p, g["ml/test_u"], g["ml/cands"], int(g["ml/topk"]), L)
-    top1 = (pred[:, 0] == g["ml/preds"][:, 0]).mean()
-    assert top1 > 0.95, top1        # deeper ranks sit on near-ties of a saturated model: not comparable
+    same = (pred == g["ml/preds"]).all(axis=1).mean()
+    assert same > 0.9, f"top-N lists identical for {same:.3f} of the users"
