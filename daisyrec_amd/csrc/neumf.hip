@@ -348,23 +348,24 @@ __global__ __launch_bounds__(kBlock) void k_nmf_pred_bwd(const float *__restrict
     for (int c = threadIdx.x; c < dg + nl; c += kBlock) unsafeAtomicAdd(gWp + c, col[c]);
 }
 
-// out[n] += sum_r X[r*ld + n]
+// out[n] += sum_r X[r*ld + n]: a block takes 64 columns x kColsumRows rows (grid = column tiles x row tiles)
+constexpr int kColsumRows = 512;
 __global__ __launch_bounds__(kBlock) void k_colsum(const float *__restrict__ X, int64_t R, int N, int64_t ld,
                                                    float *__restrict__ out) {
     __shared__ float sm[4][64];
     const int c = threadIdx.x % 64, rr = threadIdx.x / 64;
-    const int64_t rows_per_block = 1024;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t r1 = (r0 + rows_per_block < R) ? r0 + rows_per_block : R;
-    for (int n0 = 0; n0 < N; n0 += 64) {
-        float s = 0.f;
-        if (n0 + c < N)
-            for (int64_t r = r0 + rr; r < r1; r += 4) s += X[r * ld + n0 + c];
-        sm[rr][c] = s;
-        __syncthreads();
-        if (rr == 0 && n0 + c < N) unsafeAtomicAdd(out + n0 + c, sm[0][c] + sm[1][c] + sm[2][c] + sm[3][c]);
-        __syncthreads();
+    const int n = blockIdx.x * 64 + c;
+    const int64_t r0 = (int64_t)blockIdx.y * kColsumRows;
+    const int64_t r1 = (r0 + kColsumRows < R) ? r0 + kColsumRows : R;
+    float s0 = 0.f, s1 = 0.f;
+    if (n < N) {
+        int64_t r = r0 + rr;
+        for (; r + 4 < r1; r += 8) { s0 += X[r * ld + n]; s1 += X[(r + 4) * ld + n]; }
+        if (r < r1) s0 += X[r * ld + n];
     }
+    sm[rr][c] = s0 + s1;
+    __syncthreads();
+    if (rr == 0 && n < N) unsafeAtomicAdd(out + n, (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]));
 }
 
 // embedding gradients of one row r (dense tables, fp32 atomics) + the regulariser gradients
@@ -600,8 +601,8 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
             w.M = n_out; w.N = n_in; w.K = R;
             w.k_chunk = 2048;
             launch_gemm<EPI_ATOMIC>(w, s);
-            hipLaunchKernelGGL(k_colsum, dim3((unsigned)((R + 1023) / 1024)), dim3(kBlock), 0, s, dz, R, n_out,
-                               (int64_t)n_out, g.b[l - 1]);
+            hipLaunchKernelGGL(k_colsum, dim3((unsigned)((n_out + 63) / 64), (unsigned)((R + kColsumRows - 1) / kColsumRows)),
+                               dim3(kBlock), 0, s, dz, R, n_out, (int64_t)n_out, g.b[l - 1]);
             GemmOp x{};                                   // dZ_{l-1}[R, n_in] = (dZ W_l) gated
             x.A = dz; x.sam = n_out; x.sak = 1;
             x.B = p.W[l - 1]; x.sbn = 1; x.sbk = n_in;

@@ -44,3 +44,46 @@ class TorchMFBPR(nn.Module):
         out.backward()
         self.opt.step()
         return float(out.item())
+
+
+class TorchNeuMF(nn.Module):
+    """The reference's NeuMF training step out of stock PyTorch pieces (NeuMFRecommender.py:52-73,
+    118-169; dense Adam, AbstractRecommender.py:54) - the `cpu_baseline` leg of tools/bench_neumf.py."""
+
+    def __init__(self, user_num, item_num, d, num_layers, lr=0.001, reg_1=0.001, reg_2=0.001, dropout=0.0,
+                 gamma=1e-10):
+        super().__init__()
+        dm = d * 2 ** (num_layers - 1)
+        self.uG, self.iG = nn.Embedding(user_num, d), nn.Embedding(item_num, d)
+        self.uM, self.iM = nn.Embedding(user_num, dm), nn.Embedding(item_num, dm)
+        mods, n = [], 2 * dm
+        for _ in range(num_layers):
+            mods += [nn.Dropout(p=dropout), nn.Linear(n, n // 2), nn.ReLU()]
+            n //= 2
+        self.mlp = nn.Sequential(*mods)
+        self.predict = nn.Linear(2 * d, 1)
+        self.reg_1, self.reg_2, self.gamma = reg_1, reg_2, gamma
+        self.opt = torch.optim.Adam(self.parameters(), lr=lr)
+
+    def score(self, u, i):
+        g = self.uG(u) * self.iG(i)
+        x = self.mlp(torch.cat((self.uM(u), self.iM(i)), dim=-1))
+        return self.predict(torch.cat((g, x), -1)).view(-1)
+
+    def loss(self, u, i, j):
+        pos, neg = self.score(u, i), self.score(u, j)
+        out = -(self.gamma + torch.sigmoid(pos - neg)).log().sum()
+        out = out + self.reg_1 * (self.iG(i).norm(p=1) + self.iG(j).norm(p=1))
+        out = out + self.reg_1 * (self.iM(i).norm(p=1) + self.iG(j).norm(p=1))
+        out = out + self.reg_2 * (self.iG(i).norm() + self.iG(j).norm())
+        out = out + self.reg_2 * (self.iM(i).norm() + self.iG(j).norm())
+        out = out + self.reg_1 * (self.uG(u).norm(p=1) + self.uM(u).norm(p=1))
+        out = out + self.reg_2 * (self.uG(u).norm() + self.uM(u).norm())
+        return out
+
+    def step(self, u, i, j):
+        self.zero_grad()
+        out = self.loss(u, i, j)
+        out.backward()
+        self.opt.step()
+        return float(out.item())
