@@ -16,6 +16,8 @@
 // Dropout: x_{l-1} is stored already masked and scaled, so "x > 0" carries mask and ReLU gate at once.
 #include "common.h"
 
+#include <type_traits>
+
 namespace daisy {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -37,7 +39,7 @@ __host__ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint32_t strea
 struct GemmOp {
     const float *A; int64_t sam, sak;     // A(m,k) = A[m*sam + k*sak]
     const float *B; int64_t sbn, sbk;     // B(n,k) = B[n*sbn + k*sbk]
-    float *C; int64_t ldc;                // C(m,n) = C[m*ldc + n]
+    float *C; int64_t ldc, scn;           // C(m,n) = C[m*ldc + n*scn]   (scn = 0 means 1)
     int64_t M; int N; int64_t K;
     const float *bias;                    // EPI_BIAS_RELU
     const float *gate; int64_t ldg;       // EPI_GATE: out = acc * (gate(m,n) > 0 ? gate_scale : 0)
@@ -46,17 +48,25 @@ struct GemmOp {
     float drop_scale;
     uint64_t drop_seed;
     int64_t k_chunk;                      // reduction range per blockIdx.z
+    int vec_a, vec_b;                     // set by launch_gemm: operand qualifies for the float4 path
 };
 
 // C = A * B^T-style contraction over k with arbitrary strides.  WN: 32-column MFMA blocks per wave
 // (block tile = 128 x 64*WN).  Operand tiles go global -> registers -> LDS (k-major, so the MFMA
-// fragment reads are conflict free) with the next tile's loads in flight during the MFMAs.
-template <int WN, int EPI>
+// fragment reads are conflict free; two LDS stages, one barrier per k tile) with the next tile's
+// loads in flight during the MFMAs.  Interior tiles of 16-byte aligned operands take a branch-free
+// float4 path (a guarded load costs a branch and a vmcnt drain each); edge tiles, k tails and
+// unaligned operands take the guarded scalar path.
+// FAST: every tile is interior, both operands qualify for the float4 path and the k range is a multiple
+// of kBK (checked by launch_gemm) - the guarded loader and its address registers are compiled out, which
+// is what lets four waves per SIMD share the MFMA pipe.
+template <int WN, int EPI, bool FAST, bool DROP>
 __global__ __launch_bounds__(kBlock) void k_gemm(GemmOp op) {
     constexpr int BM = kGemmBM, BN = 64 * WN;
     constexpr int EA = BM * kBK / kBlock, EB = BN * kBK / kBlock;     // elements per thread per tile
-    __shared__ float As[kBK][BM + kLdsPad];
-    __shared__ float Bs[kBK][BN + kLdsPad];
+    constexpr int LA = BM + kLdsPad, LB = BN + kLdsPad;
+    __shared__ __attribute__((aligned(16))) float As[2][kBK * LA];
+    __shared__ __attribute__((aligned(16))) float Bs[2][kBK * LB];
     const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
     const int wm = wave / 2, wn = wave % 2;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
@@ -64,6 +74,7 @@ __global__ __launch_bounds__(kBlock) void k_gemm(GemmOp op) {
     const int64_t k_lo = (int64_t)blockIdx.z * op.k_chunk;
     const int64_t k_hi = (k_lo + op.k_chunk < op.K) ? (k_lo + op.k_chunk) : op.K;
     const bool a_kfast = (op.sak == 1), b_kfast = (op.sbk == 1);
+    const bool a_vec = FAST || (op.vec_a && (m0 + BM <= op.M)), b_vec = FAST || (op.vec_b && (n0 + BN <= op.N));
 
     floatx16 acc[2][WN];
 #pragma unroll
@@ -74,104 +85,177 @@ __global__ __launch_bounds__(kBlock) void k_gemm(GemmOp op) {
             for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
     float ra[EA], rb[EB];
-    auto load_tile = [&](int64_t kt) {
+    // one operand tile [rows x kBK] -> registers.  vec: float4 along the contiguous dimension
+    auto load_op = [&](const float *__restrict__ P, int64_t srow, int64_t sk, bool kfast, bool vec, int64_t row0,
+                       int64_t nrows_total, int64_t kt, auto &r, auto rows_c, auto elems_c) {
+        constexpr int ROWS = decltype(rows_c)::value, E = decltype(elems_c)::value;
+        if (FAST || (vec && kt + kBK <= k_hi)) {
+            if (kfast) {                                   // 4 lanes cover the 16 k of one row
+                const float *src = P + (row0 + tid / 4) * srow + kt + (tid % 4) * 4;
 #pragma unroll
-        for (int q = 0; q < EA; ++q) {
-            const int e = tid + q * kBlock;
-            const int kk = a_kfast ? (e % kBK) : (e / BM);
-            const int mm = a_kfast ? (e / kBK) : (e % BM);
-            const int64_t m = m0 + mm, k = kt + kk;
-            ra[q] = (m < op.M && k < k_hi) ? op.A[m * op.sam + k * op.sak] : 0.f;
-        }
+                for (int q = 0; q < E / 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4 *>(src + (int64_t)q * (kBlock / 4) * srow);
+                    r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+                }
+            } else {                                       // ROWS/4 lanes cover one k
+                const float *src = P + row0 + (tid % (ROWS / 4)) * 4 + (kt + tid / (ROWS / 4)) * sk;
 #pragma unroll
-        for (int q = 0; q < EB; ++q) {
-            const int e = tid + q * kBlock;
-            const int kk = b_kfast ? (e % kBK) : (e / BN);
-            const int nn = b_kfast ? (e / kBK) : (e % BN);
-            const int64_t n = n0 + nn, k = kt + kk;
-            rb[q] = (n < op.N && k < k_hi) ? op.B[n * op.sbn + k * op.sbk] : 0.f;
-        }
-    };
-    auto store_tile = [&]() {
+                for (int q = 0; q < E / 4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4 *>(src + (int64_t)q * (kBlock / (ROWS / 4)) * sk);
+                    r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+                }
+            }
+        } else if constexpr (!FAST) {
 #pragma unroll
-        for (int q = 0; q < EA; ++q) {
-            const int e = tid + q * kBlock;
-            const int kk = a_kfast ? (e % kBK) : (e / BM);
-            const int mm = a_kfast ? (e / kBK) : (e % BM);
-            As[kk][mm] = ra[q];
-        }
-#pragma unroll
-        for (int q = 0; q < EB; ++q) {
-            const int e = tid + q * kBlock;
-            const int kk = b_kfast ? (e % kBK) : (e / BN);
-            const int nn = b_kfast ? (e / kBK) : (e % BN);
-            Bs[kk][nn] = rb[q];
+            for (int q = 0; q < E; ++q) {
+                const int e = tid + q * kBlock;
+                const int kk = kfast ? (e % kBK) : (e / ROWS);
+                const int rr = kfast ? (e / kBK) : (e % ROWS);
+                const int64_t row = row0 + rr, k = kt + kk;
+                r[q] = (row < nrows_total && k < k_hi) ? P[row * srow + k * sk] : 0.f;
+            }
         }
     };
+    auto store_op = [&](float *__restrict__ S, int ld, bool kfast, bool vec, bool full, auto &r, auto rows_c,
+                        auto elems_c) {
+        constexpr int ROWS = decltype(rows_c)::value, E = decltype(elems_c)::value;
+        if (FAST || (vec && full)) {
+            if (kfast) {
+#pragma unroll
+                for (int q = 0; q < E / 4; ++q) {
+                    const int row = tid / 4 + q * (kBlock / 4), k = (tid % 4) * 4;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) S[(k + t) * ld + row] = r[4 * q + t];
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < E / 4; ++q) {
+                    const int row = (tid % (ROWS / 4)) * 4, k = tid / (ROWS / 4) + q * (kBlock / (ROWS / 4));
+                    *reinterpret_cast<float4 *>(S + k * ld + row) = make_float4(r[4 * q], r[4 * q + 1], r[4 * q + 2], r[4 * q + 3]);
+                }
+            }
+        } else if constexpr (!FAST) {
+#pragma unroll
+            for (int q = 0; q < E; ++q) {
+                const int e = tid + q * kBlock;
+                const int kk = kfast ? (e % kBK) : (e / ROWS);
+                const int rr = kfast ? (e / kBK) : (e % ROWS);
+                S[kk * ld + rr] = r[q];
+            }
+        }
+    };
+    using RA = std::integral_constant<int, BM>; using RB = std::integral_constant<int, BN>;
+    using NA = std::integral_constant<int, EA>; using NB = std::integral_constant<int, EB>;
 
     if (k_lo < k_hi) {
-        load_tile(k_lo);
-        store_tile();
+        load_op(op.A, op.sam, op.sak, a_kfast, a_vec, m0, op.M, k_lo, ra, RA{}, NA{});
+        load_op(op.B, op.sbn, op.sbk, b_kfast, b_vec, (int64_t)n0, (int64_t)op.N, k_lo, rb, RB{}, NB{});
+        store_op(As[0], LA, a_kfast, a_vec, k_lo + kBK <= k_hi, ra, RA{}, NA{});
+        store_op(Bs[0], LB, b_kfast, b_vec, k_lo + kBK <= k_hi, rb, RB{}, NB{});
         __syncthreads();
+        int cur = 0;
         for (int64_t kt = k_lo; kt < k_hi; kt += kBK) {
             const bool more = kt + kBK < k_hi;
-            if (more) load_tile(kt + kBK);
+            if (more) {
+                load_op(op.A, op.sam, op.sak, a_kfast, a_vec, m0, op.M, kt + kBK, ra, RA{}, NA{});
+                load_op(op.B, op.sbn, op.sbk, b_kfast, b_vec, (int64_t)n0, (int64_t)op.N, kt + kBK, rb, RB{}, NB{});
+            }
+            const float *as = As[cur] + (lane / 32) * LA + wm * 64 + lane % 32;
+            const float *bs = Bs[cur] + (lane / 32) * LB + wn * 32 * WN + lane % 32;
+            float a[2][2], b[2][WN];          // fragments of k-step s live in slot s&1: the next step's LDS
+#pragma unroll                                // reads are issued before this step's MFMAs
+            for (int mi = 0; mi < 2; ++mi) a[0][mi] = as[mi * 32];
 #pragma unroll
-            for (int kk = 0; kk < kBK; kk += 2) {
-                const int kr = kk + lane / 32, c = lane % 32;
-                float a[2], b[WN];
+            for (int ni = 0; ni < WN; ++ni) b[0][ni] = bs[ni * 32];
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi) a[mi] = As[kr][wm * 64 + mi * 32 + c];
+            for (int ks = 0; ks < kBK / 2; ++ks) {
+                const int c = ks & 1, nx = c ^ 1;
+                if (ks + 1 < kBK / 2) {
 #pragma unroll
-                for (int ni = 0; ni < WN; ++ni) b[ni] = Bs[kr][wn * 32 * WN + ni * 32 + c];
+                    for (int mi = 0; mi < 2; ++mi) a[nx][mi] = as[(2 * ks + 2) * LA + mi * 32];
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni) b[nx][ni] = bs[(2 * ks + 2) * LB + ni * 32];
+                }
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
                     for (int ni = 0; ni < WN; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][mi], b[c][ni], acc[mi][ni], 0, 0, 0);
+            }
+            if (more) {                                    // the other stage: nobody reads it now
+                const bool full = kt + 2 * kBK <= k_hi;
+                store_op(As[cur ^ 1], LA, a_kfast, a_vec, full, ra, RA{}, NA{});
+                store_op(Bs[cur ^ 1], LB, b_kfast, b_vec, full, rb, RB{}, NB{});
             }
             __syncthreads();
-            if (more) {
-                store_tile();
-                __syncthreads();
-            }
+            cur ^= 1;
         }
     }
 
-    // ---- epilogue: lane holds column (lane % 32), rows (i/4)*8 + (lane/32)*4 + i%4 of each 32x32 block
+    // ---- epilogue: lane holds column (lane % 32), rows (i/4)*8 + (lane/32)*4 + i%4 of each 32x32 block.
+    // 32-bit offsets from the tile origin (a tile spans < 2^31 elements of C: 128 rows x ldc)
+    const int scn = op.scn ? (int)op.scn : 1;
+    float *__restrict__ Ct = op.C + m0 * op.ldc + (int64_t)n0 * scn;
+    const float *__restrict__ Gt = (EPI == EPI_GATE && op.gate) ? op.gate + m0 * op.ldg + n0 : nullptr;
+    const int ldc = (int)op.ldc, ldg = (int)op.ldg;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int ni = 0; ni < WN; ++ni) {
-            const int n = n0 + wn * 32 * WN + ni * 32 + lane % 32;
+            const int nl = wn * 32 * WN + ni * 32 + lane % 32;
+            float bias = 0.f;
+            if constexpr (EPI == EPI_BIAS_RELU) bias = (FAST || n0 + nl < op.N) ? op.bias[n0 + nl] : 0.f;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int64_t m = m0 + wm * 64 + mi * 32 + (i / 4) * 8 + (lane / 32) * 4 + (i % 4);
-                if (m >= op.M || n >= op.N) continue;
+                const int ml = wm * 64 + mi * 32 + (i / 4) * 8 + (lane / 32) * 4 + (i % 4);
+                if (!FAST && (m0 + ml >= op.M || n0 + nl >= op.N)) continue;
                 float v = acc[mi][ni][i];
-                if constexpr (EPI == EPI_BIAS_RELU) v = fmaxf(v + op.bias[n], 0.f);
+                if constexpr (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
                 if constexpr (EPI == EPI_GATE)
-                    if (op.gate) v = (op.gate[m * op.ldg + n] > 0.f) ? v * op.gate_scale : 0.f;
-                if constexpr (EPI == EPI_BIAS_RELU || EPI == EPI_GATE)
+                    if (Gt) v = (Gt[ml * ldg + nl] > 0.f) ? v * op.gate_scale : 0.f;
+                if constexpr (DROP)
                     if (op.drop_thresh)
-                        v = drop_keep(op.drop_seed, op.drop_stream, (uint64_t)m * (uint64_t)op.N + n, op.drop_thresh)
+                        v = drop_keep(op.drop_seed, op.drop_stream,
+                                      (uint64_t)(m0 + ml) * (uint64_t)op.N + (uint64_t)(n0 + nl), op.drop_thresh)
                                 ? v * op.drop_scale : 0.f;
-                if constexpr (EPI == EPI_ATOMIC) unsafeAtomicAdd(op.C + m * op.ldc + n, v);
-                else op.C[m * op.ldc + n] = v;
+                if constexpr (EPI == EPI_ATOMIC) unsafeAtomicAdd(Ct + ml * ldc + nl * scn, v);
+                else Ct[ml * ldc + nl * scn] = v;
             }
         }
+}
+
+// float4 path preconditions: unit stride along one dimension, the other stride and the base 16-byte aligned
+static bool vec_ok(const float *p, int64_t s_row, int64_t s_k, int64_t k_chunk) {
+    if (((uintptr_t)p & 15) != 0) return false;
+    if (s_k == 1) return s_row % 4 == 0 && k_chunk % 4 == 0;
+    if (s_row == 1) return s_k % 4 == 0;
+    return false;
 }
 
 template <int EPI>
 static void launch_gemm(GemmOp op, hipStream_t s) {
     const int64_t splits = (op.k_chunk < op.K) ? (op.K + op.k_chunk - 1) / op.k_chunk : 1;
     if (op.k_chunk >= op.K) op.k_chunk = op.K;
+    op.vec_a = vec_ok(op.A, op.sam, op.sak, splits > 1 ? op.k_chunk : 4);
+    op.vec_b = vec_ok(op.B, op.sbn, op.sbk, splits > 1 ? op.k_chunk : 4);
+    const int bn = (op.N > 64) ? 128 : 64;
+    const bool fast = op.vec_a && op.vec_b && op.M % kGemmBM == 0 && op.N % bn == 0 && op.K % kBK == 0 &&
+                      (splits == 1 || op.k_chunk % kBK == 0);
+    dim3 grid((unsigned)((op.M + kGemmBM - 1) / kGemmBM), (unsigned)((op.N + bn - 1) / bn), (unsigned)splits);
+    auto go = [&](auto wn_c, auto fast_c, auto drop_c) {
+        hipLaunchKernelGGL((k_gemm<decltype(wn_c)::value, EPI, decltype(fast_c)::value, decltype(drop_c)::value>), grid,
+                           dim3(kBlock), 0, s, op);
+    };
+    using T = std::true_type; using F = std::false_type;
+    using W1 = std::integral_constant<int, 1>; using W2 = std::integral_constant<int, 2>;
+    constexpr bool can_drop = (EPI == EPI_BIAS_RELU || EPI == EPI_GATE);
+    const bool drop = can_drop && op.drop_thresh != 0;
     if (op.N > 64) {
-        dim3 grid((unsigned)((op.M + kGemmBM - 1) / kGemmBM), (unsigned)((op.N + 127) / 128), (unsigned)splits);
-        hipLaunchKernelGGL((k_gemm<2, EPI>), grid, dim3(kBlock), 0, s, op);
+        if (fast) { if constexpr (can_drop) { if (drop) go(W2{}, T{}, T{}); else go(W2{}, T{}, F{}); } else go(W2{}, T{}, F{}); }
+        else      { if constexpr (can_drop) { if (drop) go(W2{}, F{}, T{}); else go(W2{}, F{}, F{}); } else go(W2{}, F{}, F{}); }
     } else {
-        dim3 grid((unsigned)((op.M + kGemmBM - 1) / kGemmBM), (unsigned)((op.N + 63) / 64), (unsigned)splits);
-        hipLaunchKernelGGL((k_gemm<1, EPI>), grid, dim3(kBlock), 0, s, op);
+        if (fast) { if constexpr (can_drop) { if (drop) go(W1{}, T{}, T{}); else go(W1{}, T{}, F{}); } else go(W1{}, T{}, F{}); }
+        else      { if constexpr (can_drop) { if (drop) go(W1{}, F{}, T{}); else go(W1{}, F{}, F{}); } else go(W1{}, F{}, F{}); }
     }
 }
 
@@ -595,10 +679,18 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
         for (int l = L; l >= 1; --l) {
             const int n_out = ctx->width[l], n_in = ctx->width[l - 1];
             GemmOp w{};                                   // gW_l[n_out, n_in] += dZ^T x_{l-1}
-            w.A = dz; w.sam = 1; w.sak = n_out;
-            w.B = ctx->X[l - 1]; w.sbn = 1; w.sbk = n_in;
-            w.C = g.W[l - 1]; w.ldc = n_in;
-            w.M = n_out; w.N = n_in; w.K = R;
+            if (n_out % kGemmBM == 0) {
+                w.A = dz; w.sam = 1; w.sak = n_out;
+                w.B = ctx->X[l - 1]; w.sbn = 1; w.sbk = n_in;
+                w.C = g.W[l - 1]; w.ldc = n_in;
+                w.M = n_out; w.N = n_in;
+            } else {                                      // narrow layer: tile the wider side over M, store transposed
+                w.A = ctx->X[l - 1]; w.sam = 1; w.sak = n_in;
+                w.B = dz; w.sbn = 1; w.sbk = n_out;
+                w.C = g.W[l - 1]; w.ldc = 1; w.scn = n_in;
+                w.M = n_in; w.N = n_out;
+            }
+            w.K = R;
             w.k_chunk = 2048;
             launch_gemm<EPI_ATOMIC>(w, s);
             hipLaunchKernelGGL(k_colsum, dim3((unsigned)((n_out + 63) / 64), (unsigned)((R + kColsumRows - 1) / kColsumRows)),
