@@ -1343,6 +1343,32 @@ static BatchView plan_view(const daisy_epoch_plan *p, int64_t k) {
 
 using namespace daisy;
 
+// out[row] += sum over the row's entries of coef[e].x * X[col_e]  (a sparse-matrix x dense-matrix product
+// for entries sorted by row): the item pass's segmented reduction on a synthetic view -
+// ekey[e] = row << 1, esu[e] = (e, col), coef[e] = (value, 0).  `out` must be zero where rows have
+// entries (segments that cross a chunk are added atomically); n_entries must be even.
+namespace daisy {
+int segsum_rows(const float *X, const float2 *coef, const uint32_t *ekey, const uint2 *esu, int64_t n_entries,
+                int d, float *out, hipStream_t s) {
+    if (n_entries <= 0) return DAISY_OK;
+    if (n_entries & 1) { set_error("segsum_rows: odd entry count %lld", (long long)n_entries); return DAISY_ERR_ARG; }
+    BatchView v{};
+    v.ekey = ekey;
+    v.esu = esu;
+    v.imask = 0xFFFFFFFFu;
+    v.B = n_entries / 2;
+    int rc = dispatch_d(d, [&](auto cfg) {
+        using C = decltype(cfg);
+        hipLaunchKernelGGL((k_item_grad_chunked<C>), dim3(grid_for(n_entries, RunCfg<C>::E, 16384)), dim3(kBlock), 0,
+                           s, X, coef, v, d, out);
+        return DAISY_OK;
+    });
+    if (rc) return rc;
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+}  // namespace daisy
+
 static void view_bias(daisy_bpr_ctx *ctx) {
     BatchView &v = ctx->v;
     v.bu = ctx->bu; v.bi = ctx->bi; v.b0 = ctx->b0;

@@ -394,4 +394,8 @@ __device__ __forceinline__ void pair_coef(int loss_type, float pos, float neg, f
 }
 
 
+// sparse (entries sorted by row) x dense product on the item pass's segmented-reduction kernel (bpr_train.hip)
+int segsum_rows(const float *X, const float2 *coef, const uint32_t *ekey, const uint2 *esu, int64_t n_entries,
+                int d, float *out, hipStream_t s);
+
 }  // namespace daisy

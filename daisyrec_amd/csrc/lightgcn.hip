@@ -1,0 +1,251 @@
+// LightGCN (daisy/model/LightGCNRecommender.py) on gfx950: the normalised bipartite adjacency as a
+// row-sorted entry list on the device, the propagation out = mean_k A^k E0 and its transpose.
+// The sparse x dense products run on the item pass's segmented-reduction kernel (segsum_rows in
+// bpr_train.hip): random 256-byte row gathers, 16 rows in flight per lane group, single-owner
+// stores - an HBM-bound kernel, no MFMA.  Everything else of a LightGCN step is the MF path.
+#include "common.h"
+
+namespace daisy {
+
+__global__ void k_lg_pair_keys(const int32_t *__restrict__ users, const int32_t *__restrict__ items, int64_t n,
+                               uint64_t *__restrict__ keys) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
+        keys[t] = ((uint64_t)(uint32_t)users[t] << 32) | (uint32_t)items[t];
+}
+
+// distinct (u, i) pairs sorted by (u, i): degree counts + the swapped keys (i, u) for the item rows
+__global__ void k_lg_degrees(const uint64_t *__restrict__ pairs, int64_t m, int64_t U, int32_t *__restrict__ deg,
+                             uint64_t *__restrict__ swapped) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < m; t += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = pairs[t];
+        const uint32_t u = (uint32_t)(k >> 32), i = (uint32_t)k;
+        atomicAdd(deg + u, 1);
+        atomicAdd(deg + U + i, 1);
+        swapped[t] = ((uint64_t)i << 32) | u;
+    }
+}
+
+// entry e < m: user row (u -> U+i) from pairs[e]; entry e >= m: item row (U+i -> u) from swapped_sorted[e-m].
+// value = D^-1/2 A D^-1/2 in float64, stored as float32 (LightGCNRecommender.py:93-105)
+__global__ void k_lg_entries(const uint64_t *__restrict__ pairs, const uint64_t *__restrict__ swapped_sorted,
+                             int64_t m, int64_t U, const int32_t *__restrict__ deg, uint32_t *__restrict__ ekey,
+                             uint2 *__restrict__ esu, float2 *__restrict__ coef) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < 2 * m; e += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t row, col;
+        if (e < m) {
+            const uint64_t k = pairs[e];
+            row = (uint32_t)(k >> 32);
+            col = (uint32_t)U + (uint32_t)k;
+        } else {
+            const uint64_t k = swapped_sorted[e - m];
+            row = (uint32_t)U + (uint32_t)(k >> 32);
+            col = (uint32_t)k;
+        }
+        const double dr = pow((double)deg[row] + 1e-7, -0.5), dc = pow((double)deg[col] + 1e-7, -0.5);
+        ekey[e] = row << 1;
+        esu[e] = make_uint2((uint32_t)e, col);
+        coef[e] = make_float2((float)((dr * 1.0) * dc), 0.f);
+    }
+}
+
+__global__ void k_lg_read(const uint32_t *__restrict__ ekey, const uint2 *__restrict__ esu,
+                          const float2 *__restrict__ coef, int64_t n, int32_t *__restrict__ row,
+                          int32_t *__restrict__ col, float *__restrict__ val) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        row[e] = (int32_t)(ekey[e] >> 1);
+        col[e] = (int32_t)esu[e].y;
+        val[e] = coef[e].x;
+    }
+}
+
+// y = a*x + b*y (elementwise; x may be null for y *= b)
+__global__ void k_lg_axpby(const float *__restrict__ x, float a, float b, float *__restrict__ y, int64_t n) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        y[e] = (x ? a * x[e] : 0.f) + b * y[e];
+}
+
+__global__ __launch_bounds__(kBlock) void k_lg_reg(const float *__restrict__ E0, const int32_t *__restrict__ u,
+                                                   const int32_t *__restrict__ i, const int32_t *__restrict__ j,
+                                                   int64_t B, int64_t U, int d, int pointwise, float reg_1,
+                                                   float reg_2, const double *__restrict__ stats,
+                                                   float *__restrict__ dE0) {
+    const int lane = threadIdx.x % 16, group = threadIdx.x / 16;
+    auto inv = [&](double x) { return x > 0.0 ? (float)((double)reg_2 / x) : 0.f; };   // d|X|_F/dX = 0 at X = 0
+    const float r_u = inv(stats[DAISY_ST_NORM_U]), r_i = inv(stats[DAISY_ST_NORM_I]), r_j = inv(stats[DAISY_ST_NORM_J]);
+    const int64_t gstride = (int64_t)gridDim.x * (kBlock / 16);
+    const int nrows = pointwise ? 2 : 3;
+    for (int64_t t = (int64_t)blockIdx.x * (kBlock / 16) + group; t < B * nrows; t += gstride) {
+        const int64_t b = t / nrows;
+        const int which = (int)(t % nrows);
+        const int64_t row = which == 0 ? (int64_t)u[b] : (U + (which == 1 ? i[b] : j[b]));
+        const float r = which == 0 ? r_u : (which == 1 ? r_i : r_j);
+        for (int c = lane; c < d; c += 16) {
+            const float e = E0[row * d + c];
+            const float g = fmaf(r, e, reg_1 * sgn(e));
+            if (g != 0.f) unsafeAtomicAdd(dE0 + row * d + c, g);
+        }
+    }
+}
+
+}  // namespace daisy
+
+using namespace daisy;
+
+struct daisy_lgcn_graph {
+    int64_t U, I, nnz;
+    void *arena;
+    size_t arena_bytes;
+    uint32_t *ekey;
+    uint2 *esu;
+    float2 *coef;
+};
+
+static inline hipStream_t LS(daisy_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+extern "C" {
+
+int daisy_lgcn_graph_create(daisy_lgcn_graph **out, const int32_t *users, const int32_t *items, int64_t n,
+                            int64_t user_num, int64_t item_num, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(out != nullptr, "lgcn_graph_create: out is NULL");
+    *out = nullptr;
+    DAISY_CHECK_ARG(users && items && n > 0 && user_num > 0 && item_num > 0 &&
+                        user_num + item_num < ((int64_t)1 << 31),
+                    "lgcn_graph_create: bad argument");
+    hipStream_t s = LS(stream);
+    const int64_t N = user_num + item_num;
+    // scratch: keys, sorted keys, unique pairs, swapped, swapped sorted, counts, runs, degrees, sort temp
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+    const size_t o_k0 = take(n * 8), o_k1 = take(n * 8), o_un = take(n * 8), o_sw = take(n * 8), o_ss = take(n * 8);
+    const size_t o_cnt = take(n * 4), o_runs = take(16), o_deg = take((size_t)N * 4);
+    size_t tb = sort_keys_u64_temp_bytes(n);
+    if (rle_u64_temp_bytes(n) > tb) tb = rle_u64_temp_bytes(n);
+    const size_t o_tmp = take(tb);
+    char *scratch = nullptr;
+    DAISY_HIP(hipMalloc((void **)&scratch, off));
+    auto fail = [&](int rc) { (void)hipFree(scratch); return rc; };
+    uint64_t *k0 = (uint64_t *)(scratch + o_k0), *k1 = (uint64_t *)(scratch + o_k1), *un = (uint64_t *)(scratch + o_un);
+    uint64_t *sw = (uint64_t *)(scratch + o_sw), *ss = (uint64_t *)(scratch + o_ss);
+    uint32_t *cnt = (uint32_t *)(scratch + o_cnt), *runs = (uint32_t *)(scratch + o_runs);
+    int32_t *deg = (int32_t *)(scratch + o_deg);
+    void *tmp = scratch + o_tmp;
+    hipLaunchKernelGGL(k_lg_pair_keys, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, s, users, items, n, k0);
+    int rc = sort_keys_u64(tmp, tb, k0, k1, n, 64, s);
+    if (rc) return fail(rc);
+    rc = rle_u64(tmp, tb, k1, n, un, cnt, runs, s);
+    if (rc) return fail(rc);
+    uint32_t m32 = 0;
+    if (hipMemcpyAsync(&m32, runs, 4, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+        set_error("lgcn_graph_create: reading the pair count failed");
+        return fail(DAISY_ERR_HIP);
+    }
+    const int64_t m = m32;
+    daisy_lgcn_graph *g = new daisy_lgcn_graph();
+    g->U = user_num; g->I = item_num; g->nnz = 2 * m;
+    size_t goff = 0;
+    auto gtake = [&](size_t bytes) { size_t o = goff; goff += align_up(bytes); return o; };
+    const size_t g_k = gtake((size_t)g->nnz * 4), g_s = gtake((size_t)g->nnz * 8), g_c = gtake((size_t)g->nnz * 8);
+    g->arena_bytes = goff;
+    if (hipMalloc(&g->arena, goff) != hipSuccess) {
+        set_error("lgcn_graph_create: hipMalloc(%zu) failed", goff);
+        delete g;
+        return fail(DAISY_ERR_HIP);
+    }
+    g->ekey = (uint32_t *)((char *)g->arena + g_k);
+    g->esu = (uint2 *)((char *)g->arena + g_s);
+    g->coef = (float2 *)((char *)g->arena + g_c);
+    (void)hipMemsetAsync(deg, 0, (size_t)N * 4, s);
+    hipLaunchKernelGGL(k_lg_degrees, dim3(grid_for(m, kBlock * 4)), dim3(kBlock), 0, s, un, m, user_num, deg, sw);
+    rc = sort_keys_u64(tmp, tb, sw, ss, m, 64, s);
+    if (rc) { (void)hipFree(g->arena); delete g; return fail(rc); }
+    hipLaunchKernelGGL(k_lg_entries, dim3(grid_for(2 * m, kBlock * 4)), dim3(kBlock), 0, s, un, ss, m, user_num, deg,
+                       g->ekey, g->esu, g->coef);
+    if (hipStreamSynchronize(s) != hipSuccess || hipGetLastError() != hipSuccess) {
+        set_error("lgcn_graph_create: kernel failure");
+        (void)hipFree(g->arena); delete g;
+        return fail(DAISY_ERR_HIP);
+    }
+    (void)hipFree(scratch);
+    *out = g;
+    return DAISY_OK;
+}
+
+int daisy_lgcn_graph_destroy(daisy_lgcn_graph *g) {
+    if (!g) return DAISY_OK;
+    if (g->arena) (void)hipFree(g->arena);
+    delete g;
+    return DAISY_OK;
+}
+
+int64_t daisy_lgcn_graph_nnz(const daisy_lgcn_graph *g) { return g ? g->nnz : 0; }
+size_t daisy_lgcn_graph_bytes(const daisy_lgcn_graph *g) { return g ? g->arena_bytes : 0; }
+
+int daisy_lgcn_graph_read(const daisy_lgcn_graph *g, int32_t *row, int32_t *col, float *val,
+                          daisy_stream_t stream) {
+    DAISY_CHECK_ARG(g && row && col && val, "lgcn_graph_read: NULL argument");
+    hipLaunchKernelGGL(k_lg_read, dim3(grid_for(g->nnz, kBlock * 4)), dim3(kBlock), 0, LS(stream), g->ekey, g->esu,
+                       g->coef, g->nnz, row, col, val);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int daisy_lgcn_spmm(const daisy_lgcn_graph *g, const float *X, float *Y, int32_t d, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(g && X && Y && X != Y && d > 0, "lgcn_spmm: bad argument");
+    hipStream_t s = LS(stream);
+    DAISY_HIP(hipMemsetAsync(Y, 0, (size_t)(g->U + g->I) * d * 4, s));
+    return segsum_rows(X, g->coef, g->ekey, g->esu, g->nnz, d, Y, s);
+}
+
+int daisy_lgcn_propagate(const daisy_lgcn_graph *g, const float *E0, int32_t d, int32_t num_layers,
+                         float *work, float *out, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(g && E0 && work && out && d > 0 && num_layers >= 0, "lgcn_propagate: bad argument");
+    hipStream_t s = LS(stream);
+    const int64_t nel = (g->U + g->I) * (int64_t)d;
+    const int grid = grid_for(nel, kBlock * 4);
+    DAISY_HIP(hipMemcpyAsync(out, E0, (size_t)nel * 4, hipMemcpyDeviceToDevice, s));
+    const float *x = E0;
+    for (int k = 0; k < num_layers; ++k) {
+        float *y = work + (int64_t)(k & 1) * nel;
+        int rc = daisy_lgcn_spmm(g, x, y, d, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_lg_axpby, dim3(grid), dim3(kBlock), 0, s, y, 1.f, 1.f, out, nel);   // out += E_{k+1}
+        x = y;
+    }
+    hipLaunchKernelGGL(k_lg_axpby, dim3(grid), dim3(kBlock), 0, s, (const float *)nullptr, 0.f,
+                       1.f / (float)(num_layers + 1), out, nel);                                  // mean (:126)
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int daisy_lgcn_backprop(const daisy_lgcn_graph *g, const float *G, int32_t d, int32_t num_layers, float *work,
+                        float *dE0, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(g && G && work && dE0 && d > 0 && num_layers >= 0, "lgcn_backprop: bad argument");
+    hipStream_t s = LS(stream);
+    const int64_t nel = (g->U + g->I) * (int64_t)d;
+    const int grid = grid_for(nel, kBlock * 4);
+    const float *t = G;                               // Horner: T <- G + A T, L times
+    for (int k = 0; k < num_layers; ++k) {
+        float *y = work + (int64_t)(k & 1) * nel;
+        int rc = daisy_lgcn_spmm(g, t, y, d, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_lg_axpby, dim3(grid), dim3(kBlock), 0, s, G, 1.f, 1.f, y, nel);
+        t = y;
+    }
+    hipLaunchKernelGGL(k_lg_axpby, dim3(grid), dim3(kBlock), 0, s, t, 1.f / (float)(num_layers + 1), 1.f, dE0, nel);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int daisy_lgcn_reg_grad(const float *E0, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B,
+                        int64_t user_num, int32_t d, int32_t pointwise, float reg_1, float reg_2,
+                        const double *stats, float *dE0, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(E0 && u && i && j && stats && dE0 && B > 0 && d > 0, "lgcn_reg_grad: bad argument");
+    if (reg_1 == 0.f && reg_2 == 0.f) return DAISY_OK;
+    hipStream_t s = LS(stream);
+    hipLaunchKernelGGL(k_lg_reg, dim3(grid_for(B * 3, kBlock / 16 * 2)), dim3(kBlock), 0, s, E0, u, i, j, B, user_num,
+                       (int)d, (int)pointwise, reg_1, reg_2, stats, dE0);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+}  // extern "C"

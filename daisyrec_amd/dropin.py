@@ -22,6 +22,12 @@ def install(sampler=False):
     from .model.NeuMFRecommender import NeuMF
     ref_nm = importlib.import_module("daisy.model.NeuMFRecommender")
     ref_nm.NeuMF = NeuMF
+    from .model.LightGCNRecommender import LightGCN
+    try:                                   # imports scipy; the reference module itself needs it too
+        ref_lg = importlib.import_module("daisy.model.LightGCNRecommender")
+        ref_lg.LightGCN = LightGCN
+    except ImportError:
+        pass
     if sampler:
         from .utils.sampler import BasicNegtiveSampler
 

@@ -2,3 +2,4 @@ from .AbstractRecommender import AbstractRecommender, GeneralRecommender  # noqa
 from .MFRecommender import MF  # noqa: F401
 from .FMRecommender import FM  # noqa: F401
 from .NeuMFRecommender import NeuMF  # noqa: F401
+from .LightGCNRecommender import LightGCN  # noqa: F401

@@ -491,3 +491,76 @@ def gemm_nt(A, B):
     check(lib.daisy_gemm_nt_f32(_ptr(A, torch.float32, "A"), _ptr(B, torch.float32, "B"),
                                 _ptr(out, torch.float32, "C"), M, Nn, K, _stream()))
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# LightGCN (LightGCNRecommender.py) - see include/daisyrec_amd.h
+# ------------------------------------------------------------------------------------------------
+class LgcnGraph:
+    """Normalised adjacency A_hat = D^-1/2 A D^-1/2 of the user-item graph on the device
+    (LightGCNRecommender.py:74-107) and the products built on it."""
+
+    def __init__(self, users, items, user_num, item_num):
+        users = users.to(torch.int32).contiguous()
+        items = items.to(torch.int32).contiguous()
+        self.device = users.device
+        self.U, self.I = int(user_num), int(item_num)
+        self.N = self.U + self.I
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib.daisy_lgcn_graph_create(C.byref(self._h), _ptr(users, torch.int32, "users"),
+                                              _ptr(items, torch.int32, "items"), users.numel(), self.U, self.I,
+                                              _stream()))
+        self.nnz = int(lib.daisy_lgcn_graph_nnz(self._h))
+        self._work = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            lib.daisy_lgcn_graph_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def nbytes(self):
+        return int(lib.daisy_lgcn_graph_bytes(self._h))
+
+    def coo(self):
+        row = torch.empty(self.nnz, dtype=torch.int32, device=self.device)
+        col = torch.empty_like(row)
+        val = torch.empty(self.nnz, dtype=torch.float32, device=self.device)
+        check(lib.daisy_lgcn_graph_read(self._h, _ptr(row, torch.int32, "row"), _ptr(col, torch.int32, "col"),
+                                        _ptr(val, torch.float32, "val"), _stream()))
+        return row, col, val
+
+    def _scratch(self, d):
+        if self._work is None or self._work.numel() < 2 * self.N * d:
+            self._work = torch.empty(2 * self.N * d, dtype=torch.float32, device=self.device)
+        return self._work
+
+    def spmm(self, X):
+        Y = torch.empty_like(X)
+        check(lib.daisy_lgcn_spmm(self._h, _ptr(X, torch.float32, "X"), _ptr(Y, torch.float32, "Y"), X.shape[1],
+                                  _stream()))
+        return Y
+
+    def propagate(self, E0, num_layers, out=None):
+        """LightGCN.forward (LightGCNRecommender.py:117-129): mean_k A_hat^k E0, [N, d]."""
+        out = torch.empty_like(E0) if out is None else out
+        w = self._scratch(E0.shape[1])
+        check(lib.daisy_lgcn_propagate(self._h, _ptr(E0, torch.float32, "E0"), E0.shape[1], int(num_layers),
+                                       _ptr(w, torch.float32, "work"), _ptr(out, torch.float32, "out"), _stream()))
+        return out
+
+    def backprop(self, G, num_layers, dE0):
+        """dE0 += 1/(L+1) sum_k A_hat^k G (the transpose of propagate; A_hat is symmetric)."""
+        w = self._scratch(G.shape[1])
+        check(lib.daisy_lgcn_backprop(self._h, _ptr(G, torch.float32, "G"), G.shape[1], int(num_layers),
+                                      _ptr(w, torch.float32, "work"), _ptr(dE0, torch.float32, "dE0"), _stream()))
+
+
+def lgcn_reg_grad(E0, u, i, j, user_num, pointwise, reg_1, reg_2, stats, dE0):
+    check(lib.daisy_lgcn_reg_grad(_ptr(E0, torch.float32, "E0"), _ptr(u, torch.int32, "u"), _ptr(i, torch.int32, "i"),
+                                  _ptr(j, torch.int32, "j"), u.numel(), int(user_num), E0.shape[1], int(bool(pointwise)),
+                                  float(reg_1), float(reg_2), _ptr(stats, torch.float64, "stats"),
+                                  _ptr(dE0, torch.float32, "dE0"), _stream()))

@@ -375,6 +375,43 @@ int daisy_full_topk_from_scores(const float *scores, int64_t item_num, int32_t t
 int daisy_gemm_nt_f32(const float *A, const float *B, float *C, int64_t M, int32_t N, int32_t K,
                       daisy_stream_t stream);
 
+/* -------------------------------------------------------------------------
+ * LightGCN (daisy/model/LightGCNRecommender.py:17-210)
+ *   A_hat = D^-1/2 A D^-1/2 over the N = U + I nodes of the bipartite interaction graph  (:74-107)
+ *   out   = mean(E_0, A_hat E_0, ..., A_hat^L E_0),  E_0 = [embed_user; embed_item]        (:117-129)
+ * and the BPR (or HL/TL/CL/SL) loss of MF on the rows of `out`, regularisers on the rows of E_0
+ * (:131-169).  The propagation is a sparse x dense product: HBM-bound row gathers + a segmented
+ * reduction, run on the same kernel as MF's item pass.  The loss / gradient-wrt-out part IS the MF
+ * path (daisy_bpr_forward / _item_grad_data / _user_grad on the two halves of `out`); these entry
+ * points add the graph, the propagation and its transpose (A_hat is symmetric).
+ * ---------------------------------------------------------------------- */
+typedef struct daisy_lgcn_graph daisy_lgcn_graph;
+/* build A_hat from the training interactions (device int32[n] each; duplicate pairs collapse like the
+ * reference's dict, :88-90).  Values are formed in float64 and stored as float32 like scipy -> torch
+ * (:93-105).  Synchronises the stream once (number of distinct pairs). */
+int daisy_lgcn_graph_create(daisy_lgcn_graph **out, const int32_t *users, const int32_t *items, int64_t n,
+                            int64_t user_num, int64_t item_num, daisy_stream_t stream);
+int daisy_lgcn_graph_destroy(daisy_lgcn_graph *g);
+int64_t daisy_lgcn_graph_nnz(const daisy_lgcn_graph *g);          /* stored entries = 2 x distinct pairs */
+size_t daisy_lgcn_graph_bytes(const daisy_lgcn_graph *g);
+/* COO copy of A_hat, rows then columns ascending (inspection / tests): int32[nnz], int32[nnz], f32[nnz] */
+int daisy_lgcn_graph_read(const daisy_lgcn_graph *g, int32_t *row, int32_t *col, float *val,
+                          daisy_stream_t stream);
+/* Y = A_hat X, X and Y f32[N, d] (Y != X) */
+int daisy_lgcn_spmm(const daisy_lgcn_graph *g, const float *X, float *Y, int32_t d, daisy_stream_t stream);
+/* LightGCN.forward (:117-129): out = mean_k A_hat^k E0;  work: f32[2*N*d] scratch */
+int daisy_lgcn_propagate(const daisy_lgcn_graph *g, const float *E0, int32_t d, int32_t num_layers,
+                         float *work, float *out, daisy_stream_t stream);
+/* its transpose applied to the gradient G = dL/d out:  dE0 += 1/(L+1) sum_k A_hat^k G */
+int daisy_lgcn_backprop(const daisy_lgcn_graph *g, const float *G, int32_t d, int32_t num_layers, float *work,
+                        float *dE0, daisy_stream_t stream);
+/* regulariser gradient on the ego rows of one batch (:150-163): for every sample
+ * dE0[row] += reg_1*sign(e) + reg_2*e/|rows|_F for row in (u, U+i, U+j [pairwise only]); the three
+ * Frobenius norms are stats[DAISY_ST_NORM_U/I/J] of a finalized MF context whose sums were taken on E0 */
+int daisy_lgcn_reg_grad(const float *E0, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B,
+                        int64_t user_num, int32_t d, int32_t pointwise, float reg_1, float reg_2,
+                        const double *stats, float *dE0, daisy_stream_t stream);
+
 /* micro-benchmarks of the memory system used to place the kernels on the
  * roofline (tools/membench.py); not part of the reference surface. */
 int daisy_membench(int32_t what, float *table, int64_t rows, int32_t d, const int32_t *idx,
