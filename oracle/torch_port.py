@@ -87,3 +87,37 @@ class TorchNeuMF(nn.Module):
         out.backward()
         self.opt.step()
         return float(out.item())
+
+
+class TorchLightGCN(nn.Module):
+    """The reference's LightGCN training step out of stock PyTorch pieces (LightGCNRecommender.py:109-169:
+    torch.sparse.mm propagation recomputed per batch, dense Adam) - the `cpu_baseline` leg of
+    tools/bench_lightgcn.py.  `adj` is a torch sparse COO tensor of the normalised adjacency."""
+
+    def __init__(self, user_num, item_num, d, num_layers, adj, lr=0.01, gamma=1e-10):
+        super().__init__()
+        self.U, self.I, self.L, self.gamma = user_num, item_num, num_layers, gamma
+        self.embed_user, self.embed_item = nn.Embedding(user_num, d), nn.Embedding(item_num, d)
+        nn.init.xavier_uniform_(self.embed_user.weight)
+        nn.init.xavier_uniform_(self.embed_item.weight)
+        self.adj = adj
+        self.opt = torch.optim.Adam(self.parameters(), lr=lr)
+
+    def forward(self):
+        e = torch.cat([self.embed_user.weight, self.embed_item.weight], 0)
+        acc = [e]
+        for _ in range(self.L):
+            e = torch.sparse.mm(self.adj, e)
+            acc.append(e)
+        out = torch.stack(acc, 1).mean(1)
+        return torch.split(out, [self.U, self.I])
+
+    def step(self, u, i, j):
+        self.zero_grad()
+        eu, ei = self.forward()
+        pos = (eu[u] * ei[i]).sum(1)
+        neg = (eu[u] * ei[j]).sum(1)
+        out = -(self.gamma + torch.sigmoid(pos - neg)).log().sum()
+        out.backward()
+        self.opt.step()
+        return float(out.item())
