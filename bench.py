@@ -230,7 +230,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_step")
+                t = json.load(open(tpath))          # per-interaction figure of the profiled run x this run's batch
+                traffic = t["hbm_bytes_per_interaction"] * B if "hbm_bytes_per_interaction" in t else None
             except Exception:
                 traffic = None
         out = {

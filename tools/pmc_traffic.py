@@ -46,6 +46,7 @@ def short(name):
 
 def main():
     rd_dir, wr_dir, out = sys.argv[1:4]
+    batch = int(sys.argv[4]) if len(sys.argv) > 4 else 2097152     # interactions per step of the profiled runs (bench.py default)
     rd, wr = load(rd_dir, "FETCH_SIZE"), load(wr_dir, "WRITE_SIZE")
     table = {}
     steps = None
@@ -59,7 +60,8 @@ def main():
             if k == "k_fwd":
                 steps = cnt
     per_step = sum(v["read_bytes_per_launch"] + v["write_bytes_per_launch"] for v in table.values())
-    res = {"hbm_bytes_per_step": per_step, "steps_profiled": steps, "per_kernel": table,
+    res = {"hbm_bytes_per_step": per_step, "batch_per_step": batch, "hbm_bytes_per_interaction": per_step / batch,
+           "steps_profiled": steps, "per_kernel": table,
            "corrections": "FETCH_SIZE KiB x1024 x2 (gfx950 wide-read undercount), WRITE_SIZE KiB x1024 x1; "
                           "fabric-side counters: Infinity-Cache hits included (upper bound of HBM bytes)"}
     json.dump(res, open(out, "w"), indent=1)
