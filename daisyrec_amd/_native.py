@@ -103,6 +103,8 @@ SIGNATURES = {
     "daisy_lgcn_propagate": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p]),
     "daisy_lgcn_backprop": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p]),
     "daisy_lgcn_reg_grad": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _f32, _f32, _p, _p, _p]),
+    "daisy_axpby_f32": (C.c_int, [_p, _f32, _f32, _p, _i64, _i32, _p]),
+    "daisy_csr_row_sum": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
     "daisy_csr_workspace_bytes": (_sz, [_i64]),
     "daisy_build_user_csr": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _sz, _p]),
     "daisy_sample_neg_per_user": (C.c_int, [_p, _p, _i64, _i64, _i32, _u64, _u64, _p, _p]),

@@ -64,6 +64,32 @@ __global__ void k_lg_axpby(const float *__restrict__ x, float a, float b, float 
         y[e] = (x ? a * x[e] : 0.f) + b * y[e];
 }
 
+// out[r] = sum of X[cols[e]] over e in [indptr[r], indptr[r+1]) - one lane group per row (rows here are a
+// user's training items: tens to a few thousand entries)
+__global__ __launch_bounds__(kBlock) void k_csr_row_sum(const int64_t *__restrict__ indptr,
+                                                        const int32_t *__restrict__ cols,
+                                                        const float *__restrict__ X, int64_t R, int d,
+                                                        float *__restrict__ out) {
+    const int lane = threadIdx.x % 16, group = threadIdx.x / 16;
+    const int64_t gstride = (int64_t)gridDim.x * (kBlock / 16);
+    for (int64_t r = (int64_t)blockIdx.x * (kBlock / 16) + group; r < R; r += gstride) {
+        const int64_t e0 = indptr[r], e1 = indptr[r + 1];
+        if (e0 == e1) continue;                          // rows without entries keep their contents
+        for (int c = lane; c < d; c += 16) {
+            float s = 0.f;
+            for (int64_t e = e0; e < e1; ++e) s += X[(int64_t)cols[e] * d + c];
+            out[r * d + c] = s;
+        }
+    }
+}
+
+__global__ void k_axpby_zero(float *__restrict__ x, float a, float b, float *__restrict__ y, int64_t n, int zero_x) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        y[e] = a * x[e] + b * y[e];
+        if (zero_x) x[e] = 0.f;
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_lg_reg(const float *__restrict__ E0, const int32_t *__restrict__ u,
                                                    const int32_t *__restrict__ i, const int32_t *__restrict__ j,
                                                    int64_t B, int64_t U, int d, int pointwise, float reg_1,
@@ -232,6 +258,23 @@ int daisy_lgcn_backprop(const daisy_lgcn_graph *g, const float *G, int32_t d, in
         t = y;
     }
     hipLaunchKernelGGL(k_lg_axpby, dim3(grid), dim3(kBlock), 0, s, t, 1.f / (float)(num_layers + 1), 1.f, dE0, nel);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int daisy_axpby_f32(float *x, float a, float b, float *y, int64_t n, int32_t zero_x, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(x && y && n > 0, "axpby_f32: bad argument");
+    hipLaunchKernelGGL(k_axpby_zero, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, LS(stream), x, a, b, y, n,
+                       (int)zero_x);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int daisy_csr_row_sum(const int64_t *indptr, const int32_t *cols, const float *X, int64_t rows, int32_t d,
+                      float *out, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(indptr && cols && X && out && rows > 0 && d > 0, "csr_row_sum: bad argument");
+    hipLaunchKernelGGL(k_csr_row_sum, dim3(grid_for(rows, kBlock / 16)), dim3(kBlock), 0, LS(stream), indptr, cols, X,
+                       rows, (int)d, out);
     DAISY_LAUNCH_CHECK();
     return DAISY_OK;
 }

@@ -22,6 +22,9 @@ def install(sampler=False):
     from .model.NeuMFRecommender import NeuMF
     ref_nm = importlib.import_module("daisy.model.NeuMFRecommender")
     ref_nm.NeuMF = NeuMF
+    from .model.Item2VecRecommender import Item2Vec
+    ref_iv = importlib.import_module("daisy.model.Item2VecRecommender")
+    ref_iv.Item2Vec = Item2Vec
     from .model.LightGCNRecommender import LightGCN
     try:                                   # imports scipy; the reference module itself needs it too
         ref_lg = importlib.import_module("daisy.model.LightGCNRecommender")

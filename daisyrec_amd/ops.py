@@ -564,3 +564,16 @@ def lgcn_reg_grad(E0, u, i, j, user_num, pointwise, reg_1, reg_2, stats, dE0):
                                   _ptr(j, torch.int32, "j"), u.numel(), int(user_num), E0.shape[1], int(bool(pointwise)),
                                   float(reg_1), float(reg_2), _ptr(stats, torch.float64, "stats"),
                                   _ptr(dE0, torch.float32, "dE0"), _stream()))
+
+
+def axpby(x, a, b, y, zero_x=False):
+    """y = a*x + b*y (and x = 0 when zero_x)."""
+    check(lib.daisy_axpby_f32(_ptr(x, torch.float32, "x"), float(a), float(b), _ptr(y, torch.float32, "y"), y.numel(),
+                              int(bool(zero_x)), _stream()))
+
+
+def csr_row_sum(indptr, cols, X, out):
+    """out[r] = sum of X[cols[e]] over the CSR row r (rows without entries untouched)."""
+    check(lib.daisy_csr_row_sum(_ptr(indptr, torch.int64, "indptr"), _ptr(cols, torch.int32, "cols"),
+                                _ptr(X, torch.float32, "X"), indptr.numel() - 1, X.shape[1],
+                                _ptr(out, torch.float32, "out"), _stream()))

@@ -412,6 +412,20 @@ int daisy_lgcn_reg_grad(const float *E0, const int32_t *u, const int32_t *i, con
                         int64_t user_num, int32_t d, int32_t pointwise, float reg_1, float reg_2,
                         const double *stats, float *dE0, daisy_stream_t stream);
 
+/* -------------------------------------------------------------------------
+ * Item2Vec (rest of SURVEY.md §8f rank 4; daisy/model/Item2VecRecommender.py:15-112).
+ * Training IS the point-wise MF path on ONE shared table S (rows (target, context, label), loss CL, no
+ * regulariser): daisy_bpr_forward(P = Q = S) -> daisy_bpr_user_grad (targets) + daisy_bpr_item_grad_data
+ * (contexts) into two gradient buffers -> daisy_axpby_f32 -> daisy_adam_dense.  After training the user
+ * table is user_embedding[u] = sum of S over the user's training items (:56-59): daisy_csr_row_sum on the
+ * CSR of daisy_build_user_csr.  predict / rank / full_rank are the MF entry points.
+ * ---------------------------------------------------------------------- */
+/* y = a*x + b*y over n floats; zero_x != 0 also clears x (a consumed gradient buffer) */
+int daisy_axpby_f32(float *x, float a, float b, float *y, int64_t n, int32_t zero_x, daisy_stream_t stream);
+/* out[r] = sum_{e in [indptr[r], indptr[r+1])} X[cols[e]]  (rows with no entries are left untouched) */
+int daisy_csr_row_sum(const int64_t *indptr, const int32_t *cols, const float *X, int64_t rows, int32_t d,
+                      float *out, daisy_stream_t stream);
+
 /* micro-benchmarks of the memory system used to place the kernels on the
  * roofline (tools/membench.py); not part of the reference surface. */
 int daisy_membench(int32_t what, float *table, int64_t rows, int32_t d, const int32_t *idx,
