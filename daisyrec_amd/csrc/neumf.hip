@@ -49,7 +49,44 @@ struct GemmOp {
     uint64_t drop_seed;
     int64_t k_chunk;                      // reduction range per blockIdx.z
     int vec_a, vec_b;                     // set by launch_gemm: operand qualifies for the float4 path
+    int bf16;                             // throughput mode: bf16-input MFMA where the tile shape allows it
 };
+
+template <int WN, int EPI, bool FAST, bool DROP>
+__device__ __forceinline__ void gemm_epilogue(const GemmOp &op, floatx16 (&acc)[2][WN], int64_t m0, int n0, int wm,
+                                              int wn, int lane) {
+    // lane holds column (lane % 32), rows (i/4)*8 + (lane/32)*4 + i%4 of each 32x32 block (all MFMA
+    // 32x32 shapes share this C/D map on gfx950).  epilogue: lane holds column (lane % 32), rows (i/4)*8 + (lane/32)*4 + i%4 of each 32x32 block.
+    // 32-bit offsets from the tile origin (a tile spans < 2^31 elements of C: 128 rows x ldc)
+    const int scn = op.scn ? (int)op.scn : 1;
+    float *__restrict__ Ct = op.C + m0 * op.ldc + (int64_t)n0 * scn;
+    const float *__restrict__ Gt = (EPI == EPI_GATE && op.gate) ? op.gate + m0 * op.ldg + n0 : nullptr;
+    const int ldc = (int)op.ldc, ldg = (int)op.ldg;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) {
+            const int nl = wn * 32 * WN + ni * 32 + lane % 32;
+            float bias = 0.f;
+            if constexpr (EPI == EPI_BIAS_RELU) bias = (FAST || n0 + nl < op.N) ? op.bias[n0 + nl] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int ml = wm * 64 + mi * 32 + (i / 4) * 8 + (lane / 32) * 4 + (i % 4);
+                if (!FAST && (m0 + ml >= op.M || n0 + nl >= op.N)) continue;
+                float v = acc[mi][ni][i];
+                if constexpr (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
+                if constexpr (EPI == EPI_GATE)
+                    if (Gt) v = (Gt[ml * ldg + nl] > 0.f) ? v * op.gate_scale : 0.f;
+                if constexpr (DROP)
+                    if (op.drop_thresh)
+                        v = drop_keep(op.drop_seed, op.drop_stream,
+                                      (uint64_t)(m0 + ml) * (uint64_t)op.N + (uint64_t)(n0 + nl), op.drop_thresh)
+                                ? v * op.drop_scale : 0.f;
+                if constexpr (EPI == EPI_ATOMIC) unsafeAtomicAdd(Ct + ml * ldc + nl * scn, v);
+                else Ct[ml * ldc + nl * scn] = v;
+            }
+        }
+}
 
 // C = A * B^T-style contraction over k with arbitrary strides.  WN: 32-column MFMA blocks per wave
 // (block tile = 128 x 64*WN).  Operand tiles go global -> registers -> LDS (k-major, so the MFMA
@@ -192,36 +229,125 @@ __global__ __launch_bounds__(kBlock) void k_gemm(GemmOp op) {
         }
     }
 
-    // ---- epilogue: lane holds column (lane % 32), rows (i/4)*8 + (lane/32)*4 + i%4 of each 32x32 block.
-    // 32-bit offsets from the tile origin (a tile spans < 2^31 elements of C: 128 rows x ldc)
-    const int scn = op.scn ? (int)op.scn : 1;
-    float *__restrict__ Ct = op.C + m0 * op.ldc + (int64_t)n0 * scn;
-    const float *__restrict__ Gt = (EPI == EPI_GATE && op.gate) ? op.gate + m0 * op.ldg + n0 : nullptr;
-    const int ldc = (int)op.ldc, ldg = (int)op.ldg;
+    gemm_epilogue<WN, EPI, FAST, DROP>(op, acc, m0, n0, wm, wn, lane);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bf16-input variant (throughput mode; BASELINE configs[3] names it): operands stay fp32 in HBM, are
+// rounded to bf16 (nearest-even) on their way into LDS and multiplied by v_mfma_f32_32x32x16_bf16
+// (fp32 accumulate, 16x the fp32 MFMA rate).  LDS tiles are row-major with k contiguous - a lane's
+// fragment is 8 consecutive k = one 16-byte read - at an 80-byte row pitch (odd multiple of 16 B:
+// conflict free).  Interior, aligned tiles only (launch_gemm falls back to the fp32 kernel otherwise).
+// ---------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kBK16 = 32, kLdk16 = kBK16 + 8;
+
+__device__ __forceinline__ uint32_t bf16_rne(float f) {
+    uint32_t u = __float_as_uint(f);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+template <int WN, int EPI, bool DROP>
+__global__ __launch_bounds__(kBlock) void k_gemm_bf16(GemmOp op) {
+    constexpr int BM = kGemmBM, BN = 64 * WN;
+    constexpr int QA = BM * kBK16 / kBlock / 4, QB = BN * kBK16 / kBlock / 4;      // float4 loads per thread per tile
+    __shared__ __attribute__((aligned(16))) uint16_t As[2][BM * kLdk16];
+    __shared__ __attribute__((aligned(16))) uint16_t Bs[2][BN * kLdk16];
+    const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+    const int wm = wave / 2, wn = wave % 2;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int64_t k_lo = (int64_t)blockIdx.z * op.k_chunk;
+    const int64_t k_hi = (k_lo + op.k_chunk < op.K) ? (k_lo + op.k_chunk) : op.K;
+    const bool a_kfast = (op.sak == 1), b_kfast = (op.sbk == 1);
+
+    floatx16 acc[2][WN];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < WN; ++ni) {
-            const int nl = wn * 32 * WN + ni * 32 + lane % 32;
-            float bias = 0.f;
-            if constexpr (EPI == EPI_BIAS_RELU) bias = (FAST || n0 + nl < op.N) ? op.bias[n0 + nl] : 0.f;
+        for (int ni = 0; ni < WN; ++ni)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int ml = wm * 64 + mi * 32 + (i / 4) * 8 + (lane / 32) * 4 + (i % 4);
-                if (!FAST && (m0 + ml >= op.M || n0 + nl >= op.N)) continue;
-                float v = acc[mi][ni][i];
-                if constexpr (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
-                if constexpr (EPI == EPI_GATE)
-                    if (Gt) v = (Gt[ml * ldg + nl] > 0.f) ? v * op.gate_scale : 0.f;
-                if constexpr (DROP)
-                    if (op.drop_thresh)
-                        v = drop_keep(op.drop_seed, op.drop_stream,
-                                      (uint64_t)(m0 + ml) * (uint64_t)op.N + (uint64_t)(n0 + nl), op.drop_thresh)
-                                ? v * op.drop_scale : 0.f;
-                if constexpr (EPI == EPI_ATOMIC) unsafeAtomicAdd(Ct + ml * ldc + nl * scn, v);
-                else Ct[ml * ldc + nl * scn] = v;
+            for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+
+    float4 ra[QA], rb[QB];
+    auto load_op = [&](const float *__restrict__ P, int64_t srow, int64_t sk, bool kfast, int64_t row0, int64_t kt,
+                       auto &r, auto rows_c, auto q_c) {
+        constexpr int ROWS = decltype(rows_c)::value, Q = decltype(q_c)::value;
+        if (kfast) {                                       // 8 lanes cover the 32 k of one row
+            const float *src = P + (row0 + tid / 8) * srow + kt + (tid % 8) * 4;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) r[q] = *reinterpret_cast<const float4 *>(src + (int64_t)q * (kBlock / 8) * srow);
+        } else {                                           // ROWS/4 lanes cover one k
+            const float *src = P + row0 + (tid % (ROWS / 4)) * 4 + (kt + tid / (ROWS / 4)) * sk;
+#pragma unroll
+            for (int q = 0; q < Q; ++q)
+                r[q] = *reinterpret_cast<const float4 *>(src + (int64_t)q * (kBlock / (ROWS / 4)) * sk);
+        }
+    };
+    auto store_op = [&](uint16_t *__restrict__ S, bool kfast, auto &r, auto rows_c, auto q_c) {
+        constexpr int ROWS = decltype(rows_c)::value, Q = decltype(q_c)::value;
+        if (kfast) {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int row = tid / 8 + q * (kBlock / 8), k = (tid % 8) * 4;
+                uint2 pk;
+                pk.x = bf16_rne(r[q].x) | (bf16_rne(r[q].y) << 16);
+                pk.y = bf16_rne(r[q].z) | (bf16_rne(r[q].w) << 16);
+                *reinterpret_cast<uint2 *>(S + row * kLdk16 + k) = pk;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < Q; ++q) {
+                const int row = (tid % (ROWS / 4)) * 4, k = tid / (ROWS / 4) + q * (kBlock / (ROWS / 4));
+                S[(row + 0) * kLdk16 + k] = (uint16_t)bf16_rne(r[q].x);
+                S[(row + 1) * kLdk16 + k] = (uint16_t)bf16_rne(r[q].y);
+                S[(row + 2) * kLdk16 + k] = (uint16_t)bf16_rne(r[q].z);
+                S[(row + 3) * kLdk16 + k] = (uint16_t)bf16_rne(r[q].w);
             }
         }
+    };
+    using RA = std::integral_constant<int, BM>; using RB = std::integral_constant<int, BN>;
+    using NA = std::integral_constant<int, QA>; using NB = std::integral_constant<int, QB>;
+
+    if (k_lo < k_hi) {
+        load_op(op.A, op.sam, op.sak, a_kfast, m0, k_lo, ra, RA{}, NA{});
+        load_op(op.B, op.sbn, op.sbk, b_kfast, (int64_t)n0, k_lo, rb, RB{}, NB{});
+        store_op(As[0], a_kfast, ra, RA{}, NA{});
+        store_op(Bs[0], b_kfast, rb, RB{}, NB{});
+        __syncthreads();
+        int cur = 0;
+        for (int64_t kt = k_lo; kt < k_hi; kt += kBK16) {
+            const bool more = kt + kBK16 < k_hi;
+            if (more) {
+                load_op(op.A, op.sam, op.sak, a_kfast, m0, kt + kBK16, ra, RA{}, NA{});
+                load_op(op.B, op.sbn, op.sbk, b_kfast, (int64_t)n0, kt + kBK16, rb, RB{}, NB{});
+            }
+            const uint16_t *as = As[cur] + (wm * 64 + lane % 32) * kLdk16 + (lane / 32) * 8;
+            const uint16_t *bs = Bs[cur] + (wn * 32 * WN + lane % 32) * kLdk16 + (lane / 32) * 8;
+#pragma unroll
+            for (int ks = 0; ks < kBK16 / 16; ++ks) {
+                bf16x8 a[2], b[WN];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    a[mi] = *reinterpret_cast<const bf16x8 *>(as + mi * 32 * kLdk16 + ks * 16);
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni)
+                    b[ni] = *reinterpret_cast<const bf16x8 *>(bs + ni * 32 * kLdk16 + ks * 16);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            }
+            if (more) {
+                store_op(As[cur ^ 1], a_kfast, ra, RA{}, NA{});
+                store_op(Bs[cur ^ 1], b_kfast, rb, RB{}, NB{});
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    gemm_epilogue<WN, EPI, true, DROP>(op, acc, m0, n0, wm, wn, lane);
 }
 
 // float4 path preconditions: unit stride along one dimension, the other stride and the base 16-byte aligned
@@ -242,9 +368,14 @@ static void launch_gemm(GemmOp op, hipStream_t s) {
     const bool fast = op.vec_a && op.vec_b && op.M % kGemmBM == 0 && op.N % bn == 0 && op.K % kBK == 0 &&
                       (splits == 1 || op.k_chunk % kBK == 0);
     dim3 grid((unsigned)((op.M + kGemmBM - 1) / kGemmBM), (unsigned)((op.N + bn - 1) / bn), (unsigned)splits);
+    const bool bf16 = op.bf16 && fast && op.K % kBK16 == 0 && (splits == 1 || op.k_chunk % kBK16 == 0);
     auto go = [&](auto wn_c, auto fast_c, auto drop_c) {
-        hipLaunchKernelGGL((k_gemm<decltype(wn_c)::value, EPI, decltype(fast_c)::value, decltype(drop_c)::value>), grid,
-                           dim3(kBlock), 0, s, op);
+        if (bf16)
+            hipLaunchKernelGGL((k_gemm_bf16<decltype(wn_c)::value, EPI, decltype(drop_c)::value>), grid, dim3(kBlock), 0,
+                               s, op);
+        else
+            hipLaunchKernelGGL((k_gemm<decltype(wn_c)::value, EPI, decltype(fast_c)::value, decltype(drop_c)::value>),
+                               grid, dim3(kBlock), 0, s, op);
     };
     using T = std::true_type; using F = std::false_type;
     using W1 = std::integral_constant<int, 1>; using W2 = std::integral_constant<int, 2>;
@@ -531,6 +662,7 @@ struct daisy_neumf_ctx {
     size_t arena_bytes;
     float *X[DAISY_NEUMF_MAX_LAYERS + 1];    // X[0] = (dropped) concat input, X[l] = layer outputs
     float *G, *pred, *dpred, *DZ[2];
+    int bf16;                                // daisy_neumf_ctx_set_precision
 };
 
 static inline hipStream_t NS(daisy_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
@@ -563,6 +695,7 @@ static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p,
             op.M = R; op.N = ctx->width[l]; op.K = ctx->width[l - 1];
             op.bias = p->b[l - 1];
             op.k_chunk = op.K;
+            op.bf16 = ctx->bf16;
             if (l < L && thresh) {       // the Dropout in front of Linear l+1 acts on this output
                 op.drop_thresh = thresh; op.drop_scale = scale; op.drop_seed = seed; op.drop_stream = (uint32_t)(l + 1);
             }
@@ -593,6 +726,7 @@ int daisy_neumf_ctx_create(daisy_neumf_ctx **out, int64_t max_rows, int32_t fact
     daisy_neumf_ctx *c = new daisy_neumf_ctx();
     c->max_rows = max_rows; c->U = user_num; c->I = item_num;
     c->d = factors; c->L = num_layers; c->model = model;
+    c->bf16 = 0;
     c->dm = factors << (num_layers - 1);
     c->width[0] = 2 * c->dm;
     for (int l = 1; l <= num_layers; ++l) c->width[l] = c->width[l - 1] / 2;
@@ -625,6 +759,12 @@ int daisy_neumf_ctx_destroy(daisy_neumf_ctx *ctx) {
 }
 
 size_t daisy_neumf_ctx_bytes(const daisy_neumf_ctx *ctx) { return ctx ? ctx->arena_bytes : 0; }
+
+int daisy_neumf_ctx_set_precision(daisy_neumf_ctx *ctx, int32_t bf16_gemm) {
+    DAISY_CHECK_ARG(ctx != nullptr, "neumf_ctx_set_precision: NULL context");
+    ctx->bf16 = bf16_gemm ? 1 : 0;
+    return DAISY_OK;
+}
 
 int daisy_neumf_scores(daisy_neumf_ctx *ctx, const daisy_neumf_params *params, const int64_t *users,
                        const int64_t *items, int64_t n, int64_t C, float *out, daisy_stream_t stream) {
@@ -691,7 +831,9 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
                 w.M = n_in; w.N = n_out;
             }
             w.K = R;
-            w.k_chunk = 2048;
+            static const int wchunk = getenv("DAISY_WGRAD_CHUNK") ? atoi(getenv("DAISY_WGRAD_CHUNK")) : 2048;
+            w.k_chunk = wchunk;
+            w.bf16 = ctx->bf16;
             launch_gemm<EPI_ATOMIC>(w, s);
             hipLaunchKernelGGL(k_colsum, dim3((unsigned)((n_out + 63) / 64), (unsigned)((R + kColsumRows - 1) / kColsumRows)),
                                dim3(kBlock), 0, s, dz, R, n_out, (int64_t)n_out, g.b[l - 1]);
@@ -701,6 +843,7 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
             x.C = dz_next; x.ldc = n_in;
             x.M = R; x.N = n_in; x.K = n_out;
             x.k_chunk = x.K;
+            x.bf16 = ctx->bf16;
             if (l > 1) {                                  // ReLU (and dropout) gate of x_{l-1}
                 x.gate = ctx->X[l - 1]; x.ldg = n_in; x.gate_scale = scale;
             } else if (thresh) {                          // dropout mask of the concat input
@@ -726,8 +869,14 @@ int daisy_sgd_dense(float *W, float *g, int64_t n, float lr, daisy_stream_t stre
 
 int daisy_gemm_nt_f32(const float *A, const float *B, float *C, int64_t M, int32_t N, int32_t K,
                       daisy_stream_t stream) {
-    DAISY_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "gemm_nt_f32: bad argument");
+    return daisy_gemm_nt(A, B, C, M, N, K, 0, stream);
+}
+
+int daisy_gemm_nt(const float *A, const float *B, float *C, int64_t M, int32_t N, int32_t K, int32_t bf16,
+                  daisy_stream_t stream) {
+    DAISY_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "gemm_nt: bad argument");
     GemmOp op{};
+    op.bf16 = bf16 ? 1 : 0;
     op.A = A; op.sam = K; op.sak = 1;
     op.B = B; op.sbn = K; op.sbk = 1;
     op.C = C; op.ldc = N; op.M = M; op.N = N; op.K = K; op.k_chunk = K;

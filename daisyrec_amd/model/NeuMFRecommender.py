@@ -36,6 +36,9 @@ class NeuMF(GeneralRecommender):
         self.MLP_model = config["MLP_model"]
         self.factors = int(config["factors"])
         self.num_layers = int(config["num_layers"])
+        # knob of the native path (absent from the reference config): 'fp32' = parity mode (default),
+        # 'bf16' = bf16-input MFMA in the MLP tower (throughput mode, BASELINE configs[3])
+        self.precision = str(config.get("precision", "fp32")).lower()
         if self.model not in ("NeuMF-pre",) and self.model not in ops.NEUMF_MODELS:
             # the reference treats every other name as the full model (NeuMFRecommender.py:67-70,118-132)
             self._native_model = "NeuMF"
@@ -129,8 +132,10 @@ class NeuMF(GeneralRecommender):
         return out
 
     def _ctx(self, rows):
-        return ops.NeumfContext(rows, self.factors, self.num_layers, self.embed_user_GMF.num_embeddings,
-                                self.embed_item_GMF.num_embeddings, model=self._native_model, device=self.device)
+        ctx = ops.NeumfContext(rows, self.factors, self.num_layers, self.embed_user_GMF.num_embeddings,
+                               self.embed_item_GMF.num_embeddings, model=self._native_model, device=self.device)
+        ctx.set_precision(self.precision == "bf16")
+        return ctx
 
     # -- reference surface ---------------------------------------------------------------------------
     def forward(self, user, item):

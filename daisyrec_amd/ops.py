@@ -432,6 +432,10 @@ class NeumfContext:
     def nbytes(self):
         return int(lib.daisy_neumf_ctx_bytes(self._h))
 
+    def set_precision(self, bf16_gemm):
+        """True: bf16-input MFMA in the MLP tower (throughput mode); False (default): exact fp32."""
+        check(lib.daisy_neumf_ctx_set_precision(self._h, int(bool(bf16_gemm))))
+
     def scores(self, params, users, items=None, C_=0, n=None):
         """NeuMF.forward in eval mode: see daisy_neumf_scores for the three pair layouts."""
         users = users.to(torch.int64).contiguous()
@@ -483,13 +487,13 @@ def full_topk_from_scores(scores, topk):
     return out
 
 
-def gemm_nt(A, B):
-    """C = A @ B.T on the fp32 MFMA tile kernel of the NeuMF tower (test / bench hook)."""
+def gemm_nt(A, B, bf16=False):
+    """C = A @ B.T on the MFMA tile kernels of the NeuMF tower (test / bench hook)."""
     M, K = A.shape
     Nn = B.shape[0]
     out = torch.empty(M, Nn, dtype=torch.float32, device=A.device)
-    check(lib.daisy_gemm_nt_f32(_ptr(A, torch.float32, "A"), _ptr(B, torch.float32, "B"),
-                                _ptr(out, torch.float32, "C"), M, Nn, K, _stream()))
+    check(lib.daisy_gemm_nt(_ptr(A, torch.float32, "A"), _ptr(B, torch.float32, "B"),
+                            _ptr(out, torch.float32, "C"), M, Nn, K, int(bool(bf16)), _stream()))
     return out
 
 

@@ -218,3 +218,51 @@ def test_neumf_dropout_training_runs_and_learns(kat_neumf):
         m2 = NeuMF({**cfg, "model_name": name, "epochs": 1, "dropout": 0.0})
         m2.fit(loader)
         assert np.isfinite(m2.epoch_losses[0])
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (1024, 256, 512), (384, 64, 96), (128, 128, 32)])
+def test_mfma_gemm_nt_bf16_mode(M, N, K):
+    """bf16-input MFMA variant: exact product of the bf16-rounded operands (fp32 accumulation), asymmetric B."""
+    from daisyrec_amd import ops
+    g = torch.Generator(device=DEV)
+    g.manual_seed(M + K)
+    A = torch.randn(M, K, device=DEV, generator=g)
+    B = torch.randn(N, K, device=DEV, generator=g) + torch.arange(N, device=DEV).view(-1, 1) * 0.01
+    got = ops.gemm_nt(A, B, bf16=True)
+    want = A.bfloat16().double() @ B.bfloat16().double().T
+    assert float((got.double() - want).abs().max()) <= 1e-5 * K * float(want.abs().max() + 1)
+    exact = A.double() @ B.double().T
+    assert float((got.double() - exact).abs().max()) <= 2e-2 * float(exact.abs().max())      # bf16 rounding only
+
+
+def test_neumf_bf16_mode_tracks_the_fp32_step():
+    """precision switch: one training step in bf16 mode stays within bf16 rounding of the fp32 parity mode."""
+    from daisyrec_amd import ops
+    rng = np.random.default_rng(5)
+    U, I, d, L, B = 300, 200, 64, 3, 128                  # R = 256 rows: interior tiles -> the bf16 kernels run
+    dm = d << (L - 1)
+    shapes = {"uG": (U, d), "iG": (I, d), "uM": (U, dm), "iM": (I, dm), "Wp": (1, 2 * d), "bp": (1,)}
+    w = 2 * dm
+    for l in range(1, L + 1):
+        shapes[f"W{l}"], shapes[f"b{l}"] = (w // 2, w), (w // 2,)
+        w //= 2
+    p_np = {k: (rng.standard_normal(s) * 0.05).astype(np.float32) for k, s in shapes.items()}
+    u, i, j = (torch.as_tensor(rng.integers(0, n, B).astype(np.int32)).to(DEV) for n in (U, I, I))
+    res = []
+    for bf16 in (False, True):
+        p = _dev(p_np)
+        grads = {k: torch.zeros_like(v) for k, v in p.items()}
+        ctx = ops.NeumfContext(2 * B, d, L, U, I)
+        ctx.set_precision(bf16)
+        ctx.step_grads(p, grads, u, i, j, 0, 1e-3, 1e-3)
+        res.append((float(ctx.stats[11].cpu()), {k: v.cpu().numpy() for k, v in grads.items()}))
+        ctx.close()
+    (l32, g32), (l16, g16) = res
+    assert l32 != l16 and abs(l16 - l32) <= 2e-3 * abs(l32)
+    for k in shapes:
+        # bf16 rounding per product (~0.4 %), accumulated over three layers each way, plus ReLU gates that
+        # flip for activations within rounding of 0: a few per cent in L2, directions unchanged
+        err = np.linalg.norm(g16[k] - g32[k]) / (np.linalg.norm(g32[k]) + 1e-12)
+        cos = float((g16[k] * g32[k]).sum() / (np.linalg.norm(g16[k]) * np.linalg.norm(g32[k]) + 1e-30))
+        if np.linalg.norm(g32[k]) > 0:                  # (bp's gradient is exactly 0 under BPR)
+            assert err < 0.15 and cos > 0.99, (k, err, cos)

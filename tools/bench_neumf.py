@@ -54,7 +54,7 @@ def gemm_flops_per_sample():
     return 2 * macs * 3 * 2          # x2 flop/MAC, x3 GEMMs (fwd, dX, dW), x2 rows (pos, neg)
 
 
-def run(B, steps, dropout=0.0):
+def run(B, steps, dropout=0.0, bf16=False):
     flat, gflat, p, gr = make_params()
     m, v = torch.zeros_like(flat), torch.zeros_like(flat)
     g = torch.Generator(device=dev)
@@ -63,6 +63,7 @@ def run(B, steps, dropout=0.0):
     i = torch.randint(0, I, (B,), device=dev, generator=g, dtype=torch.int32)
     j = torch.randint(0, I, (B,), device=dev, generator=g, dtype=torch.int32)
     ctx = ops.NeumfContext(2 * B, D, L, U, I)
+    ctx.set_precision(bf16)
     def step(t):
         ctx.step_grads(p, gr, u, i, j, 0, 1e-3, 1e-3, dropout=dropout, seed=t)
         ops.adam_dense(flat, gflat, m, v, 1e-3, t)
@@ -77,7 +78,7 @@ def run(B, steps, dropout=0.0):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / steps
     fl = gemm_flops_per_sample() * B
-    out = {"B": B, "steps": steps, "dropout": dropout, "ms_per_step": ms, "samples_per_s": B / ms * 1e3,
+    out = {"B": B, "steps": steps, "dropout": dropout, "gemm_inputs": "bf16" if bf16 else "fp32", "ms_per_step": ms, "samples_per_s": B / ms * 1e3,
            "mlp_gemm_TFLOPs": fl / ms / 1e9, "frac_of_fp32_mfma_peak": fl / ms / 1e9 / PEAK_TF,
            "workspace_GB": ctx.nbytes / 1e9}
     print(json.dumps(out), flush=True)
@@ -100,6 +101,18 @@ def gemm_only():
         tf = 2.0 * M * N * K / ms / 1e9
         print(json.dumps({"gemm_nt": [M, N, K], "ms": ms, "TFLOPs": tf, "frac_of_fp32_mfma_peak": tf / PEAK_TF}),
               flush=True)
+        ops.gemm_nt(A, Bm, bf16=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(5):
+            ops.gemm_nt(A, Bm, bf16=True)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        tf = 2.0 * M * N * K / ms / 1e9
+        print(json.dumps({"gemm_nt_bf16_inputs": [M, N, K], "ms": ms, "TFLOPs": tf,
+                          "frac_of_bf16_mfma_peak": tf / 2500.0,
+                          "operand_GBps": (M * K + N * K + M * N) * 4 / ms / 1e6}), flush=True)
 
 
 def cpu_baseline(B=65536, steps=2):
@@ -127,5 +140,7 @@ if __name__ == "__main__":
     run(65536, 20)
     run(262144, 8)
     run(65536, 20, dropout=0.5)
+    run(65536, 20, bf16=True)
+    run(262144, 8, bf16=True)
     if "--no-cpu" not in sys.argv:
         cpu_baseline()
