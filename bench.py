@@ -151,6 +151,10 @@ def main():
     trainer = UserShardedBprTrainer(ctx, P, Q, 0, lr, reg, reg, item_mode=item_mode) if world > 1 else None
     user_sorted = ops.triples_user_sorted(triples)      # synthetic triples are generated in CSR order
     full_batches = n // B                      # the bench steps over full batches only (fixed B per step)
+    if world > 1:                              # shards differ by a few interactions (dedup): agree on the
+        fb = torch.tensor([full_batches], device=dev, dtype=torch.int64)     # count, every rank must take the same steps
+        dist.all_reduce(fb, op=dist.ReduceOp.MIN)
+        full_batches = int(fb.cpu())
     if a.steps is None:
         a.steps = full_batches                 # one epoch: exactly one plan build inside the timed region
 
