@@ -269,41 +269,45 @@ __global__ __launch_bounds__(kBlock) void k_gemm_bf16(GemmOp op) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
-    float4 ra[QA], rb[QB];
+    float ra[4 * QA], rb[4 * QB];
+    // k-contiguous operand: float4 along k (8 lanes cover the 32 k of a row).  Operand contiguous along
+    // its rows (the weight-gradient GEMM's two operands, W in the d-input GEMM): a thread takes ONE row
+    // and 4*Q consecutive k with scalar loads - each wave instruction still reads 64 consecutive rows of
+    // one k, 256 contiguous bytes - so that its bf16 pack is k-contiguous and lands in LDS as 16-byte
+    // writes (a float4 along the rows would have to be scattered with 2-byte stores).
     auto load_op = [&](const float *__restrict__ P, int64_t srow, int64_t sk, bool kfast, int64_t row0, int64_t kt,
                        auto &r, auto rows_c, auto q_c) {
         constexpr int ROWS = decltype(rows_c)::value, Q = decltype(q_c)::value;
-        if (kfast) {                                       // 8 lanes cover the 32 k of one row
+        if (kfast) {
             const float *src = P + (row0 + tid / 8) * srow + kt + (tid % 8) * 4;
 #pragma unroll
-            for (int q = 0; q < Q; ++q) r[q] = *reinterpret_cast<const float4 *>(src + (int64_t)q * (kBlock / 8) * srow);
-        } else {                                           // ROWS/4 lanes cover one k
-            const float *src = P + row0 + (tid % (ROWS / 4)) * 4 + (kt + tid / (ROWS / 4)) * sk;
+            for (int q = 0; q < Q; ++q) {
+                const float4 v = *reinterpret_cast<const float4 *>(src + (int64_t)q * (kBlock / 8) * srow);
+                r[4 * q] = v.x; r[4 * q + 1] = v.y; r[4 * q + 2] = v.z; r[4 * q + 3] = v.w;
+            }
+        } else {
+            const float *src = P + row0 + (tid % ROWS) + (kt + (int64_t)(tid / ROWS) * (4 * Q)) * sk;
 #pragma unroll
-            for (int q = 0; q < Q; ++q)
-                r[q] = *reinterpret_cast<const float4 *>(src + (int64_t)q * (kBlock / (ROWS / 4)) * sk);
+            for (int q = 0; q < 4 * Q; ++q) r[q] = src[(int64_t)q * sk];
         }
     };
+    auto pack2 = [](float lo, float hi) { return bf16_rne(lo) | (bf16_rne(hi) << 16); };
     auto store_op = [&](uint16_t *__restrict__ S, bool kfast, auto &r, auto rows_c, auto q_c) {
         constexpr int ROWS = decltype(rows_c)::value, Q = decltype(q_c)::value;
         if (kfast) {
 #pragma unroll
             for (int q = 0; q < Q; ++q) {
                 const int row = tid / 8 + q * (kBlock / 8), k = (tid % 8) * 4;
-                uint2 pk;
-                pk.x = bf16_rne(r[q].x) | (bf16_rne(r[q].y) << 16);
-                pk.y = bf16_rne(r[q].z) | (bf16_rne(r[q].w) << 16);
-                *reinterpret_cast<uint2 *>(S + row * kLdk16 + k) = pk;
+                *reinterpret_cast<uint2 *>(S + row * kLdk16 + k) =
+                    make_uint2(pack2(r[4 * q], r[4 * q + 1]), pack2(r[4 * q + 2], r[4 * q + 3]));
             }
         } else {
+            uint16_t *dst = S + (tid % ROWS) * kLdk16 + (tid / ROWS) * (4 * Q);
 #pragma unroll
-            for (int q = 0; q < Q; ++q) {
-                const int row = (tid % (ROWS / 4)) * 4, k = tid / (ROWS / 4) + q * (kBlock / (ROWS / 4));
-                S[(row + 0) * kLdk16 + k] = (uint16_t)bf16_rne(r[q].x);
-                S[(row + 1) * kLdk16 + k] = (uint16_t)bf16_rne(r[q].y);
-                S[(row + 2) * kLdk16 + k] = (uint16_t)bf16_rne(r[q].z);
-                S[(row + 3) * kLdk16 + k] = (uint16_t)bf16_rne(r[q].w);
-            }
+            for (int q = 0; q < Q / 2; ++q)
+                *reinterpret_cast<uint4 *>(dst + 8 * q) =
+                    make_uint4(pack2(r[8 * q], r[8 * q + 1]), pack2(r[8 * q + 2], r[8 * q + 3]),
+                               pack2(r[8 * q + 4], r[8 * q + 5]), pack2(r[8 * q + 6], r[8 * q + 7]));
         }
     };
     using RA = std::integral_constant<int, BM>; using RB = std::integral_constant<int, BN>;
