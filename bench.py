@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--reg", type=float, default=0.001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap-plan", type=int, default=0, help="build the next epoch's plan on a side stream")
+    ap.add_argument("--overlap-plan", type=int, default=1, help="build the next epoch's plan on a side stream")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 code path on one GPU)")
