@@ -147,3 +147,18 @@ def test_lightgcn_ml100k_through_the_dropin(kat_lg):
     want, _, _ = LG.lightgcn_grad(graph, model.embed_user.weight.detach().cpu().numpy(),
                                   model.embed_item.weight.detach().cpu().numpy(), b[:, 0], b[:, 1], b[:, 2], 0.0, 0.0, L)
     assert abs(loss - want) <= 1e-5 * abs(want)
+
+
+def test_lightgcn_argument_errors():
+    from daisyrec_amd import ops
+    u = torch.zeros(4, dtype=torch.int64, device=DEV)
+    with pytest.raises(ValueError):
+        ops.LgcnGraph(u, u, 0, 5)                               # no users
+    with pytest.raises((RuntimeError, ValueError)):
+        ops.LgcnGraph(u.cpu(), u.cpu(), 5, 5)                   # host tensors: no CPU fallback
+    g = ops.LgcnGraph(u, u, 5, 5)
+    assert g.nnz == 2                                           # four copies of one interaction collapse
+    X = torch.zeros(10, 8, device=DEV)
+    with pytest.raises(ValueError):
+        ops.check(ops.lib.daisy_lgcn_spmm(g._h, ops._ptr(X, torch.float32, "X"), ops._ptr(X, torch.float32, "X"), 8, None))
+    g.close()

@@ -266,3 +266,28 @@ def test_neumf_bf16_mode_tracks_the_fp32_step():
         cos = float((g16[k] * g32[k]).sum() / (np.linalg.norm(g16[k]) * np.linalg.norm(g32[k]) + 1e-30))
         if np.linalg.norm(g32[k]) > 0:                  # (bp's gradient is exactly 0 under BPR)
             assert err < 0.15 and cos > 0.99, (k, err, cos)
+
+
+def test_neumf_argument_errors():
+    from daisyrec_amd import ops
+    with pytest.raises(ValueError):
+        ops.NeumfContext(64, 6, 2, 10, 10)                      # factors must be a multiple of 4
+    with pytest.raises(ValueError):
+        ops.NeumfContext(64, 8, 9, 10, 10)                      # too many layers
+    with pytest.raises(NotImplementedError):
+        ops.NeumfContext(64, 8, 2, 10, 10, model="NeuMF-x")
+    ctx = ops.NeumfContext(8, 8, 2, 10, 10)
+    shapes = {"uG": (10, 8), "iG": (10, 8), "uM": (10, 16), "iM": (10, 16), "W1": (16, 32), "b1": (16,),
+              "W2": (8, 16), "b2": (8,), "Wp": (1, 16), "bp": (1,)}
+    p = {k: torch.zeros(s, device=DEV) for k, s in shapes.items()}
+    g = {k: torch.zeros(s, device=DEV) for k, s in shapes.items()}
+    idx = torch.zeros(8, dtype=torch.int32, device=DEV)
+    with pytest.raises(ValueError):                             # 2*8 rows > the context's 8
+        ctx.step_grads(p, g, idx, idx, idx)
+    with pytest.raises(NotImplementedError):                    # unknown loss id -> the reference's exception type
+        ctx.step_grads(p, g, idx[:4], idx[:4], idx[:4], loss_type=9)
+    with pytest.raises(ValueError):
+        ctx.step_grads(p, g, idx[:4], idx[:4], idx[:4], dropout=1.0)
+    with pytest.raises(TypeError):                              # host tensor / wrong dtype are refused, no CPU fallback
+        ctx.step_grads(p, g, idx[:4].long(), idx[:4], idx[:4])
+    ctx.close()
