@@ -1,0 +1,28 @@
+"""The drop-in route of INTEGRATION.md §1 end to end on the host: the reference's UNMODIFIED
+run_examples/test.py, driven by tools/run_daisy_example.py, builds its config / data / sampler and
+reaches `fit` of the HIP-backed class - which refuses to run without a device (no CPU fallback).
+Needs the reference checkout (build container only); skipped elsewhere."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("DAISY_REFERENCE", "/root/reference")
+
+
+@pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "daisy")), reason="reference checkout not present")
+@pytest.mark.skipif(torch.cuda.is_available(), reason="host-only check (with a device the run would train)")
+@pytest.mark.parametrize("algo", ["mf", "neumf"])
+def test_reference_driver_reaches_the_hip_classes(tmp_path, algo):
+    d = tmp_path / "daisy_checkout"                        # writable cwd: test.py writes ./log ./res
+    d.mkdir()
+    for name in ("daisy", "run_examples", "data"):
+        os.symlink(os.path.join(REF, name), d / name)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_daisy_example.py"), "--daisy", str(d), "--",
+                        "--algo_name", algo, "--epochs", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert "daisyrec_amd" in r.stderr and "no HIP device visible" in r.stderr, r.stderr[-2000:]
+    assert "model.fit(train_loader)" in r.stderr            # failed inside the reference driver's fit call
