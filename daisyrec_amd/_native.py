@@ -99,6 +99,7 @@ SIGNATURES = {
     "daisy_lgcn_graph_create": (C.c_int, [C.POINTER(_p), _p, _p, _i64, _i64, _i64, _p]),
     "daisy_lgcn_graph_destroy": (C.c_int, [_p]),
     "daisy_lgcn_graph_nnz": (_i64, [_p]),
+    "daisy_lgcn_graph_set_reproducible": (C.c_int, [_p, _i32]),
     "daisy_lgcn_graph_bytes": (_sz, [_p]),
     "daisy_lgcn_graph_read": (C.c_int, [_p, _p, _p, _p, _p]),
     "daisy_lgcn_spmm": (C.c_int, [_p, _p, _p, _i32, _p]),

@@ -58,6 +58,29 @@ __global__ void k_lg_read(const uint32_t *__restrict__ ekey, const uint2 *__rest
     }
 }
 
+// reproducible product: the lane group that sees the first entry of a row owns it and sums the row's
+// entries in stored order (fixed, so bitwise reproducible; serial over long rows - the throughput
+// path is segsum_rows)
+__global__ __launch_bounds__(kBlock) void k_lg_spmm_owner(const uint32_t *__restrict__ ekey,
+                                                          const uint2 *__restrict__ esu,
+                                                          const float2 *__restrict__ coef, int64_t n,
+                                                          const float *__restrict__ X, int d,
+                                                          float *__restrict__ Y) {
+    const int lane = threadIdx.x % 16, group = threadIdx.x / 16;
+    const int64_t gstride = (int64_t)gridDim.x * (kBlock / 16);
+    for (int64_t pos = (int64_t)blockIdx.x * (kBlock / 16) + group; pos < n; pos += gstride) {
+        const uint32_t key = ekey[pos];
+        if (pos > 0 && ekey[pos - 1] == key) continue;          // not the head of its row
+        const int64_t row = key >> 1;
+        for (int c = lane; c < d; c += 16) {
+            float acc = 0.f;
+            for (int64_t q = pos; q < n && ekey[q] == key; ++q)
+                acc = fmaf(coef[q].x, X[(int64_t)esu[q].y * d + c], acc);
+            Y[row * d + c] = acc;
+        }
+    }
+}
+
 // y = a*x + b*y (elementwise; x may be null for y *= b)
 __global__ void k_lg_axpby(const float *__restrict__ x, float a, float b, float *__restrict__ y, int64_t n) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
@@ -124,6 +147,7 @@ struct daisy_lgcn_graph {
     uint32_t *ekey;
     uint2 *esu;
     float2 *coef;
+    int reproducible;     // daisy_lgcn_graph_set_reproducible
 };
 
 static inline hipStream_t LS(daisy_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
@@ -168,6 +192,7 @@ int daisy_lgcn_graph_create(daisy_lgcn_graph **out, const int32_t *users, const 
     const int64_t m = m32;
     daisy_lgcn_graph *g = new daisy_lgcn_graph();
     g->U = user_num; g->I = item_num; g->nnz = 2 * m;
+    g->reproducible = 0;
     size_t goff = 0;
     auto gtake = [&](size_t bytes) { size_t o = goff; goff += align_up(bytes); return o; };
     const size_t g_k = gtake((size_t)g->nnz * 4), g_s = gtake((size_t)g->nnz * 8), g_c = gtake((size_t)g->nnz * 8);
@@ -203,6 +228,12 @@ int daisy_lgcn_graph_destroy(daisy_lgcn_graph *g) {
     return DAISY_OK;
 }
 
+int daisy_lgcn_graph_set_reproducible(daisy_lgcn_graph *g, int32_t flag) {
+    DAISY_CHECK_ARG(g != nullptr, "lgcn_graph_set_reproducible: NULL graph");
+    g->reproducible = flag ? 1 : 0;
+    return DAISY_OK;
+}
+
 int64_t daisy_lgcn_graph_nnz(const daisy_lgcn_graph *g) { return g ? g->nnz : 0; }
 size_t daisy_lgcn_graph_bytes(const daisy_lgcn_graph *g) { return g ? g->arena_bytes : 0; }
 
@@ -219,6 +250,13 @@ int daisy_lgcn_spmm(const daisy_lgcn_graph *g, const float *X, float *Y, int32_t
     DAISY_CHECK_ARG(g && X && Y && X != Y && d > 0, "lgcn_spmm: bad argument");
     hipStream_t s = LS(stream);
     DAISY_HIP(hipMemsetAsync(Y, 0, (size_t)(g->U + g->I) * d * 4, s));
+    if (g->reproducible) {
+        if (g->nnz > 0)
+            hipLaunchKernelGGL(k_lg_spmm_owner, dim3(grid_for(g->nnz, kBlock / 16, kMaxGridSparse)), dim3(kBlock), 0, s,
+                               g->ekey, g->esu, g->coef, g->nnz, X, (int)d, Y);
+        DAISY_LAUNCH_CHECK();
+        return DAISY_OK;
+    }
     return segsum_rows(X, g->coef, g->ekey, g->esu, g->nnz, d, Y, s);
 }
 

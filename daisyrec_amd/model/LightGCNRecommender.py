@@ -46,6 +46,10 @@ class LightGCN(GeneralRecommender):
         self.initializer = config["init_method"] if config["init_method"] != "default" else "xavier_uniform"
         self.early_stop = config["early_stop"]
 
+        # knob of the native path: 'chunked' (default here) = throughput kernels, results repeat to fp32
+        # round-off; 'sorted' = bitwise reproducible run to run (row-owner products: every row's entries are
+        # summed serially, which is slow on graphs with very popular items)
+        self.item_mode = str(config.get("item_mode", "chunked")).lower()
         self.restore_user_e = None
         self.restore_item_e = None
         self.apply(self._init_weight)
@@ -74,6 +78,7 @@ class LightGCN(GeneralRecommender):
             users = torch.as_tensor(np.ascontiguousarray(m.row)).to(self.device)
             items = torch.as_tensor(np.ascontiguousarray(m.col)).to(self.device)
             self._graph = ops.LgcnGraph(users, items, self.user_num, self.item_num)
+            self._graph.set_reproducible(self.item_mode == "sorted")
         return self._graph
 
     def forward(self):
@@ -98,7 +103,10 @@ class LightGCN(GeneralRecommender):
             ctx.stats[1:7] = 0
         ctx.finalize(self.reg_1, self.reg_2, accumulate=True)
         G.zero_()
-        ctx.item_grad_data(out[:U], out[U:], N.ITEM_CHUNKED, gQ=G[U:])
+        if self.item_mode == "sorted":       # owner-summed in plan order; reg 0: the data term only
+            ctx.item_grad(out[:U], out[U:], 0.0, 0.0, N.ITEM_SORTED, gQ=G[U:])
+        else:
+            ctx.item_grad_data(out[:U], out[U:], N.ITEM_CHUNKED, gQ=G[U:])
         ctx.user_grad(out[:U], out[U:], 0.0, 0.0, G[:U])
         self._adj().backprop(G, self.num_layers, dE0)
         if reg:

@@ -529,6 +529,10 @@ class LgcnGraph:
     def nbytes(self):
         return int(lib.daisy_lgcn_graph_bytes(self._h))
 
+    def set_reproducible(self, flag):
+        """True: row-owner products (bitwise reproducible); False (default): chunked segmented reduction."""
+        check(lib.daisy_lgcn_graph_set_reproducible(self._h, int(bool(flag))))
+
     def coo(self):
         row = torch.empty(self.nnz, dtype=torch.int32, device=self.device)
         col = torch.empty_like(row)

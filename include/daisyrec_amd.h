@@ -401,6 +401,10 @@ int daisy_lgcn_graph_create(daisy_lgcn_graph **out, const int32_t *users, const 
                             int64_t user_num, int64_t item_num, daisy_stream_t stream);
 int daisy_lgcn_graph_destroy(daisy_lgcn_graph *g);
 int64_t daisy_lgcn_graph_nnz(const daisy_lgcn_graph *g);          /* stored entries = 2 x distinct pairs */
+/* flag != 0: the products use a row-owner kernel that sums every row's entries in stored order (bitwise
+ * reproducible, slower on long rows) instead of the chunked segmented reduction (whose rows that span
+ * three or more chunks are combined with fp32 atomics in arrival order).  Default 0. */
+int daisy_lgcn_graph_set_reproducible(daisy_lgcn_graph *g, int32_t flag);
 size_t daisy_lgcn_graph_bytes(const daisy_lgcn_graph *g);
 /* COO copy of A_hat, rows then columns ascending (inspection / tests): int32[nnz], int32[nnz], f32[nnz] */
 int daisy_lgcn_graph_read(const daisy_lgcn_graph *g, int32_t *row, int32_t *col, float *val,
