@@ -1,0 +1,83 @@
+"""The user-sharded multi-GPU protocol with the REAL kernels: two ranks share the one GPU of the test box,
+collectives over gloo (RCCL refuses two ranks on one device; the RCCL path itself is covered at world size 1
+in test_gpu_parity.py).  Each rank owns a user range and its P rows; together they must reproduce the
+single-process oracle step on the union batch, through both entry points of the trainer (triples / plan)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import bpr_mf_numpy as O
+
+pytestmark = pytest.mark.gpu
+U, I, D, B, STEPS = 400, 300, 64, 4096, 3
+LR, R1, R2 = 0.05, 0.01, 0.02
+
+
+def _data():
+    rng = np.random.default_rng(11)
+    P0 = (rng.standard_normal((U, D)) * 0.2).astype(np.float32)
+    Q0 = (rng.standard_normal((I, D)) * 0.2).astype(np.float32)
+    batches = [np.stack([rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)], 1).astype(np.int32)
+               for _ in range(STEPS)]
+    return P0, Q0, batches
+
+
+def _worker(rank, world, port, out_dir, use_plan):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from daisyrec_amd import ops
+    from daisyrec_amd.sharding import UserShardedBprTrainer, shard_triples, user_range
+    dev = torch.device("cuda", 0)
+    P0, Q0, batches = _data()
+    lo, hi = user_range(U, world, rank)
+    P = torch.from_numpy(P0[lo:hi].copy()).to(dev)
+    Q = torch.from_numpy(Q0.copy()).to(dev)
+    ctx = ops.BprContext(B, D, hi - lo, I, device=dev)
+    tr = UserShardedBprTrainer(ctx, P, Q, lo, LR, R1, R2, item_mode=ops.ITEM_MODES["chunked"])
+    losses = []
+    for b in batches:
+        mine = torch.from_numpy(shard_triples(b, U, world, rank)).to(dev)
+        if use_plan:                      # one-batch plan of the rank's share (local user ids)
+            loc = mine.clone()
+            loc[:, 0] -= lo
+            plan = ops.EpochPlan(loc.shape[0], hi - lo, I, device=dev).build(loc, loc.shape[0], order="identity")
+            stats = tr.step_from_plan(plan, 0)
+            plan.close()
+        else:
+            stats = tr.step_from_triples(mine)
+        losses.append(float(stats[7].cpu()))
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), P=P.cpu().numpy(), Q=Q.cpu().numpy(), lo=lo, hi=hi,
+             losses=np.array(losses))
+    ctx.close()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("use_plan", [False, True])
+def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path, use_plan):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), use_plan), nprocs=world, join=True)
+    P, Q, batches = _data()
+    ref = []
+    for b in batches:
+        loss, P, Q = O.mf_sgd_step(P, Q, b[:, 0], b[:, 1], b[:, 2], LR, R1, R2)
+        ref.append(loss)
+    outs = [np.load(os.path.join(str(tmp_path), f"r{r}.npz")) for r in range(world)]
+    for o in outs:
+        np.testing.assert_allclose(o["losses"], ref, rtol=1e-6)                  # every rank sees the GLOBAL loss
+        np.testing.assert_allclose(o["Q"], Q, atol=1e-5)
+        np.testing.assert_allclose(o["P"], P[int(o["lo"]):int(o["hi"])], atol=1e-5)
+    np.testing.assert_allclose(outs[0]["Q"], outs[1]["Q"], atol=1e-6)            # replicas stay together
