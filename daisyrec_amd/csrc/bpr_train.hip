@@ -494,18 +494,32 @@ struct RunCfg {
 
 // FROM_STAGE: P is the per-sample stage of pre-step user rows written by the fused user pass
 // (row of entry e = stage[sample position]) instead of the user table (row = P[user]).
-template <class C, int RUN_OVERRIDE = 0, bool FROM_STAGE = false>
+// DET (bitwise reproducible, no atomics): a group does not add its run-crossing partial sums into the
+// slot but parks them (<= 2 per group: the segment it continues, the segment it hands on) and the
+// slot's finisher adds them in group order; segments shared with a neighbouring chunk leave the chunk
+// as edge records that k_item_edges chains in chunk order.  Same data movement, fixed summation order.
+struct ItemEdges {
+    float *vec;          // [2*nchunks][d]  partial gradient rows; [2c] head edge (inherited), [2c+1] tail edge
+    int32_t *item;       // [2*nchunks]     their item (-1: none)
+    float *b;            // [2*nchunks]     FM: partial coefficient sums
+    int32_t *whole;      // [nchunks]       the head edge's segment also runs on into the next chunk
+};
+
+template <class C, int RUN_OVERRIDE = 0, bool FROM_STAGE = false, bool DET = false>
 __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__restrict__ P,
                                                               const float2 *__restrict__ coef,
                                                               BatchView v, int d,
-                                                              float *__restrict__ gQ) {
+                                                              float *__restrict__ gQ, ItemEdges edges = ItemEdges{}) {
     constexpr int G = RunCfg<C, RUN_OVERRIDE>::G, RUN = RunCfg<C, RUN_OVERRIDE>::RUN,
                   E = RunCfg<C, RUN_OVERRIDE>::E;
     constexpr int ROWF = C::NE * C::LPR;
-    __shared__ float slot_acc[(G + 1) * ROWF];
+    __shared__ float slot_acc[DET ? 1 : (G + 1) * ROWF];
     __shared__ float slot_b[G + 1];              // FM: sum of the coefficients (d loss / d i_bias)
     __shared__ int slot_item[G + 1], slot_shared[G + 1];
     __shared__ int run_first[G], run_last[G];
+    __shared__ float part_acc[DET ? 2 * G * ROWF : 1];     // DET: [group][head|tail] parked partial sums
+    __shared__ float part_b[DET ? 2 * G : 1];
+    __shared__ int part_slot[DET ? 2 * G : 1];             //      the slot each belongs to (-1: unused)
 
     const int tid = threadIdx.x;
     const int lane = tid % C::LPR;
@@ -536,7 +550,11 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
         const int32_t item_prev = (cnt > 0 && t0 > 0) ? (int32_t)((k_prev & v.imask) >> 1) : -1;
         const int32_t item_next = (cnt > 0 && t1 < n) ? (int32_t)((k_next & v.imask) >> 1) : -1;
         const int32_t chunk_prev_item = (c0 > 0) ? (int32_t)((k_cprev & v.imask) >> 1) : -1;
-        for (int e = tid; e < (G + 1) * ROWF; e += kBlock) slot_acc[e] = 0.f;
+        if constexpr (!DET) {
+            for (int e = tid; e < (G + 1) * ROWF; e += kBlock) slot_acc[e] = 0.f;
+        } else {
+            if (tid < 2 * G) part_slot[tid] = -1;
+        }
         if (tid <= G) { slot_item[tid] = -1; slot_shared[tid] = 0; slot_b[tid] = 0.f; }
         const int32_t item_first = group_bcast<C>(my_item, 0);
         const int32_t item_last = __shfl(my_item, cnt > 0 ? cnt - 1 : 0, C::LPR);
@@ -590,13 +608,26 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
                     if (v.g_bi && lane == 0) v.g_bi[cur_item] = accb;
                 } else {                            // crosses a run boundary: LDS slot
                     const int s = (cur_slot >= 0) ? cur_slot : group + 1;
-                    float *dst = slot_acc + s * ROWF;
+                    if constexpr (DET) {            // park it: head partial (continued segment) or tail partial
+                        const int q = group * 2 + ((cur_slot >= 0) ? 0 : 1);
+                        float *dst = part_acc + q * ROWF;
 #pragma unroll
-                    for (int k = 0; k < C::NE; ++k) atomicAdd(dst + k * C::LPR + lane, acc.v[k]);
-                    if (lane == 0) {
-                        slot_item[s] = cur_item;
-                        atomicAdd(&slot_b[s], accb);
-                        if (to_next_chunk) slot_shared[s] = 1;
+                        for (int k = 0; k < C::NE; ++k) dst[k * C::LPR + lane] = acc.v[k];
+                        if (lane == 0) {
+                            part_slot[q] = s;
+                            part_b[q] = accb;
+                            slot_item[s] = cur_item;
+                            if (to_next_chunk) slot_shared[s] = 1;
+                        }
+                    } else {
+                        float *dst = slot_acc + s * ROWF;
+#pragma unroll
+                        for (int k = 0; k < C::NE; ++k) atomicAdd(dst + k * C::LPR + lane, acc.v[k]);
+                        if (lane == 0) {
+                            slot_item[s] = cur_item;
+                            atomicAdd(&slot_b[s], accb);
+                            if (to_next_chunk) slot_shared[s] = 1;
+                        }
                     }
                 }
             };
@@ -622,11 +653,40 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
         }
         __syncthreads();
 
+        if constexpr (DET) {
+            if (tid == 0) { edges.item[2 * chunk] = -1; edges.item[2 * chunk + 1] = -1; edges.whole[chunk] = 0; }
+            __syncthreads();
+        }
         // one write per used slot (G+1 slots over G groups)
         for (int s = group; s <= G; s += G) {
             const int r = slot_item[s];
             if (r < 0) continue;
             Row<C> g;
+            if constexpr (DET) {                    // the parked partials of this slot, in group order
+                g.zero();
+                float gb = 0.f;
+                for (int q = 0; q < 2 * G; ++q) {
+                    if (part_slot[q] != s) continue;
+                    const float *src = part_acc + q * ROWF;
+#pragma unroll
+                    for (int k = 0; k < C::NE; ++k) g.v[k] += src[k * C::LPR + lane];
+                    gb += part_b[q];
+                }
+                const bool from_prev = (s == 0), to_next = slot_shared[s] != 0;
+                if (from_prev || to_next) {
+                    const int64_t e = 2 * chunk + (from_prev ? 0 : 1);
+                    g.store(edges.vec + e * d, lane, d);
+                    if (lane == 0) {
+                        edges.item[e] = r;
+                        edges.b[e] = gb;
+                        if (from_prev && to_next) edges.whole[chunk] = 1;
+                    }
+                } else {
+                    g.store(gQ + (int64_t)r * d, lane, d);
+                    if (v.g_bi && lane == 0) v.g_bi[r] = gb;
+                }
+                continue;
+            }
             const float *src = slot_acc + s * ROWF;
 #pragma unroll
             for (int k = 0; k < C::NE; ++k) g.v[k] = src[k * C::LPR + lane];
@@ -639,6 +699,32 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
             }
         }
         __syncthreads();   // the slots are reused by the next chunk
+    }
+}
+
+// DET: chains of edge records - the chunk whose TAIL edge starts a segment owns it and adds the head edges
+// of the chunks it runs through, in chunk order (single writer per row, fixed order)
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_item_edges(ItemEdges edges, int64_t nchunks, int d,
+                                                       float *__restrict__ gQ, float *__restrict__ g_bi) {
+    const int lane = threadIdx.x % C::LPR;
+    const int group = threadIdx.x / C::LPR;
+    const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
+    for (int64_t c = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; c < nchunks; c += gstride) {
+        const int it = edges.item[2 * c + 1];
+        if (it < 0) continue;
+        Row<C> acc, t;
+        acc.load(edges.vec + (2 * c + 1) * d, lane, d);
+        float sb = edges.b[2 * c + 1];
+        for (int64_t k = c + 1; k < nchunks && edges.item[2 * k] == it; ++k) {
+            t.load(edges.vec + (2 * k) * d, lane, d);
+#pragma unroll
+            for (int q = 0; q < C::NE; ++q) acc.v[q] += t.v[q];
+            sb += edges.b[2 * k];
+            if (!edges.whole[k]) break;
+        }
+        acc.store(gQ + (int64_t)it * d, lane, d);
+        if (g_bi && lane == 0) g_bi[it] = sb;
     }
 }
 
@@ -824,8 +910,11 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
     float *__restrict__ p_sqnorm, double *__restrict__ partials) {
     constexpr int G = UserRunCfg<C>::G, RUN = UserRunCfg<C>::RUN, E = UserRunCfg<C>::E;
     constexpr int ROWF = C::NE * C::LPR;
-    __shared__ float slot_acc[(G + 1) * ROWF];
-    __shared__ float slot_n[G + 1], slot_b[G + 1];   // slot_b: FM, sum of (cp + cn) = d loss / d u_bias
+    // run-crossing partial sums are parked per group (<= 2: the run it continues, the run it hands on)
+    // and added by the slot's finisher in group order: fixed summation order, no LDS atomics
+    __shared__ float part_acc[2 * G * ROWF];
+    __shared__ float part_n[2 * G], part_b[2 * G];   // part_b: FM, sum of (cp + cn) = d loss / d u_bias
+    __shared__ int part_slot[2 * G];
     __shared__ int slot_user[G + 1], slot_next[G + 1];
     __shared__ int run_first[G], run_last[G];
 
@@ -862,8 +951,8 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
         const int32_t user_prev = (cnt > 0 && t0 > 0) ? (int32_t)(k_prev & v.umask) : -1;
         const int32_t user_next = (cnt > 0 && t1 < n) ? (int32_t)(k_next & v.umask) : -1;
         const int32_t chunk_prev_user = (c0 > 0) ? (int32_t)(k_cprev & v.umask) : -1;
-        for (int e = tid; e < (G + 1) * ROWF; e += kBlock) slot_acc[e] = 0.f;
-        if (tid <= G) { slot_user[tid] = -1; slot_n[tid] = 0.f; slot_b[tid] = 0.f; slot_next[tid] = 0; }
+        if (tid < 2 * G) part_slot[tid] = -1;
+        if (tid <= G) { slot_user[tid] = -1; slot_next[tid] = 0; }
         const int32_t user_first = group_bcast<C>(my_user, 0);
         const int32_t user_last = __shfl(my_user, cnt > 0 ? cnt - 1 : 0, C::LPR);
         if (lane == 0) {
@@ -930,13 +1019,15 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
                     }
                 } else {
                     const int s = (cur_slot >= 0) ? cur_slot : group + 1;
-                    float *dst = slot_acc + s * ROWF;
+                    const int q = group * 2 + ((cur_slot >= 0) ? 0 : 1);
+                    float *dst = part_acc + q * ROWF;
 #pragma unroll
-                    for (int k = 0; k < C::NE; ++k) atomicAdd(dst + k * C::LPR + lane, acc.v[k]);
+                    for (int k = 0; k < C::NE; ++k) dst[k * C::LPR + lane] = acc.v[k];
                     if (lane == 0) {
+                        part_slot[q] = s;
+                        part_n[q] = cn_;
+                        part_b[q] = cb_;
                         slot_user[s] = cur_user;
-                        atomicAdd(&slot_n[s], cn_);
-                        atomicAdd(&slot_b[s], cb_);
                         if (to_next_chunk) slot_next[s] = 1;
                     }
                 }
@@ -1003,17 +1094,23 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
             const int uu = slot_user[s];
             if (uu < 0) continue;
             Row<C> g;
-            const float *src = slot_acc + s * ROWF;
+            g.zero();
+            float ns = 0.f, sb = 0.f;
+            for (int q = 0; q < 2 * G; ++q) {
+                if (part_slot[q] != s) continue;
+                const float *src = part_acc + q * ROWF;
 #pragma unroll
-            for (int k = 0; k < C::NE; ++k) g.v[k] = src[k * C::LPR + lane];
-            const float ns = slot_n[s];
+                for (int k = 0; k < C::NE; ++k) g.v[k] += src[k * C::LPR + lane];
+                ns += part_n[q];
+                sb += part_b[q];
+            }
             const bool from_prev = (s == 0), to_next = slot_next[s] != 0;
             if (!from_prev && !to_next) {
                 Row<C> p;
                 p.load(P + (int64_t)uu * d, lane, d);
                 user_finish_row<C>(p, g, ns, lr, reg_1, rU);
                 p.store(P + (int64_t)uu * d, lane, d);
-                if (v.bu && lane == 0) v.bu[uu] = fmaf(-lr, slot_b[s], v.bu[uu]);
+                if (v.bu && lane == 0) v.bu[uu] = fmaf(-lr, sb, v.bu[uu]);
                 if constexpr (FUSED) {
                     const float sq = row_dot<C>(p, p);
                     if (lane == 0) p_sqnorm[uu] = sq;
@@ -1024,7 +1121,7 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
                 if (lane == 0) {
                     edge_user[e] = uu;
                     edge_n[2 * e] = ns;
-                    edge_n[2 * e + 1] = slot_b[s];
+                    edge_n[2 * e + 1] = sb;
                     if (from_prev && to_next) edge_whole[chunk] = 1;
                 }
             }
@@ -1343,13 +1440,24 @@ static BatchView plan_view(const daisy_epoch_plan *p, int64_t k) {
 
 using namespace daisy;
 
-// out[row] += sum over the row's entries of coef[e].x * X[col_e]  (a sparse-matrix x dense-matrix product
-// for entries sorted by row): the item pass's segmented reduction on a synthetic view -
-// ekey[e] = row << 1, esu[e] = (e, col), coef[e] = (value, 0).  `out` must be zero where rows have
-// entries (segments that cross a chunk are added atomically); n_entries must be even.
+// out[row] = sum over the row's entries of coef[e].x * X[col_e]  (a sparse-matrix x dense-matrix product
+// for entries sorted by row): the item pass's segmented reduction (bitwise reproducible variant) on a
+// synthetic view - ekey[e] = row << 1, esu[e] = (e, col), coef[e] = (value, 0).  Rows without entries are
+// not written; n_entries must be even.  `edges` is scratch for segsum_chunks(n_entries, d) chunks.
 namespace daisy {
+int64_t segsum_chunks(int64_t n_entries, int d) {
+    int64_t nchunks = 0;
+    (void)dispatch_d(d, [&](auto cfg) {
+        using C = decltype(cfg);
+        nchunks = (n_entries + RunCfg<C>::E - 1) / RunCfg<C>::E;
+        return DAISY_OK;
+    });
+    return nchunks;
+}
+
 int segsum_rows(const float *X, const float2 *coef, const uint32_t *ekey, const uint2 *esu, int64_t n_entries,
-                int d, float *out, hipStream_t s) {
+                int d, float *out, float *edge_vec, int32_t *edge_item, float *edge_b, int32_t *edge_whole,
+                hipStream_t s) {
     if (n_entries <= 0) return DAISY_OK;
     if (n_entries & 1) { set_error("segsum_rows: odd entry count %lld", (long long)n_entries); return DAISY_ERR_ARG; }
     BatchView v{};
@@ -1357,10 +1465,14 @@ int segsum_rows(const float *X, const float2 *coef, const uint32_t *ekey, const 
     v.esu = esu;
     v.imask = 0xFFFFFFFFu;
     v.B = n_entries / 2;
+    ItemEdges ed{edge_vec, edge_item, edge_b, edge_whole};
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
-        hipLaunchKernelGGL((k_item_grad_chunked<C>), dim3(grid_for(n_entries, RunCfg<C>::E, 16384)), dim3(kBlock), 0,
-                           s, X, coef, v, d, out);
+        const int64_t nchunks = (n_entries + RunCfg<C>::E - 1) / RunCfg<C>::E;
+        hipLaunchKernelGGL((k_item_grad_chunked<C, 0, false, true>), dim3(grid_for(n_entries, RunCfg<C>::E, 16384)),
+                           dim3(kBlock), 0, s, X, coef, v, d, out, ed);
+        hipLaunchKernelGGL((k_item_edges<C>), dim3(grid_for(nchunks, C::GROUPS_PER_BLOCK)), dim3(kBlock), 0, s, ed,
+                           nchunks, d, out, (float *)nullptr);
         return DAISY_OK;
     });
     if (rc) return rc;
@@ -1461,7 +1573,16 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
     const size_t o_coef = take((size_t)max_batch * 8);
     const size_t o_part = take((size_t)kMaxGrid * 8 * 8);
     const size_t o_tt = take((size_t)max_batch * 12);
-    const size_t n_edge = 2 * ((size_t)max_batch / 32 + 2);   // chunks hold >= 32 samples
+    // edge records: two per chunk of the user pass (B samples) or of the item pass (2B entries)
+    size_t max_chunks = 0;
+    (void)dispatch_d(d, [&](auto cfg) {
+        using C = decltype(cfg);
+        const size_t cu = ((size_t)max_batch + UserRunCfg<C>::E - 1) / UserRunCfg<C>::E;
+        const size_t ci = (2 * (size_t)max_batch + RunCfg<C>::E - 1) / RunCfg<C>::E;
+        max_chunks = (cu > ci ? cu : ci) + 2;
+        return DAISY_OK;
+    });
+    const size_t n_edge = 2 * max_chunks;
     const size_t o_ev = take(n_edge * (size_t)d * 4), o_eu = take(n_edge * 4), o_en = take(n_edge * 8);
     const size_t o_ew = take(n_edge * 4);
     const size_t o_ps = take((size_t)max_batch * (size_t)d * 4);
@@ -1655,6 +1776,9 @@ static int item_grad_impl(daisy_bpr_ctx *ctx, const float *P, const float *Q, co
         } else if (item_mode == DAISY_ITEM_CHUNKED) {
             static const int tune_run = getenv("DAISY_CHUNK_RUN") ? atoi(getenv("DAISY_CHUNK_RUN")) : 0;
             static const int tune_cap = getenv("DAISY_CHUNK_GRID") ? atoi(getenv("DAISY_CHUNK_GRID")) : 16384;
+            // 1 (default): bitwise reproducible variant (parked partials + edge records); 0: the variant that
+            // combines shared segments with fp32 atomics (kept for A/B measurements)
+            static const int tune_det = getenv("DAISY_ITEM_DET") ? atoi(getenv("DAISY_ITEM_DET")) : 1;
             if (tune_run == 4)
                 hipLaunchKernelGGL((k_item_grad_chunked<C, 4>), dim3(grid_for(2 * v.B, RunCfg<C, 4>::E, tune_cap)),
                                    dim3(kBlock), 0, s, P, ctx->coef, v, d, gQ);
@@ -1664,7 +1788,14 @@ static int item_grad_impl(daisy_bpr_ctx *ctx, const float *P, const float *Q, co
             else if (tune_run == 12)
                 hipLaunchKernelGGL((k_item_grad_chunked<C, 12>), dim3(grid_for(2 * v.B, RunCfg<C, 12>::E, tune_cap)),
                                    dim3(kBlock), 0, s, P, ctx->coef, v, d, gQ);
-            else
+            else if (tune_det) {
+                const int64_t nchunks = (2 * v.B + RunCfg<C>::E - 1) / RunCfg<C>::E;
+                ItemEdges ed{ctx->edge_vec, ctx->edge_user, ctx->edge_n, ctx->edge_whole};
+                hipLaunchKernelGGL((k_item_grad_chunked<C, 0, false, true>), dim3(grid_for(2 * v.B, RunCfg<C>::E, tune_cap)),
+                                   dim3(kBlock), 0, s, P, ctx->coef, v, d, gQ, ed);
+                hipLaunchKernelGGL((k_item_edges<C>), dim3(grid_for(nchunks, C::GROUPS_PER_BLOCK)), dim3(kBlock), 0, s,
+                                   ed, nchunks, d, gQ, v.g_bi);
+            } else
                 hipLaunchKernelGGL((k_item_grad_chunked<C>), dim3(grid_for(2 * v.B, RunCfg<C>::E, tune_cap)),
                                    dim3(kBlock), 0, s, P, ctx->coef, v, d, gQ);
             if (reg && !data_only)

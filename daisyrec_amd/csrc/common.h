@@ -394,8 +394,12 @@ __device__ __forceinline__ void pair_coef(int loss_type, float pos, float neg, f
 }
 
 
-// sparse (entries sorted by row) x dense product on the item pass's segmented-reduction kernel (bpr_train.hip)
+// sparse (entries sorted by row) x dense product on the item pass's segmented-reduction kernel (bpr_train.hip);
+// edge_* are scratch for segsum_chunks(n_entries, d) chunks: vec f32[2*chunks*d], item i32[2*chunks],
+// b f32[2*chunks], whole i32[chunks]
+int64_t segsum_chunks(int64_t n_entries, int d);
 int segsum_rows(const float *X, const float2 *coef, const uint32_t *ekey, const uint2 *esu, int64_t n_entries,
-                int d, float *out, hipStream_t s);
+                int d, float *out, float *edge_vec, int32_t *edge_item, float *edge_b, int32_t *edge_whole,
+                hipStream_t s);
 
 }  // namespace daisy

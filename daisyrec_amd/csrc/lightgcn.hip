@@ -148,7 +148,28 @@ struct daisy_lgcn_graph {
     uint2 *esu;
     float2 *coef;
     int reproducible;     // daisy_lgcn_graph_set_reproducible
+    void *edge_arena;     // scratch of the segmented reduction (edge records), sized for edge_d
+    int edge_d;
+    float *edge_vec, *edge_b;
+    int32_t *edge_item, *edge_whole;
 };
+
+// (re)allocate the edge-record scratch of the products for row width d
+static int ensure_edges(daisy_lgcn_graph *g, int d) {
+    if (g->edge_arena && g->edge_d == d) return DAISY_OK;
+    if (g->edge_arena) { (void)hipFree(g->edge_arena); g->edge_arena = nullptr; }
+    const size_t chunks = (size_t)segsum_chunks(g->nnz, d) + 2;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+    const size_t o_v = take(2 * chunks * (size_t)d * 4), o_i = take(2 * chunks * 4), o_b = take(2 * chunks * 4),
+                 o_w = take(chunks * 4);
+    DAISY_HIP(hipMalloc(&g->edge_arena, off));
+    char *base = (char *)g->edge_arena;
+    g->edge_vec = (float *)(base + o_v); g->edge_item = (int32_t *)(base + o_i);
+    g->edge_b = (float *)(base + o_b); g->edge_whole = (int32_t *)(base + o_w);
+    g->edge_d = d;
+    return DAISY_OK;
+}
 
 static inline hipStream_t LS(daisy_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
@@ -193,6 +214,7 @@ int daisy_lgcn_graph_create(daisy_lgcn_graph **out, const int32_t *users, const 
     daisy_lgcn_graph *g = new daisy_lgcn_graph();
     g->U = user_num; g->I = item_num; g->nnz = 2 * m;
     g->reproducible = 0;
+    g->edge_arena = nullptr; g->edge_d = 0;
     size_t goff = 0;
     auto gtake = [&](size_t bytes) { size_t o = goff; goff += align_up(bytes); return o; };
     const size_t g_k = gtake((size_t)g->nnz * 4), g_s = gtake((size_t)g->nnz * 8), g_c = gtake((size_t)g->nnz * 8);
@@ -224,6 +246,7 @@ int daisy_lgcn_graph_create(daisy_lgcn_graph **out, const int32_t *users, const 
 int daisy_lgcn_graph_destroy(daisy_lgcn_graph *g) {
     if (!g) return DAISY_OK;
     if (g->arena) (void)hipFree(g->arena);
+    if (g->edge_arena) (void)hipFree(g->edge_arena);
     delete g;
     return DAISY_OK;
 }
@@ -257,7 +280,11 @@ int daisy_lgcn_spmm(const daisy_lgcn_graph *g, const float *X, float *Y, int32_t
         DAISY_LAUNCH_CHECK();
         return DAISY_OK;
     }
-    return segsum_rows(X, g->coef, g->ekey, g->esu, g->nnz, d, Y, s);
+    daisy_lgcn_graph *gm = const_cast<daisy_lgcn_graph *>(g);      // scratch only: the matrix itself is untouched
+    int rc = ensure_edges(gm, d);
+    if (rc) return rc;
+    return segsum_rows(X, g->coef, g->ekey, g->esu, g->nnz, d, Y, gm->edge_vec, gm->edge_item, gm->edge_b,
+                       gm->edge_whole, s);
 }
 
 int daisy_lgcn_propagate(const daisy_lgcn_graph *g, const float *E0, int32_t d, int32_t num_layers,

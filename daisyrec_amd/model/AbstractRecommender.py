@@ -108,7 +108,10 @@ class GeneralRecommender(AbstractRecommender):
         self.device = "cuda" if torch.cuda.is_available() else "cpu"
         self.logger = config.get("logger") or logging.getLogger("daisyrec_amd")
         # knobs of the native path (absent from the reference config: defaults keep its behaviour)
-        self.item_mode = str(config.get("item_mode", "sorted")).lower()   # 'sorted' = reproducible
+        # 'chunked' (default): the throughput kernels - bitwise reproducible run to run (fixed summation
+        # order, no atomics); 'sorted': every item row summed serially in plan order (also reproducible,
+        # slower); 'atomic': fp32 atomics (kept for A/B measurements, not reproducible)
+        self.item_mode = str(config.get("item_mode", "chunked")).lower()
         self.show_progress = bool(config.get("progress", True))
         # 'loader' (default): replay the DataLoader's torch RNG order (what the reference run does);
         # 'device': shuffle=True as a keyed permutation computed on the GPU (no host permutation,

@@ -165,8 +165,9 @@ def test_lightgcn_argument_errors():
 
 
 def test_lightgcn_reproducible_mode_is_bitwise_repeatable(kat_lg):
-    """item_mode='sorted': two runs of the same training give identical bits, on a graph whose item rows span
-    many chunks; the default 'chunked' mode stays within round-off of it."""
+    """Two runs of the same training give identical bits in both modes, on a graph whose item rows span many
+    chunks ('sorted' = row-owner products, 'chunked' = the default segmented reduction with parked partials
+    and edge records); the two modes agree to round-off."""
     from daisyrec_amd.model.LightGCNRecommender import LightGCN
     from daisyrec_amd.utils.dataset import BasicDataset, get_dataloader
     rng = np.random.default_rng(1)
@@ -174,7 +175,7 @@ def test_lightgcn_reproducible_mode_is_bitwise_repeatable(kat_lg):
     gu, gi = rng.integers(0, U, n), rng.integers(0, I, n)
     samples = np.stack([gu, gi, rng.integers(0, I, n)], 1).astype(np.int32)[:8192]
     outs = {}
-    for mode in ("sorted", "sorted", "chunked"):
+    for mode in ("sorted", "sorted", "chunked", "chunked"):
         torch.manual_seed(0)
         cfg = mf_config(user_num=U, item_num=I, factors=d, num_layers=2, algo_name="lightgcn", reg_1=0.0, reg_2=0.0, lr=0.01,
                         epochs=1, item_mode=mode, batch_size=1024,
@@ -186,5 +187,7 @@ def test_lightgcn_reproducible_mode_is_bitwise_repeatable(kat_lg):
     (l0, p0, q0), (l1, p1, q1) = outs["sorted"]
     assert l0 == l1 and np.array_equal(p0, p1) and np.array_equal(q0, q1)
     lc, pc, qc = outs["chunked"][0]
+    lc1, pc1, qc1 = outs["chunked"][1]                       # the default kernels are reproducible too
+    assert lc == lc1 and np.array_equal(pc, pc1) and np.array_equal(qc, qc1)
     assert abs(lc - l0) <= 1e-6 * abs(l0)
     assert np.abs(pc - p0).max() < 0.05 and np.abs(qc - q0).max() < 0.05      # Adam: bounded by a few lr

@@ -537,3 +537,35 @@ def test_pointwise_cl_through_sampler_and_fit(ops, ml100k):
         z = _t(np.zeros(8, np.int32))
         ctx.set_batch(z, z, z)
         ctx.forward(model.embed_user.weight.data, model.embed_item.weight.data, ops.LOSS_IDS["BPR"])
+
+
+def test_chunked_mode_is_bitwise_reproducible(ops):
+    """The throughput kernels leave no summation order to chance (parked partials added in group order,
+    edge records chained in chunk order, fixed-order batch sums): two runs give identical bits - on a batch
+    with hot users and hot items whose runs cross many chunks."""
+    rng = np.random.default_rng(3)
+    U, I, d, B = 5000, 300, 64, 60000
+    P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    u = np.where(rng.random(B) < 0.3, 7, rng.integers(0, U, B)).astype(np.int32)       # a user with ~18k samples
+    i = np.where(rng.random(B) < 0.3, 5, rng.integers(0, I, B)).astype(np.int32)       # an item with ~18k entries
+    j = rng.integers(0, I, B).astype(np.int32)
+    outs = []
+    for rep in range(3):
+        P, Q = _t(P0), _t(Q0)
+        ctx = ops.BprContext(B, d, U, I)
+        sl = torch.zeros(1, dtype=torch.float64, device=DEV)
+        ctx.set_batch(_t(u), _t(i), _t(j))
+        for _ in range(3):
+            ctx.sgd_step(P, Q, 1e-3, 1e-3, 1e-3, item_mode=ops.ITEM_MODES["chunked"], step_loss=sl)
+        outs.append((float(sl.cpu()), P.cpu().numpy(), Q.cpu().numpy()))
+        ctx.close()
+    for o in outs[1:]:
+        assert o[0] == outs[0][0] and np.array_equal(o[1], outs[0][1]) and np.array_equal(o[2], outs[0][2])
+    loss, Pn, Qn = P0, Q0, None
+    Pn, Qn = P0, Q0
+    for _ in range(3):
+        loss, Pn, Qn = O.mf_sgd_step(Pn, Qn, u, i, j, 1e-3, 1e-3, 1e-3)
+    assert abs(outs[0][0] - loss) <= 1e-5 * abs(loss)
+    np.testing.assert_allclose(outs[0][1], Pn, atol=2e-5)
+    np.testing.assert_allclose(outs[0][2], Qn, atol=2e-5)

@@ -19,7 +19,7 @@ import os
 import sys
 from collections import defaultdict
 
-STEP_KERNELS = ("k_fwd", "k_reduce_partials", "k_finalize", "k_item_grad_chunked", "k_item_grad_sorted",
+STEP_KERNELS = ("k_fwd", "k_reduce_partials", "k_finalize", "k_item_grad_chunked", "k_item_edges", "k_item_grad_sorted",
                 "k_item_grad_atomic", "k_item_reg", "k_user_chunked", "k_user_edges", "k_user", "k_item_apply",
                 "k_unorm_reduce", "k_unorm", "k_row_sqnorm")
 
