@@ -16,7 +16,7 @@ import os
 import torch  # noqa: F401  (side effect: loads torch's HIP runtime first)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libdaisyrec_hip.so")
+LIB_PATH = os.environ.get("DAISY_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libdaisyrec_hip.so")
 
 DAISY_OK, DAISY_ERR_ARG, DAISY_ERR_HIP, DAISY_ERR_STATE = 0, 1, 2, 3
 LOSS_BPR, LOSS_HL, LOSS_TL, LOSS_CL, LOSS_SL = 0, 1, 2, 3, 4
