@@ -1,0 +1,95 @@
+"""Host logic of the mirror classes (no device): construction from the reference's config keys, parameter
+initialisation bit-identical to the reference's (same module order => same torch RNG stream; the golden
+files hold the reference's initial parameters), optimiser / loss name handling, and the refusal to run
+without a HIP device (no CPU fallback)."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import mf_config
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = lambda name: np.load(os.path.join(HERE, "golden", name))     # noqa: E731
+NO_GPU = not torch.cuda.is_available()
+
+
+def test_fm_init_matches_the_reference():
+    from daisyrec_amd.model.FMRecommender import FM
+    g = G("kat_fm.npz")
+    torch.manual_seed(int(g["ml/seed"]))
+    m = FM(mf_config(user_num=int(g["ml/user_num"]), item_num=int(g["ml/item_num"]), factors=int(g["ml/factors"]),
+                     algo_name="fm"))
+    np.testing.assert_array_equal(m.embed_user.weight.detach().numpy(), g["ml/P0"])
+    np.testing.assert_array_equal(m.embed_item.weight.detach().numpy(), g["ml/Q0"])
+    assert float(m.u_bias.weight.detach().abs().max()) == 0 and float(m.i_bias.weight.detach().abs().max()) == 0
+    assert m.optimizer == "sgd" and m.initializer == "normal"
+
+
+def test_neumf_init_matches_the_reference_and_model_names():
+    from daisyrec_amd.model.NeuMFRecommender import NeuMF
+    g = G("kat_neumf.npz")
+    U, I, d, L = (int(x) for x in g["ml/meta"])
+    cfg = mf_config(user_num=U, item_num=I, factors=d, num_layers=L, dropout=0.0, model_name="NeuMF", GMF_model=None,
+                    MLP_model=None, algo_name="neumf")
+    torch.manual_seed(int(g["ml/seed"]))
+    m = NeuMF(cfg)
+    for k, p in m._named().items():
+        np.testing.assert_array_equal(p.detach().numpy(), g[f"ml/{k}0"], err_msg=k)
+    assert m.optimizer == "adam" and m.initializer == "xavier_normal"
+    assert NeuMF({**cfg, "model_name": "GMF"}).predict_layer.in_features == d
+    assert NeuMF({**cfg, "model_name": "MLP"}).predict_layer.in_features == d
+    pre = NeuMF({**cfg, "model_name": "NeuMF-pre", "GMF_model": NeuMF({**cfg, "model_name": "GMF"}),
+                 "MLP_model": NeuMF({**cfg, "model_name": "MLP"})})
+    assert pre.predict_layer.in_features == 2 * d
+
+
+def test_lightgcn_and_item2vec_init_match_the_reference():
+    from daisyrec_amd.model.Item2VecRecommender import Item2Vec
+    from daisyrec_amd.model.LightGCNRecommender import LightGCN
+    g = G("kat_lightgcn.npz")
+    U, I, d, L = (int(x) for x in g["ml/meta"])
+    gu, gi = g["ml/train_users"], g["ml/train_items"]
+    torch.manual_seed(int(g["ml/seed"]))
+    m = LightGCN(mf_config(user_num=U, item_num=I, factors=d, num_layers=L, algo_name="lightgcn", reg_1=0.0, reg_2=0.0,
+                           inter_matrix=sp.coo_matrix((np.ones(len(gu), np.float32), (gu, gi)), shape=(U, I))))
+    np.testing.assert_array_equal(m.embed_user.weight.detach().numpy(), g["ml/P0"])
+    np.testing.assert_array_equal(m.embed_item.weight.detach().numpy(), g["ml/Q0"])
+    assert m.optimizer == "adam" and m.initializer == "xavier_uniform" and m.item_mode == "chunked"
+    g = G("kat_item2vec.npz")
+    U, I, d = (int(x) for x in g["ml/meta"])
+    torch.manual_seed(int(g["ml/seed"]))
+    m = Item2Vec(mf_config(user_num=U, item_num=I, factors=d, train_ur={}, algo_name="item2vec"))
+    np.testing.assert_array_equal(m.shared_embedding.weight.detach().numpy(), g["ml/S0"])
+    np.testing.assert_array_equal(m.user_embedding.weight.detach().numpy(), g["ml/Uemb0"])
+    assert m.loss_type == "CL" and m.optimizer == "adam"
+
+
+@pytest.mark.skipif(not NO_GPU, reason="host-only behaviour")
+def test_models_refuse_to_run_without_a_device():
+    from daisyrec_amd.model.FMRecommender import FM
+    from daisyrec_amd.model.Item2VecRecommender import Item2Vec
+    from daisyrec_amd.model.NeuMFRecommender import NeuMF
+    from daisyrec_amd.utils.dataset import BasicDataset, get_dataloader
+    loader = get_dataloader(BasicDataset(np.zeros((8, 3), np.int32)), batch_size=4, shuffle=False, num_workers=0)
+    models = [FM(mf_config(user_num=5, item_num=5, factors=8)),
+              NeuMF(mf_config(user_num=5, item_num=5, factors=8, num_layers=2, dropout=0.0, model_name="NeuMF",
+                              GMF_model=None, MLP_model=None)),
+              Item2Vec(mf_config(user_num=5, item_num=5, factors=8, train_ur={}))]
+    for m in models:
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            m.fit(loader)
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            m.full_rank(0)
+
+
+def test_optimizer_and_loss_names_follow_the_reference():
+    from daisyrec_amd.model.FMRecommender import FM
+    m = FM(mf_config(user_num=5, item_num=5, factors=8, optimizer="nonsense"))
+    assert m._resolve_optimizer() == "adam"                 # unknown -> Adam with a log line (AbstractRecommender.py:63-65)
+    with pytest.raises(NotImplementedError):
+        FM(mf_config(user_num=5, item_num=5, factors=8, optimizer="rmsprop"))._resolve_optimizer()
+    with pytest.raises(NotImplementedError):
+        m._build_criterion("XX")
