@@ -16,7 +16,6 @@ import torch
 import torch.nn as nn
 
 from .. import ops
-from .. import _native as N
 
 try:  # the reference shows a tqdm bar (AbstractRecommender.py:116); optional here
     from tqdm import tqdm as _tqdm

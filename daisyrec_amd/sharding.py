@@ -26,7 +26,6 @@ Per step and rank (compute stream | collective):
 """
 from __future__ import annotations
 
-import torch
 import torch.distributed as dist
 
 from . import _native as N

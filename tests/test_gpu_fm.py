@@ -8,7 +8,6 @@ import pytest
 import torch
 
 from conftest import mf_config
-from oracle import bpr_mf_numpy as O
 from oracle import fm_numpy as F
 
 pytestmark = pytest.mark.gpu

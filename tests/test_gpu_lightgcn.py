@@ -8,7 +8,6 @@ import scipy.sparse as sp
 import torch
 
 from conftest import mf_config
-from oracle import bpr_mf_numpy as O
 from oracle import lightgcn_numpy as LG
 from test_oracle_neumf import assert_params_close
 
