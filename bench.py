@@ -40,11 +40,14 @@ def parse():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=1 << 21, help="interactions per GPU per step")
     ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c3", "tiny"])
-    ap.add_argument("--item-mode", default="chunked", choices=["fused", "chunked", "atomic", "sorted"])
+    ap.add_argument("--item-mode", default="fused", choices=["fused", "chunked", "atomic", "sorted"])
+    ap.add_argument("--plan", default="auto", choices=["auto", "indexed", "sorted"],
+                    help="epoch plan layout: indexed = partitioned (staged step only), sorted = radix-sorted")
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--reg", type=float, default=0.001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap-plan", type=int, default=1, help="build the next epoch's plan on a side stream")
+    ap.add_argument("--overlap-plan", type=int, default=0,
+                    help="build the next epoch's plan on a side stream (two plans in ping-pong; measured slower with the partitioned plan)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 code path on one GPU)")
@@ -150,6 +153,8 @@ def main():
     item_mode = ops.ITEM_MODES[a.item_mode]
     trainer = UserShardedBprTrainer(ctx, P, Q, 0, lr, reg, reg, item_mode=item_mode) if world > 1 else None
     user_sorted = ops.triples_user_sorted(triples)      # synthetic triples are generated in CSR order
+    plan_kind = a.plan if a.plan != "auto" else ("indexed" if a.item_mode == "fused" else "sorted")
+    index = ops.TrainIndex(triples, U_loc, I, user_sorted=user_sorted) if plan_kind == "indexed" else None
     full_batches = n // B                      # the bench steps over full batches only (fixed B per step)
     if world > 1:                              # shards differ by a few interactions (dedup): agree on the
         fb = torch.tensor([full_batches], device=dev, dtype=torch.int64)     # count, every rank must take the same steps
@@ -165,13 +170,19 @@ def main():
     side = torch.cuda.Stream(device=dev) if a.overlap_plan else None
     state = {"epoch": 0, "k": None, "cur": 0, "ready": None}
 
+    def build_plan(slot, epoch):
+        if index is not None:
+            plans[slot].build_indexed(index, B, order="feistel", seed=2022 + rank, epoch=epoch)
+        else:
+            plans[slot].build(triples, B, order="feistel", seed=2022 + rank, epoch=epoch, user_sorted=user_sorted)
+
     def build(slot, epoch, stream=None):
         if stream is None:
-            plans[slot].build(triples, B, order="feistel", seed=2022 + rank, epoch=epoch, user_sorted=user_sorted)
+            build_plan(slot, epoch)
             return None
         stream.wait_stream(torch.cuda.current_stream())      # the slot's previous epoch has been consumed
         with torch.cuda.stream(stream):
-            plans[slot].build(triples, B, order="feistel", seed=2022 + rank, epoch=epoch, user_sorted=user_sorted)
+            build_plan(slot, epoch)
             return stream.record_event()
 
     def step():
@@ -248,6 +259,7 @@ def main():
                        "item_mode": a.item_mode, "id_distribution": a.dist, "interactions_per_gpu": n,
                        "parallelism": f"user-sharded dp{world}" if world > 1 else "single GPU",
                        "plan_bytes": plan.nbytes * len(plans), "plan_overlapped": bool(a.overlap_plan),
+                       "plan_layout": plan_kind, "index_bytes": index.nbytes if index is not None else 0,
                        "semantics": "batch-synchronous (autograd + SGD.step equivalent), shuffle=True (device Feistel permutation per epoch)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

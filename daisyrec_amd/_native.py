@@ -27,7 +27,8 @@ PLAN_POINTWISE = 2
 STATS_LEN = 16
 ST_LOSS_DATA, ST_L1_U, ST_L1_I, ST_L1_J, ST_SQ_U, ST_SQ_I, ST_SQ_J = range(7)
 ST_LOSS, ST_NORM_U, ST_NORM_I, ST_NORM_J = 7, 8, 9, 10
-ABI_VERSION = 2
+ST_SQ_U_PRE = 13
+ABI_VERSION = 3
 
 _p = C.c_void_p
 _i32, _i64, _u64, _f32, _sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
@@ -62,8 +63,19 @@ SIGNATURES = {
     "daisy_epoch_plan_bytes": (_sz, [_p]),
     "daisy_epoch_plan_build": (C.c_int, [_p, _p, _i64, _p, _i32, _u64, _u64, _i64, _i32, _i32, _p]),
     "daisy_epoch_plan_num_batches": (_i64, [_p]),
+    "daisy_epoch_plan_validate": (C.c_int, [_p, _p]),
+    "daisy_bpr_ctx_validate_batch": (C.c_int, [_p, _p]),
     "daisy_epoch_plan_read_batch": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, C.POINTER(_i64), _p]),
     "daisy_feistel_positions": (C.c_int, [_i64, _u64, _u64, _p, _p]),
+    "daisy_train_index_create": (C.c_int, [C.POINTER(_p), _p, _i64, _i64, _i64, _i32, _i32, _p]),
+    "daisy_train_index_destroy": (C.c_int, [_p]),
+    "daisy_train_index_bytes": (_sz, [_p]),
+    "daisy_epoch_plan_build_indexed": (C.c_int, [_p, _p, _p, _i32, _u64, _u64, _i64, _p]),
+    "daisy_bpr_ctx_invalidate_cache": (C.c_int, [_p]),
+    "daisy_bpr_staged_prenorm": (C.c_int, [_p, _p, _p, _p]),
+    "daisy_bpr_staged_user": (C.c_int, [_p, _p, _p, _i32, _f32, _f32, _f32, _f32, _p, _p]),
+    "daisy_bpr_staged_item": (C.c_int, [_p, _i32, _p, _p, _p, _f32, _f32, _f32, _p, _p]),
+    "daisy_item_apply_counts": (C.c_int, [_p, _p, _p, _i64, _i32, _f32, _f32, _f32, _p, _p]),
     "daisy_bpr_forward": (C.c_int, [_p, _p, _p, _i32, _f32, _p, _p]),
     "daisy_bpr_finalize": (C.c_int, [_p, _p, _f32, _f32, _p, _p, _p]),
     "daisy_bpr_item_grad": (C.c_int, [_p, _p, _p, _p, _f32, _f32, _p, _i32, _p]),

@@ -1,0 +1,159 @@
+// Internal types shared by the training translation units (bpr_train.hip: the phase kernels
+// over the sorted epoch plan; bpr_staged.hip: the partitioned epoch plan and the staged step).
+#pragma once
+
+#include "common.h"
+
+namespace daisy {
+
+constexpr uint32_t kNegBit = 0x80000000u;
+
+// What the step kernels see of the current batch (pointers into an epoch plan).
+//   sample s in [0,B):  user = ukey[s] & umask,  (pos item, neg item) = ij[s]
+//                       samples of one user are contiguous (stable order)
+//   entry  q in [0,2B): item = (ekey[q] & imask) >> 1, negative slot = ekey[q] & 1 (ascending, stable),
+//                       esu[q] = (sample position s | kNegBit for the negative slot, user of s)
+struct BatchView {
+    const uint32_t *ukey;
+    const int2 *ij;
+    const uint32_t *ekey;
+    const uint2 *esu;
+    // run-length encoding of the batch's entry keys: run m in [run_off[0], run_off[1]) has
+    // run_key[m] = item << 1 | neg and run_cnt[m] entries (an item owns 1 or 2 adjacent runs)
+    const uint32_t *run_key, *run_cnt;
+    const int32_t *run_off;
+    uint32_t umask, imask;
+    // point-wise losses (CL / SL, MFRecommender.py:75-81): ij[s] = (item, label); the "negative"
+    // slot of a sample is an inert copy of its item (coefficient 0, not counted by the regulariser)
+    int32_t pointwise;
+    int64_t B;
+    // FM (FMRecommender.py:61-68): score += u_bias[u] + i_bias[item] + bias_; bu == nullptr -> plain MF.
+    // g_bi accumulates like gQ (zero between steps, consumed by k_item_apply); g_bu / g_b0 are only
+    // written by the gradient-output user pass (Adam); the SGD user pass updates bu and b0 in place.
+    float *bu, *bi, *b0;
+    float *g_bu, *g_bi, *g_b0;
+};
+
+}  // namespace daisy
+
+// What the STAGED step (bpr_staged.hip) sees of the current batch.  Either layout of the epoch plan
+// can feed it:
+//   sample s in [0,B):  user = s_user[s] & umask, (pos item, neg item) = s_ij[s], samples of one user contiguous;
+//                       stage slot of the sample = s_pos ? s_pos[s] - pos_base : s      (a bijection onto [0,B))
+//   entry  q in [0,E):  item = (e_key[q] & imask) >> 1, negative slot = e_key[q] & 1 (ascending, stable);
+//                       stage slot of the sample it belongs to = (e_pos[q*e_stride] & ~kNegBit) - pos_base
+namespace daisy {
+struct StreamView {
+    const uint32_t *s_user;
+    const int2 *s_ij;
+    const uint32_t *s_pos;
+    const uint32_t *e_key;
+    const uint32_t *e_pos;
+    uint32_t umask, imask;
+    int32_t e_stride;
+    uint32_t pos_base;
+    int64_t B, E;
+};
+}  // namespace daisy
+
+// Static index of a training set (built once per fit): the triples in CSR (user-sorted) order and
+// their item entries sorted by item.  The partitioned epoch plan is two stable one-digit partitions
+// of these arrays by batch id.
+struct daisy_train_index {
+    int64_t n, U, I;
+    int32_t user_base;
+    const int32_t *triples;   // [n][3] CSR order: the caller's array, or `sorted_copy`
+    int32_t *sorted_copy;     // owned copy when the caller's array was not user-sorted
+    const uint32_t *orig;     // [n] row of the caller's array behind CSR row t (NULL: identity); epoch positions
+                              //     (perm / Feistel / identity) always refer to the caller's rows
+    uint32_t *ent_t;          // [2n] triple index | slot << 31, sorted by ent_key (stable: t ascending)
+    uint32_t *ent_key;        // [2n] item << 1 | slot
+    size_t bytes;
+};
+
+// Epoch plan: the whole epoch laid out batch by batch (see the header comment of bpr_train.hip).
+// Two layouts:
+//   kind 0 (sorted, daisy_epoch_plan_build):          packed sort keys + run lists; every phase kernel reads it
+//   kind 1 (partitioned, daisy_epoch_plan_build_indexed): plain SoA records, 32 B per interaction; staged step only
+struct daisy_epoch_plan {
+    int64_t max_triples, U, I;
+    void *arena;          // kind 0 buffers (allocated by the first daisy_epoch_plan_build)
+    size_t arena_bytes, temp_bytes;
+    // double buffers of the two radix sorts
+    uint32_t *k32[2];     // [2n] 32-bit keys
+    uint64_t *k64[2];     // [2n] 64-bit keys (only when batch bits + id bits > 32)
+    uint64_t *v64[2];     // [2n] payloads
+    uint32_t *ukey;       // [n]  sorted sample keys (batch << ubits | user)
+    uint64_t *uval;       // [n]  (i, j)
+    uint32_t *ekey;       // [2n] sorted entry keys (batch << ibits | item)
+    uint64_t *eval;       // [2n] (s | neg, u)
+    uint32_t *run_key;    // [2n]  item << 1 | neg of every run of equal entry keys
+    uint32_t *run_cnt;    // [2n]  its length
+    int32_t *run_off;     // [max_triples+2] first run of every batch; [num_batches] = total
+    uint32_t *run_total;  // [1]   number of runs (device)
+    int *bad;             // [1]   bit 0: an id of the last build lay outside the tables, bit 1: a bad permutation entry
+    uint32_t umask, imask;
+    void *temp;
+    int64_t n, batch_size, num_batches;
+    int32_t pointwise;
+    bool built;
+    int32_t kind;
+    // kind 1 buffers (allocated by the first daisy_epoch_plan_build_indexed): record set [x] of the LSD passes
+    void *parena;
+    size_t parena_bytes, ptemp_bytes;
+    uint32_t *p_user[2], *p_pos[2];     // [n]   samples: user, epoch position
+    int2 *p_ij[2];                      // [n]            (pos item, neg item)
+    uint32_t *p_ekey[2], *p_epos[2];    // [2n]  entries: item << 1 | slot, epoch position of the sample
+    uint32_t *p_tmp_pos;                // [2n]  positions computed by the counting pass
+    uint32_t *p_counts, *p_offsets;     // [ndig * ntiles] per-tile digit counts / their exclusive scan
+    uint32_t *p_inv;                    // [n]   inverse of an explicit permutation (DAISY_ORDER_PERM)
+    void *ptemp;                        // rocPRIM scan scratch
+    void *parena2;                      // second record set (plans with more than 256 batches: LSD passes ping-pong)
+    int32_t p_cur;                      // record set holding the finished plan
+};
+
+struct daisy_bpr_ctx {
+    int64_t max_batch, U, I;
+    int d;
+    void *arena;
+    size_t arena_bytes;
+    float2 *coef;        // (dL/dpos, dL/dneg) per sample   [max_batch]
+    double *partials;    // per-workgroup sums              [kMaxGrid*8]
+    int32_t *tmp_triples;  // [max_batch*3] staging for daisy_bpr_set_batch
+    float *edge_vec;     // [2*nchunks][d] partial user gradients of runs that cross a chunk boundary
+    int32_t *edge_user;  // [2*nchunks]    their user (-1: none); [2c] head edge, [2c+1] tail edge
+    float *edge_n;       // [2*nchunks][2] their sample counts and (FM) coefficient sums
+    int32_t *edge_whole; // [nchunks]      the head edge's run also fills the whole chunk
+    float *p_stage;      // [max_batch][d] updated user rows of the fused step, committed after the item pass
+    float *p_sqnorm;     // [U] cache of |P[u]|^2 (fused step: the user-side Frobenius norm before the pass)
+    const float *p_sqnorm_of;   // table the cache describes (NULL = invalid)
+    daisy_epoch_plan *own_plan;   // 1-batch plan used by set_batch / set_batch_from_triples
+    daisy::BatchView v;
+    daisy::StreamView sv;  // the same batch as the staged step sees it
+    int32_t batch_kind;   // layout of the plan the current batch comes from (0: v and sv valid, 1: only sv)
+    float *edge_cnt;      // staged step, edge records of the item pass: [2*nchunks][2] (n_pos, n_neg)
+    int32_t pointwise;   // batches set through set_batch* hold (user, item, label) rows
+    int last_item_mode;  // mode of the last daisy_bpr_item_grad: the user pass of the same step follows it
+    float *bu, *bi, *b0, *g_bu, *g_bi, *g_b0;   // FM bias parameters (daisy_bpr_ctx_set_bias); bu == nullptr: MF
+    bool batch_set, fwd_done;
+};
+
+
+namespace daisy {
+// bpr_staged.hip
+bool staged_supported(const daisy_bpr_ctx *ctx, int loss_type);
+int staged_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int loss_type, float gamma, float lr, float reg_1,
+                    float reg_2, double *stats, double *epoch_acc, double *step_loss, hipStream_t s);
+StreamView plan_stream_view(const daisy_epoch_plan *plan, int64_t k);
+int plan_read_batch_partitioned(const daisy_epoch_plan *plan, int64_t k, int32_t *u, int32_t *i, int32_t *j,
+                                int32_t *ent_item, uint32_t *ent_s, int32_t *ent_u, int64_t *B_out_host,
+                                hipStream_t s);
+// bpr_train.hip: fixed-order reduction of `nblocks` x 8 per-workgroup sums into stats[0..6,12]; finalize: also
+// the norms and the loss (finalize_stats)
+int launch_reduce_partials(const double *partials, int nblocks, double *stats, bool finalize, float reg_1,
+                           float reg_2, double *epoch_acc, double *step_loss, hipStream_t s);
+// shared device helpers
+__device__ __forceinline__ float inv_or_zero(double n, float reg_2) {
+    return (n > 0.0) ? (float)((double)reg_2 / n) : 0.f;  // d|X|_F/dX = 0 at X = 0 (torch)
+}
+}  // namespace daisy

@@ -1,0 +1,1405 @@
+// The STAGED SGD step and the PARTITIONED epoch plan (gfx950 / MI355X).
+//
+// Reference semantics: the same batch-synchronous step as bpr_train.hip
+//   loader    daisy/utils/dataset.py:5-27          forward   daisy/model/MFRecommender.py:63-68
+//   loss      MFRecommender.py:70-97, loss.py:5-33 backward  AbstractRecommender.py:125
+//   SGD       AbstractRecommender.py:56,126
+//
+// Why a second organisation of the step.  The phase kernels of bpr_train.hip move 8.3 table rows per
+// interaction (k_fwd 3, item pass 2 + a random 8-byte coefficient gather per entry that costs a full
+// 128-byte fabric request, user pass 3.3) and the PMC counters say every one of them already runs at the
+// fabric rate for the bytes it moves (profiles/r01_*): the lever left is FEWER BYTES.  Here:
+//
+//   k_unorm          sum over the batch of |P[u]|^2 from a per-row cache (4 B / sample): the one batch-wide
+//                    quantity the user update needs BEFORE it runs (reg_2 * p / |P[u]|_F, MFRecommender.py:94)
+//   k_staged_user    forward + user update in ONE pass over the user-grouped samples: gathers p_u, q_i, q_j
+//                    once, forms both scores, the loss term and c = dL/dx, accumulates the seven batch sums,
+//                    updates P[u] in place (single owner per row, run/slot/edge reduction like bpr_train.hip)
+//                    and writes m_s = c_s * p_u(pre-step) to stage[slot(s)]: one 256-B row per sample
+//   k_staged_item    segmented reduction over the item-sorted entries: gQ[i] = sum_e (+/-) m_{s(e)} - the
+//                    coefficient rides inside the staged row, so an entry costs ONE row gather and no
+//                    coefficient gather; the segment's owner then applies regulariser + SGD to Q[i] IN PLACE
+//                    (no gQ round trip, no run lists, no separate apply pass).  Multi-GPU: writes the data
+//                    term + (n_pos, n_neg) per item instead, for a reduce-scatter.
+//
+// Row traffic per interaction at d=64:  user pass 2 Q rows + 0.43 P rows read, 0.43 P rows + 1 stage row
+// written; item pass 2 stage rows read (+ the touched Q rows once) = ~1.5 KB instead of ~2.1 KB.
+// (BPR / HL have dL/dneg = -dL/dpos, so one premultiplied row serves both entries of a sample; TOP1 keeps
+// the plain row in the stage and gathers its two coefficients.)
+//
+// The PARTITIONED epoch plan replaces the two payload-carrying radix sorts per epoch (112 B and 80 ps per
+// interaction) by two stable one-digit partitions: the training set is indexed ONCE per fit (triples in
+// CSR order, item entries sorted by item: daisy_train_index), and since a stable partition of a sorted
+// list by batch id leaves every batch sorted, one counting pass + one scatter pass per epoch lay the epoch
+// out batch by batch.  The batch id of triple t is pos(t) / B with pos = identity, the inverse of an
+// explicit permutation, or the keyed Feistel bijection of (seed, epoch) computed in registers; the stage
+// slot of a sample is pos(t) - k*B, which both its sample record and its two entry records can compute
+// without ever meeting.  32 B of plan per interaction.
+#include <stdlib.h>
+#include <string.h>
+
+#include "bpr_internal.h"
+
+namespace daisy {
+
+static inline hipStream_t S(daisy_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// =============================================================================
+// partitioned epoch plan
+// =============================================================================
+constexpr int kPartThreads = 256;
+constexpr int kPartK = 8;                              // records per thread per sub-tile
+constexpr int kPartSub = kPartThreads * kPartK;        // 2048 records sorted in LDS at a time
+constexpr int kPartWaves = kPartThreads / kWave;
+
+struct PosFn {            // position of triple t in the epoch order
+    int mode;             // daisy_order_mode
+    FeistelKey fk;
+    const uint32_t *inv;  // DAISY_ORDER_PERM: inv[t] = p with perm[p] = t
+    const uint32_t *orig; // CSR row -> row of the caller's triple array (NULL: the array was in CSR order)
+    uint64_t n;
+};
+__device__ __forceinline__ uint32_t pos_of(const PosFn &f, uint32_t t) {
+    if (f.orig) t = f.orig[t];
+    if (f.mode == DAISY_ORDER_FEISTEL) return (uint32_t)feistel_position((uint64_t)t, f.n, f.fk);
+    if (f.mode == DAISY_ORDER_PERM) return f.inv[t];
+    return t;
+}
+struct BatchDiv { uint32_t B, M0; int shift; };   // batch id = p / B without a hardware divide
+static BatchDiv make_batch_div(int64_t B) {
+    BatchDiv bd;
+    bd.B = (uint32_t)B;
+    bd.M0 = (B >= 2) ? (uint32_t)(((uint64_t)1 << 32) / (uint64_t)B) : 0u;
+    bd.shift = -1;
+    if ((B & (B - 1)) == 0) { bd.shift = 0; while (((int64_t)1 << bd.shift) < B) ++bd.shift; }
+    return bd;
+}
+__device__ __forceinline__ uint32_t batch_of(uint32_t p, const BatchDiv &bd) {
+    if (bd.shift >= 0) return p >> bd.shift;          // power-of-two batch (uniform branch)
+    uint32_t q = __umulhi(p, bd.M0);        // floor(p*floor(2^32/B)/2^32) in {q_true-1, q_true}
+    uint32_t r = p - q * bd.B;
+    while (r >= bd.B) { r -= bd.B; ++q; }
+    return q;
+}
+
+struct PartSrc {
+    const int32_t *triples; int32_t user_base;          // samples, static source (CSR-ordered triples)
+    const uint32_t *user; const int2 *ij;               // samples, record source (LSD pass >= 1)
+    const uint32_t *ent_t;                              // entries, static source: triple index | slot << 31
+    const uint32_t *key;                                // entries: item << 1 | slot
+    const uint32_t *pos;                                // epoch positions (record source, or the counting pass's scratch)
+};
+struct PartDst { uint32_t *user; int2 *ij; uint32_t *key; uint32_t *pos; };
+
+// lanes of this wave that hold the same digit (the AMD counterpart of match.any: one ballot per digit bit)
+__device__ __forceinline__ uint64_t match_digit(uint32_t dgt, bool valid, int nbits) {
+    uint64_t peers = __ballot(valid);
+    for (int b = 0; b < nbits; ++b) {
+        const bool bit = (dgt >> b) & 1u;
+        const uint64_t m = __ballot(bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
+
+// KIND 0: samples from the static source   1: entries from the static source   2: records of a previous pass
+// (pos read).  The static kinds compute the epoch position and park it in pos_out (when given) for the
+// scatter pass: the Feistel evaluation is the ALU bound of the plan build.
+template <int KIND>
+__global__ __launch_bounds__(kPartThreads) void k_part_count(PartSrc src, PosFn pf, BatchDiv bd, int64_t n,
+                                                             int shift, int nbits, int ndig, int64_t tile_elems,
+                                                             int64_t ntiles, uint32_t *__restrict__ pos_out,
+                                                             uint32_t *__restrict__ counts) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t lds_t[KIND == 1 ? kPartSub : 1];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * tile_elems;
+    const int64_t hi = (lo + tile_elems < n) ? lo + tile_elems : n;
+    if (KIND != 2 && pf.mode == DAISY_ORDER_FEISTEL) {
+        // Cycle walking inside a lock-step wave costs the MAXIMUM walk length of its 64 lanes per element
+        // (~3.5 network passes instead of the 1.34 average at n = 0.75 * 2^2h).  So every lane owns a strip of
+        // elements and steps through it at its own pace: each trip of the loop is one useful network pass for
+        // every lane, and the lanes only wait for each other at the end of the strip.
+        const uint32_t nn = (uint32_t)pf.n;
+        for (int64_t sub = lo; sub < hi; sub += kPartSub) {
+            if constexpr (KIND == 1) {
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < kPartK; ++k) {
+                    const int64_t e = sub + k * kPartThreads + threadIdx.x;
+                    lds_t[k * kPartThreads + threadIdx.x] = (e < hi) ? (src.ent_t[e] & ~kNegBit) : 0u;
+                }
+                __syncthreads();
+            }
+            int j = 0;
+            int64_t e = sub + threadIdx.x;
+            bool active = e < hi;
+            auto first = [&]() -> uint32_t {
+                uint32_t t;
+                if constexpr (KIND == 1) t = lds_t[j * kPartThreads + threadIdx.x];
+                else t = (uint32_t)e;
+                return pf.orig ? pf.orig[t] : t;
+            };
+            uint32_t x = active ? first() : 0u;
+            while (active) {
+                x = feistel_once(x, pf.fk);
+                if (x < nn) {
+                    if (pos_out) pos_out[e] = x;
+                    atomicAdd(&hist[(batch_of(x, bd) >> shift) & 255u], 1u);
+                    ++j;
+                    e += kPartThreads;
+                    active = (j < kPartK) && (e < hi);
+                    if (active) x = first();
+                }
+            }
+        }
+    } else {
+        const uint64_t lt_mask = ((uint64_t)1 << (threadIdx.x % kWave)) - 1;
+        for (int64_t base = lo; base < hi; base += kPartThreads) {
+            const int64_t e = base + threadIdx.x;
+            const bool valid = e < hi;
+            uint32_t p = 0;
+            if (valid) {
+                if constexpr (KIND == 0) p = pos_of(pf, (uint32_t)e);
+                else if constexpr (KIND == 1) p = pos_of(pf, src.ent_t[e] & ~kNegBit);
+                else p = src.pos[e];
+                if constexpr (KIND != 2) { if (pos_out) pos_out[e] = p; }
+            }
+            const uint32_t dgt = (batch_of(p, bd) >> shift) & 255u;
+            const uint64_t peers = match_digit(dgt, valid, nbits);          // one LDS atomic per digit per wave
+            if (valid && (peers & lt_mask) == 0) atomicAdd(&hist[dgt], (uint32_t)__popcll(peers));
+        }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < ndig) counts[(int64_t)threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
+}
+
+// Stable scatter of one LSD digit.  A tile is cut into sub-tiles of 2048 records; a wave takes 512
+// consecutive records of the sub-tile in 8 rounds of 64 (coalesced reads, and the round order = the record
+// order, so ranks are stable), the sub-tile is sorted by digit in LDS and leaves as one contiguous piece per
+// bucket.  SAMPLES: records (user, i, j, pos); else (key, pos).  STATIC: samples come from the triple array
+// and their position is src.pos (parked by the counting pass) or recomputed (entries always carry theirs in src.pos).
+template <bool SAMPLES, bool STATIC>
+__global__ __launch_bounds__(kPartThreads) void k_part_scatter(PartSrc src, PosFn pf, BatchDiv bd, int64_t n,
+                                                               int shift, int nbits, int ndig,
+                                                               int64_t tile_elems, int64_t ntiles,
+                                                               const uint32_t *__restrict__ offsets,
+                                                               PartDst dst) {
+    __shared__ uint4 rec4[SAMPLES ? kPartSub : 1];
+    __shared__ uint2 rec2[SAMPLES ? 1 : kPartSub];
+    __shared__ uint8_t sdig[kPartSub];
+    __shared__ uint32_t wcnt[kPartWaves][256];
+    __shared__ uint32_t tstart[256], goff[256], tot[256];
+    __shared__ uint32_t wsum[kPartWaves];
+
+    const int tid = threadIdx.x, wave = tid / kWave, wl = tid % kWave;
+    const uint64_t lt_mask = ((uint64_t)1 << wl) - 1;
+    goff[tid] = (tid < ndig) ? offsets[(int64_t)tid * ntiles + blockIdx.x] : 0u;
+    const int64_t lo = (int64_t)blockIdx.x * tile_elems;
+    const int64_t hi = (lo + tile_elems < n) ? lo + tile_elems : n;
+
+    for (int64_t sub = lo; sub < hi; sub += kPartSub) {
+#pragma unroll
+        for (int w = 0; w < kPartWaves; ++w) wcnt[w][tid] = 0;
+        __syncthreads();
+        uint32_t r_a[kPartK], r_b[kPartK], r_c[kPartK], r_p[kPartK], r_rank[kPartK], r_dig[kPartK];
+        const int64_t wbase = sub + (int64_t)wave * (kWave * kPartK);
+#pragma unroll
+        for (int r = 0; r < kPartK; ++r) {
+            const int64_t e = wbase + r * kWave + wl;
+            const bool valid = e < hi;
+            const int64_t ec = valid ? e : hi - 1;
+            if constexpr (SAMPLES) {
+                if constexpr (STATIC) {
+                    const int32_t *row = src.triples + 3 * ec;
+                    r_a[r] = (uint32_t)(row[0] - src.user_base);
+                    r_b[r] = (uint32_t)row[1];
+                    r_c[r] = (uint32_t)row[2];
+                    r_p[r] = src.pos ? src.pos[ec] : pos_of(pf, (uint32_t)ec);
+                } else {
+                    const int2 ij = src.ij[ec];
+                    r_a[r] = src.user[ec];
+                    r_b[r] = (uint32_t)ij.x;
+                    r_c[r] = (uint32_t)ij.y;
+                    r_p[r] = src.pos[ec];
+                }
+            } else {
+                r_a[r] = src.key[ec];
+                r_p[r] = src.pos[ec];
+            }
+            const uint32_t dgt = (batch_of(r_p[r], bd) >> shift) & 255u;
+            const uint64_t peers = match_digit(dgt, valid, nbits);
+            const uint32_t base = wcnt[wave][dgt];                  // all lanes read ...
+            const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+            if (valid && rank == 0) wcnt[wave][dgt] = base + (uint32_t)__popcll(peers);   // ... then one lane per digit writes
+            r_rank[r] = base + rank;
+            r_dig[r] = valid ? dgt : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        // digit totals of the sub-tile, their exclusive scan, and the waves' offsets inside each digit
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kPartWaves; ++w) { const uint32_t c = wcnt[w][tid]; wcnt[w][tid] = t; t += c; }
+        tot[tid] = t;
+        uint32_t inc = t;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t up = __shfl_up(inc, off, kWave);
+            if (wl >= off) inc += up;
+        }
+        if (wl == kWave - 1) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t wprefix = 0;
+#pragma unroll
+        for (int w = 0; w < kPartWaves; ++w) if (w < wave) wprefix += wsum[w];
+        tstart[tid] = wprefix + inc - t;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kPartK; ++r) {
+            if (r_dig[r] != 0xFFFFFFFFu) {
+                const uint32_t x = tstart[r_dig[r]] + wcnt[wave][r_dig[r]] + r_rank[r];
+                if constexpr (SAMPLES) rec4[x] = make_uint4(r_a[r], r_b[r], r_c[r], r_p[r]);
+                else rec2[x] = make_uint2(r_a[r], r_p[r]);
+                sdig[x] = (uint8_t)r_dig[r];
+            }
+        }
+        __syncthreads();
+        const int cnt = (int)((hi - sub < kPartSub) ? (hi - sub) : kPartSub);
+        for (int x = tid; x < cnt; x += kPartThreads) {
+            const uint32_t dg = sdig[x];
+            const int64_t o = (int64_t)goff[dg] + (x - tstart[dg]);
+            if constexpr (SAMPLES) {
+                const uint4 q = rec4[x];
+                dst.user[o] = q.x;
+                dst.ij[o] = make_int2((int)q.y, (int)q.z);
+                dst.pos[o] = q.w;
+            } else {
+                const uint2 q = rec2[x];
+                dst.key[o] = q.x;
+                dst.pos[o] = q.y;
+            }
+        }
+        __syncthreads();
+        goff[tid] += tot[tid];
+    }
+}
+
+// inv[perm[p]] = p  (DAISY_ORDER_PERM: perm[p] = triple served at position p)
+__global__ void k_invert_perm(const int64_t *__restrict__ perm, int64_t n, uint32_t *__restrict__ inv) {
+    for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = perm[p];
+        if (t >= 0 && t < n) inv[t] = (uint32_t)p;
+    }
+}
+
+// ---- static index ---------------------------------------------------------------------------------------
+// bad[0] |= 1 when a (user - user_base, item, item) lies outside [0,U) x [0,I) x [0,I)
+__global__ void k_index_entries(const int32_t *__restrict__ triples, int64_t n, int32_t user_base, int64_t U,
+                                int64_t I, uint32_t *__restrict__ key, uint32_t *__restrict__ val,
+                                uint32_t *__restrict__ ukey, uint32_t *__restrict__ uval, int *__restrict__ bad) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t *row = triples + 3 * t;
+        const int64_t u = (int64_t)row[0] - user_base, i = row[1], j = row[2];
+        const bool ok = u >= 0 && u < U && i >= 0 && i < I && j >= 0 && j < I;
+        if (!ok) atomicOr(bad, 1);
+        if (key) {
+            key[2 * t] = ok ? ((uint32_t)i << 1) : 0u;
+            val[2 * t] = (uint32_t)t;
+            key[2 * t + 1] = ok ? (((uint32_t)j << 1) | 1u) : 1u;
+            val[2 * t + 1] = (uint32_t)t | kNegBit;
+        }
+        if (ukey) { ukey[t] = ok ? (uint32_t)u : 0u; uval[t] = (uint32_t)t; }
+    }
+}
+
+__global__ void k_gather_triples(const int32_t *__restrict__ triples, const uint32_t *__restrict__ order, int64_t n,
+                                 int32_t *__restrict__ out) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t *row = triples + 3 * (int64_t)order[e];
+        out[3 * e] = row[0]; out[3 * e + 1] = row[1]; out[3 * e + 2] = row[2];
+    }
+}
+
+__global__ void k_read_partitioned(StreamView v, int32_t *__restrict__ u, int32_t *__restrict__ i,
+                                   int32_t *__restrict__ j, int32_t *__restrict__ ent_item,
+                                   uint32_t *__restrict__ ent_s, int32_t *__restrict__ ent_u) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < v.E; e += (int64_t)gridDim.x * blockDim.x) {
+        if (e < v.B) {
+            u[e] = (int32_t)(v.s_user[e] & v.umask);
+            i[e] = v.s_ij[e].x;
+            j[e] = v.s_ij[e].y;
+        }
+        const uint32_t k = v.e_key[e] & v.imask;
+        if (ent_item) ent_item[e] = (int32_t)(k >> 1);
+        if (ent_s) ent_s[e] = ((v.e_pos[e * v.e_stride] & ~kNegBit) - v.pos_base) | ((k & 1u) ? kNegBit : 0u);
+        if (ent_u) ent_u[e] = -1;          // this layout does not carry the user with the entry
+    }
+}
+
+StreamView plan_stream_view(const daisy_epoch_plan *p, int64_t k) {
+    const int64_t lo = k * p->batch_size;
+    const int c = p->p_cur;
+    StreamView v;
+    v.B = (p->n - lo < p->batch_size) ? (p->n - lo) : p->batch_size;
+    v.E = 2 * v.B;
+    v.s_user = p->p_user[c] + lo;
+    v.s_ij = p->p_ij[c] + lo;
+    v.s_pos = p->p_pos[c] + lo;
+    v.e_key = p->p_ekey[c] + 2 * lo;
+    v.e_pos = p->p_epos[c] + 2 * lo;
+    v.e_stride = 1;
+    v.umask = v.imask = 0xFFFFFFFFu;
+    v.pos_base = (uint32_t)lo;
+    return v;
+}
+
+int plan_read_batch_partitioned(const daisy_epoch_plan *plan, int64_t k, int32_t *u, int32_t *i, int32_t *j,
+                                int32_t *ent_item, uint32_t *ent_s, int32_t *ent_u, int64_t *B_out_host,
+                                hipStream_t s) {
+    const StreamView v = plan_stream_view(plan, k);
+    hipLaunchKernelGGL(k_read_partitioned, dim3(grid_for(v.E, kBlock)), dim3(kBlock), 0, s, v, u, i, j, ent_item,
+                       ent_s, ent_u);
+    DAISY_LAUNCH_CHECK();
+    if (B_out_host) *B_out_host = v.B;
+    return DAISY_OK;
+}
+
+// record set x of the partitioned layout lives in one allocation: user[n] pos[n] ij[n] ekey[2n] epos[2n]
+static int plan_need_partitioned(daisy_epoch_plan *p, int set) {
+    void **slot = set ? &p->parena2 : &p->parena;
+    if (*slot) return DAISY_OK;
+    const size_t n = (size_t)p->max_triples;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+    const size_t o_u = take(n * 4), o_p = take(n * 4);   // adjacent: together they are the 2n-word scratch of the entry pass
+    const size_t o_ij = take(n * 8), o_ek = take(n * 8), o_ep = take(n * 8);
+    size_t o_cnt = 0, o_tmp = 0, o_inv = 0, cnt_elems = 0;
+    if (set == 0) {
+        const int64_t max_tiles = (2 * (int64_t)n + kPartSub - 1) / kPartSub;
+        const int64_t tiles = max_tiles < 16384 ? max_tiles : 16384 + 1;
+        cnt_elems = (size_t)256 * (size_t)(tiles + 1);
+        p->ptemp_bytes = exclusive_scan_u32_temp_bytes((int64_t)cnt_elems);
+        o_cnt = take(cnt_elems * 4 * 2);   // counts, then their exclusive scan
+        o_tmp = take(p->ptemp_bytes);
+        o_inv = take(n * 4);
+    }
+    void *mem = nullptr;
+    hipError_t e = hipMalloc(&mem, off);
+    if (e != hipSuccess) {
+        set_error("epoch_plan_build_indexed: hipMalloc(%zu) failed: %s", off, hipGetErrorString(e));
+        return DAISY_ERR_HIP;
+    }
+    *slot = mem;
+    p->parena_bytes += off;
+    char *b = (char *)mem;
+    p->p_user[set] = (uint32_t *)(b + o_u);
+    p->p_pos[set] = (uint32_t *)(b + o_p);
+    p->p_ij[set] = (int2 *)(b + o_ij);
+    p->p_ekey[set] = (uint32_t *)(b + o_ek);
+    p->p_epos[set] = (uint32_t *)(b + o_ep);
+    if (set == 0) {
+        p->p_counts = (uint32_t *)(b + o_cnt);
+        p->p_offsets = p->p_counts + cnt_elems;
+        p->ptemp = b + o_tmp;
+        p->p_inv = (uint32_t *)(b + o_inv);
+    }
+    return DAISY_OK;
+}
+
+static void part_tiling(int64_t n, int64_t &tile_elems, int64_t &ntiles) {
+    int64_t subs = (n + (int64_t)kPartSub * 16384 - 1) / ((int64_t)kPartSub * 16384);
+    if (subs < 1) subs = 1;
+    tile_elems = subs * kPartSub;
+    ntiles = (n + tile_elems - 1) / tile_elems;
+}
+
+static int plan_build_partitioned(daisy_epoch_plan *p, const daisy_train_index *ix, const int64_t *perm,
+                                  int order_mode, uint64_t seed, uint64_t epoch, int64_t batch_size,
+                                  hipStream_t s) {
+    const int64_t n = ix->n;
+    const int64_t nb = (n + batch_size - 1) / batch_size;
+    const int bbits = (nb > 1) ? bits_for(nb) : 1;
+    const int passes = (bbits + 7) / 8;
+    int rc = plan_need_partitioned(p, 0);
+    if (rc) return rc;
+    if (passes > 1 && (rc = plan_need_partitioned(p, 1))) return rc;
+    PosFn pf;
+    pf.mode = order_mode;
+    pf.fk = make_feistel_key((uint64_t)n, seed, epoch);
+    pf.inv = p->p_inv;
+    pf.orig = ix->orig;
+    pf.n = (uint64_t)n;
+    if (order_mode == DAISY_ORDER_PERM) {
+        hipLaunchKernelGGL(k_invert_perm, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, perm, n, p->p_inv);
+        DAISY_LAUNCH_CHECK();
+    }
+    const BatchDiv bd = make_batch_div(batch_size);
+
+    // ---- entries first: their counting pass parks the positions in the (still unused) sample arrays of
+    // the destination set; then the samples
+    for (int what = 0; what < 2; ++what) {
+        const bool entries = (what == 0);
+        const int64_t m = entries ? 2 * n : n;
+        int64_t tile_elems, ntiles;
+        part_tiling(m, tile_elems, ntiles);
+        for (int pass = 0; pass < passes; ++pass) {
+            const int shift = 8 * pass;
+            const int bits_here = (bbits - shift < 8) ? (bbits - shift) : 8;
+            const int64_t dig_here = (pass == passes - 1) ? ((nb - 1) >> shift) + 1 : 256;
+            const int ndig = (int)(dig_here < 256 ? dig_here : 256);
+            // LSD passes ping-pong between the record sets and end in set 0
+            const int dset = ((passes - 1 - pass) & 1);
+            const int sset = dset ^ 1;
+            PartSrc src;
+            memset(&src, 0, sizeof(src));
+            PartDst dst;
+            dst.user = p->p_user[dset]; dst.ij = p->p_ij[dset];
+            dst.key = p->p_ekey[dset];
+            dst.pos = entries ? p->p_epos[dset] : p->p_pos[dset];
+            uint32_t *scratch_pos = p->p_user[dset];            // 2n words: p_user | p_pos of the destination set
+            if (pass == 0) {
+                src.triples = ix->triples; src.user_base = ix->user_base;
+                src.ent_t = ix->ent_t; src.key = ix->ent_key;
+                if (entries) {
+                    src.pos = scratch_pos;
+                    hipLaunchKernelGGL((k_part_count<1>), dim3((unsigned)ntiles), dim3(kPartThreads), 0, s, src, pf,
+                                       bd, m, shift, bits_here, ndig, tile_elems, ntiles, scratch_pos, p->p_counts);
+                } else {
+                    // the Feistel positions of the samples are parked in the (otherwise unused) inverse-permutation
+                    // buffer; identity / explicit orders are a load or nothing, so they are simply re-evaluated
+                    uint32_t *park = (order_mode == DAISY_ORDER_FEISTEL) ? p->p_inv : nullptr;
+                    src.pos = park;
+                    hipLaunchKernelGGL((k_part_count<0>), dim3((unsigned)ntiles), dim3(kPartThreads), 0, s, src, pf,
+                                       bd, m, shift, bits_here, ndig, tile_elems, ntiles, park, p->p_counts);
+                }
+            } else {
+                src.user = p->p_user[sset]; src.ij = p->p_ij[sset]; src.key = p->p_ekey[sset];
+                src.pos = entries ? p->p_epos[sset] : p->p_pos[sset];
+                hipLaunchKernelGGL((k_part_count<2>), dim3((unsigned)ntiles), dim3(kPartThreads), 0, s, src, pf, bd,
+                                   m, shift, bits_here, ndig, tile_elems, ntiles, (uint32_t *)nullptr, p->p_counts);
+            }
+            DAISY_LAUNCH_CHECK();
+            rc = exclusive_scan_u32(p->ptemp, p->ptemp_bytes, p->p_counts, p->p_offsets, (int64_t)ndig * ntiles, s);
+            if (rc) return rc;
+            const dim3 g((unsigned)ntiles), b(kPartThreads);
+            if (entries)
+                hipLaunchKernelGGL((k_part_scatter<false, false>), g, b, 0, s, src, pf, bd, m, shift, bits_here, ndig,
+                                   tile_elems, ntiles, p->p_offsets, dst);
+            else if (pass == 0)
+                hipLaunchKernelGGL((k_part_scatter<true, true>), g, b, 0, s, src, pf, bd, m, shift, bits_here, ndig,
+                                   tile_elems, ntiles, p->p_offsets, dst);
+            else
+                hipLaunchKernelGGL((k_part_scatter<true, false>), g, b, 0, s, src, pf, bd, m, shift, bits_here, ndig,
+                                   tile_elems, ntiles, p->p_offsets, dst);
+            DAISY_LAUNCH_CHECK();
+        }
+    }
+    p->p_cur = 0;
+    p->n = n; p->batch_size = batch_size; p->num_batches = nb; p->built = true;
+    p->pointwise = 0;
+    p->kind = 1;
+    return DAISY_OK;
+}
+
+// =============================================================================
+// staged step kernels
+// =============================================================================
+// samples per lane group per chunk in the user pass (3 row gathers each).  Measured at d=64: 4 (128 VGPRs,
+// 4 waves/SIMD) beats 8 (178 VGPRs, 2 waves/SIMD) by 10 % at C2 shapes and ties at C3 shapes.
+template <class C>
+struct StagedUserCfg {
+    static constexpr int RUN_BY_REGS = (C::NE <= 8) ? 4 : 2;
+    static constexpr int RUN = RUN_BY_REGS < C::LPR ? RUN_BY_REGS : C::LPR;
+    static constexpr int G = C::GROUPS_PER_BLOCK;
+    static constexpr int E = G * RUN;
+};
+template <class C>
+struct StagedItemCfg {
+    static constexpr int RUN_BY_REGS = (C::NE <= 4) ? 16 : ((C::NE <= 8) ? 4 : 2);
+    static constexpr int RUN = RUN_BY_REGS < C::LPR ? RUN_BY_REGS : C::LPR;
+    static constexpr int G = C::GROUPS_PER_BLOCK;
+    static constexpr int E = G * RUN;
+};
+
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_row_sqnorm(const float *__restrict__ W, int64_t rows, int d,
+                                                       float *__restrict__ out) {
+    const int lane = threadIdx.x % C::LPR;
+    const int group = threadIdx.x / C::LPR;
+    const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
+    for (int64_t r = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; r < rows; r += gstride) {
+        Row<C> w;
+        w.load(W + r * d, lane, d);
+        const float s = row_dot<C>(w, w);
+        if (lane == 0) out[r] = s;
+    }
+}
+
+// partials[block] = sum over the block's samples of |P[u_s]|^2 (from the cache)
+__global__ __launch_bounds__(kBlock) void k_unorm(const float *__restrict__ p_sqnorm, StreamView v,
+                                                  double *__restrict__ partials) {
+    double acc = 0.0;
+    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < v.B;
+         s += (int64_t)gridDim.x * blockDim.x)
+        acc += (double)p_sqnorm[v.s_user[s] & v.umask];
+    __shared__ double sm[kBlock / kWave];
+    const double w = wave_sum_f64(acc);
+    if ((threadIdx.x % kWave) == 0) sm[threadIdx.x / kWave] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < kBlock / kWave; ++k) t += sm[k];
+        partials[blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_unorm_reduce(const double *__restrict__ partials, int nblocks,
+                                                         double *__restrict__ stats) {
+    __shared__ double sm[kBlock];
+    double t = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) t += partials[b];
+    sm[threadIdx.x] = t;
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) stats[DAISY_ST_SQ_U_PRE] = sm[0];
+}
+
+template <class C>
+__device__ __forceinline__ void user_finish_row(Row<C> &p, const Row<C> &acc, float n, float lr,
+                                                float reg_1, float rU) {
+    const float w1 = reg_1 * n, w2 = rU * n;
+#pragma unroll
+    for (int k = 0; k < C::NE; ++k) {
+        const float g = acc.v[k] + fmaf(w2, p.v[k], w1 * sgn(p.v[k]));
+        p.v[k] = fmaf(-lr, g, p.v[k]);
+    }
+}
+
+struct UserEdges {
+    float *vec;        // [2*nchunks][d] partial user gradients of runs that cross a chunk boundary
+    int32_t *user;     // [2*nchunks]    their user (-1: none); [2c] head edge, [2c+1] tail edge
+    float *n;          // [2*nchunks]    their sample counts
+    int32_t *whole;    // [nchunks]      the head edge's run also fills the whole chunk
+};
+
+// Forward + user update in one pass over the user-grouped samples (see the header comment).
+//   in-run user:          its group owns P[u]: P[u] -= lr*(sum_s c_s(q_i - q_j) + n*reg(p)), in place
+//   run crossing groups:  partial sums parked in LDS, added by the slot's finisher in group order
+//   run crossing chunks:  edge records, chained by k_staged_user_edges in chunk order
+// (no atomics, fixed summation order: bitwise reproducible).  PREMUL: stage[slot] = dL/dpos * p_u, valid for
+// the losses with dL/dneg = -dL/dpos (BPR, HL); otherwise stage[slot] = p_u and coef[slot] = (dL/dpos, dL/dneg).
+// HAS_POS: the stage slot of a sample comes from the plan (partitioned layout) instead of its position.
+template <class C, bool PREMUL, bool HAS_POS>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 ? 4 : 2, 8))) void k_staged_user(
+    float *__restrict__ P, const float *__restrict__ Q, StreamView v, int d, const double *__restrict__ stats,
+    float lr, float reg_1, float reg_2, int loss_type, float gamma, float *__restrict__ stage,
+    float2 *__restrict__ coef, float *__restrict__ p_sqnorm, double *__restrict__ partials, UserEdges ed) {
+    constexpr int G = StagedUserCfg<C>::G, RUN = StagedUserCfg<C>::RUN, E = StagedUserCfg<C>::E;
+    constexpr int ROWF = C::NE * C::LPR;
+    __shared__ float part_acc[2 * G * ROWF];
+    __shared__ float part_n[2 * G];
+    __shared__ int part_slot[2 * G];
+    __shared__ int slot_user[G + 1], slot_next[G + 1];
+    __shared__ int run_first[G], run_last[G];
+
+    const int tid = threadIdx.x;
+    const int lane = tid % C::LPR;
+    const int group = tid / C::LPR;
+    const int64_t n = v.B;
+    const int64_t nchunks = (n + E - 1) / E;
+    const float rU = inv_or_zero(sqrt(stats[DAISY_ST_SQ_U_PRE]), reg_2);
+    float acc7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int64_t c0 = chunk * E;
+        const int64_t t0 = c0 + (int64_t)group * RUN;
+        const int64_t t1 = (t0 + RUN < n) ? (t0 + RUN) : n;
+        const int cnt = (t0 < n) ? (int)(t1 - t0) : 0;
+
+        // ---- hop 1: metadata of the run (lane x <- sample x) and its neighbours; every load is
+        // unconditional on a clamped address (a branch around a load drains vmcnt first)
+        const int64_t last = n - 1;
+        const int64_t il = (t0 + lane < n) ? (t0 + lane) : last;
+        const uint32_t k_me = v.s_user[il] & v.umask;
+        const int2 ij_me = v.s_ij[il];
+        uint32_t slot_me = (uint32_t)il;
+        if constexpr (HAS_POS) slot_me = v.s_pos[il] - v.pos_base;
+        const uint32_t k_prev = v.s_user[(t0 > 0) ? ((t0 - 1 < n) ? t0 - 1 : last) : 0] & v.umask;
+        const uint32_t k_next = v.s_user[(t1 < n) ? t1 : last] & v.umask;
+        const uint32_t k_cprev = v.s_user[(c0 > 0) ? c0 - 1 : 0] & v.umask;
+        const int32_t my_user = (lane < cnt) ? (int32_t)k_me : -1;
+        const int2 my_ij = (lane < cnt) ? ij_me : make_int2(0, 0);
+        const int32_t user_prev = (cnt > 0 && t0 > 0) ? (int32_t)k_prev : -1;
+        const int32_t user_next = (cnt > 0 && t1 < n) ? (int32_t)k_next : -1;
+        const int32_t chunk_prev_user = (c0 > 0) ? (int32_t)k_cprev : -1;
+        if (tid < 2 * G) part_slot[tid] = -1;
+        if (tid <= G) { slot_user[tid] = -1; slot_next[tid] = 0; }
+        const int32_t user_first = group_bcast<C>(my_user, 0);
+        const int32_t user_last = __shfl(my_user, cnt > 0 ? cnt - 1 : 0, C::LPR);
+        if (lane == 0) {
+            run_first[group] = cnt > 0 ? user_first : -2;
+            run_last[group] = cnt > 0 ? user_last : -2;
+        }
+
+        // ---- hop 2: the three rows of every sample of the run
+        Row<C> qi[RUN], qj[RUN], pr[RUN];
+        if (__all(cnt == RUN)) {        // wave-uniform: no branch between the 3*RUN gathers
+#pragma unroll
+            for (int x = 0; x < RUN; ++x) {
+                qi[x].load(Q + (int64_t)group_bcast<C>(my_ij.x, x) * d, lane, d);
+                qj[x].load(Q + (int64_t)group_bcast<C>(my_ij.y, x) * d, lane, d);
+                pr[x].load(P + (int64_t)group_bcast<C>(my_user, x) * d, lane, d);
+            }
+        } else {
+#pragma unroll
+            for (int x = 0; x < RUN; ++x) {
+                const int32_t ux = group_bcast<C>(my_user, x);
+                const int ix = group_bcast<C>(my_ij.x, x);
+                const int jx = group_bcast<C>(my_ij.y, x);
+                if (x < cnt) {
+                    qi[x].load(Q + (int64_t)ix * d, lane, d);
+                    qj[x].load(Q + (int64_t)jx * d, lane, d);
+                    pr[x].load(P + (int64_t)ux * d, lane, d);
+                } else {
+                    qi[x].zero(); qj[x].zero(); pr[x].zero();
+                }
+            }
+        }
+        __syncthreads();
+
+        if (cnt > 0) {
+            const bool cont = (t0 > 0) && (user_prev == user_first);
+            int cur_slot = -1;
+            if (cont) {
+                if (group == 0) cur_slot = 0;
+                else {
+                    int gs = group - 1;
+                    while (gs > 0 && run_first[gs] == user_first && run_last[gs - 1] == user_first) --gs;
+                    const bool inherited = (gs == 0) && (run_first[0] == user_first) && (c0 > 0) &&
+                                           (chunk_prev_user == user_first);
+                    cur_slot = inherited ? 0 : gs + 1;
+                }
+            }
+            // ---- forward: scores of the run's samples -> lane x; one loss epilogue per run, a sample per lane
+            float my_sp = 0.f, my_sn = 0.f;
+#pragma unroll
+            for (int x = 0; x < RUN; ++x) {
+                if (x < cnt) {
+                    const float sp = row_dot<C>(pr[x], qi[x]);
+                    const float sn = row_dot<C>(pr[x], qj[x]);
+                    if (lane == x) { my_sp = sp; my_sn = sn; }
+#pragma unroll
+                    for (int k = 0; k < C::NE; ++k) {
+                        acc7[1] += fabsf(pr[x].v[k]);
+                        acc7[2] += fabsf(qi[x].v[k]);
+                        acc7[3] += fabsf(qj[x].v[k]);
+                        acc7[4] = fmaf(pr[x].v[k], pr[x].v[k], acc7[4]);
+                        acc7[5] = fmaf(qi[x].v[k], qi[x].v[k], acc7[5]);
+                        acc7[6] = fmaf(qj[x].v[k], qj[x].v[k], acc7[6]);
+                    }
+                }
+            }
+            float2 my_c = make_float2(0.f, 0.f);
+            if (lane < cnt) {
+                float term;
+                pair_coef(loss_type, my_sp, my_sn, gamma, term, my_c.x, my_c.y);
+                acc7[0] += term;
+                if constexpr (!PREMUL) coef[slot_me] = my_c;
+            }
+
+            // ---- user gradient over the runs of equal users; the staged rows leave on the way
+            int32_t cur_user = user_first;
+            Row<C> pcur = pr[0];                     // pre-step P row of the current run's user
+            Row<C> acc;
+            acc.zero();
+            float cn_ = 0.f;
+            auto finish = [&](bool ends_here, bool to_next_chunk, const Row<C> &prow) {
+                if (cur_slot < 0 && ends_here) {     // this group owns P[cur_user]
+                    Row<C> pn = prow;
+                    user_finish_row<C>(pn, acc, cn_, lr, reg_1, rU);
+                    pn.store(P + (int64_t)cur_user * d, lane, d);
+                    const float sq = row_dot<C>(pn, pn);
+                    if (lane == 0) p_sqnorm[cur_user] = sq;
+                } else {
+                    const int s = (cur_slot >= 0) ? cur_slot : group + 1;
+                    const int q = group * 2 + ((cur_slot >= 0) ? 0 : 1);
+                    float *dst = part_acc + q * ROWF;
+#pragma unroll
+                    for (int k = 0; k < C::NE; ++k) dst[k * C::LPR + lane] = acc.v[k];
+                    if (lane == 0) {
+                        part_slot[q] = s;
+                        part_n[q] = cn_;
+                        slot_user[s] = cur_user;
+                        if (to_next_chunk) slot_next[s] = 1;
+                    }
+                }
+            };
+#pragma unroll
+            for (int x = 0; x < RUN; ++x) {
+                if (x < cnt) {
+                    const int32_t ux = group_bcast<C>(my_user, x);
+                    const float cp = group_bcast<C>(my_c.x, x);
+                    const float cn = group_bcast<C>(my_c.y, x);
+                    const uint32_t sl = group_bcast<C>(slot_me, x);
+                    if (ux != cur_user) {
+                        finish(true, false, pcur);
+                        cur_user = ux;
+                        cur_slot = -1;
+                        pcur = pr[x];
+                        acc.zero();
+                        cn_ = 0.f;
+                    }
+                    if constexpr (PREMUL) {
+                        Row<C> m;
+#pragma unroll
+                        for (int k = 0; k < C::NE; ++k) m.v[k] = cp * pr[x].v[k];
+                        m.store(stage + (int64_t)sl * d, lane, d);
+                    } else {
+                        pr[x].store(stage + (int64_t)sl * d, lane, d);
+                    }
+#pragma unroll
+                    for (int k = 0; k < C::NE; ++k)
+                        acc.v[k] = fmaf(cp, qi[x].v[k], fmaf(cn, qj[x].v[k], acc.v[k]));
+                    cn_ += 1.f;
+                }
+            }
+            const bool continues = (t1 < n) && (user_next == cur_user);
+            finish(!continues, continues && (group == G - 1), pcur);
+        }
+        __syncthreads();
+
+        // ---- one finisher per used slot; runs shared with a neighbouring chunk go to the edges
+        if (tid == 0) { ed.user[2 * chunk] = -1; ed.user[2 * chunk + 1] = -1; ed.whole[chunk] = 0; }
+        __syncthreads();
+        for (int s = group; s <= G; s += G) {
+            const int uu = slot_user[s];
+            if (uu < 0) continue;
+            Row<C> g;
+            g.zero();
+            float ns = 0.f;
+            for (int q = 0; q < 2 * G; ++q) {
+                if (part_slot[q] != s) continue;
+                const float *src = part_acc + q * ROWF;
+#pragma unroll
+                for (int k = 0; k < C::NE; ++k) g.v[k] += src[k * C::LPR + lane];
+                ns += part_n[q];
+            }
+            const bool from_prev = (s == 0), to_next = slot_next[s] != 0;
+            if (!from_prev && !to_next) {
+                Row<C> p;
+                p.load(P + (int64_t)uu * d, lane, d);
+                user_finish_row<C>(p, g, ns, lr, reg_1, rU);
+                p.store(P + (int64_t)uu * d, lane, d);
+                const float sq = row_dot<C>(p, p);
+                if (lane == 0) p_sqnorm[uu] = sq;
+            } else {
+                const int64_t e = 2 * chunk + (from_prev ? 0 : 1);
+                g.store(ed.vec + e * d, lane, d);
+                if (lane == 0) {
+                    ed.user[e] = uu;
+                    ed.n[e] = ns;
+                    if (from_prev && to_next) ed.whole[chunk] = 1;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    __shared__ double sm7[kBlock / kWave][8];
+    const int wave = tid / kWave;
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        const double w = wave_sum_f64((double)acc7[k]);
+        if ((tid % kWave) == 0) sm7[wave][k] = w;
+    }
+    __syncthreads();
+    if (tid < 7) {
+        double t = 0.0;
+#pragma unroll
+        for (int w = 0; w < kBlock / kWave; ++w) t += sm7[w][tid];
+        partials[(int64_t)blockIdx.x * 8 + tid] = t;
+    }
+    if (tid == 7) partials[(int64_t)blockIdx.x * 8 + 7] = 0.0;   // (no FM biases on the staged path)
+}
+
+// chains of edge records: the chunk whose TAIL edge starts a run owns it.  A user whose run crosses a
+// chunk boundary is touched by nobody else in this step, so P[u] is still the pre-step row here.
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_staged_user_edges(float *__restrict__ P, int64_t nchunks, int d,
+                                                              const double *__restrict__ stats, float lr,
+                                                              float reg_1, float reg_2, UserEdges ed,
+                                                              float *__restrict__ p_sqnorm) {
+    const int lane = threadIdx.x % C::LPR;
+    const int group = threadIdx.x / C::LPR;
+    const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
+    const float rU = inv_or_zero(sqrt(stats[DAISY_ST_SQ_U_PRE]), reg_2);
+    for (int64_t c = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; c < nchunks; c += gstride) {
+        const int uu = ed.user[2 * c + 1];
+        if (uu < 0) continue;
+        Row<C> acc, t;
+        acc.load(ed.vec + (2 * c + 1) * d, lane, d);
+        float ns = ed.n[2 * c + 1];
+        for (int64_t k = c + 1; k < nchunks && ed.user[2 * k] == uu; ++k) {
+            t.load(ed.vec + (2 * k) * d, lane, d);
+#pragma unroll
+            for (int q = 0; q < C::NE; ++q) acc.v[q] += t.v[q];
+            ns += ed.n[2 * k];
+            if (!ed.whole[k]) break;
+        }
+        Row<C> p;
+        p.load(P + (int64_t)uu * d, lane, d);
+        user_finish_row<C>(p, acc, ns, lr, reg_1, rU);
+        p.store(P + (int64_t)uu * d, lane, d);
+        const float sq = row_dot<C>(p, p);
+        if (lane == 0) p_sqnorm[uu] = sq;
+    }
+}
+
+struct ItemEdges2 {
+    float *vec;          // [2*nchunks][d]  partial gradient rows; [2c] head edge (inherited), [2c+1] tail edge
+    int32_t *item;       // [2*nchunks]     their item (-1: none)
+    float *cnt;          // [2*nchunks][2]  their (n_pos, n_neg)
+    int32_t *whole;      // [nchunks]       the head edge's segment also runs on into the next chunk
+};
+
+// what the owner of a finished segment does with  g = sum_e w_e * stage[slot(e)]  and the entry counts:
+//   APPLY:  Q[item] -= lr * (g + reg_1*(np+nn)*sign(q) + reg_2*(np/|Q[i]|_F + nn/|Q[j]|_F)*q)   (MFRecommender.py:88-89)
+//   else:   gQ[item] = g (data term), cnt[item] = (np, nn): what a multi-GPU step reduce-scatters
+template <class C, bool APPLY>
+__device__ __forceinline__ void item_commit(float *__restrict__ Qo, float *__restrict__ cnt_out, int64_t item,
+                                            const Row<C> &g, float np, float nn, int lane, int d, float lr,
+                                            float reg_1, float rI, float rJ) {
+    if constexpr (APPLY) {
+        Row<C> q;
+        q.load(Qo + item * d, lane, d);
+        const float w1 = reg_1 * (np + nn), w2 = np * rI + nn * rJ;
+#pragma unroll
+        for (int k = 0; k < C::NE; ++k) {
+            const float gg = g.v[k] + fmaf(w2, q.v[k], w1 * sgn(q.v[k]));
+            q.v[k] = fmaf(-lr, gg, q.v[k]);
+        }
+        q.store(Qo + item * d, lane, d);
+    } else {
+        g.store(Qo + item * d, lane, d);
+        if (lane == 0) { cnt_out[2 * item] = np; cnt_out[2 * item + 1] = nn; }
+    }
+}
+
+// Item pass over the staged rows (see the header comment): the run/slot/edge segmented reduction of
+// k_item_grad_chunked<DET> (bpr_train.hip) with the coefficient inside the gathered row and the commit in
+// the owner.  A workgroup takes a chunk of G*RUN consecutive entries, every lane group a run of RUN.
+template <class C, bool PREMUL, bool APPLY>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_staged_item(const float *__restrict__ stage,
+                                                        const float2 *__restrict__ coef, StreamView v, int d,
+                                                        float *__restrict__ Qo, float *__restrict__ cnt_out,
+                                                        const double *__restrict__ stats, float lr,
+                                                        float reg_1, float reg_2, ItemEdges2 ed) {
+    constexpr int G = StagedItemCfg<C>::G, RUN = StagedItemCfg<C>::RUN, E = StagedItemCfg<C>::E;
+    constexpr int ROWF = C::NE * C::LPR;
+    __shared__ int slot_item[G + 1], slot_shared[G + 1];
+    __shared__ int run_first[G], run_last[G];
+    __shared__ float part_acc[2 * G * ROWF];               // [group][head|tail] parked partial sums
+    __shared__ float part_np[2 * G], part_nn[2 * G];
+    __shared__ int part_slot[2 * G];                       //      the slot each belongs to (-1: unused)
+
+    const int tid = threadIdx.x;
+    const int lane = tid % C::LPR;
+    const int group = tid / C::LPR;
+    const int64_t n = v.E;
+    const int64_t nchunks = (n + E - 1) / E;
+    float rI = 0.f, rJ = 0.f;
+    if constexpr (APPLY) {
+        rI = inv_or_zero(stats[DAISY_ST_NORM_I], reg_2);
+        rJ = inv_or_zero(stats[DAISY_ST_NORM_J], reg_2);
+    }
+
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+        const int64_t c0 = chunk * E;
+        const int64_t t0 = c0 + (int64_t)group * RUN;
+        const int64_t t1 = (t0 + RUN < n) ? (t0 + RUN) : n;
+        const int cnt = (t0 < n) ? (int)(t1 - t0) : 0;       // entries of this run
+
+        // ---- hop 1: the run's metadata, lane x <- entry x, plus the entries around the run
+        const int64_t last = n - 1;
+        const int64_t il = (t0 + lane < n) ? (t0 + lane) : last;
+        const uint32_t k_me = v.e_key[il] & v.imask;
+        const uint32_t slot_me = (v.e_pos[il * v.e_stride] & ~kNegBit) - v.pos_base;
+        const uint32_t k_prev = v.e_key[(t0 > 0) ? ((t0 - 1 < n) ? t0 - 1 : last) : 0] & v.imask;
+        const uint32_t k_next = v.e_key[(t1 < n) ? t1 : last] & v.imask;
+        const uint32_t k_cprev = v.e_key[(c0 > 0) ? c0 - 1 : 0] & v.imask;
+        const int32_t my_item = (lane < cnt) ? (int32_t)(k_me >> 1) : -1;
+        const int32_t my_neg = (int32_t)(k_me & 1u);
+        const int32_t item_prev = (cnt > 0 && t0 > 0) ? (int32_t)(k_prev >> 1) : -1;
+        const int32_t item_next = (cnt > 0 && t1 < n) ? (int32_t)(k_next >> 1) : -1;
+        const int32_t chunk_prev_item = (c0 > 0) ? (int32_t)(k_cprev >> 1) : -1;
+        if (tid < 2 * G) part_slot[tid] = -1;
+        if (tid <= G) { slot_item[tid] = -1; slot_shared[tid] = 0; }
+        const int32_t item_first = group_bcast<C>(my_item, 0);
+        const int32_t item_last = __shfl(my_item, cnt > 0 ? cnt - 1 : 0, C::LPR);
+        if (lane == 0) {
+            run_first[group] = cnt > 0 ? item_first : -2;
+            run_last[group] = cnt > 0 ? item_last : -2;
+        }
+
+        // ---- hop 2: all staged rows of the run (and, for the losses whose two coefficients differ, theirs)
+        float my_w;
+        if constexpr (PREMUL) {
+            my_w = (lane < cnt) ? (my_neg ? -1.f : 1.f) : 0.f;
+        } else {
+            const float2 c2 = coef[slot_me];
+            my_w = (lane < cnt) ? (my_neg ? c2.y : c2.x) : 0.f;
+        }
+        Row<C> p[RUN];
+        if (__all(cnt == RUN)) {        // wave-uniform: every run of this wave is full
+#pragma unroll
+            for (int x = 0; x < RUN; ++x) p[x].load(stage + (int64_t)group_bcast<C>(slot_me, x) * d, lane, d);
+        } else {
+#pragma unroll
+            for (int x = 0; x < RUN; ++x) {
+                const uint32_t sx = group_bcast<C>(slot_me, x);
+                if (x < cnt) p[x].load(stage + (int64_t)sx * d, lane, d);
+                else p[x].zero();
+            }
+        }
+        __syncthreads();
+
+        if (cnt > 0) {
+            const bool cont = (t0 > 0) && (item_prev == item_first);
+            int cur_slot = -1;                      // >= 0: the current segment began before this run
+            if (cont) {
+                if (group == 0) cur_slot = 0;       // inherited from the previous chunk
+                else {
+                    int gs = group - 1;
+                    while (gs > 0 && run_first[gs] == item_first && run_last[gs - 1] == item_first) --gs;
+                    const bool inherited = (gs == 0) && (run_first[0] == item_first) && (c0 > 0) &&
+                                           (chunk_prev_item == item_first);
+                    cur_slot = inherited ? 0 : gs + 1;
+                }
+            }
+            int32_t cur_item = item_first;
+            Row<C> acc;
+            acc.zero();
+            float np = 0.f, nn = 0.f;
+            auto finish = [&](bool ends_here, bool to_next_chunk) {
+                if (cur_slot < 0 && ends_here) {    // interior: this group owns the item's row
+                    item_commit<C, APPLY>(Qo, cnt_out, cur_item, acc, np, nn, lane, d, lr, reg_1, rI, rJ);
+                } else {                            // crosses a run boundary: park it for the slot's finisher
+                    const int s = (cur_slot >= 0) ? cur_slot : group + 1;
+                    const int q = group * 2 + ((cur_slot >= 0) ? 0 : 1);
+                    float *dst = part_acc + q * ROWF;
+#pragma unroll
+                    for (int k = 0; k < C::NE; ++k) dst[k * C::LPR + lane] = acc.v[k];
+                    if (lane == 0) {
+                        part_slot[q] = s;
+                        part_np[q] = np;
+                        part_nn[q] = nn;
+                        slot_item[s] = cur_item;
+                        if (to_next_chunk) slot_shared[s] = 1;
+                    }
+                }
+            };
+#pragma unroll
+            for (int x = 0; x < RUN; ++x) {
+                if (x < cnt) {
+                    const int32_t it = group_bcast<C>(my_item, x);
+                    const float wx = group_bcast<C>(my_w, x);
+                    const float ng = (float)group_bcast<C>(my_neg, x);
+                    if (it != cur_item) {           // previous segment ended inside this run
+                        finish(true, false);
+                        cur_item = it;
+                        cur_slot = -1;
+                        acc.zero();
+                        np = 0.f; nn = 0.f;
+                    }
+#pragma unroll
+                    for (int k = 0; k < C::NE; ++k) acc.v[k] = fmaf(wx, p[x].v[k], acc.v[k]);
+                    np += 1.f - ng;
+                    nn += ng;
+                }
+            }
+            const bool continues = (t1 < n) && (item_next == cur_item);
+            finish(!continues, continues && (group == G - 1));
+        }
+        __syncthreads();
+
+        if (tid == 0) { ed.item[2 * chunk] = -1; ed.item[2 * chunk + 1] = -1; ed.whole[chunk] = 0; }
+        __syncthreads();
+        // one finisher per used slot (G+1 slots over G groups): the parked partials in group order
+        for (int s = group; s <= G; s += G) {
+            const int r = slot_item[s];
+            if (r < 0) continue;
+            Row<C> g;
+            g.zero();
+            float sp = 0.f, sn = 0.f;
+            for (int q = 0; q < 2 * G; ++q) {
+                if (part_slot[q] != s) continue;
+                const float *src = part_acc + q * ROWF;
+#pragma unroll
+                for (int k = 0; k < C::NE; ++k) g.v[k] += src[k * C::LPR + lane];
+                sp += part_np[q];
+                sn += part_nn[q];
+            }
+            const bool from_prev = (s == 0), to_next = slot_shared[s] != 0;
+            if (from_prev || to_next) {
+                const int64_t e = 2 * chunk + (from_prev ? 0 : 1);
+                g.store(ed.vec + e * d, lane, d);
+                if (lane == 0) {
+                    ed.item[e] = r;
+                    ed.cnt[2 * e] = sp;
+                    ed.cnt[2 * e + 1] = sn;
+                    if (from_prev && to_next) ed.whole[chunk] = 1;
+                }
+            } else {
+                item_commit<C, APPLY>(Qo, cnt_out, r, g, sp, sn, lane, d, lr, reg_1, rI, rJ);
+            }
+        }
+        __syncthreads();   // the slots are reused by the next chunk
+    }
+}
+
+// chains of edge records - the chunk whose TAIL edge starts a segment owns it and adds the head edges of
+// the chunks it runs through, in chunk order (single writer per row, fixed order)
+template <class C, bool APPLY>
+__global__ __launch_bounds__(kBlock) void k_staged_item_edges(ItemEdges2 ed, int64_t nchunks, int d,
+                                                              float *__restrict__ Qo, float *__restrict__ cnt_out,
+                                                              const double *__restrict__ stats, float lr,
+                                                              float reg_1, float reg_2) {
+    const int lane = threadIdx.x % C::LPR;
+    const int group = threadIdx.x / C::LPR;
+    const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
+    float rI = 0.f, rJ = 0.f;
+    if constexpr (APPLY) {
+        rI = inv_or_zero(stats[DAISY_ST_NORM_I], reg_2);
+        rJ = inv_or_zero(stats[DAISY_ST_NORM_J], reg_2);
+    }
+    for (int64_t c = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; c < nchunks; c += gstride) {
+        const int it = ed.item[2 * c + 1];
+        if (it < 0) continue;
+        Row<C> acc, t;
+        acc.load(ed.vec + (2 * c + 1) * d, lane, d);
+        float sp = ed.cnt[2 * (2 * c + 1)], sn = ed.cnt[2 * (2 * c + 1) + 1];
+        for (int64_t k = c + 1; k < nchunks && ed.item[2 * k] == it; ++k) {
+            t.load(ed.vec + (2 * k) * d, lane, d);
+#pragma unroll
+            for (int q = 0; q < C::NE; ++q) acc.v[q] += t.v[q];
+            sp += ed.cnt[2 * (2 * k)];
+            sn += ed.cnt[2 * (2 * k) + 1];
+            if (!ed.whole[k]) break;
+        }
+        item_commit<C, APPLY>(Qo, cnt_out, it, acc, sp, sn, lane, d, lr, reg_1, rI, rJ);
+    }
+}
+
+// Q[r] -= lr*(g[r] + regulariser from the GLOBAL entry counts); g[r] = 0, cnt[r] = 0: the owner's share of a
+// multi-GPU step after the reduce-scatter of (gQ, cnt)
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_item_apply_counts(float *__restrict__ Q, float *__restrict__ g,
+                                                              float *__restrict__ cnt, int64_t rows, int d,
+                                                              float lr, float reg_1, float reg_2,
+                                                              const double *__restrict__ stats) {
+    const int lane = threadIdx.x % C::LPR;
+    const int group = threadIdx.x / C::LPR;
+    const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
+    const float rI = inv_or_zero(stats[DAISY_ST_NORM_I], reg_2);
+    const float rJ = inv_or_zero(stats[DAISY_ST_NORM_J], reg_2);
+    for (int64_t r = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; r < rows; r += gstride) {
+        const float np = cnt[2 * r], nn = cnt[2 * r + 1];
+        if (np + nn == 0.f) continue;              // untouched by every rank: the row does not move
+        Row<C> gr, z;
+        gr.load(g + r * d, lane, d);
+        item_commit<C, true>(Q, nullptr, r, gr, np, nn, lane, d, lr, reg_1, rI, rJ);
+        z.zero();
+        z.store(g + r * d, lane, d);
+        if (lane == 0) { cnt[2 * r] = 0.f; cnt[2 * r + 1] = 0.f; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side of the staged step
+// ---------------------------------------------------------------------------------------------------------
+bool staged_supported(const daisy_bpr_ctx *ctx, int loss_type) {
+    return loss_type >= DAISY_LOSS_BPR && loss_type <= DAISY_LOSS_TL && !ctx->bu &&
+           !(ctx->batch_kind == 0 && ctx->v.pointwise);
+}
+
+static int staged_check(daisy_bpr_ctx *ctx, int loss_type, const char *who) {
+    if (!ctx->batch_set) { set_error("%s: no batch set", who); return DAISY_ERR_STATE; }
+    if (loss_type < DAISY_LOSS_BPR || loss_type > DAISY_LOSS_SL) {
+        set_error("Invalid loss type: %d", loss_type);
+        return DAISY_ERR_ARG;
+    }
+    if (!staged_supported(ctx, loss_type)) {
+        set_error("%s: the staged step covers the pairwise losses (BPR, HL, TL) without FM biases", who);
+        return DAISY_ERR_ARG;
+    }
+    return DAISY_OK;
+}
+
+static int staged_prenorm(daisy_bpr_ctx *ctx, const float *P, double *stats, hipStream_t s) {
+    const StreamView &v = ctx->sv;
+    const int d = ctx->d;
+    int rc = dispatch_d(d, [&](auto cfg) {
+        using C = decltype(cfg);
+        if (ctx->p_sqnorm_of != P) {   // (re)build the squared-norm cache: one dense pass over P
+            hipLaunchKernelGGL((k_row_sqnorm<C>), dim3(grid_for(ctx->U, C::GROUPS_PER_BLOCK * 4)), dim3(kBlock), 0, s,
+                               P, ctx->U, d, ctx->p_sqnorm);
+            ctx->p_sqnorm_of = P;
+        }
+        return DAISY_OK;
+    });
+    if (rc) return rc;
+    const int gn = grid_for(v.B, kBlock * 4);
+    hipLaunchKernelGGL(k_unorm, dim3(gn), dim3(kBlock), 0, s, ctx->p_sqnorm, v, ctx->partials);
+    hipLaunchKernelGGL(k_unorm_reduce, dim3(1), dim3(kBlock), 0, s, ctx->partials, gn, stats);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+static inline bool premul_loss(int loss_type) { return loss_type == DAISY_LOSS_BPR || loss_type == DAISY_LOSS_HL; }
+
+static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_type, float gamma, float lr,
+                       float reg_1, float reg_2, double *stats, int *grid_out, hipStream_t s) {
+    const StreamView &v = ctx->sv;
+    const int d = ctx->d;
+    const bool premul = premul_loss(loss_type), has_pos = v.s_pos != nullptr;
+    UserEdges ed{ctx->edge_vec, ctx->edge_user, ctx->edge_n, ctx->edge_whole};
+    int rc = dispatch_d(d, [&](auto cfg) {
+        using C = decltype(cfg);
+        const int64_t nchunks = (v.B + StagedUserCfg<C>::E - 1) / StagedUserCfg<C>::E;
+        const int gu = grid_for(nchunks, 1, kMaxGrid);
+        *grid_out = gu;
+#define DAISY_LAUNCH_SU(PM, HP)                                                                                   \
+        hipLaunchKernelGGL((k_staged_user<C, PM, HP>), dim3(gu), dim3(kBlock), 0, s, P, Q, v, d, stats, lr, reg_1, \
+                           reg_2, loss_type, gamma, ctx->p_stage, ctx->coef, ctx->p_sqnorm, ctx->partials, ed)
+        if (premul && has_pos) DAISY_LAUNCH_SU(true, true);
+        else if (premul) DAISY_LAUNCH_SU(true, false);
+        else if (has_pos) DAISY_LAUNCH_SU(false, true);
+        else DAISY_LAUNCH_SU(false, false);
+#undef DAISY_LAUNCH_SU
+        hipLaunchKernelGGL((k_staged_user_edges<C>), dim3(grid_for(nchunks, C::GROUPS_PER_BLOCK)), dim3(kBlock), 0, s,
+                           P, nchunks, d, stats, lr, reg_1, reg_2, ed, ctx->p_sqnorm);
+        return DAISY_OK;
+    });
+    if (rc) return rc;
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+// apply != 0: Qo = Q, updated in place; else Qo = gQ (data term), cnt_out f32[I][2]
+static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_out, bool apply, float lr,
+                       float reg_1, float reg_2, const double *stats, hipStream_t s) {
+    const StreamView &v = ctx->sv;
+    const int d = ctx->d;
+    const bool premul = premul_loss(loss_type);
+    ItemEdges2 ed{ctx->edge_vec, ctx->edge_user, ctx->edge_cnt, ctx->edge_whole};
+    int rc = dispatch_d(d, [&](auto cfg) {
+        using C = decltype(cfg);
+        const int64_t nchunks = (v.E + StagedItemCfg<C>::E - 1) / StagedItemCfg<C>::E;
+        const dim3 g(grid_for(v.E, StagedItemCfg<C>::E, 16384)), b(kBlock), ge(grid_for(nchunks, C::GROUPS_PER_BLOCK));
+#define DAISY_LAUNCH_SI(PM, AP)                                                                                   \
+        do {                                                                                                     \
+            hipLaunchKernelGGL((k_staged_item<C, PM, AP>), g, b, 0, s, ctx->p_stage, ctx->coef, v, d, Qo, cnt_out, \
+                               stats, lr, reg_1, reg_2, ed);                                                     \
+            hipLaunchKernelGGL((k_staged_item_edges<C, AP>), ge, b, 0, s, ed, nchunks, d, Qo, cnt_out, stats, lr, \
+                               reg_1, reg_2);                                                                    \
+        } while (0)
+        if (premul && apply) DAISY_LAUNCH_SI(true, true);
+        else if (premul) DAISY_LAUNCH_SI(true, false);
+        else if (apply) DAISY_LAUNCH_SI(false, true);
+        else DAISY_LAUNCH_SI(false, false);
+#undef DAISY_LAUNCH_SI
+        return DAISY_OK;
+    });
+    if (rc) return rc;
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int staged_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int loss_type, float gamma, float lr, float reg_1,
+                    float reg_2, double *stats, double *epoch_acc, double *step_loss, hipStream_t s) {
+    int rc = staged_check(ctx, loss_type, "sgd_step");
+    if (rc) return rc;
+    if ((rc = staged_prenorm(ctx, P, stats, s))) return rc;
+    int gu = 0;
+    if ((rc = staged_user(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, stats, &gu, s))) return rc;
+    if ((rc = launch_reduce_partials(ctx->partials, gu, stats, true, reg_1, reg_2, epoch_acc, step_loss, s))) return rc;
+    if ((rc = staged_item(ctx, loss_type, Q, nullptr, true, lr, reg_1, reg_2, stats, s))) return rc;
+    ctx->fwd_done = false;
+    return DAISY_OK;
+}
+
+}  // namespace daisy
+
+using namespace daisy;
+
+// =============================================================================
+// C ABI
+// =============================================================================
+extern "C" {
+
+int daisy_train_index_create(daisy_train_index **out, const int32_t *triples, int64_t n_triples, int64_t user_num,
+                             int64_t item_num, int32_t user_base, int32_t flags, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(out && triples, "train_index_create: NULL argument");
+    DAISY_CHECK_ARG(n_triples > 0 && n_triples < ((int64_t)1 << 30), "train_index_create: n_triples=%lld out of range",
+                    (long long)n_triples);
+    DAISY_CHECK_ARG(user_num > 0 && user_num <= INT32_MAX && item_num > 0 && item_num < ((int64_t)1 << 30),
+                    "train_index_create: user_num/item_num out of range");
+    hipStream_t s = S(stream);
+    const int64_t n = n_triples;
+    const bool sorted = (flags & DAISY_PLAN_TRIPLES_USER_SORTED) != 0;
+    daisy_train_index *ix = new daisy_train_index();
+    memset(ix, 0, sizeof(*ix));
+    ix->n = n; ix->U = user_num; ix->I = item_num; ix->user_base = user_base;
+    // scratch: unsorted entry pairs [2n] x2, (unsorted user pairs [n] x2 + sorted pairs [n] x2), bad flag, sort temp
+    const size_t t_sort = sort_pairs_i32_temp_bytes(2 * n);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+    const size_t o_k = take((size_t)n * 8), o_v = take((size_t)n * 8);
+    const size_t o_uk = take((size_t)n * 4), o_uv = take((size_t)n * 4), o_uk2 = take((size_t)n * 4);
+    const size_t o_bad = take(256), o_tmp = take(t_sort);
+    char *scratch = nullptr;
+    void *keep = nullptr;
+    const size_t keep_bytes = align_up((size_t)n * 8) * 2 + (sorted ? 0 : align_up((size_t)n * 12) + align_up((size_t)n * 4));
+    hipError_t e = hipMalloc((void **)&scratch, off);
+    if (e == hipSuccess) e = hipMalloc(&keep, keep_bytes);
+    if (e != hipSuccess) {
+        set_error("train_index_create: hipMalloc failed: %s", hipGetErrorString(e));
+        if (scratch) (void)hipFree(scratch);
+        delete ix;
+        return DAISY_ERR_HIP;
+    }
+    ix->ent_t = (uint32_t *)keep;
+    ix->ent_key = (uint32_t *)((char *)keep + align_up((size_t)n * 8));
+    ix->sorted_copy = sorted ? nullptr : (int32_t *)((char *)keep + 2 * align_up((size_t)n * 8));
+    uint32_t *orig = sorted ? nullptr : (uint32_t *)((char *)keep + 2 * align_up((size_t)n * 8) + align_up((size_t)n * 12));
+    ix->orig = orig;
+    ix->bytes = keep_bytes;
+    int *bad = (int *)(scratch + o_bad);
+    uint32_t *k = (uint32_t *)(scratch + o_k), *v = (uint32_t *)(scratch + o_v);
+    uint32_t *uk = (uint32_t *)(scratch + o_uk), *uv = (uint32_t *)(scratch + o_uv);
+    uint32_t *uk2 = (uint32_t *)(scratch + o_uk2);
+    int rc = DAISY_OK;
+    auto fail = [&](int code) {
+        (void)hipFree(scratch);
+        (void)hipFree(keep);
+        delete ix;
+        return code;
+    };
+    if (hipMemsetAsync(bad, 0, 4, s) != hipSuccess) return fail(DAISY_ERR_HIP);
+    const int32_t *src = triples;
+    if (!sorted) {   // CSR order first: stable sort of the row indices by user, then one gather
+        hipLaunchKernelGGL(k_index_entries, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, triples, n, user_base,
+                           user_num, item_num, (uint32_t *)nullptr, (uint32_t *)nullptr, uk, uv, bad);
+        rc = sort_pairs_i32(scratch + o_tmp, t_sort, (const int32_t *)uk, (int32_t *)uk2, (const int32_t *)uv,
+                            (int32_t *)orig, n, bits_for(user_num), s);
+        if (rc) return fail(rc);
+        hipLaunchKernelGGL(k_gather_triples, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, triples, orig, n,
+                           ix->sorted_copy);
+        src = ix->sorted_copy;
+    }
+    ix->triples = src;
+    hipLaunchKernelGGL(k_index_entries, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, src, n, user_base, user_num,
+                       item_num, k, v, (uint32_t *)nullptr, (uint32_t *)nullptr, bad);
+    rc = sort_pairs_i32(scratch + o_tmp, t_sort, (const int32_t *)k, (int32_t *)ix->ent_key, (const int32_t *)v,
+                        (int32_t *)ix->ent_t, 2 * n, bits_for(item_num) + 1, s);
+    if (rc) return fail(rc);
+    int bad_host = 0;
+    if (hipMemcpyAsync(&bad_host, bad, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipStreamSynchronize(s) != hipSuccess) {
+        set_error("train_index_create: reading the validation flag failed");
+        return fail(DAISY_ERR_HIP);
+    }
+    (void)hipFree(scratch);
+    if (bad_host) {
+        set_error("index out of range in the training triples: need %d <= user < %lld and 0 <= item < %lld "
+                  "(the reference raises IndexError in nn.Embedding, MFRecommender.py:64-65)",
+                  user_base, (long long)(user_base + user_num), (long long)item_num);
+        (void)hipFree(keep);
+        delete ix;
+        return DAISY_ERR_ARG;
+    }
+    *out = ix;
+    return DAISY_OK;
+}
+
+int daisy_train_index_destroy(daisy_train_index *index) {
+    if (!index) return DAISY_OK;
+    hipError_t e = hipFree(index->ent_t);
+    delete index;
+    if (e != hipSuccess) {
+        set_error("train_index_destroy: hipFree failed: %s", hipGetErrorString(e));
+        return DAISY_ERR_HIP;
+    }
+    return DAISY_OK;
+}
+
+size_t daisy_train_index_bytes(const daisy_train_index *index) { return index ? index->bytes : 0; }
+
+int daisy_epoch_plan_build_indexed(daisy_epoch_plan *plan, const daisy_train_index *index, const int64_t *perm,
+                                   int32_t order_mode, uint64_t seed, uint64_t epoch, int64_t batch_size,
+                                   daisy_stream_t stream) {
+    DAISY_CHECK_ARG(plan && index, "epoch_plan_build_indexed: NULL argument");
+    DAISY_CHECK_ARG(index->n <= plan->max_triples && index->U == plan->U && index->I == plan->I,
+                    "epoch_plan_build_indexed: the index (n %lld, U %lld, I %lld) does not fit the plan",
+                    (long long)index->n, (long long)index->U, (long long)index->I);
+    DAISY_CHECK_ARG(batch_size > 0 && batch_size < ((int64_t)1 << 31), "epoch_plan_build_indexed: bad batch_size");
+    DAISY_CHECK_ARG(order_mode >= DAISY_ORDER_IDENTITY && order_mode <= DAISY_ORDER_FEISTEL,
+                    "epoch_plan_build_indexed: bad order_mode %d", order_mode);
+    DAISY_CHECK_ARG(order_mode != DAISY_ORDER_PERM || perm != nullptr,
+                    "epoch_plan_build_indexed: DAISY_ORDER_PERM needs perm");
+    return plan_build_partitioned(plan, index, perm, order_mode, seed, epoch, batch_size, S(stream));
+}
+
+int daisy_bpr_ctx_invalidate_cache(daisy_bpr_ctx *ctx) {
+    DAISY_CHECK_ARG(ctx != nullptr, "ctx_invalidate_cache: NULL context");
+    ctx->p_sqnorm_of = nullptr;
+    return DAISY_OK;
+}
+
+int daisy_bpr_staged_prenorm(daisy_bpr_ctx *ctx, const float *P, double *stats, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(ctx && P && stats, "staged_prenorm: NULL argument");
+    if (!ctx->batch_set) { set_error("staged_prenorm: no batch set"); return DAISY_ERR_STATE; }
+    return staged_prenorm(ctx, P, stats, S(stream));
+}
+
+int daisy_bpr_staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int32_t loss_type, float gamma, float lr,
+                          float reg_1, float reg_2, double *stats, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(ctx && P && Q && stats, "staged_user: NULL argument");
+    int rc = staged_check(ctx, loss_type, "staged_user");
+    if (rc) return rc;
+    if (ctx->p_sqnorm_of != P) {
+        set_error("staged_user: daisy_bpr_staged_prenorm has not run on this table");
+        return DAISY_ERR_STATE;
+    }
+    int gu = 0;
+    if ((rc = staged_user(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, stats, &gu, S(stream)))) return rc;
+    return launch_reduce_partials(ctx->partials, gu, stats, false, 0.f, 0.f, nullptr, nullptr, S(stream));
+}
+
+int daisy_bpr_staged_item(daisy_bpr_ctx *ctx, int32_t loss_type, float *Q, float *gQ, float *cnt, float lr,
+                          float reg_1, float reg_2, const double *stats, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(ctx && stats && ((Q && !gQ) || (!Q && gQ && cnt)),
+                    "staged_item: give either Q (apply in place) or gQ + cnt (gradient output)");
+    int rc = staged_check(ctx, loss_type, "staged_item");
+    if (rc) return rc;
+    return staged_item(ctx, loss_type, Q ? Q : gQ, cnt, Q != nullptr, lr, reg_1, reg_2, stats, S(stream));
+}
+
+int daisy_item_apply_counts(float *Q, float *g, float *cnt, int64_t rows, int32_t d, float lr, float reg_1,
+                            float reg_2, const double *stats, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(Q && g && cnt && stats && rows > 0, "item_apply_counts: bad argument");
+    int rc = dispatch_d(d, [&](auto cfg) {
+        using C = decltype(cfg);
+        hipLaunchKernelGGL((k_item_apply_counts<C>), dim3(grid_for(rows, C::GROUPS_PER_BLOCK * 2)), dim3(kBlock), 0,
+                           S(stream), Q, g, cnt, rows, (int)d, lr, reg_1, reg_2, stats);
+        return DAISY_OK;
+    });
+    if (rc) return rc;
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+}  // extern "C"

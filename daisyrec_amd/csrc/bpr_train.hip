@@ -28,87 +28,9 @@
 // HBM/L2 view: a d=64 row is 256 B = 16 lanes x float4, one coalesced request
 // per quarter wave; four rows are in flight per wave instruction.
 #include <stdlib.h>
+#include <string.h>
 
-#include "common.h"
-
-namespace daisy {
-
-constexpr uint32_t kNegBit = 0x80000000u;
-
-// What the step kernels see of the current batch (pointers into an epoch plan).
-//   sample s in [0,B):  user = ukey[s] & umask,  (pos item, neg item) = ij[s]
-//                       samples of one user are contiguous (stable order)
-//   entry  q in [0,2B): item = (ekey[q] & imask) >> 1, negative slot = ekey[q] & 1 (ascending, stable),
-//                       esu[q] = (sample position s | kNegBit for the negative slot, user of s)
-struct BatchView {
-    const uint32_t *ukey;
-    const int2 *ij;
-    const uint32_t *ekey;
-    const uint2 *esu;
-    // run-length encoding of the batch's entry keys: run m in [run_off[0], run_off[1]) has
-    // run_key[m] = item << 1 | neg and run_cnt[m] entries (an item owns 1 or 2 adjacent runs)
-    const uint32_t *run_key, *run_cnt;
-    const int32_t *run_off;
-    uint32_t umask, imask;
-    // point-wise losses (CL / SL, MFRecommender.py:75-81): ij[s] = (item, label); the "negative"
-    // slot of a sample is an inert copy of its item (coefficient 0, not counted by the regulariser)
-    int32_t pointwise;
-    int64_t B;
-    // FM (FMRecommender.py:61-68): score += u_bias[u] + i_bias[item] + bias_; bu == nullptr -> plain MF.
-    // g_bi accumulates like gQ (zero between steps, consumed by k_item_apply); g_bu / g_b0 are only
-    // written by the gradient-output user pass (Adam); the SGD user pass updates bu and b0 in place.
-    float *bu, *bi, *b0;
-    float *g_bu, *g_bi, *g_b0;
-};
-
-}  // namespace daisy
-
-// Epoch plan: the whole epoch laid out batch by batch (see header comment).
-struct daisy_epoch_plan {
-    int64_t max_triples, U, I;
-    void *arena;
-    size_t arena_bytes, temp_bytes;
-    // double buffers of the two radix sorts
-    uint32_t *k32[2];     // [2n] 32-bit keys
-    uint64_t *k64[2];     // [2n] 64-bit keys (only when batch bits + id bits > 32)
-    uint64_t *v64[2];     // [2n] payloads
-    uint32_t *ukey;       // [n]  sorted sample keys (batch << ubits | user)
-    uint64_t *uval;       // [n]  (i, j)
-    uint32_t *ekey;       // [2n] sorted entry keys (batch << ibits | item)
-    uint64_t *eval;       // [2n] (s | neg, u)
-    uint32_t *run_key;    // [2n]  item << 1 | neg of every run of equal entry keys
-    uint32_t *run_cnt;    // [2n]  its length
-    int32_t *run_off;     // [max_triples+2] first run of every batch; [num_batches] = total
-    uint32_t *run_total;  // [1]   number of runs (device)
-    uint32_t umask, imask;
-    void *temp;
-    int64_t n, batch_size, num_batches;
-    int32_t pointwise;
-    bool built;
-};
-
-struct daisy_bpr_ctx {
-    int64_t max_batch, U, I;
-    int d;
-    void *arena;
-    size_t arena_bytes;
-    float2 *coef;        // (dL/dpos, dL/dneg) per sample   [max_batch]
-    double *partials;    // per-workgroup sums              [kMaxGrid*8]
-    int32_t *tmp_triples;  // [max_batch*3] staging for daisy_bpr_set_batch
-    float *edge_vec;     // [2*nchunks][d] partial user gradients of runs that cross a chunk boundary
-    int32_t *edge_user;  // [2*nchunks]    their user (-1: none); [2c] head edge, [2c+1] tail edge
-    float *edge_n;       // [2*nchunks][2] their sample counts and (FM) coefficient sums
-    int32_t *edge_whole; // [nchunks]      the head edge's run also fills the whole chunk
-    float *p_stage;      // [max_batch][d] updated user rows of the fused step, committed after the item pass
-    float *p_sqnorm;     // [U] cache of |P[u]|^2 (fused step: the user-side Frobenius norm before the pass)
-    const float *p_sqnorm_of;   // table the cache describes (NULL = invalid)
-    daisy_epoch_plan *own_plan;   // 1-batch plan used by set_batch / set_batch_from_triples
-    daisy::BatchView v;
-    int32_t pointwise;   // batches set through set_batch* hold (user, item, label) rows
-    int last_item_mode;  // mode of the last daisy_bpr_item_grad: the user pass of the same step follows it
-    float *bu, *bi, *b0, *g_bu, *g_bi, *g_b0;   // FM bias parameters (daisy_bpr_ctx_set_bias); bu == nullptr: MF
-    bool batch_set, fwd_done;
-};
+#include "bpr_internal.h"
 
 namespace daisy {
 
@@ -118,21 +40,30 @@ static inline hipStream_t S(daisy_stream_t s) { return reinterpret_cast<hipStrea
 // epoch plan kernels
 // ---------------------------------------------------------------------------
 // order_mode: 0 identity, 1 explicit permutation (perm[p] = triple at position p), 2 Feistel
+// ids outside [0,U) x [0,I) x [0,I) (point-wise rows: the third column is a label) raise *bad and are
+// replaced by 0, so that no later kernel reads or writes outside the tables (daisy_epoch_plan_validate
+// reports it; the reference raises IndexError in nn.Embedding, MFRecommender.py:64-65)
 template <class KeyT>
 __global__ void k_plan_keys(const int32_t *__restrict__ triples, const int64_t *__restrict__ perm,
                             int order_mode, FeistelKey fk, int64_t n, int64_t start, int64_t B,
-                            int32_t user_base, int ubits, KeyT *__restrict__ key,
-                            uint64_t *__restrict__ val) {
+                            int32_t user_base, int ubits, int64_t U, int64_t I, int pointwise,
+                            int *__restrict__ bad, KeyT *__restrict__ key, uint64_t *__restrict__ val) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
          e += (int64_t)gridDim.x * blockDim.x) {
         int64_t t, p;
         if (order_mode == 1) { p = e; t = perm[e]; }
         else if (order_mode == 2) { t = e; p = (int64_t)feistel_position((uint64_t)e, (uint64_t)n, fk); }
         else { t = e; p = e; }
+        if (order_mode == 1 && (t < 0 || t >= n)) { atomicOr(bad, 2); t = 0; }
         const int32_t *row = triples + 3 * (t + start);
-        const uint32_t uu = (uint32_t)(row[0] - user_base);
-        key[e] = (KeyT)(((uint64_t)(p / B) << ubits) | uu);
-        val[e] = ((uint64_t)(uint32_t)row[2] << 32) | (uint32_t)row[1];      // (j, i)
+        int64_t uu = (int64_t)row[0] - user_base;
+        int32_t ri = row[1], rj = row[2];
+        if (uu < 0 || uu >= U || ri < 0 || ri >= I || (!pointwise && (rj < 0 || rj >= I))) {
+            atomicOr(bad, 1);
+            uu = 0; ri = 0; rj = 0;
+        }
+        key[e] = (KeyT)(((uint64_t)(p / B) << ubits) | (uint64_t)uu);
+        val[e] = ((uint64_t)(uint32_t)rj << 32) | (uint32_t)ri;      // (j, i)
     }
 }
 
@@ -375,10 +306,6 @@ __global__ void k_finalize(double *__restrict__ stats, float reg_1, float reg_2,
     if (threadIdx.x == 0 && blockIdx.x == 0) finalize_stats(stats, reg_1, reg_2, epoch_acc, step_loss);
 }
 
-__device__ __forceinline__ float inv_or_zero(double n, float reg_2) {
-    return (n > 0.0) ? (float)((double)reg_2 / n) : 0.f;  // d|X|_F/dX = 0 at X = 0 (torch)
-}
-
 // ---------------------------------------------------------------------------
 // item gradient, legacy mode: one fp32 atomic row per entry (kept for A/B
 // measurements; 0.3 TB/s on MI355X)
@@ -495,8 +422,6 @@ struct RunCfg {
     static constexpr int E = G * RUN;
 };
 
-// FROM_STAGE: P is the per-sample stage of pre-step user rows written by the fused user pass
-// (row of entry e = stage[sample position]) instead of the user table (row = P[user]).
 // DET (bitwise reproducible, no atomics): a group does not add its run-crossing partial sums into the
 // slot but parks them (<= 2 per group: the segment it continues, the segment it hands on) and the
 // slot's finisher adds them in group order; segments shared with a neighbouring chunk leave the chunk
@@ -508,7 +433,7 @@ struct ItemEdges {
     int32_t *whole;      // [nchunks]       the head edge's segment also runs on into the next chunk
 };
 
-template <class C, int RUN_OVERRIDE = 0, bool FROM_STAGE = false, bool DET = false>
+template <class C, int RUN_OVERRIDE = 0, bool DET = false>
 __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__restrict__ P,
                                                               const float2 *__restrict__ coef,
                                                               BatchView v, int d,
@@ -573,13 +498,13 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
         if (__all(cnt == RUN)) {        // wave-uniform: every run of this wave is full
 #pragma unroll
             for (int x = 0; x < RUN; ++x) {
-                const uint32_t ux = group_bcast<C>(FROM_STAGE ? (my_su.x & ~kNegBit) : my_su.y, x);
+                const uint32_t ux = group_bcast<C>(my_su.y, x);
                 p[x].load(P + (int64_t)ux * d, lane, d);
             }
         } else {
 #pragma unroll
             for (int x = 0; x < RUN; ++x) {
-                const uint32_t ux = group_bcast<C>(FROM_STAGE ? (my_su.x & ~kNegBit) : my_su.y, x);
+                const uint32_t ux = group_bcast<C>(my_su.y, x);
                 if (x < cnt) p[x].load(P + (int64_t)ux * d, lane, d);
                 else p[x].zero();
             }
@@ -901,19 +826,12 @@ __device__ __forceinline__ void user_finish_row(Row<C> &p, const Row<C> &acc, fl
     }
 }
 
-// FUSED (single-GPU throughput step): the forward pass rides along - the group already holds
-// p_u, q_i, q_j of every sample, so it also forms the scores, the loss term and (dL/dpos, dL/dneg),
-// writes them to coef[] for the item pass, accumulates the seven batch sums, and saves the
-// PRE-STEP user row of every sample to stage[s]: P is updated in place here, and the item pass
-// that follows reads the user rows from the stage instead of P.  |P[u]|_F for the regulariser
-// comes from the row-norm cache (stats[NORM_U_PRE]), which every writer keeps current.
-template <class C, bool FUSED>
+template <class C>
 __global__ __launch_bounds__(kBlock) void k_user_chunked(
-    float *__restrict__ P, const float *__restrict__ Q, BatchView v, float2 *__restrict__ coef,
+    float *__restrict__ P, const float *__restrict__ Q, BatchView v, const float2 *__restrict__ coef,
     int d, const double *__restrict__ stats, float lr, float reg_1, float reg_2,
     float *__restrict__ edge_vec, int32_t *__restrict__ edge_user, float *__restrict__ edge_n,
-    int32_t *__restrict__ edge_whole, int loss_type, float gamma, float *__restrict__ stage,
-    float *__restrict__ p_sqnorm, double *__restrict__ partials) {
+    int32_t *__restrict__ edge_whole) {
     constexpr int G = UserRunCfg<C>::G, RUN = UserRunCfg<C>::RUN, E = UserRunCfg<C>::E;
     constexpr int ROWF = C::NE * C::LPR;
     // run-crossing partial sums are parked per group (<= 2: the run it continues, the run it hands on)
@@ -929,8 +847,7 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
     const int group = tid / C::LPR;
     const int64_t n = v.B;
     const int64_t nchunks = (n + E - 1) / E;
-    const float rU = inv_or_zero(stats[FUSED ? DAISY_ST_NORM_U_PRE : DAISY_ST_NORM_U], reg_2);
-    float acc7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float rU = inv_or_zero(stats[DAISY_ST_NORM_U], reg_2);
 
     for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const int64_t c0 = chunk * E;
@@ -944,11 +861,8 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
         const int64_t il = (t0 + lane < n) ? (t0 + lane) : last;
         const uint32_t k_me = v.ukey[il];
         const int2 ij_me = v.ij[il];
-        float2 my_c = make_float2(0.f, 0.f);
-        if constexpr (!FUSED) {
-            const float2 c_me = coef[il];
-            if (lane < cnt) my_c = c_me;
-        }
+        const float2 c_me = coef[il];
+        const float2 my_c = (lane < cnt) ? c_me : make_float2(0.f, 0.f);
         const uint32_t k_prev = v.ukey[(t0 > 0) ? ((t0 - 1 < n) ? t0 - 1 : last) : 0];
         const uint32_t k_next = v.ukey[(t1 < n) ? t1 : last];
         const uint32_t k_cprev = v.ukey[(c0 > 0) ? c0 - 1 : 0];
@@ -1019,10 +933,6 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
                     user_finish_row<C>(pn, acc, cn_, lr, reg_1, rU);
                     pn.store(P + (int64_t)cur_user * d, lane, d);
                     if (v.bu && lane == 0) v.bu[cur_user] = fmaf(-lr, cb_, v.bu[cur_user]);
-                    if constexpr (FUSED) {
-                        const float sq = row_dot<C>(pn, pn);
-                        if (lane == 0) p_sqnorm[cur_user] = sq;
-                    }
                 } else {
                     const int s = (cur_slot >= 0) ? cur_slot : group + 1;
                     const int q = group * 2 + ((cur_slot >= 0) ? 0 : 1);
@@ -1038,34 +948,6 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
                     }
                 }
             };
-            if constexpr (FUSED) {
-                // scores of the run's samples -> lane x; one loss epilogue per run, a sample per lane
-                float my_sp = 0.f, my_sn = 0.f;
-#pragma unroll
-                for (int x = 0; x < RUN; ++x) {
-                    if (x < cnt) {
-                        const float sp = row_dot<C>(pr[x], qi[x]);
-                        const float sn = row_dot<C>(pr[x], qj[x]);
-                        if (lane == x) { my_sp = sp; my_sn = sn; }
-#pragma unroll
-                        for (int k = 0; k < C::NE; ++k) {
-                            acc7[1] += fabsf(pr[x].v[k]);
-                            acc7[2] += fabsf(qi[x].v[k]);
-                            acc7[3] += fabsf(qj[x].v[k]);
-                            acc7[4] = fmaf(pr[x].v[k], pr[x].v[k], acc7[4]);
-                            acc7[5] = fmaf(qi[x].v[k], qi[x].v[k], acc7[5]);
-                            acc7[6] = fmaf(qj[x].v[k], qj[x].v[k], acc7[6]);
-                        }
-                        pr[x].store(stage + (t0 + x) * d, lane, d);   // pre-step row for the item pass
-                    }
-                }
-                if (lane < cnt) {
-                    float term;
-                    pair_coef(loss_type, my_sp, my_sn, gamma, term, my_c.x, my_c.y);
-                    coef[t0 + lane] = my_c;
-                    acc7[0] += term;
-                }
-            }
 #pragma unroll
             for (int x = 0; x < RUN; ++x) {
                 if (x < cnt) {
@@ -1117,10 +999,6 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
                 user_finish_row<C>(p, g, ns, lr, reg_1, rU);
                 p.store(P + (int64_t)uu * d, lane, d);
                 if (v.bu && lane == 0) v.bu[uu] = fmaf(-lr, sb, v.bu[uu]);
-                if constexpr (FUSED) {
-                    const float sq = row_dot<C>(p, p);
-                    if (lane == 0) p_sqnorm[uu] = sq;
-                }
             } else {
                 const int64_t e = 2 * chunk + (from_prev ? 0 : 1);
                 g.store(edge_vec + e * d, lane, d);
@@ -1134,31 +1012,12 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
         }
         __syncthreads();
     }
-    if constexpr (!FUSED) {
-        if (v.bu && blockIdx.x == 0 && tid == 0)           // the global bias (FMRecommender.py:59)
-            v.b0[0] = fmaf(-lr, (float)stats[DAISY_ST_SUM_COEF], v.b0[0]);
-    }
-    if constexpr (FUSED) {
-        __shared__ double sm7[kBlock / kWave][8];
-        const int wave = tid / kWave;
-#pragma unroll
-        for (int k = 0; k < 7; ++k) {
-            const double w = wave_sum_f64((double)acc7[k]);
-            if ((tid % kWave) == 0) sm7[wave][k] = w;
-        }
-        __syncthreads();
-        if (tid < 7) {
-            double t = 0.0;
-#pragma unroll
-            for (int w = 0; w < kBlock / kWave; ++w) t += sm7[w][tid];
-            partials[(int64_t)blockIdx.x * 8 + tid] = t;
-        }
-        if (tid == 7) partials[(int64_t)blockIdx.x * 8 + 7] = 0.0;   // (no biases on the fused path)
-    }
+    if (v.bu && blockIdx.x == 0 && tid == 0)               // the global bias (FMRecommender.py:59)
+        v.b0[0] = fmaf(-lr, (float)stats[DAISY_ST_SUM_COEF], v.b0[0]);
 }
 
 // chains of edge records: the chunk whose TAIL edge starts a run owns it
-template <class C, bool FUSED>
+template <class C>
 __global__ __launch_bounds__(kBlock) void k_user_edges(float *__restrict__ P, int64_t nchunks, int d,
                                                        const double *__restrict__ stats, float lr,
                                                        float reg_1, float reg_2,
@@ -1166,12 +1025,11 @@ __global__ __launch_bounds__(kBlock) void k_user_edges(float *__restrict__ P, in
                                                        const int32_t *__restrict__ edge_user,
                                                        const float *__restrict__ edge_n,
                                                        const int32_t *__restrict__ edge_whole,
-                                                       float *__restrict__ p_sqnorm,
                                                        float *__restrict__ u_bias) {
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
-    const float rU = inv_or_zero(stats[FUSED ? DAISY_ST_NORM_U_PRE : DAISY_ST_NORM_U], reg_2);
+    const float rU = inv_or_zero(stats[DAISY_ST_NORM_U], reg_2);
     for (int64_t c = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; c < nchunks; c += gstride) {
         const int uu = edge_user[2 * c + 1];
         if (uu < 0) continue;
@@ -1191,66 +1049,7 @@ __global__ __launch_bounds__(kBlock) void k_user_edges(float *__restrict__ P, in
         user_finish_row<C>(p, acc, ns, lr, reg_1, rU);
         p.store(P + (int64_t)uu * d, lane, d);
         if (u_bias && lane == 0) u_bias[uu] = fmaf(-lr, sb, u_bias[uu]);
-        if constexpr (FUSED) {
-            const float sq = row_dot<C>(p, p);
-            if (lane == 0) p_sqnorm[uu] = sq;
-        }
     }
-}
-
-// ---------------------------------------------------------------------------
-// Fused single-GPU SGD step (throughput mode).  k_fwd and the user pass read the
-// same rows; fusing them (k_user_chunked<FUSED>) needs |P[u]|_F - a batch-wide
-// sum - BEFORE the pass, which a per-row cache of squared norms provides
-// (k_unorm: 4 B per sample instead of a 256-B row):
-//   k_unorm -> k_user_chunked<FUSED> (coef, sums, pre-step rows to the stage, P in place)
-//   -> k_user_edges -> k_reduce_partials<true> -> k_item_grad_chunked<FROM_STAGE> -> k_item_apply
-// Row traffic per interaction: 2.6 r + 1.6 w | 2 r   instead of   3 r | 2 r | 2.6 r + 0.6 w.
-// ---------------------------------------------------------------------------
-template <class C>
-__global__ __launch_bounds__(kBlock) void k_row_sqnorm(const float *__restrict__ W, int64_t rows, int d,
-                                                       float *__restrict__ out) {
-    const int lane = threadIdx.x % C::LPR;
-    const int group = threadIdx.x / C::LPR;
-    const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
-    for (int64_t r = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; r < rows; r += gstride) {
-        Row<C> w;
-        w.load(W + r * d, lane, d);
-        const float s = row_dot<C>(w, w);
-        if (lane == 0) out[r] = s;
-    }
-}
-
-// partials[block] = sum over the block's samples of |P[u_s]|^2 (from the cache)
-__global__ __launch_bounds__(kBlock) void k_unorm(const float *__restrict__ p_sqnorm, BatchView v,
-                                                  double *__restrict__ partials) {
-    double acc = 0.0;
-    for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < v.B;
-         s += (int64_t)gridDim.x * blockDim.x)
-        acc += (double)p_sqnorm[v.ukey[s] & v.umask];
-    __shared__ double sm[kBlock / kWave];
-    const double w = wave_sum_f64(acc);
-    if ((threadIdx.x % kWave) == 0) sm[threadIdx.x / kWave] = w;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int k = 0; k < kBlock / kWave; ++k) t += sm[k];
-        partials[blockIdx.x] = t;
-    }
-}
-
-__global__ __launch_bounds__(kBlock) void k_unorm_reduce(const double *__restrict__ partials, int nblocks,
-                                                         double *__restrict__ stats) {
-    __shared__ double sm[kBlock];
-    double t = 0.0;
-    for (int b = threadIdx.x; b < nblocks; b += kBlock) t += partials[b];
-    sm[threadIdx.x] = t;
-    __syncthreads();
-    for (int off = kBlock / 2; off > 0; off >>= 1) {
-        if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) stats[DAISY_ST_NORM_U_PRE] = sqrt(sm[0]);
 }
 
 // torch.optim.Adam single-tensor math (exp_avg.lerp_, addcmul_, addcdiv_), dense
@@ -1277,8 +1076,16 @@ __global__ __launch_bounds__(kBlock) void k_adam_dense(float *__restrict__ W, fl
 // ---------------------------------------------------------------------------
 static int plan_alloc(daisy_epoch_plan **out, int64_t max_triples, int64_t U, int64_t I) {
     daisy_epoch_plan *p = new daisy_epoch_plan();
+    memset(p, 0, sizeof(*p));          // no device memory yet: each layout allocates at its first build
     p->max_triples = max_triples; p->U = U; p->I = I;
-    p->n = 0; p->batch_size = 0; p->num_batches = 0; p->built = false;
+    *out = p;
+    return DAISY_OK;
+}
+
+// buffers of the sorted layout (kind 0)
+static int plan_need_sorted(daisy_epoch_plan *p) {
+    if (p->arena) return DAISY_OK;
+    const int64_t max_triples = p->max_triples;
     const size_t n2 = 2 * (size_t)max_triples;
     const size_t ta = sort_pairs_u32_u64_temp_bytes(n2), tb = sort_pairs_u64_u64_temp_bytes(n2);
     const size_t tc = rle_u32_temp_bytes(n2), td = rle_u64_temp_bytes(n2);
@@ -1298,8 +1105,9 @@ static int plan_alloc(daisy_epoch_plan **out, int64_t max_triples, int64_t U, in
     p->arena_bytes = off;
     hipError_t e = hipMalloc(&p->arena, p->arena_bytes);
     if (e != hipSuccess) {
-        set_error("epoch_plan_create: hipMalloc(%zu) failed: %s", p->arena_bytes, hipGetErrorString(e));
-        delete p;
+        set_error("epoch_plan_build: hipMalloc(%zu) failed: %s", p->arena_bytes, hipGetErrorString(e));
+        p->arena = nullptr;
+        p->arena_bytes = 0;
         return DAISY_ERR_HIP;
     }
     char *b = (char *)p->arena;
@@ -1314,17 +1122,19 @@ static int plan_alloc(daisy_epoch_plan **out, int64_t max_triples, int64_t U, in
     p->run_cnt = (uint32_t *)(b + o_sn);
     p->run_off = (int32_t *)(b + o_so);
     p->run_total = (uint32_t *)(b + o_rt);
+    p->bad = (int *)(b + o_rt + 64);
     p->ekey = nullptr; p->eval = nullptr;
     p->umask = p->imask = 0;
     p->temp = b + o_tmp;
-    *out = p;
     return DAISY_OK;
 }
 
 static int plan_free(daisy_epoch_plan *p) {
-    hipError_t e = hipFree(p->arena);
+    hipError_t e = p->arena ? hipFree(p->arena) : hipSuccess;
     for (int k = 0; k < 2; ++k)
         if (p->k64[k]) (void)hipFree(p->k64[k]);
+    if (p->parena) (void)hipFree(p->parena);
+    if (p->parena2) (void)hipFree(p->parena2);
     delete p;
     if (e != hipSuccess) {
         set_error("epoch_plan_destroy: hipFree failed: %s", hipGetErrorString(e));
@@ -1359,13 +1169,16 @@ static int plan_build(daisy_epoch_plan *p, const int32_t *triples, int64_t n, in
     const bool wide = (ubits + bbits > 32) || (ibits1 + bbits > 32);
     const bool presorted = (flags & DAISY_PLAN_TRIPLES_USER_SORTED) && order_mode != DAISY_ORDER_PERM;
     const int pointwise = (flags & DAISY_PLAN_POINTWISE) ? 1 : 0;
+    int rc = plan_need_sorted(p);
+    if (rc) return rc;
     const int s_begin = presorted ? ubits : 0;      // user bits ride along unsorted
     FeistelKey fk = make_feistel_key((uint64_t)n, seed, epoch);
     const int g1 = grid_for(n, kBlock), g2 = grid_for(2 * n, kBlock);
-    int rc;
+    DAISY_HIP(hipMemsetAsync(p->bad, 0, sizeof(int), s));
     if (!wide) {
         hipLaunchKernelGGL((k_plan_keys<uint32_t>), dim3(g1), dim3(kBlock), 0, s, triples, perm,
-                           order_mode, fk, n, start, batch_size, user_base, ubits, p->k32[0], p->v64[0]);
+                           order_mode, fk, n, start, batch_size, user_base, ubits, p->U, p->I, pointwise, p->bad,
+                           p->k32[0], p->v64[0]);
         DAISY_LAUNCH_CHECK();
         if (ubits + bbits > s_begin) {
             rc = sort_pairs_u32_u64(p->temp, p->temp_bytes, p->k32[0], p->ukey, p->v64[0], p->uval, n,
@@ -1392,7 +1205,8 @@ static int plan_build(daisy_epoch_plan *p, const int32_t *triples, int64_t n, in
     } else {
         if ((rc = plan_need_k64(p))) return rc;
         hipLaunchKernelGGL((k_plan_keys<uint64_t>), dim3(g1), dim3(kBlock), 0, s, triples, perm,
-                           order_mode, fk, n, start, batch_size, user_base, ubits, p->k64[0], p->v64[0]);
+                           order_mode, fk, n, start, batch_size, user_base, ubits, p->U, p->I, pointwise, p->bad,
+                           p->k64[0], p->v64[0]);
         DAISY_LAUNCH_CHECK();
         rc = sort_pairs_u64_u64(p->temp, p->temp_bytes, p->k64[0], p->k64[1], p->v64[0], p->uval, n,
                                 s_begin, ubits + bbits, s);
@@ -1421,6 +1235,7 @@ static int plan_build(daisy_epoch_plan *p, const int32_t *triples, int64_t n, in
     p->eval = p->v64[1];
     p->n = n; p->batch_size = batch_size; p->num_batches = nb; p->built = true;
     p->pointwise = pointwise;
+    p->kind = 0;
     return DAISY_OK;
 }
 
@@ -1440,6 +1255,28 @@ static BatchView plan_view(const daisy_epoch_plan *p, int64_t k) {
     v.pointwise = p->pointwise;
     v.bu = v.bi = v.b0 = v.g_bu = v.g_bi = v.g_b0 = nullptr;
     return v;
+}
+
+int launch_reduce_partials(const double *partials, int nblocks, double *stats, bool finalize, float reg_1,
+                           float reg_2, double *epoch_acc, double *step_loss, hipStream_t s) {
+    if (finalize)
+        hipLaunchKernelGGL((k_reduce_partials<true>), dim3(1), dim3(kBlock), 0, s, partials, nblocks, stats, reg_1,
+                           reg_2, epoch_acc, step_loss);
+    else
+        hipLaunchKernelGGL((k_reduce_partials<false>), dim3(1), dim3(kBlock), 0, s, partials, nblocks, stats, 0.f,
+                           0.f, (double *)nullptr, (double *)nullptr);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+// the same batch as the staged step reads it (stage slot = grouped sample position)
+static StreamView stream_view_of(const BatchView &v) {
+    StreamView sv;
+    sv.s_user = v.ukey; sv.s_ij = v.ij; sv.s_pos = nullptr;
+    sv.e_key = v.ekey; sv.e_pos = reinterpret_cast<const uint32_t *>(v.esu); sv.e_stride = 2;
+    sv.umask = v.umask; sv.imask = v.imask; sv.pos_base = 0;
+    sv.B = v.B; sv.E = 2 * v.B;
+    return sv;
 }
 
 }  // namespace daisy
@@ -1475,7 +1312,7 @@ int segsum_rows(const float *X, const float2 *coef, const uint32_t *ekey, const 
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
         const int64_t nchunks = (n_entries + RunCfg<C>::E - 1) / RunCfg<C>::E;
-        hipLaunchKernelGGL((k_item_grad_chunked<C, 0, false, true>), dim3(grid_for(n_entries, RunCfg<C>::E, 16384)),
+        hipLaunchKernelGGL((k_item_grad_chunked<C, 0, true>), dim3(grid_for(n_entries, RunCfg<C>::E, 16384)),
                            dim3(kBlock), 0, s, X, coef, v, d, out, ed);
         hipLaunchKernelGGL((k_item_edges<C>), dim3(grid_for(nchunks, C::GROUPS_PER_BLOCK)), dim3(kBlock), 0, s, ed,
                            nchunks, d, out, (float *)nullptr);
@@ -1513,7 +1350,9 @@ int daisy_epoch_plan_destroy(daisy_epoch_plan *plan) {
     return plan_free(plan);
 }
 
-size_t daisy_epoch_plan_bytes(const daisy_epoch_plan *plan) { return plan ? plan->arena_bytes : 0; }
+size_t daisy_epoch_plan_bytes(const daisy_epoch_plan *plan) {
+    return plan ? plan->arena_bytes + plan->parena_bytes : 0;
+}
 
 int64_t daisy_epoch_plan_num_batches(const daisy_epoch_plan *plan) {
     return (plan && plan->built) ? plan->num_batches : 0;
@@ -1536,6 +1375,34 @@ int daisy_epoch_plan_build(daisy_epoch_plan *plan, const int32_t *triples, int64
                       flags, S(stream));
 }
 
+static int report_bad_ids(const int *bad_dev, const char *who, int64_t U, int64_t I, hipStream_t s) {
+    int bad = 0;
+    DAISY_HIP(hipMemcpyAsync(&bad, bad_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+    DAISY_HIP(hipStreamSynchronize(s));
+    if (bad & 2) { set_error("%s: index out of range in the epoch permutation", who); return DAISY_ERR_ARG; }
+    if (bad & 1) {
+        set_error("%s: index out of range in the batch: need 0 <= user - user_base < %lld and 0 <= item < %lld "
+                  "(the reference raises IndexError in nn.Embedding, MFRecommender.py:64-65)", who, (long long)U,
+                  (long long)I);
+        return DAISY_ERR_ARG;
+    }
+    return DAISY_OK;
+}
+
+int daisy_epoch_plan_validate(const daisy_epoch_plan *plan, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(plan != nullptr, "epoch_plan_validate: NULL plan");
+    if (!plan->built) { set_error("epoch_plan_validate: plan has not been built"); return DAISY_ERR_STATE; }
+    if (plan->kind == 1) return DAISY_OK;            // a train index is validated when it is created
+    return report_bad_ids(plan->bad, "epoch_plan_build", plan->U, plan->I, S(stream));
+}
+
+int daisy_bpr_ctx_validate_batch(const daisy_bpr_ctx *ctx, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(ctx != nullptr, "ctx_validate_batch: NULL context");
+    if (!ctx->batch_set) { set_error("ctx_validate_batch: no batch set"); return DAISY_ERR_STATE; }
+    if (!ctx->own_plan || !ctx->own_plan->built || ctx->v.ukey != ctx->own_plan->ukey) return DAISY_OK;   // from an epoch plan
+    return report_bad_ids(ctx->own_plan->bad, "set_batch", ctx->U, ctx->I, S(stream));
+}
+
 int daisy_epoch_plan_read_batch(const daisy_epoch_plan *plan, int64_t k, int32_t *u, int32_t *i,
                                 int32_t *j, int32_t *ent_item, uint32_t *ent_s, int32_t *ent_u,
                                 int64_t *B_out_host, daisy_stream_t stream) {
@@ -1543,6 +1410,7 @@ int daisy_epoch_plan_read_batch(const daisy_epoch_plan *plan, int64_t k, int32_t
     if (!plan->built) { set_error("epoch_plan_read_batch: plan has not been built"); return DAISY_ERR_STATE; }
     DAISY_CHECK_ARG(k >= 0 && k < plan->num_batches, "epoch_plan_read_batch: batch %lld not in 0..%lld",
                     (long long)k, (long long)plan->num_batches);
+    if (plan->kind == 1) return plan_read_batch_partitioned(plan, k, u, i, j, ent_item, ent_s, ent_u, B_out_host, S(stream));
     const BatchView v = plan_view(plan, k);
     hipLaunchKernelGGL(k_unpack_batch, dim3(grid_for(2 * v.B, kBlock)), dim3(kBlock), 0, S(stream), v, u, i,
                        j, ent_item, ent_s, ent_u);
@@ -1553,7 +1421,7 @@ int daisy_epoch_plan_read_batch(const daisy_epoch_plan *plan, int64_t k, int32_t
 
 int daisy_feistel_positions(int64_t n, uint64_t seed, uint64_t epoch, int64_t *out,
                             daisy_stream_t stream) {
-    DAISY_CHECK_ARG(out && n > 0, "feistel_positions: bad argument");
+    DAISY_CHECK_ARG(out && n > 0 && n <= ((int64_t)1 << 30), "feistel_positions: n must be in 1..2^30");
     FeistelKey fk = make_feistel_key((uint64_t)n, seed, epoch);
     hipLaunchKernelGGL(k_feistel_perm, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, S(stream), n, fk, out);
     DAISY_LAUNCH_CHECK();
@@ -1585,12 +1453,16 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
         using C = decltype(cfg);
         const size_t cu = ((size_t)max_batch + UserRunCfg<C>::E - 1) / UserRunCfg<C>::E;
         const size_t ci = (2 * (size_t)max_batch + RunCfg<C>::E - 1) / RunCfg<C>::E;
-        max_chunks = (cu > ci ? cu : ci) + 2;
+        const size_t cs = ((size_t)max_batch + C::GROUPS_PER_BLOCK * 2 - 1) / (C::GROUPS_PER_BLOCK * 2);   // staged user pass, RUN >= 2
+        max_chunks = (cu > ci ? cu : ci);
+        if (cs > max_chunks) max_chunks = cs;
+        max_chunks += 2;
         return DAISY_OK;
     });
     const size_t n_edge = 2 * max_chunks;
     const size_t o_ev = take(n_edge * (size_t)d * 4), o_eu = take(n_edge * 4), o_en = take(n_edge * 8);
     const size_t o_ew = take(n_edge * 4);
+    const size_t o_ec = take(n_edge * 8);
     const size_t o_ps = take((size_t)max_batch * (size_t)d * 4);
     const size_t o_pn = take((size_t)user_num * 4);
     c->arena_bytes = off;
@@ -1608,6 +1480,8 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
     c->edge_user = (int32_t *)(base + o_eu);
     c->edge_n = (float *)(base + o_en);
     c->edge_whole = (int32_t *)(base + o_ew);
+    c->edge_cnt = (float *)(base + o_ec);
+    c->batch_kind = 0;
     c->p_stage = (float *)(base + o_ps);
     c->p_sqnorm = (float *)(base + o_pn);
     c->p_sqnorm_of = nullptr;
@@ -1669,8 +1543,17 @@ int daisy_bpr_set_batch_from_plan(daisy_bpr_ctx *ctx, const daisy_epoch_plan *pl
     DAISY_CHECK_ARG(plan->batch_size <= ctx->max_batch && plan->U == ctx->U && plan->I == ctx->I,
                     "set_batch_from_plan: plan (batch %lld, U %lld, I %lld) does not fit the context",
                     (long long)plan->batch_size, (long long)plan->U, (long long)plan->I);
-    ctx->v = plan_view(plan, k);
-    view_bias(ctx);
+    if (plan->kind == 1) {            // partitioned layout: only the staged step can read it
+        ctx->sv = plan_stream_view(plan, k);
+        memset(&ctx->v, 0, sizeof(ctx->v));
+        ctx->v.B = ctx->sv.B;
+        ctx->batch_kind = 1;
+    } else {
+        ctx->v = plan_view(plan, k);
+        ctx->sv = stream_view_of(ctx->v);
+        ctx->batch_kind = 0;
+        view_bias(ctx);
+    }
     ctx->batch_set = true; ctx->fwd_done = false;
     return DAISY_OK;
 }
@@ -1691,6 +1574,8 @@ int daisy_bpr_set_batch_from_triples(daisy_bpr_ctx *ctx, const int32_t *triples,
                     0, 0, B, user_base, ctx->pointwise ? DAISY_PLAN_POINTWISE : 0, S(stream));
     if (rc) return rc;
     ctx->v = plan_view(ctx->own_plan, 0);
+    ctx->sv = stream_view_of(ctx->v);
+    ctx->batch_kind = 0;
     view_bias(ctx);
     ctx->batch_set = true; ctx->fwd_done = false;
     return DAISY_OK;
@@ -1715,6 +1600,11 @@ static int forward_impl(daisy_bpr_ctx *ctx, const float *P, const float *Q, int3
     DAISY_CHECK_ARG(loss_type >= DAISY_LOSS_BPR && loss_type <= DAISY_LOSS_SL,
                     "Invalid loss type: %d", loss_type);
     if (!ctx->batch_set) { set_error("forward: no batch set"); return DAISY_ERR_STATE; }
+    if (ctx->batch_kind != 0) {
+        set_error("%s: the current batch comes from a partitioned plan (daisy_epoch_plan_build_indexed), which only "
+                  "daisy_bpr_sgd_step / daisy_bpr_fit_epoch_sgd with DAISY_ITEM_FUSED and the daisy_bpr_staged_* phases read", "forward");
+        return DAISY_ERR_STATE;
+    }
     DAISY_CHECK_ARG((loss_type >= DAISY_LOSS_CL) == (ctx->v.pointwise != 0),
                     "forward: loss type %d does not match the batch layout (point-wise=%d)", loss_type,
                     ctx->v.pointwise);
@@ -1797,7 +1687,7 @@ static int item_grad_impl(daisy_bpr_ctx *ctx, const float *P, const float *Q, co
             else if (tune_det) {
                 const int64_t nchunks = (2 * v.B + RunCfg<C>::E - 1) / RunCfg<C>::E;
                 ItemEdges ed{ctx->edge_vec, ctx->edge_user, ctx->edge_n, ctx->edge_whole};
-                hipLaunchKernelGGL((k_item_grad_chunked<C, 0, false, true>), dim3(grid_for(2 * v.B, RunCfg<C>::E, tune_cap)),
+                hipLaunchKernelGGL((k_item_grad_chunked<C, 0, true>), dim3(grid_for(2 * v.B, RunCfg<C>::E, tune_cap)),
                                    dim3(kBlock), 0, s, P, ctx->coef, v, d, gQ, ed);
                 hipLaunchKernelGGL((k_item_edges<C>), dim3(grid_for(nchunks, C::GROUPS_PER_BLOCK)), dim3(kBlock), 0, s,
                                    ed, nchunks, d, gQ, v.g_bi);
@@ -1840,6 +1730,11 @@ int daisy_bpr_item_grad_reg(daisy_bpr_ctx *ctx, const float *Q, const double *st
                             float reg_2, float *gQ, daisy_stream_t stream) {
     DAISY_CHECK_ARG(ctx && Q && stats && gQ, "item_grad_reg: NULL argument");
     if (!ctx->batch_set) { set_error("item_grad_reg: no batch set"); return DAISY_ERR_STATE; }
+    if (ctx->batch_kind != 0) {
+        set_error("%s: the current batch comes from a partitioned plan (daisy_epoch_plan_build_indexed), which only "
+                  "daisy_bpr_sgd_step / daisy_bpr_fit_epoch_sgd with DAISY_ITEM_FUSED and the daisy_bpr_staged_* phases read", "item_grad_reg");
+        return DAISY_ERR_STATE;
+    }
     if (reg_1 == 0.f && reg_2 == 0.f) return DAISY_OK;
     const BatchView &v = ctx->v;
     const int d = ctx->d;
@@ -1858,7 +1753,7 @@ int daisy_bpr_item_grad_reg(daisy_bpr_ctx *ctx, const float *Q, const double *st
 static int user_pass(daisy_bpr_ctx *ctx, float *P, const float *Q, const double *stats, float lr,
                      float reg_1, float reg_2, float *gP, bool sgd, daisy_stream_t stream,
                      bool chunked = false) {
-    ctx->p_sqnorm_of = nullptr;   // P rows change (or an optimiser outside will change them)
+    ctx->p_sqnorm_of = nullptr;   // P rows change behind the row-norm cache of the staged step
     if (!ctx->fwd_done) { set_error("user update: forward has not run for this batch"); return DAISY_ERR_STATE; }
     hipStream_t s = S(stream);
     const BatchView &v = ctx->v;
@@ -1869,12 +1764,12 @@ static int user_pass(daisy_bpr_ctx *ctx, float *P, const float *Q, const double 
         const int grid = grid_for(v.B, C::GROUPS_PER_BLOCK * 2);
         if (sgd && chunked && user_kernel == 1 && C::NE <= 4) {
             const int64_t nchunks = (v.B + UserRunCfg<C>::E - 1) / UserRunCfg<C>::E;
-            hipLaunchKernelGGL((k_user_chunked<C, false>), dim3(grid_for(nchunks, 1, 16384)), dim3(kBlock), 0,
+            hipLaunchKernelGGL((k_user_chunked<C>), dim3(grid_for(nchunks, 1, 16384)), dim3(kBlock), 0,
                                s, P, Q, v, ctx->coef, d, stats, lr, reg_1, reg_2, ctx->edge_vec,
-                               ctx->edge_user, ctx->edge_n, ctx->edge_whole, 0, 0.f, nullptr, nullptr, nullptr);
-            hipLaunchKernelGGL((k_user_edges<C, false>), dim3(grid_for(nchunks, C::GROUPS_PER_BLOCK)),
+                               ctx->edge_user, ctx->edge_n, ctx->edge_whole);
+            hipLaunchKernelGGL((k_user_edges<C>), dim3(grid_for(nchunks, C::GROUPS_PER_BLOCK)),
                                dim3(kBlock), 0, s, P, nchunks, d, stats, lr, reg_1, reg_2, ctx->edge_vec,
-                               ctx->edge_user, ctx->edge_n, ctx->edge_whole, nullptr, v.bu);
+                               ctx->edge_user, ctx->edge_n, ctx->edge_whole, v.bu);
         } else if (sgd)
             hipLaunchKernelGGL((k_user<C, true>), dim3(grid), dim3(kBlock), 0, s, P, Q, v, ctx->coef, d,
                                stats, lr, reg_1, reg_2, gP);
@@ -1913,6 +1808,10 @@ static int item_apply_impl(daisy_bpr_ctx *ctx, float *Q, float *gQ, float lr, in
                            daisy_stream_t stream) {
     DAISY_CHECK_ARG(ctx && Q && gQ, "item_sgd_apply: NULL argument");
     if (!dense && !ctx->batch_set) { set_error("item_sgd_apply: no batch set"); return DAISY_ERR_STATE; }
+    if (!dense && ctx->batch_kind != 0) {
+        set_error("item_sgd_apply: the current batch comes from a partitioned plan; only dense != 0 applies there");
+        return DAISY_ERR_STATE;
+    }
     hipStream_t s = S(stream);
     const int d = ctx->d;
     const BatchView &v = ctx->v;
@@ -1949,61 +1848,20 @@ int daisy_adam_dense(float *W, float *g, float *m, float *v, int64_t n, float lr
     return DAISY_OK;
 }
 
-// throughput mode of one whole step (see the comment above k_row_sqnorm)
-static int sgd_step_fused(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t loss_type, float gamma, float lr,
-                          float reg_1, float reg_2, float *gQ, double *stats, double *epoch_acc,
-                          double *step_loss, daisy_stream_t stream) {
-    DAISY_CHECK_ARG(ctx && P && Q && gQ && stats, "sgd_step: NULL argument");
-    DAISY_CHECK_ARG(loss_type >= DAISY_LOSS_BPR && loss_type <= DAISY_LOSS_TL, "Invalid loss type: %d",
-                    loss_type);
-    if (!ctx->batch_set) { set_error("sgd_step: no batch set"); return DAISY_ERR_STATE; }
-    hipStream_t s = S(stream);
-    const BatchView &v = ctx->v;
-    const int d = ctx->d;
-    const bool reg = (reg_1 != 0.f) || (reg_2 != 0.f);
-    int rc = dispatch_d(d, [&](auto cfg) {
-        using C = decltype(cfg);
-        if (ctx->p_sqnorm_of != P) {   // (re)build the squared-norm cache: one dense pass over P
-            hipLaunchKernelGGL((k_row_sqnorm<C>), dim3(grid_for(ctx->U, C::GROUPS_PER_BLOCK * 4)),
-                               dim3(kBlock), 0, s, P, ctx->U, d, ctx->p_sqnorm);
-            ctx->p_sqnorm_of = P;
-        }
-        const int gn = grid_for(v.B, kBlock * 4);
-        hipLaunchKernelGGL(k_unorm, dim3(gn), dim3(kBlock), 0, s, ctx->p_sqnorm, v, ctx->partials);
-        hipLaunchKernelGGL(k_unorm_reduce, dim3(1), dim3(kBlock), 0, s, ctx->partials, gn, stats);
-        if constexpr (C::NE <= 4) {
-            const int64_t nchunks = (v.B + UserRunCfg<C>::E - 1) / UserRunCfg<C>::E;
-            const int gu = grid_for(nchunks, 1, kMaxGrid);
-            hipLaunchKernelGGL((k_user_chunked<C, true>), dim3(gu), dim3(kBlock), 0, s, P, Q, v, ctx->coef, d,
-                               stats, lr, reg_1, reg_2, ctx->edge_vec, ctx->edge_user, ctx->edge_n,
-                               ctx->edge_whole, (int)loss_type, gamma, ctx->p_stage, ctx->p_sqnorm,
-                               ctx->partials);
-            hipLaunchKernelGGL((k_user_edges<C, true>), dim3(grid_for(nchunks, C::GROUPS_PER_BLOCK)),
-                               dim3(kBlock), 0, s, P, nchunks, d, stats, lr, reg_1, reg_2, ctx->edge_vec,
-                               ctx->edge_user, ctx->edge_n, ctx->edge_whole, ctx->p_sqnorm, nullptr);
-            hipLaunchKernelGGL((k_reduce_partials<true>), dim3(1), dim3(kBlock), 0, s, ctx->partials, gu,
-                               stats, reg_1, reg_2, epoch_acc, step_loss);
-            hipLaunchKernelGGL((k_item_grad_chunked<C, 0, true>), dim3(grid_for(2 * v.B, RunCfg<C>::E, 16384)),
-                               dim3(kBlock), 0, s, ctx->p_stage, ctx->coef, v, d, gQ);
-        }
-        return DAISY_OK;
-    });
-    if (rc) return rc;
-    DAISY_LAUNCH_CHECK();
-    ctx->fwd_done = true;
-    return item_apply_impl(ctx, Q, gQ, lr, 0, stats, reg_1, reg_2, reg, stream);
-}
-
 int daisy_bpr_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t loss_type, float gamma,
                        float lr, float reg_1, float reg_2, float *gQ, double *stats,
                        double *epoch_acc, double *step_loss, int32_t item_mode,
                        daisy_stream_t stream) {
+    DAISY_CHECK_ARG(ctx && P && Q && stats, "sgd_step: NULL argument");
+    if (!ctx->batch_set) { set_error("sgd_step: no batch set"); return DAISY_ERR_STATE; }
     if (item_mode == DAISY_ITEM_FUSED) {
-        if (ctx->d <= 64 && !ctx->v.pointwise && !ctx->bu)   // rows of <= 4 floats per lane: the fused kernel fits the register budget
-            return sgd_step_fused(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, gQ, stats, epoch_acc,
-                                  step_loss, stream);
+        // the staged step (bpr_staged.hip): pairwise losses without FM biases; anything else runs the phase kernels
+        if (staged_supported(ctx, loss_type))
+            return staged_sgd_step(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, stats, epoch_acc, step_loss,
+                                   S(stream));
         item_mode = DAISY_ITEM_CHUNKED;
     }
+    DAISY_CHECK_ARG(gQ != nullptr, "sgd_step: gQ is NULL");
     int rc;
     if ((rc = forward_impl(ctx, P, Q, loss_type, gamma, stats, true, reg_1, reg_2, epoch_acc, step_loss,
                            stream))) return rc;

@@ -263,40 +263,63 @@ __host__ __device__ __forceinline__ uint64_t philox_u64(uint64_t seed, uint64_t 
 }
 
 // ----------------------------------------------------------------------------
-// Keyed bijection of [0, n): 6-round balanced Feistel network on 2h bits with
-// cycle walking (the construction behind thrust::shuffle).  Round keys come from
-// Philox on the host.  Identical to oracle/bpr_mf_numpy.py::feistel_position.
+// Keyed bijection of [0, n), n <= 2^30: 4-round balanced Feistel network on 2h bits with cycle
+// walking - the construction behind thrust::shuffle.  Round keys come from Philox on the host.
+// The plan builders evaluate it ~3x per interaction per epoch and it is their ALU bound, so the
+// round function is built from FULL-RATE integer instructions only: two multiply-xorshift steps
+// with 24-bit multiplies (v_mul_u32_u24; a 32-bit v_mul_lo_u32 is quarter rate on CDNA) - the
+// half-block is at most 15 bits wide, so 24-bit operands lose nothing.
+// Identical to oracle/bpr_mf_numpy.py::feistel_positions.
 // ----------------------------------------------------------------------------
-constexpr int kFeistelRounds = 6;
+constexpr int kFeistelRounds = 4;
 struct FeistelKey {
     uint32_t k[kFeistelRounds];
     int half_bits;
 };
-__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {  // murmur3 finalizer
+__host__ __device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) {   // low 32 bits of (a mod 2^24)*(b mod 2^24)
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return (uint32_t)((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu));
+#endif
+}
+__host__ __device__ __forceinline__ uint32_t feistel_round(uint32_t r, uint32_t key) {
+    uint32_t x = r ^ key;
+    x = mul24(x, 0xCC9E2Du);
+    x ^= x >> 15;
+    x = mul24(x, 0x85EBCBu);
+    x ^= x >> 13;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {  // murmur3 finalizer (other hashes of the library)
     x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
     return x;
 }
-__host__ __device__ __forceinline__ uint64_t feistel_position(uint64_t x, uint64_t n,
-                                                              const FeistelKey &fk) {
+// one pass through the network: a bijection of [0, 2^(2h)); cycle walking repeats it until the value is < n
+__host__ __device__ __forceinline__ uint32_t feistel_once(uint32_t x, const FeistelKey &fk) {
     const int h = fk.half_bits;
-    const uint64_t mask = ((uint64_t)1 << h) - 1;
-    do {
-        uint64_t L = x >> h, R = x & mask;
+    const uint32_t mask = (1u << h) - 1u;
+    uint32_t L = x >> h, R = x & mask;
 #pragma unroll
-        for (int r = 0; r < kFeistelRounds; ++r) {
-            const uint64_t f = (uint64_t)mix32((uint32_t)R ^ fk.k[r]) & mask;
-            const uint64_t t = L ^ f;
-            L = R;
-            R = t;
-        }
-        x = (L << h) | R;
-    } while (x >= n);
+    for (int r = 0; r < kFeistelRounds; ++r) {
+        const uint32_t t = L ^ (feistel_round(R, fk.k[r]) & mask);
+        L = R;
+        R = t;
+    }
+    return (L << h) | R;
+}
+__host__ __device__ __forceinline__ uint32_t feistel_position32(uint32_t x, uint32_t n, const FeistelKey &fk) {
+    do x = feistel_once(x, fk);
+    while (x >= n);
     return x;
+}
+__host__ __device__ __forceinline__ uint64_t feistel_position(uint64_t x, uint64_t n, const FeistelKey &fk) {
+    return (uint64_t)feistel_position32((uint32_t)x, (uint32_t)n, fk);
 }
 inline FeistelKey make_feistel_key(uint64_t n, uint64_t seed, uint64_t epoch) {
     FeistelKey fk;
     int bits = 2;
-    while (bits < 62 && ((uint64_t)1 << bits) < n) bits += 2;   // even bit count >= log2(n)
+    while (bits < 30 && ((uint64_t)1 << bits) < n) bits += 2;   // even bit count >= log2(n); n <= 2^30
     fk.half_bits = bits / 2;
     for (int r = 0; r < kFeistelRounds; ++r)
         fk.k[r] = (uint32_t)philox_u64(seed, epoch | ((uint64_t)1 << 61), (uint64_t)r);

@@ -107,10 +107,12 @@ class GeneralRecommender(AbstractRecommender):
         self.device = "cuda" if torch.cuda.is_available() else "cpu"
         self.logger = config.get("logger") or logging.getLogger("daisyrec_amd")
         # knobs of the native path (absent from the reference config: defaults keep its behaviour)
-        # 'chunked' (default): the throughput kernels - bitwise reproducible run to run (fixed summation
-        # order, no atomics); 'sorted': every item row summed serially in plan order (also reproducible,
-        # slower); 'atomic': fp32 atomics (kept for A/B measurements, not reproducible)
-        self.item_mode = str(config.get("item_mode", "chunked")).lower()
+        # 'fused' (default): the staged step over the partitioned epoch plan (forward fused into the user
+        # pass, item rows committed by their segment owner) for SGD + pairwise loss without biases, the
+        # chunked phase kernels otherwise; 'chunked': the phase kernels; 'sorted': every item row summed
+        # serially in plan order.  All three are bitwise reproducible run to run (fixed summation order, no
+        # atomics).  'atomic': fp32 atomics (kept for A/B measurements, not reproducible)
+        self.item_mode = str(config.get("item_mode", "fused")).lower()
         self.show_progress = bool(config.get("progress", True))
         # 'loader' (default): replay the DataLoader's torch RNG order (what the reference run does);
         # 'device': shuffle=True as a keyed permutation computed on the GPU (no host permutation,
@@ -162,8 +164,19 @@ class GeneralRecommender(AbstractRecommender):
         B = int(train_loader.batch_size)
         if train_loader.drop_last:
             n = (n // B) * B
+        self.epoch_losses = []
+        if n == 0:
+            # an empty loader: the reference's batch loop does not run, every epoch's loss is 0.0
+            # (AbstractRecommender.py:117-137)
+            for _ in range(self.epochs):
+                self.epoch_losses.append(0.0)
+                if self.early_stop:
+                    self.logger.info("Satisfy early stop mechanism")
+                    break
+            return
+        B = min(B, n)            # fewer rows than one batch: a single partial batch, like the DataLoader
         P, Q = self.embed_user.weight.data, self.embed_item.weight.data
-        ctx = ops.BprContext(min(B, max(n, 1)), P.shape[1], P.shape[0], Q.shape[0], device=P.device)
+        ctx = ops.BprContext(B, P.shape[1], P.shape[0], Q.shape[0], device=P.device)
         plan = ops.EpochPlan(n, P.shape[0], Q.shape[0], device=P.device)
         biases = self._biases() if hasattr(self, "_biases") else None     # FM: (u_bias, i_bias, bias_)
         adam = _AdamState(P, Q, self.lr, biases) if opt == "adam" else None
@@ -173,24 +186,38 @@ class GeneralRecommender(AbstractRecommender):
                          g_bias=adam.g[2] if adam is not None else None)
         user_sorted = ops.triples_user_sorted(triples[:n])
         pointwise = loss_id in ops.POINTWISE_LOSSES      # rows are (user, item, label), sampler.py:93-98
-        self.epoch_losses = []
+        # the staged step over the partitioned plan: SGD, pairwise loss, no FM biases
+        staged = (item_mode == ops.ITEM_MODES["fused"] and adam is None and not pointwise and biases is None)
+        if item_mode == ops.ITEM_MODES["fused"] and not staged:
+            item_mode = ops.ITEM_MODES["chunked"]
+        index = None
         last_loss = 0.0
         try:
+            if staged:      # indexed once per fit (also validates the id ranges)
+                index = ops.TrainIndex(triples[:n], P.shape[0], Q.shape[0], user_sorted=user_sorted)
             epochs = range(1, self.epochs + 1)
             bar = _tqdm(epochs) if (_tqdm is not None and self.show_progress) else None
             for epoch in (bar if bar is not None else epochs):
                 self.train()
                 from torch.utils.data import SequentialSampler
                 if self.shuffle_mode == "device" and not isinstance(train_loader.sampler, SequentialSampler):
-                    plan.build(triples, B, order="feistel", seed=self.seed, epoch=epoch, n_triples=n,
-                               user_sorted=user_sorted, pointwise=pointwise)
+                    order, perm = "feistel", None
                 else:
                     perm = self._epoch_order(train_loader, triples.shape[0])
                     if perm is not None:
-                        perm = perm[:n].contiguous().to(self.device)
-                    # radix sorts lay the epoch out batch by batch, in the DataLoader's order
-                    plan.build(triples, B, order="identity" if perm is None else "perm", perm=perm,
-                               n_triples=n, user_sorted=user_sorted, pointwise=pointwise)
+                        if n < triples.shape[0]:            # drop_last: the first n positions of the order
+                            perm = perm[:n]
+                            if bool((perm >= n).any()):
+                                raise NotImplementedError("drop_last with a shuffled loader is not supported on "
+                                                          "the HIP path (the dropped rows change per epoch)")
+                        perm = perm.contiguous().to(self.device)
+                    order = "identity" if perm is None else "perm"
+                # the epoch laid out batch by batch, in the DataLoader's order
+                if staged:
+                    plan.build_indexed(index, B, order=order, perm=perm, seed=self.seed, epoch=epoch)
+                else:
+                    plan.build(triples, B, order=order, perm=perm, seed=self.seed, epoch=epoch, n_triples=n,
+                               user_sorted=user_sorted, pointwise=pointwise)
                 ctx.epoch_acc.zero_()
                 if adam is None:
                     ctx.fit_epoch_sgd(plan, P, Q, self.lr, self.reg_1, self.reg_2, loss_type=loss_id,
@@ -218,6 +245,8 @@ class GeneralRecommender(AbstractRecommender):
             torch.cuda.synchronize()
             ctx.close()
             plan.close()
+            if index is not None:
+                index.close()
 
 
 class _AdamState:

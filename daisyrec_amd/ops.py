@@ -51,6 +51,39 @@ def _ws(nbytes, device):
     return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
 
 
+class TrainIndex:
+    """Owner of a native ``daisy_train_index``: the training triples in CSR order + their item entries
+    sorted by item, built once per fit (BasicDataset's triple array is immutable, dataset.py:21).
+    Raises ValueError when an id lies outside the tables (the reference: IndexError in nn.Embedding)."""
+
+    def __init__(self, triples, user_num: int, item_num: int, user_base: int = 0, user_sorted=None):
+        if user_sorted is None:
+            user_sorted = triples_user_sorted(triples)
+        self.triples = triples            # kept alive: a user-sorted array is indexed in place
+        self.n = int(triples.shape[0])
+        self.user_num, self.item_num = int(user_num), int(item_num)
+        self._h = C.c_void_p()
+        with torch.cuda.device(triples.device):
+            check(lib.daisy_train_index_create(C.byref(self._h), _ptr(triples, torch.int32, "triples"), self.n,
+                                               self.user_num, self.item_num, int(user_base),
+                                               N.PLAN_TRIPLES_USER_SORTED if user_sorted else 0, _stream()))
+
+    @property
+    def nbytes(self):
+        return int(lib.daisy_train_index_bytes(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            check(lib.daisy_train_index_destroy(self._h))
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class EpochPlan:
     """Owner of a native ``daisy_epoch_plan``: one epoch laid out batch by batch in HBM
     (replaces a pass over DataLoader(BasicDataset(triples)), dataset.py:5-27)."""
@@ -66,15 +99,31 @@ class EpochPlan:
                                               int(item_num)))
 
     def build(self, triples, batch_size, order="identity", perm=None, seed=0, epoch=0, user_base=0,
-              n_triples=None, user_sorted=False, pointwise=False):
+              n_triples=None, user_sorted=False, pointwise=False, validate=None):
         """user_sorted=True promises that `triples` is sorted by user (use `triples_user_sorted`
-        to check once): grouping by user then costs one radix pass instead of a full sort."""
+        to check once): grouping by user then costs one radix pass instead of a full sort.
+        validate: check the id ranges after the build (one host sync; ValueError like the reference's
+        IndexError).  Default: the first build over a given triple array (and every explicit permutation)."""
         n = triples.shape[0] if n_triples is None else int(n_triples)
         mode = ORDER_MODES[order] if isinstance(order, str) else int(order)
         flags = (N.PLAN_TRIPLES_USER_SORTED if user_sorted else 0) | (N.PLAN_POINTWISE if pointwise else 0)
         check(lib.daisy_epoch_plan_build(self._h, _ptr(triples, torch.int32, "triples"), n,
                                          _ptr(perm, torch.int64, "perm"), mode, int(seed), int(epoch),
                                          int(batch_size), int(user_base), flags, _stream()))
+        sig = (triples.data_ptr(), n, int(user_base), triples._version)
+        if validate is None:
+            validate = sig != getattr(self, "_validated", None)
+        if validate:
+            check(lib.daisy_epoch_plan_validate(self._h, _stream()))
+            self._validated = sig
+        return self
+
+    def build_indexed(self, index: "TrainIndex", batch_size, order="identity", perm=None, seed=0, epoch=0):
+        """The partitioned layout (32 B per interaction, two one-digit partitions of the static index
+        instead of two radix sorts); feeds the staged step (item_mode 'fused') only."""
+        mode = ORDER_MODES[order] if isinstance(order, str) else int(order)
+        check(lib.daisy_epoch_plan_build_indexed(self._h, index._h, _ptr(perm, torch.int64, "perm"), mode,
+                                                 int(seed), int(epoch), int(batch_size), _stream()))
         return self
 
     @property
@@ -140,6 +189,38 @@ class BprContext:
         self.stats = torch.zeros(N.STATS_LEN, dtype=torch.float64, device=self.device)
         self.epoch_acc = torch.zeros(2, dtype=torch.float64, device=self.device)
         self.gQ = torch.zeros(self.item_num, self.d, dtype=torch.float32, device=self.device)
+        self._p_key = None        # (data_ptr, torch version counter) of the P the row-norm cache describes
+
+    def _sync_norm_cache(self, P):
+        """The staged step keeps |P[u]|^2 per row inside the context.  The native side tracks every write
+        that goes through it; torch-side in-place edits of P show up in the tensor's version counter."""
+        key = (P.data_ptr(), P._version)
+        if key != self._p_key:
+            check(lib.daisy_bpr_ctx_invalidate_cache(self._h))
+            self._p_key = key
+
+    def invalidate_cache(self):
+        check(lib.daisy_bpr_ctx_invalidate_cache(self._h))
+        self._p_key = None
+
+    # -- the staged step in phases (multi-GPU form) ------------------------------------------------
+    def staged_prenorm(self, P):
+        self._sync_norm_cache(P)
+        check(lib.daisy_bpr_staged_prenorm(self._h, _ptr(P, torch.float32, "P"),
+                                           _ptr(self.stats, torch.float64, "stats"), _stream()))
+
+    def staged_user(self, P, Q, lr, reg_1, reg_2, loss_type=N.LOSS_BPR, gamma=1e-10):
+        check(lib.daisy_bpr_staged_user(self._h, _ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"),
+                                        int(loss_type), float(gamma), float(lr), float(reg_1), float(reg_2),
+                                        _ptr(self.stats, torch.float64, "stats"), _stream()))
+
+    def staged_item(self, lr, reg_1, reg_2, Q=None, gQ=None, cnt=None, loss_type=N.LOSS_BPR):
+        """Q given: SGD on the touched item rows in place.  gQ + cnt given instead: the data term of the
+        item gradient and the per-item (n_pos, n_neg) for a reduce-scatter."""
+        check(lib.daisy_bpr_staged_item(self._h, int(loss_type), _ptr(Q, torch.float32, "Q"),
+                                        _ptr(gQ, torch.float32, "gQ"), _ptr(cnt, torch.float32, "cnt"),
+                                        float(lr), float(reg_1), float(reg_2),
+                                        _ptr(self.stats, torch.float64, "stats"), _stream()))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -174,17 +255,23 @@ class BprContext:
         self._bias = (u_bias, i_bias, bias, g_u_bias, g_i_bias, g_bias)     # keep the storage alive
 
     # -- batch -------------------------------------------------------------
-    def set_batch_from_triples(self, triples, idx=None, start=0, B=None, user_base=0):
+    def set_batch_from_triples(self, triples, idx=None, start=0, B=None, user_base=0, validate=True):
+        """validate: raise ValueError when an id lies outside the tables (one host sync; the reference raises
+        IndexError in nn.Embedding).  Unvalidated out-of-range ids are treated as id 0, never dereferenced."""
         n = triples.shape[0]
         if B is None:
             B = idx.numel() if idx is not None else n - start
         check(lib.daisy_bpr_set_batch_from_triples(
             self._h, _ptr(triples, torch.int32, "triples"), n,
             _ptr(idx, torch.int64, "idx"), int(start), int(B), int(user_base), _stream()))
+        if validate:
+            check(lib.daisy_bpr_ctx_validate_batch(self._h, _stream()))
 
-    def set_batch(self, u, i, j):
+    def set_batch(self, u, i, j, validate=True):
         check(lib.daisy_bpr_set_batch(self._h, _ptr(u, torch.int32, "u"), _ptr(i, torch.int32, "i"),
                                       _ptr(j, torch.int32, "j"), u.numel(), _stream()))
+        if validate:
+            check(lib.daisy_bpr_ctx_validate_batch(self._h, _stream()))
 
     def set_batch_from_plan(self, plan, k):
         check(lib.daisy_bpr_set_batch_from_plan(self._h, plan._h, int(k), _stream()))
@@ -238,6 +325,8 @@ class BprContext:
 
     def sgd_step(self, P, Q, lr, reg_1, reg_2, loss_type=N.LOSS_BPR, gamma=1e-10,
                  item_mode=N.ITEM_CHUNKED, step_loss=None, accumulate=True):
+        if item_mode == N.ITEM_FUSED:
+            self._sync_norm_cache(P)
         check(lib.daisy_bpr_sgd_step(
             self._h, _ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"), int(loss_type),
             float(gamma), float(lr), float(reg_1), float(reg_2), _ptr(self.gQ, torch.float32, "gQ"),
@@ -248,12 +337,21 @@ class BprContext:
     def fit_epoch_sgd(self, plan, P, Q, lr, reg_1, reg_2, loss_type=N.LOSS_BPR, gamma=1e-10,
                       item_mode=N.ITEM_CHUNKED, step_losses=None):
         """Every batch of a built plan (one epoch), enqueued natively."""
+        if item_mode == N.ITEM_FUSED:
+            self._sync_norm_cache(P)
         check(lib.daisy_bpr_fit_epoch_sgd(
             self._h, plan._h, _ptr(P, torch.float32, "P"), _ptr(Q, torch.float32, "Q"),
             int(loss_type), float(gamma), float(lr), float(reg_1), float(reg_2),
             _ptr(self.gQ, torch.float32, "gQ"), _ptr(self.stats, torch.float64, "stats"),
             _ptr(self.epoch_acc, torch.float64, "epoch_acc"),
             _ptr(step_losses, torch.float64, "step_losses"), int(item_mode), _stream()))
+
+
+def item_apply_counts(Q, g, cnt, lr, reg_1, reg_2, stats):
+    """Row owner's SGD step from reduced (g, cnt) (multi-GPU staged step); clears g and cnt."""
+    check(lib.daisy_item_apply_counts(_ptr(Q, torch.float32, "Q"), _ptr(g, torch.float32, "g"),
+                                      _ptr(cnt, torch.float32, "cnt"), Q.shape[0], Q.shape[1], float(lr),
+                                      float(reg_1), float(reg_2), _ptr(stats, torch.float64, "stats"), _stream()))
 
 
 def adam_dense(W, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
@@ -290,6 +388,7 @@ def mf_rank_topk(P, Q, us, cands, topk, return_scores=False, biases=None):
     us = us.to(torch.int64).contiguous()
     cands = cands.to(torch.int64).contiguous()
     B, Cn = cands.shape
+    topk = min(int(topk), int(Cn))          # rank_list[:, :topk] truncates (MFRecommender.py:119)
     out = torch.empty(B, topk, dtype=torch.int64, device=P.device)
     scores = torch.empty(B, Cn, dtype=torch.float32, device=P.device) if return_scores else None
     nbytes = lib.daisy_mf_rank_workspace_bytes(B, Cn)
@@ -306,6 +405,7 @@ def mf_rank_topk(P, Q, us, cands, topk, return_scores=False, biases=None):
 def mf_full_rank(P, Q, u, topk, biases=None):
     """MF.full_rank (MFRecommender.py:126-133) -> int64 [topk]; biases: FM.full_rank (FMRecommender.py:125-133)."""
     I = Q.shape[0]
+    topk = min(int(topk), int(I))           # argsort(...)[:topk] truncates (MFRecommender.py:131)
     out = torch.empty(topk, dtype=torch.int64, device=P.device)
     ws = _ws(lib.daisy_mf_full_rank_workspace_bytes(I), P.device)
     bu, bi, b0 = _bias_ptrs(biases)

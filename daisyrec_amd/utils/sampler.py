@@ -6,9 +6,13 @@ Mirror of daisy/utils/sampler.py:3-103 (``AbstractSampler`` / ``BasicNegtiveSamp
 every interaction of user ``u`` carries the same ``num_ng`` negatives, drawn uniformly
 with replacement from the items ``u`` has not interacted with (sampler.py:84-89,91,100-101).
 
+The point-wise CL / SL layouts (sampler.py:93-98) are produced too.  Like the reference, sampling
+raises ValueError when some user id in range(user_num) has interacted with every item
+(np.random.choice on an empty complement, sampler.py:84-89).
+
 Not reproduced: numpy's MT19937 stream (a device generator cannot follow it; the draws
-are Philox4x32-10 keyed by config['seed']), the popularity-mixed branches and the
-point-wise CL/SL layouts (sampler.py:64-80,93-98) — outside the BPR hot path.
+are Philox4x32-10 keyed by config['seed']) and the popularity-mixed branches
+(sampler.py:64-80) — outside the uniform hot path.
 """
 from __future__ import annotations
 
@@ -55,8 +59,11 @@ class BasicNegtiveSampler(AbstractSampler):
             us = np.fromiter((u for u, s in self.ur.items() for _ in s), dtype=np.int32)
             it = np.fromiter((i for _, s in self.ur.items() for i in s), dtype=np.int32)
             return us, it
-        return (self.df[self.uid_name].to_numpy().astype(np.int32),
-                self.df[self.iid_name].to_numpy().astype(np.int32))
+        # no train_ur given (the reference would fail on self.ur[u]): the positives are the distinct
+        # (user, item) pairs of df - duplicates would inflate the CSR rows the sampler searches
+        pairs = np.unique(np.stack([self.df[self.uid_name].to_numpy().astype(np.int32),
+                                    self.df[self.iid_name].to_numpy().astype(np.int32)], 1), axis=0)
+        return np.ascontiguousarray(pairs[:, 0]), np.ascontiguousarray(pairs[:, 1])
 
     def sampling_device(self):
         """Triples as an int32 [N*num_ng, 3] DEVICE tensor."""
@@ -73,6 +80,10 @@ class BasicNegtiveSampler(AbstractSampler):
         indptr, csr = ops.build_user_csr(torch.from_numpy(pu).to(self.device),
                                          torch.from_numpy(pi).to(self.device), self.user_num)
         js = ops.sample_neg_per_user(indptr, csr, self.item_num, self.num_ng, self.seed, self.epoch)
+        if bool((js < 0).any().item()):
+            # a user who has interacted with every item: np.random.choice(np.setdiff1d(...)) on an empty
+            # array in the reference (sampler.py:84-89)
+            raise ValueError("'a' cannot be empty unless no samples are taken")
         users = torch.from_numpy(self.df[self.uid_name].to_numpy().astype(np.int32)).to(self.device)
         items = torch.from_numpy(self.df[self.iid_name].to_numpy().astype(np.int32)).to(self.device)
         triples = ops.expand_triples(users, items, js)

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DAISY_ABI_VERSION 2
+#define DAISY_ABI_VERSION 3
 
 typedef void *daisy_stream_t; /* hipStream_t */
 
@@ -53,8 +53,10 @@ enum daisy_item_mode {
     DAISY_ITEM_ATOMIC = 0,  /* one fp32 atomic row per entry (kept for A/B measurements only) */
     DAISY_ITEM_SORTED = 1,  /* one owner per row, entries summed in plan order: bitwise reproducible */
     DAISY_ITEM_CHUNKED = 2, /* segmented reduction through LDS accumulators (throughput mode) */
-    DAISY_ITEM_FUSED = 3    /* daisy_bpr_sgd_step only: CHUNKED item kernel + forward fused into the
-                               user pass (per-row norm cache, staged user rows); elsewhere = CHUNKED */
+    DAISY_ITEM_FUSED = 3    /* daisy_bpr_sgd_step / daisy_bpr_fit_epoch_sgd only: the STAGED step (forward fused
+                               into the user pass, coefficient-scaled user rows staged for the item pass,
+                               item rows committed by the owner of their segment); pairwise losses without
+                               FM biases, otherwise = CHUNKED.  Bitwise reproducible. */
 };
 
 /* order of an epoch (what DataLoader(shuffle=...) decides, dataset.py:5-7) */
@@ -77,9 +79,11 @@ enum daisy_stats_slot {
     DAISY_ST_NORM_U = 8,    /* |P[u]|_F (written by finalize)                  */
     DAISY_ST_NORM_I = 9,
     DAISY_ST_NORM_J = 10,
-    DAISY_ST_NORM_U_PRE = 11, /* |P[u]|_F from the row-norm cache (fused step only)   */
+    DAISY_ST_NORM_U_PRE = 11, /* (unused since ABI 3; see DAISY_ST_SQ_U_PRE)                 */
     DAISY_ST_SUM_COEF = 12,   /* sum_b (dL/dpos + dL/dneg) = dL/d bias_ (FM); a batch sum like 0..6:
                                  multi-GPU callers all-reduce it with them before finalize       */
+    DAISY_ST_SQ_U_PRE = 13,   /* staged step: sum P[u]^2 over the batch from the row-norm cache, known
+                                 BEFORE the user pass (a sum: multi-GPU callers all-reduce it)    */
     DAISY_STATS_LEN = 16
 };
 
@@ -124,6 +128,13 @@ int daisy_epoch_plan_build(daisy_epoch_plan *plan, const int32_t *triples, int64
                            int64_t batch_size, int32_t user_base, int32_t flags,
                            daisy_stream_t stream);
 int64_t daisy_epoch_plan_num_batches(const daisy_epoch_plan *plan);
+/* daisy_epoch_plan_build only enqueues; ids outside [0,user_num) x [0,item_num) (after user_base) are
+ * replaced by 0 there - never an out-of-bounds access - and remembered.  This call synchronises the stream
+ * and returns DAISY_ERR_ARG if the last build saw one (the reference raises IndexError in nn.Embedding,
+ * MFRecommender.py:64-65).  daisy_bpr_ctx_validate_batch: the same for the batch last set with
+ * daisy_bpr_set_batch / daisy_bpr_set_batch_from_triples. */
+int daisy_epoch_plan_validate(const daisy_epoch_plan *plan, daisy_stream_t stream);
+int daisy_bpr_ctx_validate_batch(const daisy_bpr_ctx *ctx, daisy_stream_t stream);
 /* copy batch k of a built plan into caller buffers (inspection / tests): u,i,j int32 [B]
  * grouped by user; optional item entries [2B] sorted by item: ent_item, ent_s (sample
  * position | 0x80000000 for the negative slot), ent_u (user of that sample).
@@ -134,6 +145,57 @@ int daisy_epoch_plan_read_batch(const daisy_epoch_plan *plan, int64_t k, int32_t
 /* out[t] = position of triple t in the DAISY_ORDER_FEISTEL order of (seed, epoch) */
 int daisy_feistel_positions(int64_t n, uint64_t seed, uint64_t epoch, int64_t *out,
                             daisy_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Static index of a training set + the PARTITIONED epoch plan (ABI 3).
+ * BasicDataset holds one immutable triple array for the whole fit (dataset.py:21); only the batch
+ * membership changes per epoch (DataLoader(shuffle=True), dataset.py:5-7).  So the set is indexed once -
+ * triples in CSR (user-sorted) order, their 2n item entries sorted by item - and an epoch plan is two
+ * stable one-digit partitions of those arrays by batch id (a stable partition of a sorted list leaves
+ * every batch sorted): 32 B of plan per interaction instead of 112, one counting + one scatter pass
+ * instead of two payload-carrying radix sorts.  The resulting plan feeds the staged step
+ * (DAISY_ITEM_FUSED) only.
+ * daisy_train_index_create validates 0 <= user - user_base < user_num, 0 <= item < item_num for every
+ * triple (one host sync) and returns DAISY_ERR_ARG where the reference raises IndexError in
+ * nn.Embedding (MFRecommender.py:64-65).  flags: DAISY_PLAN_TRIPLES_USER_SORTED - the array is already
+ * in CSR order and is used in place (the caller keeps it alive); otherwise the index owns a sorted copy.
+ * ---------------------------------------------------------------------- */
+typedef struct daisy_train_index daisy_train_index;
+int daisy_train_index_create(daisy_train_index **out, const int32_t *triples, int64_t n_triples,
+                             int64_t user_num, int64_t item_num, int32_t user_base, int32_t flags,
+                             daisy_stream_t stream);
+int daisy_train_index_destroy(daisy_train_index *index);
+size_t daisy_train_index_bytes(const daisy_train_index *index);
+/* same batches as daisy_epoch_plan_build on the same (order_mode, perm | seed, epoch, batch_size): batch k
+ * holds the triples at epoch positions [k*B, (k+1)*B), grouped by user (CSR order inside a batch); its
+ * entries are sorted by item, ties in CSR order */
+int daisy_epoch_plan_build_indexed(daisy_epoch_plan *plan, const daisy_train_index *index,
+                                   const int64_t *perm, int32_t order_mode, uint64_t seed, uint64_t epoch,
+                                   int64_t batch_size, daisy_stream_t stream);
+
+/* The staged step keeps |P[u]|^2 of every row in the context; every entry point that writes P through the
+ * context keeps it current or drops it.  A caller that changes P by other means calls this first. */
+int daisy_bpr_ctx_invalidate_cache(daisy_bpr_ctx *ctx);
+
+/* The staged step in phases (what daisy_bpr_sgd_step(DAISY_ITEM_FUSED) runs back to back), so that a
+ * multi-GPU step can put its collectives between them:
+ *   prenorm : stats[DAISY_ST_SQ_U_PRE] = sum_b |P[u_b]|^2                      -> all-reduce (8 B)
+ *   user    : forward + criterion + user-side backward + SGD on the touched rows of P
+ *             (MFRecommender.py:63-97, AbstractRecommender.py:125-126); stats[0..6] = the batch sums
+ *                                                                              -> all-reduce, daisy_bpr_finalize
+ *   item    : item-side backward.  Q != NULL: + SGD on the touched rows of Q in place (needs the finalized
+ *             norms in stats); gQ/cnt != NULL instead: gQ[r] = data term of dL/dQ[r] and cnt[r] = (number
+ *             of positive, negative entries) f32[I][2] for the touched rows (others untouched: keep both
+ *             zero between steps)                                             -> reduce-scatter both
+ *   daisy_item_apply_counts : the row owner's SGD step from reduced (g, cnt): adds the regulariser
+ *             share from the GLOBAL counts, clears g and cnt. */
+int daisy_bpr_staged_prenorm(daisy_bpr_ctx *ctx, const float *P, double *stats, daisy_stream_t stream);
+int daisy_bpr_staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int32_t loss_type, float gamma,
+                          float lr, float reg_1, float reg_2, double *stats, daisy_stream_t stream);
+int daisy_bpr_staged_item(daisy_bpr_ctx *ctx, int32_t loss_type, float *Q, float *gQ, float *cnt, float lr,
+                          float reg_1, float reg_2, const double *stats, daisy_stream_t stream);
+int daisy_item_apply_counts(float *Q, float *g, float *cnt, int64_t rows, int32_t d, float lr, float reg_1,
+                            float reg_2, const double *stats, daisy_stream_t stream);
 
 /* batches set with daisy_bpr_set_batch / _from_triples are (user, item, label) rows (CL / SL) */
 int daisy_bpr_ctx_set_pointwise(daisy_bpr_ctx *ctx, int32_t pointwise);

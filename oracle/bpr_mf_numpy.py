@@ -301,8 +301,9 @@ def expand_triples(users, pos_items, js):
 # --------------------------------------------------------------------------
 # Device shuffle (DAISY_ORDER_FEISTEL): a keyed bijection of [0, n) that stands in
 # for RandomSampler's torch.randperm (dataset.py:5-7, shuffle=True) on the
-# throughput path.  6-round balanced Feistel network on 2h bits, murmur3
-# finaliser as round function, Philox round keys, cycle walking.
+# throughput path.  4-round balanced Feistel network on 2h bits, a two-step
+# multiply-xorshift round function on 24-bit multiplies (full-rate on CDNA),
+# Philox round keys, cycle walking.
 # --------------------------------------------------------------------------
 def _mix32(x):
     x = np.asarray(x, dtype=np.uint64) & np.uint64(_M32)
@@ -314,26 +315,70 @@ def _mix32(x):
     return x
 
 
+FEISTEL_ROUNDS = 4
+
+
+def _mul24(a, b):
+    """low 32 bits of (a mod 2^24) * (b mod 2^24): v_mul_u32_u24"""
+    return ((a & np.uint64(0xFFFFFF)) * np.uint64(b & 0xFFFFFF)) & np.uint64(_M32)
+
+
+def _feistel_round(r, key):
+    x = (r ^ key) & np.uint64(_M32)
+    x = _mul24(x, 0xCC9E2D)
+    x ^= x >> np.uint64(15)
+    x = _mul24(x, 0x85EBCB)
+    x ^= x >> np.uint64(13)
+    return x
+
+
 def feistel_positions(n, seed, epoch=0):
     """pos[t] for t in 0..n-1 (a permutation of 0..n-1)."""
+    assert n <= (1 << 30)
     bits = 2
-    while bits < 62 and (1 << bits) < n:
+    while bits < 30 and (1 << bits) < n:
         bits += 2
     h = np.uint64(bits // 2)
     mask = np.uint64((1 << (bits // 2)) - 1)
-    keys = [np.uint64(_draw_u64(seed, epoch | (1 << 61), r) & _M32) for r in range(6)]
+    keys = [np.uint64(_draw_u64(seed, epoch | (1 << 61), r) & _M32) for r in range(FEISTEL_ROUNDS)]
     x = np.arange(n, dtype=np.uint64)
     todo = np.ones(n, dtype=bool)
     while todo.any():
         v = x[todo]
         L, R = v >> h, v & mask
-        for r in range(6):
-            f = _mix32(R ^ keys[r]) & mask
+        for r in range(FEISTEL_ROUNDS):
+            f = _feistel_round(R, keys[r]) & mask
             L, R = R, L ^ f
         v = (L << h) | R
         x[todo] = v
         todo[todo] = v >= np.uint64(n)
     return x.astype(np.int64)
+
+
+def partitioned_plan(triples, pos, batch_size, user_base=0):
+    """The partitioned epoch plan (daisy_epoch_plan_build_indexed): what one pass over
+    DataLoader(BasicDataset(triples), batch_size, shuffle) serves (dataset.py:5-27), laid out batch by
+    batch.  `pos[t]` = position of triple t in the epoch order (identity, inverse of the sampler's
+    permutation, or feistel_positions).  Static index: triples in CSR order (stable sort by user), their
+    2n entries (item << 1 | slot) stably sorted; the plan is the stable partition of both by batch id.
+    Returns (samples int64 [n,3] with user - user_base, sample_pos [n], entry_key [2n], entry_pos [2n])."""
+    triples = np.asarray(triples, dtype=np.int64)
+    pos = np.asarray(pos, dtype=np.int64)
+    order = np.argsort(triples[:, 0], kind="stable")          # CSR order
+    tri, p = triples[order], pos[order]
+    n = len(tri)
+    batch = p // batch_size
+    so = np.argsort(batch, kind="stable")
+    samples = tri[so].copy()
+    samples[:, 0] -= user_base
+    key = np.empty(2 * n, dtype=np.int64)
+    key[0::2] = tri[:, 1] << 1
+    key[1::2] = (tri[:, 2] << 1) | 1
+    t = np.repeat(np.arange(n), 2)
+    eo = np.argsort(key, kind="stable")                       # static item index
+    ekey, et = key[eo], t[eo]
+    bo = np.argsort(batch[et], kind="stable")
+    return samples, p[so], ekey[bo], p[et[bo]]
 
 
 def build_candidates(indptr_te, items_te, indptr_tr, items_tr, users, item_num, cand_num, seed):

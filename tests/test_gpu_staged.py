@@ -1,0 +1,215 @@
+"""The partitioned epoch plan and the staged step (csrc/bpr_staged.hip): index work bit-exact against
+the oracle's restatement, the step against oracle.mf_sgd_step (MFRecommender.py:63-97 + SGD) on the
+same batches, the phase form against the single call, bitwise reproducibility, id validation."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bpr_mf_numpy as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _triples(n, U, I, seed, sort=False):
+    rng = np.random.default_rng(seed)
+    t = np.stack([rng.integers(0, U, n), rng.integers(0, I, n), rng.integers(0, I, n)], 1).astype(np.int32)
+    if sort:
+        t = t[np.argsort(t[:, 0], kind="stable")]
+    return t
+
+
+def _plan_batches(plan, nb, B):
+    out = []
+    for k in range(nb):
+        u, i, j, ei, es, eu = (t.cpu().numpy() for t in plan.read_batch(k, B))
+        out.append((np.stack([u, i, j], 1).astype(np.int64), ei.astype(np.int64), es.astype(np.uint32)))
+    return out
+
+
+@pytest.mark.parametrize("n,B,U,I,sort", [(1000, 64, 300, 200, False), (4097, 256, 300, 200, True),
+                                          (513, 1000, 50, 70, False), (7, 1, 5, 5, False),
+                                          (70000, 100, 900, 1200, False),        # 700 batches: two LSD passes
+                                          (300000, 4096, 20000, 3000, True)])
+def test_partitioned_plan_bit_exact(n, B, U, I, sort):
+    from daisyrec_amd import ops
+    tri = _triples(n, U, I, n, sort)
+    t_dev = torch.from_numpy(tri).to(DEV)
+    index = ops.TrainIndex(t_dev, U, I)
+    plan = ops.EpochPlan(n, U, I)
+    nb = (n + B - 1) // B
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(n))
+    inv = np.empty(n, dtype=np.int64)
+    inv[perm.numpy()] = np.arange(n)
+    cases = [("identity", None, np.arange(n)), ("perm", perm.to(DEV), inv),
+             ("feistel", None, O.feistel_positions(n, 99, 3))]
+    for order, pm, pos in cases:
+        plan.build_indexed(index, B, order=order, perm=pm, seed=99, epoch=3)
+        assert plan.num_batches == nb
+        samples, spos, ekey, epos = O.partitioned_plan(tri, pos, B)
+        got = _plan_batches(plan, nb, B)
+        for k in range(nb):
+            lo, hi = k * B, min((k + 1) * B, n)
+            rows, ei, es = got[k]
+            assert np.array_equal(rows, samples[lo:hi]), (order, k)
+            # the batch holds exactly the triples the loader would serve at positions [lo, hi)
+            assert np.array_equal(np.sort(spos[lo:hi]), np.arange(lo, hi))
+            assert np.array_equal(ei, ekey[2 * lo:2 * hi] >> 1), (order, k)
+            want_s = ((epos[2 * lo:2 * hi] - lo) | ((ekey[2 * lo:2 * hi] & 1) << 31)).astype(np.uint32)
+            assert np.array_equal(es, want_s), (order, k)
+    index.close()
+    plan.close()
+
+
+def test_index_rejects_out_of_range_ids():
+    from daisyrec_amd import ops
+    tri = _triples(500, 40, 30, 1)
+    for col, bad in ((0, 40), (1, 30), (2, -1), (0, -3)):
+        t = tri.copy()
+        t[123, col] = bad
+        with pytest.raises(ValueError, match="out of range"):
+            ops.TrainIndex(torch.from_numpy(t).to(DEV), 40, 30)
+    ops.TrainIndex(torch.from_numpy(tri).to(DEV), 40, 30).close()
+    # user_base shifts the accepted window (user-sharded tables)
+    t = tri.copy()
+    t[:, 0] += 1000
+    ops.TrainIndex(torch.from_numpy(t).to(DEV), 40, 30, user_base=1000).close()
+    with pytest.raises(ValueError, match="out of range"):
+        ops.TrainIndex(torch.from_numpy(t).to(DEV), 40, 30, user_base=0)
+
+
+def _tables(U, I, d, seed, scale=0.1):
+    rng = np.random.default_rng(seed)
+    return ((rng.standard_normal((U, d)) * scale).astype(np.float32),
+            (rng.standard_normal((I, d)) * scale).astype(np.float32))
+
+
+@pytest.mark.parametrize("d", [64, 32, 8, 20, 128, 100, 7, 256])
+@pytest.mark.parametrize("loss", ["BPR", "HL", "TL"])
+def test_staged_epoch_matches_oracle(d, loss):
+    """A whole epoch through the partitioned plan + fit_epoch_sgd(fused), replayed by the oracle on the
+    batches the plan serves: hot users/items, runs that cross lane groups and chunks, a partial batch."""
+    from daisyrec_amd import ops
+    U, I, n, B = 37, 23, 1500, 400         # heavy collisions: every row is shared inside a batch
+    tri = _triples(n, U, I, d)
+    P0, Q0 = _tables(U, I, d, d + 1)
+    t_dev = torch.from_numpy(tri).to(DEV)
+    index, plan = ops.TrainIndex(t_dev, U, I), ops.EpochPlan(n, U, I)
+    plan.build_indexed(index, B, order="feistel", seed=5, epoch=1)
+    nb = plan.num_batches
+    P, Q = torch.from_numpy(P0).to(DEV), torch.from_numpy(Q0).to(DEV)
+    ctx = ops.BprContext(B, d, U, I)
+    sl = torch.zeros(nb, dtype=torch.float64, device=DEV)
+    lid = ops.LOSS_IDS[loss]
+    ctx.fit_epoch_sgd(plan, P, Q, 0.05, 1e-3, 2e-3, loss_type=lid, item_mode=ops.ITEM_MODES["fused"], step_losses=sl)
+    torch.cuda.synchronize()
+    Pn, Qn = P0.astype(np.float64), Q0.astype(np.float64)
+    for k, (rows, _, _) in enumerate(_plan_batches(plan, nb, B)):
+        want, Pn, Qn = O.mf_sgd_step(Pn, Qn, rows[:, 0], rows[:, 1], rows[:, 2], 0.05, 1e-3, 2e-3, loss_type=lid)
+        assert abs(float(sl[k].cpu()) - want) <= 1e-5 * abs(want), (k, float(sl[k].cpu()), want)
+    assert np.abs(P.cpu().numpy() - Pn).max() < 5e-6 and np.abs(Q.cpu().numpy() - Qn).max() < 5e-6
+    ctx.close(); plan.close(); index.close()
+
+
+def test_staged_large_batch_against_chunked_and_reproducible():
+    """Throughput shapes (runs across chunks on both sides): the staged step equals the phase kernels to
+    round-off, touches the same rows, and two runs give identical bits."""
+    from daisyrec_amd import ops
+    U, I, d, n, B = 20000, 3000, 64, 400000, 131072
+    tri = _triples(n, U, I, 3, sort=True)
+    tri[:5000, 0] = 7                      # one very long user run
+    tri[5000:9000, 1] = 11                 # one very hot item
+    tri = tri[np.argsort(tri[:, 0], kind="stable")]
+    t_dev = torch.from_numpy(tri).to(DEV)
+    P0, Q0 = _tables(U, I, d, 9, 0.05)
+    index, plan, plan0 = ops.TrainIndex(t_dev, U, I), ops.EpochPlan(n, U, I), ops.EpochPlan(n, U, I)
+    plan.build_indexed(index, B, order="feistel", seed=1, epoch=0)
+    plan0.build(t_dev, B, order="feistel", seed=1, epoch=0, user_sorted=True)
+    outs = []
+    for mode, pl in (("fused", plan), ("fused", plan), ("chunked", plan0), ("fused", plan0)):
+        P, Q = torch.from_numpy(P0).to(DEV), torch.from_numpy(Q0).to(DEV)
+        ctx = ops.BprContext(B, d, U, I)
+        ctx.fit_epoch_sgd(pl, P, Q, 0.01, 1e-3, 1e-3, item_mode=ops.ITEM_MODES[mode])
+        torch.cuda.synchronize()
+        outs.append((P.cpu().numpy(), Q.cpu().numpy(), float(ctx.epoch_acc[0].cpu())))
+        ctx.close()
+    a, b, c, e = outs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]      # reproducible
+    for x in (c, e):                                                                    # same step, other kernels / layout
+        assert abs(a[2] - x[2]) <= 1e-6 * abs(x[2])
+        assert np.abs(a[0] - x[0]).max() < 2e-6 and np.abs(a[1] - x[1]).max() < 2e-6
+    # the same rows move (a row is untouched iff every element kept its bits)
+    assert np.array_equal((a[0] != P0).any(1), (c[0] != P0).any(1))
+    assert np.array_equal((a[1] != Q0).any(1), (c[1] != Q0).any(1))
+    plan.close(); plan0.close(); index.close()
+
+
+def test_staged_phases_equal_single_call():
+    """prenorm -> user -> finalize -> item(gQ, cnt) -> apply_counts (the multi-GPU form) = sgd_step(fused)."""
+    from daisyrec_amd import ops
+    U, I, d, B = 500, 300, 64, 5000
+    tri = _triples(B, U, I, 4)
+    P0, Q0 = _tables(U, I, d, 5)
+    u, i, j = (torch.from_numpy(tri[:, c].copy()).to(DEV) for c in range(3))
+    res = []
+    for phased in (False, True):
+        P, Q = torch.from_numpy(P0).to(DEV), torch.from_numpy(Q0).to(DEV)
+        ctx = ops.BprContext(B, d, U, I)
+        ctx.set_batch(u, i, j)
+        if not phased:
+            ctx.sgd_step(P, Q, 0.02, 1e-3, 1e-3, item_mode=ops.ITEM_MODES["fused"])
+        else:
+            cnt = torch.zeros(I, 2, device=DEV)
+            ctx.staged_prenorm(P)
+            ctx.staged_user(P, Q, 0.02, 1e-3, 1e-3)
+            ctx.finalize(1e-3, 1e-3)
+            ctx.staged_item(0.02, 1e-3, 1e-3, gQ=ctx.gQ, cnt=cnt)
+            ops.item_apply_counts(Q, ctx.gQ, cnt, 0.02, 1e-3, 1e-3, ctx.stats)
+            torch.cuda.synchronize()
+            assert float(ctx.gQ.abs().max().cpu()) == 0.0 and float(cnt.abs().max().cpu()) == 0.0
+        torch.cuda.synchronize()
+        res.append((P.cpu().numpy(), Q.cpu().numpy(), float(ctx.stats[7].cpu())))
+        ctx.close()
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][2] == res[1][2]
+    assert np.abs(res[0][1] - res[1][1]).max() < 1e-7
+    want, Pn, Qn = O.mf_sgd_step(P0, Q0, tri[:, 0], tri[:, 1], tri[:, 2], 0.02, 1e-3, 1e-3)
+    assert abs(res[0][2] - want) <= 1e-5 * abs(want)
+    assert np.abs(res[0][0] - Pn).max() < 3e-6 and np.abs(res[0][1] - Qn).max() < 3e-6
+
+
+def test_norm_cache_follows_torch_side_edits():
+    """P changed by a torch op between two staged steps: the wrapper sees the version counter move and the
+    row-norm cache is rebuilt (a stale cache would put the wrong |P[u]|_F into the user update)."""
+    from daisyrec_amd import ops
+    U, I, d, B = 200, 100, 32, 1000
+    tri = _triples(B, U, I, 8)
+    P0, Q0 = _tables(U, I, d, 2)
+    u, i, j = (torch.from_numpy(tri[:, c].copy()).to(DEV) for c in range(3))
+    P, Q = torch.from_numpy(P0).to(DEV), torch.from_numpy(Q0).to(DEV)
+    ctx = ops.BprContext(B, d, U, I)
+    ctx.set_batch(u, i, j)
+    ctx.sgd_step(P, Q, 0.02, 0.0, 0.5, item_mode=ops.ITEM_MODES["fused"])
+    P.mul_(3.0)                                           # torch-side edit
+    P1, Q1 = P.cpu().numpy().copy(), Q.cpu().numpy().copy()
+    ctx.set_batch(u, i, j)
+    ctx.sgd_step(P, Q, 0.02, 0.0, 0.5, item_mode=ops.ITEM_MODES["fused"])
+    torch.cuda.synchronize()
+    _, Pn, Qn = O.mf_sgd_step(P1, Q1, tri[:, 0], tri[:, 1], tri[:, 2], 0.02, 0.0, 0.5)
+    assert np.abs(P.cpu().numpy() - Pn).max() < 5e-6 and np.abs(Q.cpu().numpy() - Qn).max() < 5e-6
+    ctx.close()
+
+
+def test_partitioned_plan_refused_by_phase_kernels():
+    from daisyrec_amd import ops
+    U, I, d, n = 50, 40, 16, 300
+    t_dev = torch.from_numpy(_triples(n, U, I, 1)).to(DEV)
+    index, plan = ops.TrainIndex(t_dev, U, I), ops.EpochPlan(n, U, I)
+    plan.build_indexed(index, 100)
+    ctx = ops.BprContext(100, d, U, I)
+    P, Q = (torch.zeros(x, d, device=DEV) for x in (U, I))
+    ctx.set_batch_from_plan(plan, 0)
+    with pytest.raises(RuntimeError, match="partitioned plan"):
+        ctx.forward(P, Q)
+    with pytest.raises(RuntimeError):
+        ctx.sgd_step(P, Q, 0.1, 0, 0, item_mode=ops.ITEM_MODES["chunked"])
+    ctx.close(); plan.close(); index.close()
