@@ -5,21 +5,29 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
+`python bench.py --gpus N` with N > 1 and no launcher around it spawns its N ranks itself (one process
+per GPU, RCCL) and refuses to run when the box has fewer than N GPUs: it never reports a smaller job
+under a bigger name.
+
 A "step" is one batch-synchronous SGD step (zero_grad / calc_loss / backward / step of the
 reference, AbstractRecommender.py:119-126) over one batch of B interactions per GPU, B stated
-in `config`.  Inputs (tables, triples, epoch permutation state) are resident in HBM when the
-timed region starts; the per-epoch device shuffle that falls inside the timed steps IS timed.
+in `config`.  Inputs (tables, triples, the per-fit index) are resident in HBM when the timed region
+starts; the per-epoch plan builds (the device side of DataLoader(shuffle=True)) that fall inside the
+timed steps ARE timed.  Default timed region: two epochs of full batches.
 
 N=1  : BASELINE.json configs[1]  U=1M, I=100k, nnz=50M, d=64 (uniform ids), SGD, lr .01, reg .001.
-N>1  : weak scaling of that shard — every rank owns 1M users / 50M interactions (users sharded,
-       Q replicated, RCCL all-reduce of the item gradient).  `--workload c3` instead splits
-       BASELINE configs[2] (10M x 1M x 500M) over the ranks (total work fixed: strong scaling).
+N>1  : BASELINE.json configs[2]  U=10M, I=1M, nnz=500M split by user over the N ranks (strong scaling:
+       total work fixed; Q replicated; reduce-scatter / owner apply / all-gather of the item update over
+       RCCL), and - unless --no-ref - the SAME workload on one GPU measured by rank 0 afterwards, so the
+       N-GPU / 1-GPU ratio on configs[2] can be read off one JSON line.  `--workload c2` weak-scales
+       configs[1] instead (every rank owns 1M users / 50M interactions).
 
 Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -36,9 +44,10 @@ HBM_PEAK_GBS = 8000.0                                        # MI355X_MICROARCH.
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=None, help="default: one epoch of full batches")
+    ap.add_argument("--steps", type=int, default=None, help="default: two epochs of full batches")
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=1 << 21, help="interactions per GPU per step")
+    ap.add_argument("--batch", type=int, default=None,
+                    help="interactions per GPU per step (default 2M at N=1, 8M per rank at N>1)")
     ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c3", "tiny"])
     ap.add_argument("--item-mode", default="fused", choices=["fused", "chunked", "atomic", "sorted"])
     ap.add_argument("--plan", default="auto", choices=["auto", "indexed", "sorted"],
@@ -46,9 +55,11 @@ def parse():
     ap.add_argument("--dist", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--reg", type=float, default=0.001)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ref", action="store_true", help="N>1: skip the same-workload 1-GPU measurement")
     ap.add_argument("--overlap-plan", type=int, default=0,
-                    help="build the next epoch's plan on a side stream (two plans in ping-pong; measured slower with the partitioned plan)")
-    ap.add_argument("--cpu-steps", type=int, default=3)
+                    help="build the next epoch's plan on a side stream (two plans in ping-pong; measured slower "
+                         "with the partitioned plan)")
+    ap.add_argument("--cpu-steps", type=int, default=10)
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 code path on one GPU)")
     return ap.parse_args()
@@ -81,50 +92,32 @@ def synth_triples(U, I, nnz, seed, device, dist_kind="uniform"):
     return triples
 
 
-def cpu_baseline(U, I, d, B, steps, reg):
-    """The reference's CPU/PyTorch path (oracle/torch_port.py restates it with the same stock
-    ops) timed on this host's cores on a bounded sample: `steps` steps at the SAME batch size."""
+def cpu_baseline(U, I, d, B, batches, reg):
+    """The reference's CPU/PyTorch path (oracle/torch_port.py restates it with the same stock ops; the
+    reference checkout does not exist on the GPU box) timed on this host's cores on a bounded sample:
+    the first len(batches)-1 batches of the GPU run's own epoch (same triples, same B), one more as warm-up."""
     from oracle.torch_port import TorchMFBPR
     torch.manual_seed(2022)
     m = TorchMFBPR(U, I, d, 0.01, reg, reg)
-    g = torch.Generator()
-    g.manual_seed(1)
-    batches = [(torch.randint(0, U, (B,), generator=g), torch.randint(0, I, (B,), generator=g),
-                torch.randint(0, I, (B,), generator=g)) for _ in range(steps + 1)]
     m.step(*batches[0])                                    # warm-up (allocations, thread pool)
     t0 = time.perf_counter()
     for b in batches[1:]:
         m.step(*b)
     dt = time.perf_counter() - t0
+    steps = len(batches) - 1
     return {"value": steps * B / dt, "unit": "interactions/s", "cores": torch.get_num_threads(),
             "kind": "port",
-            "sample": f"{steps} SGD steps at B={B} on U={U}, I={I}, d={d} (oracle/torch_port.py: "
-                      f"nn.Embedding + autograd + optim.SGD, dense grads like the reference), {dt:.1f}s"}
+            "sample": f"{steps} SGD steps at B={B} on the first batches of the GPU run's epoch (U={U}, I={I}, d={d}; "
+                      f"oracle/torch_port.py: nn.Embedding + autograd + optim.SGD, dense grads like the reference), "
+                      f"{dt:.1f}s"}
 
 
-def main():
-    a = parse()
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus and world > 1:
-        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
-    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
-    local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if a.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-
+def run_workload(a, rank, world, dev, wl, want_cpu_batches=0):
+    """Build the data of `wl` for (rank, world) in HBM, run warmup + timed steps, return the measurements."""
     from daisyrec_amd import ops
     from daisyrec_amd.sharding import UserShardedBprTrainer
 
     d = 64
-    wl = a.workload if a.workload != "auto" else "c2"
     if wl == "c2":
         U_loc, I, nnz_loc, scaling = 1_000_000, 100_000, 50_000_000, "weak"
         name = ("BASELINE configs[1]: MF+BPR synthetic 1M users x 100K items x 50M nnz, d=64" if world == 1 else
@@ -133,11 +126,12 @@ def main():
     elif wl == "c3":
         U_tot, I, nnz_tot, scaling = 10_000_000, 1_000_000, 500_000_000, "strong"
         U_loc, nnz_loc = U_tot // world, nnz_tot // world
-        name = f"BASELINE configs[2]: 10M users x 1M items x 500M nnz, d=64, user-sharded over {world} GPU(s)"
+        name = f"BASELINE configs[2]: MF+BPR synthetic 10M users x 1M items x 500M nnz, d=64, user-sharded over {world} GPU(s)"
     else:
         U_loc, I, nnz_loc, scaling = 20_000, 5_000, 1_000_000, "weak"
         name = "tiny smoke workload (NOT a BASELINE config)"
-    B = min(a.batch, nnz_loc)
+    B = a.batch if a.batch is not None else ((1 << 21) if world == 1 else (1 << 23))
+    B = min(B, nnz_loc)
     lr, reg = 0.01, a.reg
 
     # ---- data + model resident in HBM -------------------------------------------------
@@ -149,7 +143,6 @@ def main():
     g.manual_seed(7 + rank)
     P = torch.empty(U_loc, d, device=dev).normal_(0.0, 0.01, generator=g)
     ctx = ops.BprContext(B, d, U_loc, I, device=dev)
-    plan = ops.EpochPlan(n, U_loc, I, device=dev)
     item_mode = ops.ITEM_MODES[a.item_mode]
     trainer = UserShardedBprTrainer(ctx, P, Q, 0, lr, reg, reg, item_mode=item_mode) if world > 1 else None
     user_sorted = ops.triples_user_sorted(triples)      # synthetic triples are generated in CSR order
@@ -160,13 +153,10 @@ def main():
         fb = torch.tensor([full_batches], device=dev, dtype=torch.int64)     # count, every rank must take the same steps
         dist.all_reduce(fb, op=dist.ReduceOp.MIN)
         full_batches = int(fb.cpu())
-    if a.steps is None:
-        a.steps = full_batches                 # one epoch: exactly one plan build inside the timed region
+    assert full_batches >= 1, "batch larger than the rank's interaction count"
+    steps = a.steps if a.steps is not None else 2 * full_batches
 
-    # Two plans in ping-pong: while epoch e trains on the main stream, the plan of epoch e+1
-    # (DataLoader(shuffle=True) on the device: a fresh keyed permutation, radix sorts lay the
-    # epoch out batch by batch grouped by user / by item) is built on a side stream.
-    plans = [plan, ops.EpochPlan(n, U_loc, I, device=dev)] if a.overlap_plan else [plan]
+    plans = [ops.EpochPlan(n, U_loc, I, device=dev) for _ in range(2 if a.overlap_plan else 1)]
     side = torch.cuda.Stream(device=dev) if a.overlap_plan else None
     state = {"epoch": 0, "k": None, "cur": 0, "ready": None}
 
@@ -215,13 +205,12 @@ def main():
 
     for _ in range(a.warmup):
         step()
-    # start the timed region on an epoch boundary: every timed epoch then contains exactly one
-    # plan build (with --overlap-plan: the build of the NEXT epoch, running beside the steps)
+    # start the timed region on an epoch boundary: every timed epoch then contains exactly one plan build
     state["k"] = full_batches if (a.overlap_plan and state["k"] is not None) else None
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     barrier()
     t0 = time.perf_counter()
-    for k in range(a.steps):
+    for k in range(steps):
         ev[k][0].record()
         step()
         ev[k][1].record()
@@ -234,49 +223,132 @@ def main():
     loss_sum, nan_cnt = (float(x) for x in ctx.epoch_acc.cpu())
     assert nan_cnt == 0 and loss_sum == loss_sum, "NaN loss during the benchmark"
     step_ms = sorted(s.elapsed_time(e) for s, e in ev)
-    gpu_ms_mean = sum(step_ms) / len(step_ms)
+    cpu_batches = []
+    if want_cpu_batches:                       # the first batches of the last built epoch, for the CPU leg
+        for k in range(min(want_cpu_batches, full_batches)):
+            u, i, j = plans[state["cur"]].read_batch(k, B)[:3]
+            cpu_batches.append(tuple(x.to(torch.int64).cpu() for x in (u, i, j)))
+    res = {"name": name, "scaling": scaling, "B": B, "d": d, "n": n, "U": U_loc, "I": I, "steps": steps, "dt": dt,
+           "lr": lr, "reg": reg, "step_ms": step_ms, "plan_kind": plan_kind, "cpu_batches": cpu_batches,
+           "plan_bytes": sum(p.nbytes for p in plans), "index_bytes": index.nbytes if index is not None else 0,
+           "staged": trainer.staged if trainer is not None else (a.item_mode == "fused")}
+    ctx.close()
+    for p in plans:
+        p.close()
+    if index is not None:
+        index.close()
+    del triples, P, Q
+    torch.cuda.empty_cache()
+    return res
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    ndev = torch.cuda.device_count()
+    if world != a.gpus:
+        if world > 1:
+            raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+        # --gpus N without a launcher: spawn the N ranks here; never run a smaller job under the bigger name
+        if a.backend == "nccl" and ndev < a.gpus:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: this box has {ndev} GPU(s); refusing to run a "
+                             f"{ndev}-GPU job labelled n_gpus={a.gpus}")
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        import torch.multiprocessing as mp
+        mp.spawn(_spawned, args=(a.gpus, port, sys.argv[1:]), nprocs=a.gpus, join=True)
+        return
+    if a.backend == "nccl" and world > ndev:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but only {ndev} GPU(s) are visible (one rank per GPU)")
+    local_rank = local_rank % ndev
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+
+    wl = a.workload if a.workload != "auto" else ("c2" if world == 1 else "c3")
+    want_cpu = (a.cpu_steps + 1) if (world == 1 and rank == 0 and not a.no_cpu_baseline) else 0
+    r = run_workload(a, rank, world, dev, wl, want_cpu)
+    ref = None
+    if world > 1 and wl == "c3" and not a.no_ref:
+        # the same workload on ONE GPU (rank 0; the others wait), so that the N-GPU / 1-GPU ratio on
+        # BASELINE configs[2] is on this line
+        if rank == 0:
+            a1 = argparse.Namespace(**vars(a))
+            a1.batch, a1.steps = (1 << 21), None
+            r1 = run_workload(a1, 0, 1, dev, wl, 0)
+            ref = {"value": r1["steps"] * r1["B"] / r1["dt"], "unit": "interactions/s", "n_gpus": 1,
+                   "steps": r1["steps"], "ms_per_step": r1["dt"] / r1["steps"] * 1e3, "batch": r1["B"],
+                   "workload": r1["name"],
+                   "roofline_frac": ALGO_BYTES_PER_INTERACTION_SGD(64) * r1["B"] / (r1["dt"] / r1["steps"]) / 1e9 / HBM_PEAK_GBS}
+        dist.barrier()
 
     if rank == 0:
-        value = a.steps * B * world / dt
+        B, d, steps, dt = r["B"], r["d"], r["steps"], r["dt"]
+        step_ms = r["step_ms"]
+        gpu_ms_mean = sum(step_ms) / len(step_ms)
+        value = steps * B * world / dt
         algo = ALGO_BYTES_PER_INTERACTION_SGD(d) * B                       # bytes per step per GPU
-        eff_ms = max(gpu_ms_mean, dt / a.steps * 1e3) if world == 1 else gpu_ms_mean   # never better than wall
+        eff_ms = max(gpu_ms_mean, dt / steps * 1e3) if world == 1 else gpu_ms_mean   # never better than wall
         achieved = algo / (eff_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                t = json.load(open(tpath))          # per-interaction figure of the profiled run x this run's batch
-                traffic = t["hbm_bytes_per_interaction"] * B if "hbm_bytes_per_interaction" in t else None
+        if os.path.exists(tpath) and wl == "c2" and world == 1 and a.item_mode == "fused":
+            try:        # per-interaction figure of the committed PMC passes of THIS kernel chain x this run's batch
+                t = json.load(open(tpath))
+                traffic = t["hbm_bytes_per_interaction"] * B
+                traffic_src = t.get("source", "profiles/pmc_traffic.json")
             except Exception:
                 traffic = None
+        if r["staged"]:
+            chain = ("one SGD step = k_unorm + k_staged_user (+edges) + k_reduce_partials + k_staged_item (+edges)"
+                     + (" + RCCL reduce-scatter / k_item_apply_counts / all-gather" if world > 1 else ""))
+        else:
+            chain = "one SGD step = k_fwd + k_reduce_partials + k_item_grad_" + a.item_mode + " + k_user + k_item_apply"
         out = {
             "metric": "BPR training interactions/sec at d=64; achieved HBM GB/s vs peak",
-            "value": value, "unit": "interactions/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": scaling,
+            "value": value, "unit": "interactions/s", "n_gpus": world, "steps": steps, "warmup": a.warmup,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": r["scaling"],
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": name, "batch_per_gpu": B, "global_batch": B * world, "d": d,
-                       "optimizer": "sgd", "lr": lr, "reg_1": reg, "reg_2": reg, "loss": "BPR",
-                       "item_mode": a.item_mode, "id_distribution": a.dist, "interactions_per_gpu": n,
+            "config": {"workload": r["name"], "batch_per_gpu": B, "global_batch": B * world, "d": d,
+                       "optimizer": "sgd", "lr": r["lr"], "reg_1": r["reg"], "reg_2": r["reg"], "loss": "BPR",
+                       "item_mode": a.item_mode, "id_distribution": a.dist, "interactions_per_gpu": r["n"],
                        "parallelism": f"user-sharded dp{world}" if world > 1 else "single GPU",
-                       "plan_bytes": plan.nbytes * len(plans), "plan_overlapped": bool(a.overlap_plan),
-                       "plan_layout": plan_kind, "index_bytes": index.nbytes if index is not None else 0,
+                       "plan_layout": r["plan_kind"], "plan_bytes": r["plan_bytes"], "index_bytes": r["index_bytes"],
+                       "plan_bytes_per_interaction": r["plan_bytes"] / r["n"], "plan_overlapped": bool(a.overlap_plan),
                        "semantics": "batch-synchronous (autograd + SGD.step equivalent), shuffle=True (device Feistel permutation per epoch)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": ("one SGD step = k_unorm + k_user_fused + k_reduce_partials + k_item_grad_chunked + k_user_commit + k_item_apply"
-                                    if a.item_mode == "fused" else
-                                    "one SGD step = k_fwd + k_reduce_partials + k_item_grad_" + a.item_mode + " + k_user + k_item_apply")
-                                   + " (+ the epoch plan build amortised over its batches)",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": chain + " (+ the epoch plan build amortised over its batches)",
                          "algorithmic_bytes_per_interaction": ALGO_BYTES_PER_INTERACTION_SGD(d),
                          "gpu_ms_per_step_events": gpu_ms_mean, "gpu_ms_per_step_median": step_ms[len(step_ms) // 2]},
         }
-        if world == 1 and not a.no_cpu_baseline:
-            del triples
-            out["cpu_baseline"] = cpu_baseline(U_loc, I, d, B, a.cpu_steps, reg)
+        if ref is not None:
+            out["single_gpu_same_workload"] = ref
+            out["speedup_vs_single_gpu_same_workload"] = value / ref["value"]
+        if r["cpu_batches"]:
+            out["cpu_baseline"] = cpu_baseline(r["U"], r["I"], d, B, r["cpu_batches"], r["reg"])
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _spawned(local_rank, world, port, argv):
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.argv = [sys.argv[0]] + list(argv)
+    main()
 
 
 if __name__ == "__main__":

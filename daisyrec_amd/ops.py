@@ -190,6 +190,7 @@ class BprContext:
         self.epoch_acc = torch.zeros(2, dtype=torch.float64, device=self.device)
         self.gQ = torch.zeros(self.item_num, self.d, dtype=torch.float32, device=self.device)
         self._p_key = None        # (data_ptr, torch version counter) of the P the row-norm cache describes
+        self._bias = None
 
     def _sync_norm_cache(self, P):
         """The staged step keeps |P[u]|^2 per row inside the context.  The native side tracks every write
@@ -221,6 +222,11 @@ class BprContext:
                                         _ptr(gQ, torch.float32, "gQ"), _ptr(cnt, torch.float32, "cnt"),
                                         float(lr), float(reg_1), float(reg_2),
                                         _ptr(self.stats, torch.float64, "stats"), _stream()))
+
+    def item_apply_counts(self, Q_rows, g_rows, cnt_rows, lr, reg_1, reg_2):
+        """The row owner's SGD step of a multi-GPU staged step: Q_rows -= lr*(g_rows + regulariser from the
+        reduced entry counts and the finalized global norms); clears g_rows and cnt_rows."""
+        item_apply_counts(Q_rows, g_rows, cnt_rows, lr, reg_1, reg_2, self.stats)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

@@ -5,27 +5,39 @@ AbstractRecommender.py:99); this is the data-parallel form of the same step:
 
 * users — and with them their interactions and their rows of P — are split into
   contiguous ranges, one per rank: P traffic is rank-local, no collective;
-* Q (item table) is replicated; each rank forms a partial item gradient gQ from its own
-  samples and the ranks SUM-all-reduce it (RCCL over xGMI) — the one real exchange;
-* the three sums of squares under the non-squared Frobenius regulariser
-  (MFRecommender.py:88-89,94-95) and the loss are batch-wide, so the 7 batch sums are
-  all-reduced (56 bytes) before any update.
+* Q (item table) is replicated; each rank forms a partial item gradient from its own
+  samples — the one real exchange;
+* the batch-wide sums under the non-squared Frobenius regulariser
+  (MFRecommender.py:88-89,94-95) and the loss are all-reduced (a few doubles) before
+  any row that depends on them moves.
 
 The union of the per-rank batches is one global batch: the result equals the single-GPU
 step on that union up to fp32 summation order.
 
-Per step and rank (compute stream | collective):
-    forward -> stats[0:7]              | all_reduce(stats[0:7]) async --+  (56 B, latency bound)
-    item_grad_data -> gQ (no norms)    |   overlapped                 <+
-    wait; finalize; item_grad_reg      |
-                                       | all_reduce(gQ) async  --+
-    user_sgd (reads Q pre-step)        |   overlapped           <+
-    wait; item_sgd_apply(dense)        |
-(the reproducible item modes form data term and regulariser in one kernel, so there the first
- all-reduce is waited for before item_grad)
+STAGED protocol (item_mode 'fused', the default; kernels of csrc/bpr_staged.hip).  The item
+exchange costs I/N rows of apply work per rank instead of I, and its wire volume is the
+reduce-scatter + all-gather pair a ring all-reduce is made of:
+
+    prenorm                  sum_b |P[u_b]|^2 from the row-norm cache   | all_reduce (8 B)
+    staged_user              forward + user rows of P in place          |
+                             stats[0:7] = the batch sums                | all_reduce (56 B) --+
+    staged_item -> gQ, cnt   data term of dL/dQ + per-item entry counts |   overlapped        <+
+    finalize                 the GLOBAL loss and norms                  |
+                                                                        | reduce_scatter(gQ), reduce_scatter(cnt)
+    item_apply_counts        rank r: SGD on its rows [r*I/N,(r+1)*I/N)  |
+                             of Q, regulariser from the GLOBAL counts   | all_gather(Q rows), in place
+    (gQ, cnt are re-zeroed behind the reduce-scatter)
+
+Per step and rank at d=64: 2*(N-1)/N * I * 264 B on the wire (I=1M, N=8: 2 x 231 MB), against
+B_local interactions of compute; DESIGN.md section 5 has the budget.
+
+PHASE protocol (item modes 'chunked' / 'sorted', or a backend without the staged phases):
+forward -> all_reduce(stats) -> item_grad -> all_reduce(gQ) overlapped with user_sgd -> dense
+item_sgd_apply.  Kept for the modes the staged step does not cover.
 """
 from __future__ import annotations
 
+import torch
 import torch.distributed as dist
 
 from . import _native as N
@@ -52,24 +64,71 @@ class UserShardedBprTrainer:
     table; both are updated in place."""
 
     def __init__(self, ctx, P_local, Q, user_lo, lr, reg_1, reg_2, loss_type=N.LOSS_BPR,
-                 gamma=1e-10, item_mode=N.ITEM_CHUNKED, group=None, overlap=True):
+                 gamma=1e-10, item_mode=N.ITEM_FUSED, group=None, overlap=True):
         self.ctx, self.P, self.Q = ctx, P_local, Q
         self.user_lo = int(user_lo)
         self.lr, self.reg_1, self.reg_2 = float(lr), float(reg_1), float(reg_2)
         self.loss_type, self.gamma, self.item_mode = int(loss_type), float(gamma), int(item_mode)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.overlap = bool(overlap)
+        if getattr(ctx, "_bias", None) is not None:
+            # FM's bias gradients (stats[SUM_COEF], g_i_bias) are not part of either exchange: the replicas
+            # would drift apart silently
+            raise NotImplementedError("UserShardedBprTrainer: contexts with FM biases are not supported")
+        self.staged = (self.item_mode == N.ITEM_FUSED and hasattr(ctx, "staged_user")
+                       and self.loss_type in (N.LOSS_BPR, N.LOSS_HL, N.LOSS_TL))
+        if self.item_mode == N.ITEM_FUSED and not self.staged:
+            self.item_mode = N.ITEM_CHUNKED
+        # collectives the backend lacks are emulated with the ones it has (gloo: no reduce_scatter);
+        # "nccl" (= RCCL on ROCm) runs the real ones
+        self._native_rs = self.world > 1 and dist.get_backend(group) == "nccl"
+        if self.staged:
+            I, d = Q.shape
+            self.rows = (I + self.world - 1) // self.world          # item rows per owner
+            Ipad = self.rows * self.world
+            self.gQ = torch.zeros(Ipad, d, dtype=torch.float32, device=Q.device)
+            self.cnt = torch.zeros(Ipad, 2, dtype=torch.float32, device=Q.device)
+            self.g_own = torch.zeros(self.rows, d, dtype=torch.float32, device=Q.device)
+            self.c_own = torch.zeros(self.rows, 2, dtype=torch.float32, device=Q.device)
+            self.Q_gather = Q if Ipad == I else torch.zeros(Ipad, d, dtype=torch.float32, device=Q.device)
+            self.own_lo = self.rank * self.rows
+            self.own_hi = min(self.own_lo + self.rows, I)
 
+    # -- collectives -----------------------------------------------------------------------------
     def _all_reduce(self, t, async_op=False):
         if self.world == 1:
             return None
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
-    def step_from_triples(self, triples, idx=None, start=0, B=None):
+    def _reduce_scatter(self, out, full):
+        """out[rows] = sum over ranks of full[rank*rows:(rank+1)*rows]"""
+        if self.world == 1:
+            out.copy_(full)
+        elif self._native_rs:
+            dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.all_reduce(full, op=dist.ReduceOp.SUM, group=self.group)
+            out.copy_(full[self.rank * self.rows:(self.rank + 1) * self.rows])
+
+    def _all_gather_rows(self, full, own):
+        """full[r*rows:(r+1)*rows] = rank r's `own`; `own` may be that very slice of `full`"""
+        if self.world == 1:
+            return
+        if self._native_rs:
+            dist.all_gather_into_tensor(full, own, group=self.group)
+        else:
+            parts = [torch.empty_like(own) for _ in range(self.world)]
+            dist.all_gather(parts, own.clone(), group=self.group)
+            for r, p in enumerate(parts):
+                full[r * self.rows:(r + 1) * self.rows].copy_(p)
+
+    # -- entry points ----------------------------------------------------------------------------
+    def step_from_triples(self, triples, idx=None, start=0, B=None, validate=True):
         """One global step; `triples` are this rank's rows (global user ids)."""
         c = self.ctx
-        c.set_batch_from_triples(triples, idx=idx, start=start, B=B, user_base=self.user_lo)
+        c.set_batch_from_triples(triples, idx=idx, start=start, B=B, user_base=self.user_lo, validate=validate)
         return self._step()
 
     def step_from_plan(self, plan, k):
@@ -77,14 +136,47 @@ class UserShardedBprTrainer:
         self.ctx.set_batch_from_plan(plan, k)
         return self._step()
 
-    def step(self, u_local, i, j):
-        self.ctx.set_batch(u_local, i, j)
+    def step(self, u_local, i, j, validate=True):
+        self.ctx.set_batch(u_local, i, j, validate=validate)
         return self._step()
 
     def _step(self):
+        return self._step_staged() if self.staged else self._step_phases()
+
+    def _step_staged(self):
+        c, I = self.ctx, self.Q.shape[0]
+        c.staged_prenorm(self.P)
+        self._all_reduce(c.stats[N.ST_SQ_U_PRE:N.ST_SQ_U_PRE + 1])
+        c.staged_user(self.P, self.Q, self.lr, self.reg_1, self.reg_2, self.loss_type, self.gamma)
+        w0 = self._all_reduce(c.stats[:7], async_op=self.overlap)
+        c.staged_item(self.lr, self.reg_1, self.reg_2, gQ=self.gQ[:I], cnt=self.cnt[:I],
+                      loss_type=self.loss_type)          # overlaps the 56-byte all-reduce
+        if w0 is not None:
+            w0.wait()
+        c.finalize(self.reg_1, self.reg_2)               # every rank: the GLOBAL loss and norms
+        self._reduce_scatter(self.g_own, self.gQ)
+        self._reduce_scatter(self.c_own, self.cnt)
+        self.gQ.zero_()
+        self.cnt.zero_()
+        n_own = self.own_hi - self.own_lo
+        if n_own > 0:
+            q_own = self.Q[self.own_lo:self.own_hi]
+            c.item_apply_counts(q_own, self.g_own[:n_own], self.c_own[:n_own], self.lr, self.reg_1, self.reg_2)
+        if self.world > 1:
+            if self.Q_gather is self.Q:
+                self._all_gather_rows(self.Q, self.Q[self.own_lo:self.own_lo + self.rows])
+            else:                                        # I not a multiple of the world size: padded staging
+                own = self.Q_gather[self.own_lo:self.own_lo + self.rows]
+                if n_own > 0:
+                    own[:n_own].copy_(self.Q[self.own_lo:self.own_hi])
+                self._all_gather_rows(self.Q_gather, own)
+                self.Q.copy_(self.Q_gather[:I])
+        return c.stats
+
+    def _step_phases(self):
         c = self.ctx
         c.forward(self.P, self.Q, self.loss_type, self.gamma)
-        split = self.item_mode in (N.ITEM_CHUNKED, N.ITEM_FUSED) and hasattr(c, "item_grad_data")
+        split = self.item_mode == N.ITEM_CHUNKED and hasattr(c, "item_grad_data")
         if split:
             w0 = self._all_reduce(c.stats[:7], async_op=self.overlap)
             c.item_grad_data(self.P, self.Q, self.item_mode)      # overlaps the 56-byte all-reduce

@@ -13,13 +13,13 @@ class OracleContext:
         self.epoch_acc = torch.zeros(2, dtype=torch.float64)
         self.gQ = torch.zeros(item_num, d, dtype=torch.float32)
 
-    def set_batch_from_triples(self, triples, idx=None, start=0, B=None, user_base=0):
+    def set_batch_from_triples(self, triples, idx=None, start=0, B=None, user_base=0, validate=True):
         t = triples.numpy() if isinstance(triples, torch.Tensor) else triples
         rows = t[idx.numpy()] if idx is not None else t[start:start + (B if B is not None else len(t) - start)]
         self.u = rows[:, 0].astype(np.int64) - user_base
         self.i, self.j = rows[:, 1].astype(np.int64), rows[:, 2].astype(np.int64)
 
-    def set_batch(self, u, i, j):
+    def set_batch(self, u, i, j, validate=True):
         self.u, self.i, self.j = (np.asarray(x).astype(np.int64) for x in (u, i, j))
 
     def forward(self, P, Q, loss_type=0, gamma=1e-10):
@@ -81,3 +81,40 @@ class OracleContext:
     def item_sgd_apply(self, Q, lr, dense=False, gQ=None):
         Q.sub_(lr * self.gQ)
         self.gQ.zero_()
+
+    # ---- the staged phases (csrc/bpr_staged.hip), restated: prenorm -> user -> finalize -> item -> apply
+    def staged_prenorm(self, P):
+        pu = P.numpy().astype(np.float64)[self.u]
+        self.stats[13] = (pu * pu).sum()
+
+    def staged_user(self, P, Q, lr, reg_1, reg_2, loss_type=0, gamma=1e-10):
+        self.forward(P, Q, loss_type, gamma)                       # local batch sums + coefficients
+        P64, Q64 = P.numpy().astype(np.float64), Q.numpy().astype(np.float64)
+        self.pu_pre = P64[self.u].copy()                           # what the stage holds: pre-step rows
+        qi, qj = Q64[self.i], Q64[self.j]
+        nU = float(self.stats[13]) ** 0.5                          # GLOBAL |P[u]|_F (all-reduced before this call)
+        g = np.zeros_like(P64)
+        np.add.at(g, self.u, self.cp[:, None] * qi + self.cn[:, None] * qj + reg_1 * np.sign(self.pu_pre)
+                  + reg_2 * self._fro(self.pu_pre, nU))
+        P.copy_(torch.from_numpy((P64 - lr * g).astype(np.float32)))
+
+    def staged_item(self, lr, reg_1, reg_2, Q=None, gQ=None, cnt=None, loss_type=0):
+        assert Q is None, "the oracle backend only restates the gradient-output form"
+        g = np.zeros((self.item_num, self.d))
+        c = np.zeros((self.item_num, 2))
+        np.add.at(g, self.i, self.cp[:, None] * self.pu_pre)
+        np.add.at(g, self.j, self.cn[:, None] * self.pu_pre)
+        np.add.at(c[:, 0], self.i, 1.0)
+        np.add.at(c[:, 1], self.j, 1.0)
+        gQ += torch.from_numpy(g.astype(np.float32))
+        cnt += torch.from_numpy(c.astype(np.float32))
+
+    def item_apply_counts(self, Q_rows, g_rows, cnt_rows, lr, reg_1, reg_2):
+        nI, nJ = float(self.stats[9]), float(self.stats[10])
+        q = Q_rows.numpy().astype(np.float64)
+        npos, nneg = cnt_rows[:, 0:1].numpy().astype(np.float64), cnt_rows[:, 1:2].numpy().astype(np.float64)
+        g = g_rows.numpy().astype(np.float64) + reg_1 * (npos + nneg) * np.sign(q) \
+            + reg_2 * (npos * self._fro(q, nI) + nneg * self._fro(q, nJ))
+        Q_rows.copy_(torch.from_numpy((q - lr * g).astype(np.float32)))
+        g_rows.zero_()
+        cnt_rows.zero_()

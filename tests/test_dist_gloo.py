@@ -24,7 +24,7 @@ def _data():
     return P0, Q0, batches
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, mode):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from daisyrec_amd.sharding import UserShardedBprTrainer, shard_triples, user_range
@@ -33,8 +33,11 @@ def _worker(rank, world, port, out_dir):
     lo, hi = user_range(U, world, rank)
     P = torch.from_numpy(P0[lo:hi].copy())
     Q = torch.from_numpy(Q0.copy())
+    from daisyrec_amd import _native as N
     ctx = OracleContext(B, D, hi - lo, I)
-    tr = UserShardedBprTrainer(ctx, P, Q, lo, LR, R1, R2, overlap=(rank % 2 == 0))
+    tr = UserShardedBprTrainer(ctx, P, Q, lo, LR, R1, R2, overlap=(rank % 2 == 0),
+                               item_mode={"fused": N.ITEM_FUSED, "chunked": N.ITEM_CHUNKED}[mode])
+    assert tr.staged == (mode == "fused")
     losses = []
     for b in batches:
         mine = shard_triples(b, U, world, rank)
@@ -53,11 +56,16 @@ def _free_port():
     return p
 
 
-def test_two_rank_user_sharding_equals_single_process(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("mode,world", [("fused", 2), ("chunked", 2), ("fused", 4)])
+def test_user_sharding_equals_single_process(tmp_path, mode, world):
+    """staged protocol (reduce-scatter / owner apply / all-gather; world 3: item rows not divisible by the
+    world size) and the phase protocol (dense all-reduce)"""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), mode), nprocs=world, join=True)
     P, Q, batches = _data()
     ref_losses = []
     for b in batches:
@@ -69,7 +77,8 @@ def test_two_rank_user_sharding_equals_single_process(tmp_path):
         np.testing.assert_allclose(o["Q"], Q, atol=2e-6)                     # replicas stay identical
         np.testing.assert_allclose(o["P"], P[int(o["lo"]):int(o["hi"])], atol=2e-6)
         assert abs(float(o["acc"]) - sum(ref_losses)) < 1e-6
-    np.testing.assert_array_equal(outs[0]["Q"], outs[1]["Q"])
+    for o in outs[1:]:
+        np.testing.assert_array_equal(outs[0]["Q"], o["Q"])
 
 
 def test_user_range_partition():

@@ -27,27 +27,42 @@ def _data():
     return P0, Q0, batches
 
 
-def _worker(rank, world, port, out_dir, use_plan):
+def _worker(rank, world, port, out_dir, use_plan, mode, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from daisyrec_amd import ops
     from daisyrec_amd.sharding import UserShardedBprTrainer, shard_triples, user_range
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", rank if backend == "nccl" else 0)
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     P0, Q0, batches = _data()
     lo, hi = user_range(U, world, rank)
     P = torch.from_numpy(P0[lo:hi].copy()).to(dev)
     Q = torch.from_numpy(Q0.copy()).to(dev)
     ctx = ops.BprContext(B, D, hi - lo, I, device=dev)
-    tr = UserShardedBprTrainer(ctx, P, Q, lo, LR, R1, R2, item_mode=ops.ITEM_MODES["chunked"])
+    tr = UserShardedBprTrainer(ctx, P, Q, lo, LR, R1, R2, item_mode=ops.ITEM_MODES[mode])
+    assert tr.staged == (mode == "fused")
     losses = []
     for b in batches:
         mine = torch.from_numpy(shard_triples(b, U, world, rank)).to(dev)
         if use_plan:                      # one-batch plan of the rank's share (local user ids)
             loc = mine.clone()
             loc[:, 0] -= lo
-            plan = ops.EpochPlan(loc.shape[0], hi - lo, I, device=dev).build(loc, loc.shape[0], order="identity")
+            plan = ops.EpochPlan(loc.shape[0], hi - lo, I, device=dev)
+            index = None
+            if mode == "fused":           # the partitioned layout the staged step normally reads
+                index = ops.TrainIndex(loc, hi - lo, I)
+                plan.build_indexed(index, loc.shape[0], order="identity")
+            else:
+                plan.build(loc, loc.shape[0], order="identity")
             stats = tr.step_from_plan(plan, 0)
+            torch.cuda.synchronize()
             plan.close()
+            if index is not None:
+                index.close()
         else:
             stats = tr.step_from_triples(mine)
         losses.append(float(stats[7].cpu()))
@@ -66,10 +81,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("use_plan", [False, True])
-def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path, use_plan):
-    world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), use_plan), nprocs=world, join=True)
+def _check(tmp_path, world):
     P, Q, batches = _data()
     ref = []
     for b in batches:
@@ -80,4 +92,55 @@ def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path, use_plan):
         np.testing.assert_allclose(o["losses"], ref, rtol=1e-6)                  # every rank sees the GLOBAL loss
         np.testing.assert_allclose(o["Q"], Q, atol=1e-5)
         np.testing.assert_allclose(o["P"], P[int(o["lo"]):int(o["hi"])], atol=1e-5)
-    np.testing.assert_allclose(outs[0]["Q"], outs[1]["Q"], atol=1e-6)            # replicas stay together
+    for o in outs[1:]:
+        np.testing.assert_allclose(outs[0]["Q"], o["Q"], atol=1e-6)              # replicas stay together
+
+
+@pytest.mark.parametrize("mode", ["fused", "chunked"])
+@pytest.mark.parametrize("use_plan", [False, True])
+def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path, use_plan, mode):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), use_plan, mode), nprocs=world, join=True)
+    _check(tmp_path, world)
+
+
+def test_item_rows_not_divisible_by_the_world_size(tmp_path):
+    """the staged protocol's padded path: a world size that does not divide the item count"""
+    world = 4 if I % 4 else 7
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), False, "fused"), nprocs=world, join=True)
+    _check(tmp_path, world)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (this box has one)")
+@pytest.mark.parametrize("mode", ["fused", "chunked"])
+def test_rccl_ranks_equal_the_single_process_step(tmp_path, mode):
+    """The same check over the real collectives (reduce_scatter_tensor / all_gather_into_tensor / all_reduce
+    on RCCL), one rank per GPU: runs on the first box that has more than one GPU."""
+    world = min(torch.cuda.device_count(), 8)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True, mode, "nccl"), nprocs=world, join=True)
+    _check(tmp_path, world)
+
+
+def test_bench_refuses_more_gpus_than_the_box_has():
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    want = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(want), "--workload", "tiny"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "refusing" in (r.stderr + r.stdout)
+    assert '"n_gpus"' not in r.stdout
+
+
+def test_bench_self_spawns_its_ranks():
+    """`python bench.py --gpus 2` without a launcher spawns 2 ranks (gloo here: both share the one GPU)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "tiny",
+                        "--backend", "gloo", "--batch", "65536", "--steps", "6", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2 * 65536 and out["value"] > 0
