@@ -3,7 +3,8 @@ the HIP path: rebinds the names those scripts import (test.py:4,21-22; tune.py:7
 
     import daisyrec_amd.dropin as d; d.install()          # before `import run_examples.test`
 
-or, where the reference checkout exists:  python tools/run_reference_driver.py --algo_name mf ...
+or, where the reference checkout exists:
+    python tools/run_daisy_example.py --daisy /path/to/daisyRec -- --algo_name mf ...
 """
 from __future__ import annotations
 

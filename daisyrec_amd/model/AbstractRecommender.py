@@ -232,6 +232,10 @@ class GeneralRecommender(AbstractRecommender):
                     # AbstractRecommender.py:122-123 (checked once per epoch instead of per batch)
                     raise ValueError("Loss=Nan or Infinity: current settings does not fit the recommender")
                 self.epoch_losses.append(current_loss)
+                log_path = os.environ.get("DAISY_AMD_EPOCH_LOG")    # evidence trail of driver runs (tests/test_gpu_driver.py)
+                if log_path:
+                    with open(log_path, "a") as fh:
+                        fh.write(f"{type(self).__name__} epoch {epoch} loss {current_loss!r}\n")
                 if bar is not None:
                     bar.set_description(f"[Epoch {epoch:03d}]")
                     bar.set_postfix(loss=current_loss)

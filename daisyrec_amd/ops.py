@@ -7,6 +7,7 @@ Nothing in this module computes on the host or falls back to torch ops.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import torch
 
@@ -110,12 +111,13 @@ class EpochPlan:
         check(lib.daisy_epoch_plan_build(self._h, _ptr(triples, torch.int32, "triples"), n,
                                          _ptr(perm, torch.int64, "perm"), mode, int(seed), int(epoch),
                                          int(batch_size), int(user_base), flags, _stream()))
-        sig = (triples.data_ptr(), n, int(user_base), triples._version)
-        if validate is None:
-            validate = sig != getattr(self, "_validated", None)
+        if validate is None:       # the same tensor object, unchanged since its last validated build, is not re-read
+            ref = getattr(self, "_validated", None)
+            same = ref is not None and ref[0]() is triples and ref[1:] == (n, int(user_base), triples._version)
+            validate = (not same) or mode == N.ORDER_PERM
         if validate:
             check(lib.daisy_epoch_plan_validate(self._h, _stream()))
-            self._validated = sig
+            self._validated = (weakref.ref(triples), n, int(user_base), triples._version)
         return self
 
     def build_indexed(self, index: "TrainIndex", batch_size, order="identity", perm=None, seed=0, epoch=0):

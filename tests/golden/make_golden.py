@@ -166,12 +166,14 @@ class _TqdmCapture:
         _TqdmCapture.epoch_losses.append(float(loss))
 
 
-def make_ml100k(epochs=3):
+def make_ml100k(epochs=3, out="ml100k_c1.npz", **over):
+    """`over`: config overrides (e.g. optimizer='adam', lr=0.001 -> ml100k_c1_adam.npz: the same run with
+    torch.optim.Adam, AbstractRecommender.py:54)"""
     cwd = os.getcwd()
     os.chdir(REF)                        # data_path is relative ('data/'); nothing is written
     try:
         cfg = base_config(factors=32, num_ng=1, epochs=epochs, early_stop=False,
-                          algo_name="mf", dataset="ml-100k")
+                          algo_name="mf", dataset="ml-100k", **over)
         seed_all(cfg["seed"])            # config.py:21-42 (CPU part)
         df = RawDataReader(cfg).get_data()
         pre = Preprocessor(cfg)
@@ -208,7 +210,7 @@ def make_ml100k(epochs=3):
     finally:
         os.chdir(cwd)
     np.savez_compressed(
-        os.path.join(HERE, "ml100k_c1.npz"),
+        os.path.join(HERE, out),
         user_num=np.int64(cfg["user_num"]), item_num=np.int64(cfg["item_num"]),
         hyper=np.array([cfg["lr"], cfg["reg_1"], cfg["reg_2"]], dtype=np.float64),
         factors=np.int64(32), batch_size=np.int64(cfg["batch_size"]), epochs=np.int64(epochs),
@@ -220,8 +222,7 @@ def make_ml100k(epochs=3):
         test_u=np.array(test_u, dtype=np.int64), cands=cands,
         preds=preds.astype(np.float32), full_rank16=full.astype(np.int64),
     )
-    print("ml100k_c1.npz: samples", samples.shape, "epoch losses", epoch_losses,
-          "preds", preds.shape)
+    print(out, ": samples", samples.shape, "epoch losses", epoch_losses, "preds", preds.shape)
 
 
 # ----------------------------------------------------------------------------
@@ -253,3 +254,4 @@ if __name__ == "__main__":  # pragma: no cover
     make_kat_steps()
     make_rank_kat()
     make_ml100k()
+    make_ml100k(out="ml100k_c1_adam.npz", optimizer="adam", lr=0.001)
