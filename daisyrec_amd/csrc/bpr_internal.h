@@ -148,6 +148,12 @@ StreamView plan_stream_view(const daisy_epoch_plan *plan, int64_t k);
 int plan_read_batch_partitioned(const daisy_epoch_plan *plan, int64_t k, int32_t *u, int32_t *i, int32_t *j,
                                 int32_t *ent_item, uint32_t *ent_s, int32_t *ent_u, int64_t *B_out_host,
                                 hipStream_t s);
+// bpr_small.hip: every step of an epoch inside one persistent workgroup (batches of a few hundred samples)
+constexpr int kSmallBatchMax = 256;
+bool small_epoch_supported(const daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, int loss_type);
+int small_fit_epoch(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, float *P, float *Q, int loss_type, float gamma,
+                    float lr, float reg_1, float reg_2, double *stats, double *epoch_acc, double *step_losses,
+                    hipStream_t s);
 // bpr_train.hip: fixed-order reduction of `nblocks` x 8 per-workgroup sums into stats[0..6,12]; finalize: also
 // the norms and the loss (finalize_stats)
 int launch_reduce_partials(const double *partials, int nblocks, double *stats, bool finalize, float reg_1,

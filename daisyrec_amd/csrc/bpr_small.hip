@@ -1,0 +1,312 @@
+// Small-batch epochs (the reference's default batch_size = 256, basic.yaml:23; BASELINE configs[0]):
+// one persistent workgroup runs EVERY step of an epoch.
+//
+// At B = 256 a step moves ~100 KB; the phase kernels of bpr_train.hip spend 23-29 us per step on it, all of
+// it the dependency chain of five to seven kernel launches (measured: a captured hipGraph of the chain was
+// not faster - the cost is kernel-boundary latency on the GPU, not host work).  Here the chain's phases are
+// separated by workgroup barriers instead of kernel boundaries, inside ONE kernel per epoch, and the rows a
+// step gathers are staged in LDS once (160 KB per CU) so that every later phase reads them from there:
+//
+//   A  forward: 3 row gathers per sample -> registers -> LDS; both scores, loss term, c = dL/dx -> LDS;
+//      the seven batch sums reduced across the workgroup in fixed order              (MFRecommender.py:63-97)
+//   B  item side: the lane group that sees the head of an item's run of entries owns the row, sums
+//      c_e * p_u(e) over the run in plan order from the STAGED user rows, adds the regulariser (the
+//      pre-step item row is the staged q of its own sample) and writes Q[i] in place;
+//      user side, same phase: the group at the head of a user's run sums over the STAGED item rows and writes
+//      P[u] in place - nobody reads the tables during this phase, only the pre-step copies in LDS.
+//      (d too wide for three staged rows per sample: the user rows stay in global memory, and the user side
+//      waits behind one more barrier for the item side to finish reading them.)
+//
+// Global traffic per step = the 3B gathered rows + one write per distinct row; the index arrays of step k+1
+// are fetched while step k computes.  Every sum runs in plan order on a single owner: bitwise reproducible.
+// One workgroup = one CU: right for batches of a few hundred samples, hopeless for large ones (the dispatcher
+// in bpr_train.hip only comes here for B <= kSmallBatchMax and rows that fit the LDS).
+#include <stdlib.h>
+
+#include "bpr_internal.h"
+
+namespace daisy {
+
+constexpr int kSmallThreads = 1024;
+constexpr size_t kSmallLdsRows = 128 * 1024;      // dynamic LDS for the staged rows (static arrays take ~22 KB of the 160)
+
+struct SmallPlan {           // the sorted layout of daisy_epoch_plan (kind 0), whole epoch
+    const uint32_t *ukey;
+    const int2 *ij;
+    const uint32_t *ekey;
+    const uint2 *esu;
+    uint32_t umask, imask;
+    int64_t n, B, nb;
+};
+
+// metadata of one step in LDS (filled one step ahead: no global index load sits on a step's critical path)
+struct SmallMeta {
+    uint32_t ukey[kSmallBatchMax];
+    int2 ij[kSmallBatchMax];
+    uint32_t item[2 * kSmallBatchMax];       // entry -> item
+    uint2 su[2 * kSmallBatchMax];            // entry -> (sample | neg bit, user)
+};
+
+// row <-> LDS (the staged rows are laid out like table rows: d floats, chunk c of lane l at (c*LPR + l)*VEC)
+template <class C>
+__device__ __forceinline__ void lds_store_row(float *dst, const Row<C> &r, int lane, int d) {
+#pragma unroll
+    for (int c = 0; c < C::NV; ++c) {
+        const int e = (c * C::LPR + lane) * C::VEC;
+        if (C::EXACT || e < d) {
+#pragma unroll
+            for (int k = 0; k < C::VEC; ++k) dst[e + k] = r.v[c * C::VEC + k];
+        }
+    }
+}
+template <class C>
+__device__ __forceinline__ void lds_load_row(Row<C> &r, const float *src, int lane, int d) {
+#pragma unroll
+    for (int c = 0; c < C::NV; ++c) {
+        const int e = (c * C::LPR + lane) * C::VEC;
+#pragma unroll
+        for (int k = 0; k < C::VEC; ++k) r.v[c * C::VEC + k] = (C::EXACT || e < d) ? src[e + k] : 0.f;
+    }
+}
+
+template <class C, bool STAGE_P>
+__global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
+    float *__restrict__ P, float *__restrict__ Q, SmallPlan pl, int d, int dpad, int loss_type, float gamma, float lr,
+    float reg_1, float reg_2, double *__restrict__ stats, double *__restrict__ epoch_acc,
+    double *__restrict__ step_losses) {
+    constexpr int G = kSmallThreads / C::LPR;
+    constexpr int NW = kSmallThreads / kWave;
+    constexpr int UN = (C::NE <= 4) ? 2 : 1;            // samples whose 3 row gathers are issued together per lane group
+    constexpr int PT = (3 * kSmallBatchMax + kSmallThreads - 1) / kSmallThreads;   // metadata words per thread
+    extern __shared__ float s_rows[];                  // [B][dpad] q_i | [B][dpad] q_j | (STAGE_P: [B][dpad] p_u)
+    __shared__ SmallMeta s_meta[2];
+    __shared__ float2 s_coef[kSmallBatchMax];          // (dL/dpos, dL/dneg)
+    __shared__ double s_part[NW][8];
+    __shared__ double s_stats[DAISY_STATS_LEN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid % C::LPR;
+    const int group = tid / C::LPR;
+    const int wave = tid / kWave;
+    float *const s_qi = s_rows;
+    float *const s_qj = s_rows + (size_t)pl.B * dpad;
+    float *const s_p = s_rows + 2 * (size_t)pl.B * dpad;
+    double acc_epoch = 0.0, nan_epoch = 0.0;           // thread 0 only
+
+    // element x of a step's metadata: x < B samples, then 2B entries
+    uint32_t pre_a[PT];
+    uint2 pre_b[PT];
+    auto fetch = [&](int64_t k) {                      // global -> registers (issued a whole step ahead)
+        const int64_t lo = k * pl.B;
+        const int Bk = (int)((pl.n - lo < pl.B) ? (pl.n - lo) : pl.B);
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            const int x = t * kSmallThreads + tid;
+            if (x < Bk) {
+                pre_a[t] = pl.ukey[lo + x] & pl.umask;
+                const int2 v = pl.ij[lo + x];
+                pre_b[t] = make_uint2((uint32_t)v.x, (uint32_t)v.y);
+            } else if (x < 3 * Bk) {
+                pre_a[t] = (pl.ekey[2 * lo + (x - Bk)] & pl.imask) >> 1;
+                pre_b[t] = pl.esu[2 * lo + (x - Bk)];
+            }
+        }
+    };
+    auto stash = [&](int64_t k) {                      // registers -> LDS buffer k & 1
+        const int64_t lo = k * pl.B;
+        const int Bk = (int)((pl.n - lo < pl.B) ? (pl.n - lo) : pl.B);
+        SmallMeta &m = s_meta[k & 1];
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            const int x = t * kSmallThreads + tid;
+            if (x < Bk) { m.ukey[x] = pre_a[t]; m.ij[x] = make_int2((int)pre_b[t].x, (int)pre_b[t].y); }
+            else if (x < 3 * Bk) { m.item[x - Bk] = pre_a[t]; m.su[x - Bk] = pre_b[t]; }
+        }
+    };
+    if (pl.nb > 0) { fetch(0); stash(0); }
+    __syncthreads();
+
+    for (int64_t k = 0; k < pl.nb; ++k) {
+        const int64_t lo = k * pl.B;
+        const int Bk = (int)((pl.n - lo < pl.B) ? (pl.n - lo) : pl.B);
+        const SmallMeta &m = s_meta[k & 1];
+        if (k + 1 < pl.nb) fetch(k + 1);               // lands while this step computes
+
+        // ---- A: forward; the gathered rows stay in LDS for phase B
+        float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int s0 = group; s0 < Bk; s0 += UN * G) {
+            Row<C> p[UN], qi[UN], qj[UN];
+#pragma unroll
+            for (int y = 0; y < UN; ++y) {
+                const int s = s0 + y * G;
+                if (s < Bk) {
+                    const int2 it = m.ij[s];
+                    p[y].load(P + (int64_t)m.ukey[s] * d, lane, d);
+                    qi[y].load(Q + (int64_t)it.x * d, lane, d);
+                    qj[y].load(Q + (int64_t)it.y * d, lane, d);
+                }
+            }
+#pragma unroll
+            for (int y = 0; y < UN; ++y) {
+                const int s = s0 + y * G;
+                if (s < Bk) {
+                    lds_store_row<C>(s_qi + (size_t)s * dpad, qi[y], lane, d);
+                    lds_store_row<C>(s_qj + (size_t)s * dpad, qj[y], lane, d);
+                    if constexpr (STAGE_P) lds_store_row<C>(s_p + (size_t)s * dpad, p[y], lane, d);
+                    const float pos = row_dot<C>(p[y], qi[y]);
+                    const float neg = row_dot<C>(p[y], qj[y]);
+#pragma unroll
+                    for (int e = 0; e < C::NE; ++e) {
+                        acc[1] += fabsf(p[y].v[e]);
+                        acc[2] += fabsf(qi[y].v[e]);
+                        acc[3] += fabsf(qj[y].v[e]);
+                        acc[4] = fmaf(p[y].v[e], p[y].v[e], acc[4]);
+                        acc[5] = fmaf(qi[y].v[e], qi[y].v[e], acc[5]);
+                        acc[6] = fmaf(qj[y].v[e], qj[y].v[e], acc[6]);
+                    }
+                    if (lane == 0) {
+                        float term, cp, cn;
+                        pair_coef(loss_type, pos, neg, gamma, term, cp, cn);
+                        s_coef[s] = make_float2(cp, cn);
+                        acc[0] += term;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 7; ++q) {
+            const double w = wave_sum_f64((double)acc[q]);
+            if ((tid % kWave) == 0) s_part[wave][q] = w;
+        }
+        __syncthreads();
+        if (tid < 7) {
+            double t = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += s_part[w][tid];
+            s_stats[tid] = t;
+        }
+        __syncthreads();
+        const float rU = inv_or_zero(sqrt(s_stats[DAISY_ST_SQ_U]), reg_2), rI = inv_or_zero(sqrt(s_stats[DAISY_ST_SQ_I]), reg_2),
+                    rJ = inv_or_zero(sqrt(s_stats[DAISY_ST_SQ_J]), reg_2);
+        if (tid == 0) {       // MFRecommender.py:88-89,94-95 (slots 7..10 are written here and read by nobody until the end)
+            const double nU = sqrt(s_stats[DAISY_ST_SQ_U]), nI = sqrt(s_stats[DAISY_ST_SQ_I]),
+                         nJ = sqrt(s_stats[DAISY_ST_SQ_J]);
+            const double loss = s_stats[DAISY_ST_LOSS_DATA] +
+                                (double)reg_1 * (s_stats[DAISY_ST_L1_I] + s_stats[DAISY_ST_L1_J]) +
+                                (double)reg_2 * (nI + nJ) + (double)reg_1 * s_stats[DAISY_ST_L1_U] + (double)reg_2 * nU;
+            s_stats[DAISY_ST_LOSS] = loss;
+            s_stats[DAISY_ST_NORM_U] = nU; s_stats[DAISY_ST_NORM_I] = nI; s_stats[DAISY_ST_NORM_J] = nJ;
+            acc_epoch += loss;
+            if (!(loss == loss) || isinf(loss)) nan_epoch += 1.0;
+            if (step_losses) step_losses[k] = loss;
+        }
+
+        // ---- B, item side: entries sorted by item; the head of a run owns Q[item]
+        const int nE = 2 * Bk;
+        for (int e = group; e < nE; e += G) {
+            const uint32_t r = m.item[e];
+            if (e > 0 && m.item[e - 1] == r) continue;
+            const uint32_t s_head = m.su[e].x;
+            Row<C> a, qr;          // the pre-step Q[r] is the staged q of the head entry's own sample
+            lds_load_row<C>(qr, ((s_head & kNegBit) ? s_qj : s_qi) + (size_t)(s_head & ~kNegBit) * dpad, lane, d);
+            a.zero();
+            float np = 0.f, nn = 0.f;
+            for (int q = e; q < nE && m.item[q] == r; ++q) {
+                const uint2 su = m.su[q];
+                const bool is_neg = (su.x & kNegBit) != 0;
+                const float2 c2 = s_coef[su.x & ~kNegBit];
+                const float c = is_neg ? c2.y : c2.x;
+                np += is_neg ? 0.f : 1.f;
+                nn += is_neg ? 1.f : 0.f;
+                Row<C> pr;
+                if constexpr (STAGE_P) lds_load_row<C>(pr, s_p + (size_t)(su.x & ~kNegBit) * dpad, lane, d);
+                else pr.load(P + (int64_t)su.y * d, lane, d);
+#pragma unroll
+                for (int x = 0; x < C::NE; ++x) a.v[x] = fmaf(c, pr.v[x], a.v[x]);
+            }
+            const float w1 = reg_1 * (np + nn), w2 = np * rI + nn * rJ;
+#pragma unroll
+            for (int x = 0; x < C::NE; ++x) {
+                const float g = a.v[x] + fmaf(w2, qr.v[x], w1 * sgn(qr.v[x]));
+                qr.v[x] = fmaf(-lr, g, qr.v[x]);
+            }
+            qr.store(Q + (int64_t)r * d, lane, d);      // nobody reads Q before the next step's phase A
+        }
+        if constexpr (!STAGE_P) __syncthreads();        // the item side read P from global memory
+
+        // ---- B, user side: samples grouped by user; the head of a run owns P[u]
+        for (int s = group; s < Bk; s += G) {
+            const uint32_t uu = m.ukey[s];
+            if (s > 0 && m.ukey[s - 1] == uu) continue;
+            Row<C> p, a;
+            if constexpr (STAGE_P) lds_load_row<C>(p, s_p + (size_t)s * dpad, lane, d);
+            else p.load(P + (int64_t)uu * d, lane, d);
+            a.zero();
+            float cnt = 0.f;
+            for (int q = s; q < Bk && m.ukey[q] == uu; ++q) {
+                const float2 c = s_coef[q];
+                Row<C> qi, qj;
+                lds_load_row<C>(qi, s_qi + (size_t)q * dpad, lane, d);
+                lds_load_row<C>(qj, s_qj + (size_t)q * dpad, lane, d);
+#pragma unroll
+                for (int x = 0; x < C::NE; ++x) a.v[x] = fmaf(c.x, qi.v[x], fmaf(c.y, qj.v[x], a.v[x]));
+                cnt += 1.f;
+            }
+            const float w1 = reg_1 * cnt, w2 = rU * cnt;
+#pragma unroll
+            for (int x = 0; x < C::NE; ++x) {
+                const float g = a.v[x] + fmaf(w2, p.v[x], w1 * sgn(p.v[x]));
+                p.v[x] = fmaf(-lr, g, p.v[x]);
+            }
+            p.store(P + (int64_t)uu * d, lane, d);
+        }
+        if (k + 1 < pl.nb) stash(k + 1);
+        __syncthreads();
+    }
+    if (tid < DAISY_STATS_LEN && pl.nb > 0) stats[tid] = (tid <= DAISY_ST_NORM_J) ? s_stats[tid] : 0.0;   // the last step's
+    if (tid == 0 && epoch_acc) { epoch_acc[0] += acc_epoch; epoch_acc[1] += nan_epoch; }
+}
+
+static inline int small_dpad(int d) { return (d + 3) / 4 * 4; }     // float4-aligned rows (a lane group reads one row per LDS cycle: no padding needed)
+
+bool small_epoch_supported(const daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, int loss_type) {
+    static const int enabled = getenv("DAISY_SMALL_EPOCH") ? atoi(getenv("DAISY_SMALL_EPOCH")) : 1;
+    return enabled && plan->kind == 0 && !plan->pointwise && plan->batch_size <= kSmallBatchMax && !ctx->bu &&
+           loss_type >= DAISY_LOSS_BPR && loss_type <= DAISY_LOSS_TL && plan->batch_size <= ctx->max_batch &&
+           2 * (size_t)plan->batch_size * small_dpad(ctx->d) * sizeof(float) <= kSmallLdsRows;
+}
+
+int small_fit_epoch(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, float *P, float *Q, int loss_type, float gamma,
+                    float lr, float reg_1, float reg_2, double *stats, double *epoch_acc, double *step_losses,
+                    hipStream_t s) {
+    SmallPlan pl;
+    pl.ukey = plan->ukey;
+    pl.ij = reinterpret_cast<const int2 *>(plan->uval);
+    pl.ekey = plan->ekey;
+    pl.esu = reinterpret_cast<const uint2 *>(plan->eval);
+    pl.umask = plan->umask; pl.imask = plan->imask;
+    pl.n = plan->n; pl.B = plan->batch_size; pl.nb = plan->num_batches;
+    const int d = ctx->d, dpad = small_dpad(d);
+    const size_t row_bytes = (size_t)plan->batch_size * dpad * sizeof(float);
+    const bool stage_p = 3 * row_bytes <= kSmallLdsRows;
+    const size_t shmem = (stage_p ? 3 : 2) * row_bytes;
+    int rc = dispatch_d(d, [&](auto cfg) {
+        using C = decltype(cfg);
+        auto launch = [&](auto kern) -> int {
+            DAISY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)kSmallLdsRows));
+            hipLaunchKernelGGL(kern, dim3(1), dim3(kSmallThreads), shmem, s, P, Q, pl, d, dpad, loss_type, gamma, lr,
+                               reg_1, reg_2, stats, epoch_acc, step_losses);
+            return DAISY_OK;
+        };
+        return stage_p ? launch(k_small_epoch<C, true>) : launch(k_small_epoch<C, false>);
+    });
+    if (rc) return rc;
+    DAISY_LAUNCH_CHECK();
+    ctx->p_sqnorm_of = nullptr;          // P rows changed behind the staged step's row-norm cache
+    ctx->batch_set = false;
+    ctx->fwd_done = false;
+    return DAISY_OK;
+}
+
+}  // namespace daisy

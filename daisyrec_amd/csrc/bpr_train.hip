@@ -1878,8 +1878,16 @@ int daisy_bpr_fit_epoch_sgd(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, fl
                             int32_t loss_type, float gamma, float lr, float reg_1, float reg_2,
                             float *gQ, double *stats, double *epoch_acc, double *step_losses,
                             int32_t item_mode, daisy_stream_t stream) {
-    DAISY_CHECK_ARG(ctx && plan, "fit_epoch: NULL argument");
+    DAISY_CHECK_ARG(ctx && plan && P && Q && stats, "fit_epoch: NULL argument");
     if (!plan->built) { set_error("fit_epoch: plan has not been built"); return DAISY_ERR_STATE; }
+    DAISY_CHECK_ARG(loss_type >= DAISY_LOSS_BPR && loss_type <= DAISY_LOSS_SL, "Invalid loss type: %d", loss_type);
+    // batches of a few hundred samples (the reference's default 256): all steps of the epoch inside one
+    // persistent workgroup - the step is bound by kernel-boundary latency there, not by bandwidth
+    if ((item_mode == DAISY_ITEM_CHUNKED || item_mode == DAISY_ITEM_FUSED) && small_epoch_supported(ctx, plan, loss_type)) {
+        DAISY_CHECK_ARG(plan->U == ctx->U && plan->I == ctx->I, "fit_epoch: plan does not fit the context");
+        return small_fit_epoch(ctx, plan, P, Q, loss_type, gamma, lr, reg_1, reg_2, stats, epoch_acc, step_losses,
+                               S(stream));
+    }
     for (int64_t k = 0; k < plan->num_batches; ++k) {
         int rc = daisy_bpr_set_batch_from_plan(ctx, plan, k, stream);
         if (rc) return rc;

@@ -187,8 +187,11 @@ class GeneralRecommender(AbstractRecommender):
         user_sorted = ops.triples_user_sorted(triples[:n])
         pointwise = loss_id in ops.POINTWISE_LOSSES      # rows are (user, item, label), sampler.py:93-98
         # the staged step over the partitioned plan: SGD, pairwise loss, no FM biases
-        staged = (item_mode == ops.ITEM_MODES["fused"] and adam is None and not pointwise and biases is None)
-        if item_mode == ops.ITEM_MODES["fused"] and not staged:
+        # (batches of a few hundred samples go through the sorted plan instead: fit_epoch_sgd then runs the
+        # whole epoch inside one persistent workgroup, csrc/bpr_small.hip)
+        staged = (item_mode == ops.ITEM_MODES["fused"] and adam is None and not pointwise and biases is None
+                  and B > ops.SMALL_BATCH_MAX)
+        if item_mode == ops.ITEM_MODES["fused"] and not staged and B > ops.SMALL_BATCH_MAX:
             item_mode = ops.ITEM_MODES["chunked"]
         index = None
         last_loss = 0.0

@@ -18,6 +18,7 @@ LOSS_IDS = {"BPR": N.LOSS_BPR, "HL": N.LOSS_HL, "TL": N.LOSS_TL, "CL": N.LOSS_CL
 POINTWISE_LOSSES = (N.LOSS_CL, N.LOSS_SL)
 ITEM_MODES = {"atomic": N.ITEM_ATOMIC, "sorted": N.ITEM_SORTED, "chunked": N.ITEM_CHUNKED,
               "fused": N.ITEM_FUSED}
+SMALL_BATCH_MAX = 256      # kSmallBatchMax (csrc/bpr_internal.h): fit_epoch_sgd runs such epochs in one persistent workgroup
 ORDER_MODES = {"identity": N.ORDER_IDENTITY, "perm": N.ORDER_PERM, "feistel": N.ORDER_FEISTEL}
 
 

@@ -64,7 +64,7 @@ class UserShardedBprTrainer:
     table; both are updated in place."""
 
     def __init__(self, ctx, P_local, Q, user_lo, lr, reg_1, reg_2, loss_type=N.LOSS_BPR,
-                 gamma=1e-10, item_mode=N.ITEM_FUSED, group=None, overlap=True):
+                 gamma=1e-10, item_mode=N.ITEM_FUSED, group=None, overlap=True, always_collective=False):
         self.ctx, self.P, self.Q = ctx, P_local, Q
         self.user_lo = int(user_lo)
         self.lr, self.reg_1, self.reg_2 = float(lr), float(reg_1), float(reg_2)
@@ -73,6 +73,9 @@ class UserShardedBprTrainer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.overlap = bool(overlap)
+        # issue the collectives even in a group of one rank (they are identities there): lets a single-GPU box
+        # drive the real RCCL entry points
+        self.collective = self.world > 1 or (bool(always_collective) and dist.is_initialized())
         if getattr(ctx, "_bias", None) is not None:
             # FM's bias gradients (stats[SUM_COEF], g_i_bias) are not part of either exchange: the replicas
             # would drift apart silently
@@ -83,7 +86,7 @@ class UserShardedBprTrainer:
             self.item_mode = N.ITEM_CHUNKED
         # collectives the backend lacks are emulated with the ones it has (gloo: no reduce_scatter);
         # "nccl" (= RCCL on ROCm) runs the real ones
-        self._native_rs = self.world > 1 and dist.get_backend(group) == "nccl"
+        self._native_rs = self.collective and dist.get_backend(group) == "nccl"
         if self.staged:
             I, d = Q.shape
             self.rows = (I + self.world - 1) // self.world          # item rows per owner
@@ -98,13 +101,13 @@ class UserShardedBprTrainer:
 
     # -- collectives -----------------------------------------------------------------------------
     def _all_reduce(self, t, async_op=False):
-        if self.world == 1:
+        if not self.collective:
             return None
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def _reduce_scatter(self, out, full):
         """out[rows] = sum over ranks of full[rank*rows:(rank+1)*rows]"""
-        if self.world == 1:
+        if not self.collective:
             out.copy_(full)
         elif self._native_rs:
             dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=self.group)
@@ -114,7 +117,7 @@ class UserShardedBprTrainer:
 
     def _all_gather_rows(self, full, own):
         """full[r*rows:(r+1)*rows] = rank r's `own`; `own` may be that very slice of `full`"""
-        if self.world == 1:
+        if not self.collective:
             return
         if self._native_rs:
             dist.all_gather_into_tensor(full, own, group=self.group)
@@ -162,7 +165,7 @@ class UserShardedBprTrainer:
         if n_own > 0:
             q_own = self.Q[self.own_lo:self.own_hi]
             c.item_apply_counts(q_own, self.g_own[:n_own], self.c_own[:n_own], self.lr, self.reg_1, self.reg_2)
-        if self.world > 1:
+        if self.collective:
             if self.Q_gather is self.Q:
                 self._all_gather_rows(self.Q, self.Q[self.own_lo:self.own_lo + self.rows])
             else:                                        # I not a multiple of the world size: padded staging
@@ -192,5 +195,5 @@ class UserShardedBprTrainer:
         c.user_sgd(self.P, self.Q, self.lr, self.reg_1, self.reg_2)   # overlaps the all-reduce
         if work is not None:
             work.wait()
-        c.item_sgd_apply(self.Q, self.lr, dense=self.world > 1)
+        c.item_sgd_apply(self.Q, self.lr, dense=self.collective)
         return c.stats

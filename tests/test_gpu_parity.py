@@ -377,8 +377,9 @@ def test_c2_scale_step_properties(ops):
 
 
 def test_sharded_trainer_on_rccl_world1(ops):
-    """The multi-GPU step protocol (daisyrec_amd/sharding.py) on the real backend: with one rank
-    the RCCL all-reduces are identities, so the sharded step must equal daisy_bpr_sgd_step."""
+    """The multi-GPU step protocols (daisyrec_amd/sharding.py) on the real backend: in a group of one rank
+    RCCL's all_reduce / reduce_scatter_tensor / all_gather_into_tensor are identities, so the sharded step
+    (staged and phase protocol) must equal the single-GPU step."""
     import os
     import torch.distributed as dist
     from daisyrec_amd.sharding import UserShardedBprTrainer
@@ -395,17 +396,20 @@ def test_sharded_trainer_on_rccl_world1(ops):
         Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
         tri = np.stack([rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)], 1).astype(np.int32)
         loss, Pn, Qn = O.mf_sgd_step(P0, Q0, tri[:, 0], tri[:, 1], tri[:, 2], 0.01, 1e-3, 1e-3)
-        for overlap in (True, False):
+        for overlap, mode in ((True, "fused"), (False, "fused"), (True, "chunked"), (False, "sorted")):
             P, Q = _t(P0), _t(Q0)
             ctx = ops.BprContext(B, d, U, I)
-            tr = UserShardedBprTrainer(ctx, P, Q, 0, 0.01, 1e-3, 1e-3, overlap=overlap)
-            tr.world = 2 if overlap else 1          # force the collective + dense-apply code path
+            tr = UserShardedBprTrainer(ctx, P, Q, 0, 0.01, 1e-3, 1e-3, overlap=overlap,
+                                       item_mode=ops.ITEM_MODES[mode], always_collective=True)
+            assert tr.collective and tr.staged == (mode == "fused")
             stats = tr.step_from_triples(_t(tri))
             torch.cuda.synchronize()
             assert abs(float(stats[7].cpu()) - loss) <= 1e-5 * abs(loss)
             np.testing.assert_allclose(P.cpu().numpy(), Pn, atol=3e-6)
             np.testing.assert_allclose(Q.cpu().numpy(), Qn, atol=3e-6)
             assert float(ctx.gQ.abs().max().cpu()) == 0.0
+            if tr.staged:
+                assert float(tr.gQ.abs().max().cpu()) == 0.0 and float(tr.cnt.abs().max().cpu()) == 0.0
             ctx.close()
     finally:
         if created:

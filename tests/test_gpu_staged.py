@@ -213,3 +213,42 @@ def test_partitioned_plan_refused_by_phase_kernels():
     with pytest.raises(RuntimeError):
         ctx.sgd_step(P, Q, 0.1, 0, 0, item_mode=ops.ITEM_MODES["chunked"])
     ctx.close(); plan.close(); index.close()
+
+
+@pytest.mark.parametrize("d,B,loss", [(32, 256, "BPR"), (64, 256, "HL"), (20, 100, "TL"), (128, 100, "BPR"), (8, 1, "BPR"), (256, 50, "BPR"), (100, 77, "BPR")])
+def test_small_batch_epoch_in_one_workgroup(d, B, loss):
+    """B <= 256 over the sorted plan: fit_epoch_sgd runs every step of the epoch inside one persistent
+    workgroup (csrc/bpr_small.hip).  Same users and items recur from step to step, so a stale cache line
+    between the phases or the steps would show; checked against the oracle stepping through the same batches."""
+    from daisyrec_amd import ops
+    U, I, n = 60, 45, 2600 if B > 1 else 40
+    tri = _triples(n, U, I, d + B)
+    P0, Q0 = _tables(U, I, d, B)
+    t_dev = torch.from_numpy(tri).to(DEV)
+    plan = ops.EpochPlan(n, U, I).build(t_dev, B, order="feistel", seed=3, epoch=2)
+    nb = plan.num_batches
+    lid = ops.LOSS_IDS[loss]
+    res = []
+    for env_small in (True, False):
+        P, Q = torch.from_numpy(P0).to(DEV), torch.from_numpy(Q0).to(DEV)
+        ctx = ops.BprContext(B, d, U, I)
+        sl = torch.zeros(nb, dtype=torch.float64, device=DEV)
+        mode = ops.ITEM_MODES["fused" if env_small else "sorted"]       # 'sorted' keeps the per-step phase kernels
+        ctx.fit_epoch_sgd(plan, P, Q, 0.05, 1e-3, 2e-3, loss_type=lid, item_mode=mode, step_losses=sl)
+        torch.cuda.synchronize()
+        res.append((P.cpu().numpy(), Q.cpu().numpy(), sl.cpu().numpy(), float(ctx.epoch_acc[0].cpu()),
+                    float(ctx.stats[7].cpu())))
+        ctx.close()
+    Pn, Qn = P0.astype(np.float64), Q0.astype(np.float64)
+    want = []
+    for k in range(nb):
+        u, i, j = (t.cpu().numpy().astype(np.int64) for t in plan.read_batch(k, B)[:3])
+        w, Pn, Qn = O.mf_sgd_step(Pn, Qn, u, i, j, 0.05, 1e-3, 2e-3, loss_type=lid)
+        want.append(w)
+    for P, Q, sl, acc, last in res:
+        np.testing.assert_allclose(sl, want, rtol=1e-5)
+        assert abs(acc - sum(want)) <= 1e-5 * abs(sum(want)) and abs(last - want[-1]) <= 1e-5 * abs(want[-1])
+        tol = 1e-5 * max(1.0, d / 64)            # fp32 dot products over d terms, nine collision-heavy steps
+        assert np.abs(P - Pn).max() < tol and np.abs(Q - Qn).max() < tol
+    assert np.abs(res[0][0] - res[1][0]).max() < 2e-6 and np.abs(res[0][1] - res[1][1]).max() < 2e-6
+    plan.close()
