@@ -1071,6 +1071,32 @@ __global__ __launch_bounds__(kBlock) void k_adam_dense(float *__restrict__ W, fl
     }
 }
 
+// torch.optim.Adagrad single-tensor math (defaults): state_sum.addcmul_(g, g); w.addcdiv_(g, sqrt(state_sum) + eps, -lr)
+__global__ __launch_bounds__(kBlock) void k_adagrad_dense(float *__restrict__ W, float *__restrict__ g,
+                                                          float *__restrict__ ss, int64_t n, float lr, float eps) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const float gg = g[e];
+        const float s2 = fmaf(gg, gg, ss[e]);
+        W[e] = W[e] - lr * (gg / (sqrtf(s2) + eps));
+        ss[e] = s2;
+        g[e] = 0.f;
+    }
+}
+
+// torch.optim.RMSprop single-tensor math (defaults): sq.mul_(alpha).addcmul_(g, g, 1-alpha); w.addcdiv_(g, sqrt(sq) + eps, -lr)
+__global__ __launch_bounds__(kBlock) void k_rmsprop_dense(float *__restrict__ W, float *__restrict__ g,
+                                                          float *__restrict__ sq, int64_t n, float lr, float alpha,
+                                                          float eps) {
+    const float w2 = 1.f - alpha;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const float gg = g[e];
+        const float s2 = fmaf(w2 * gg, gg, alpha * sq[e]);
+        W[e] = W[e] - lr * (gg / (sqrtf(s2) + eps));
+        sq[e] = s2;
+        g[e] = 0.f;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // plan construction (host side)
 // ---------------------------------------------------------------------------
@@ -1844,6 +1870,23 @@ int daisy_adam_dense(float *W, float *g, float *m, float *v, int64_t n, float lr
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(k_adam_dense, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, S(stream), W, g, m,
                        v, n, (float)((double)lr / bc1), beta1, beta2, eps, (float)sqrt(bc2));
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int daisy_adagrad_dense(float *W, float *g, float *state_sum, int64_t n, float lr, float eps, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(W && g && state_sum && n > 0, "adagrad_dense: bad argument");
+    hipLaunchKernelGGL(k_adagrad_dense, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, S(stream), W, g, state_sum, n, lr,
+                       eps);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int daisy_rmsprop_dense(float *W, float *g, float *square_avg, int64_t n, float lr, float alpha, float eps,
+                        daisy_stream_t stream) {
+    DAISY_CHECK_ARG(W && g && square_avg && n > 0, "rmsprop_dense: bad argument");
+    hipLaunchKernelGGL(k_rmsprop_dense, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, S(stream), W, g, square_avg, n,
+                       lr, alpha, eps);
     DAISY_LAUNCH_CHECK();
     return DAISY_OK;
 }

@@ -22,7 +22,7 @@ try:  # the reference shows a tqdm bar (AbstractRecommender.py:116); optional he
 except Exception:  # pragma: no cover
     _tqdm = None
 
-NATIVE_OPTIMIZERS = ("sgd", "adam")
+NATIVE_OPTIMIZERS = ("sgd", "adam", "adagrad", "rmsprop")
 KNOWN_OPTIMIZERS = ("adam", "sgd", "adagrad", "rmsprop", "sparse_adam")
 
 
@@ -67,17 +67,18 @@ class AbstractRecommender(nn.Module):
         raise NotImplementedError
 
     def _resolve_optimizer(self, name=None):
-        """AbstractRecommender.py:48-67: unknown names fall back to Adam with a log
-        line.  Known torch optimisers without a HIP kernel are refused loudly
-        instead of silently running something else."""
+        """AbstractRecommender.py:48-67: unknown names fall back to Adam with a log line.  'sparse_adam'
+        builds optim.SparseAdam in the reference, which refuses the dense gradients of its (non-sparse)
+        nn.Embedding tables at the first step: the same RuntimeError is raised here (pinned by
+        tests/golden/kat_optimizers.npz)."""
         name = str(self.optimizer if name is None else name).lower()
         if name not in KNOWN_OPTIMIZERS:
             if self.logger is not None:
                 self.logger.info("Received unrecognized optimizer, set default Adam optimizer")
             name = "adam"
-        if name not in NATIVE_OPTIMIZERS:
-            raise NotImplementedError(
-                f"optimizer '{name}' has no HIP kernel on the MF hot path (native: {NATIVE_OPTIMIZERS})")
+        if name == "sparse_adam":
+            raise RuntimeError("SparseAdam does not support dense gradients, please consider Adam instead")
+        assert name in NATIVE_OPTIMIZERS
         return name
 
     def _init_weight(self, m):
@@ -179,7 +180,7 @@ class GeneralRecommender(AbstractRecommender):
         ctx = ops.BprContext(B, P.shape[1], P.shape[0], Q.shape[0], device=P.device)
         plan = ops.EpochPlan(n, P.shape[0], Q.shape[0], device=P.device)
         biases = self._biases() if hasattr(self, "_biases") else None     # FM: (u_bias, i_bias, bias_)
-        adam = _AdamState(P, Q, self.lr, biases) if opt == "adam" else None
+        adam = _AdamState(P, Q, self.lr, biases, kind=opt) if opt != "sgd" else None      # any dense optimiser but SGD
         if biases is not None:
             g_i_bias = adam.g[1] if adam is not None else torch.zeros(Q.shape[0], device=P.device)
             ctx.set_bias(*biases, g_u_bias=adam.g[0] if adam is not None else None, g_i_bias=g_i_bias,
@@ -257,26 +258,23 @@ class GeneralRecommender(AbstractRecommender):
 
 
 class _AdamState:
-    """Dense torch.optim.Adam state for the two tables (AbstractRecommender.py:54)."""
+    """Dense optimiser state (torch.optim.Adam by default; Adagrad / RMSprop through `kind`) for the two tables
+    and, for FM, the three bias tensors (AbstractRecommender.py:54-61)."""
 
-    def __init__(self, P, Q, lr, biases=None):
-        self.lr, self.t = lr, 0
+    def __init__(self, P, Q, lr, biases=None, kind="adam"):
+        self.opt = ops.DenseOptimizer(kind, lr)
         self.gP = torch.zeros_like(P)
-        self.mP, self.vP = torch.zeros_like(P), torch.zeros_like(P)
-        self.mQ, self.vQ = torch.zeros_like(Q), torch.zeros_like(Q)
-        # FM: dense Adam state and gradient buffers of (u_bias, i_bias, bias_)
+        # FM: gradient buffers of (u_bias, i_bias, bias_)
         self.w = [] if biases is None else [b.view(-1) for b in biases]
         self.g = [torch.zeros_like(b) for b in self.w]
-        self.m = [torch.zeros_like(b) for b in self.w]
-        self.v = [torch.zeros_like(b) for b in self.w]
 
     def step(self, ctx, P, Q, reg_1, reg_2, loss_id, item_mode):
-        self.t += 1
+        self.opt.next_step()
         ctx.forward(P, Q, loss_id)
         ctx.finalize(reg_1, reg_2)
         ctx.item_grad(P, Q, reg_1, reg_2, item_mode)
         ctx.user_grad(P, Q, reg_1, reg_2, self.gP)
-        ops.adam_dense(P, self.gP, self.mP, self.vP, self.lr, self.t)
-        ops.adam_dense(Q, ctx.gQ, self.mQ, self.vQ, self.lr, self.t)   # also zeroes gQ
-        for w, g, m, v in zip(self.w, self.g, self.m, self.v):
-            ops.adam_dense(w, g, m, v, self.lr, self.t)
+        self.opt.step(P, self.gP)
+        self.opt.step(Q, ctx.gQ)          # also zeroes gQ
+        for w, g in zip(self.w, self.g):
+            self.opt.step(w, g)

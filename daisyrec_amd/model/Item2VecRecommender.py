@@ -80,7 +80,7 @@ class Item2Vec(GeneralRecommender):
         if train_loader.drop_last:
             n = (n // B) * B
         gA, gB = torch.zeros_like(S), torch.zeros_like(S)
-        m, v = (torch.zeros_like(S), torch.zeros_like(S)) if opt == "adam" else (None, None)
+        optim = ops.DenseOptimizer(opt, self.lr)
         ctx = ops.BprContext(min(B, max(n, 1)), S.shape[1], S.shape[0], S.shape[0], device=S.device)
         ctx.set_pointwise(True)
         self.epoch_losses, last_loss, step = [], 0.0, 0
@@ -97,10 +97,8 @@ class Item2Vec(GeneralRecommender):
                     t, c, y = (rows[:, k].contiguous() for k in range(3))
                     step += 1
                     self._step(ctx, S, gA, gB, t, c, y)
-                    if opt == "adam":
-                        ops.adam_dense(S, gA, m, v, self.lr, step)          # also clears gA
-                    else:
-                        ops.sgd_dense(S, gA, self.lr)
+                    optim.next_step()
+                    optim.step(S, gA)          # also clears the gradient
                 acc = ctx.epoch_acc.cpu()
                 current_loss = float(acc[0])
                 if float(acc[1]) > 0 or current_loss != current_loss:

@@ -142,7 +142,7 @@ class LightGCN(GeneralRecommender):
             n = (n // B) * B
         out, G, dE0 = torch.empty_like(E0), torch.empty_like(E0), torch.zeros_like(E0)
         gflat = dE0.view(-1)
-        m, v = (torch.zeros_like(self._flat), torch.zeros_like(self._flat)) if opt == "adam" else (None, None)
+        optim = ops.DenseOptimizer(opt, self.lr)
         ctx = ops.BprContext(min(B, max(n, 1)), self.factors, self.user_num, self.item_num, device=self.device)
         ctx.set_pointwise(loss_id in ops.POINTWISE_LOSSES)
         self.epoch_losses, last_loss, step = [], 0.0, 0
@@ -159,10 +159,8 @@ class LightGCN(GeneralRecommender):
                     u, i, j = (rows[:, k].contiguous() for k in range(3))
                     step += 1
                     self._batch_grads(ctx, E0, out, G, dE0, u, i, j, loss_id)
-                    if opt == "adam":
-                        ops.adam_dense(self._flat, gflat, m, v, self.lr, step)     # also clears the gradient
-                    else:
-                        ops.sgd_dense(self._flat, gflat, self.lr)
+                    optim.next_step()
+                    optim.step(self._flat, gflat)          # also clears the gradient
                 acc = ctx.epoch_acc.cpu()
                 current_loss = float(acc[0])
                 if float(acc[1]) > 0 or current_loss != current_loss:

@@ -178,7 +178,7 @@ class NeuMF(GeneralRecommender):
             n = (n // B) * B
         gflat = torch.zeros_like(self._flat)
         grads = self._views_like_flat(gflat)
-        m, v = (torch.zeros_like(self._flat), torch.zeros_like(self._flat)) if opt == "adam" else (None, None)
+        optim = ops.DenseOptimizer(opt, self.lr)
         ctx = self._ctx(2 * min(B, max(n, 1)))
         acc = torch.zeros(2, dtype=torch.float64, device=self.device)
         self.epoch_losses, last_loss, step = [], 0.0, 0
@@ -197,10 +197,8 @@ class NeuMF(GeneralRecommender):
                     ctx.step_grads(p, grads, u, i, j, loss_id, self.reg_1, self.reg_2, dropout=self.dropout,
                                    seed=(self.seed << 32) | step)
                     acc[0] += ctx.stats[N.NST_LOSS]
-                    if opt == "adam":
-                        ops.adam_dense(self._flat, gflat, m, v, self.lr, step)
-                    else:
-                        ops.sgd_dense(self._flat, gflat, self.lr)
+                    optim.next_step()
+                    optim.step(self._flat, gflat)          # also clears the gradient
                 current_loss = float(acc[0].cpu())
                 if current_loss != current_loss or current_loss in (float("inf"), float("-inf")):
                     raise ValueError("Loss=Nan or Infinity: current settings does not fit the recommender")

@@ -369,6 +369,47 @@ def adam_dense(W, g, m, v, lr, step, beta1=0.9, beta2=0.999, eps=1e-8):
                                float(lr), float(beta1), float(beta2), float(eps), int(step), _stream()))
 
 
+def adagrad_dense(W, g, state_sum, lr, eps=1e-10):
+    check(lib.daisy_adagrad_dense(_ptr(W, torch.float32, "W"), _ptr(g, torch.float32, "g"),
+                                  _ptr(state_sum, torch.float32, "state_sum"), W.numel(), float(lr), float(eps), _stream()))
+
+
+def rmsprop_dense(W, g, square_avg, lr, alpha=0.99, eps=1e-8):
+    check(lib.daisy_rmsprop_dense(_ptr(W, torch.float32, "W"), _ptr(g, torch.float32, "g"),
+                                  _ptr(square_avg, torch.float32, "square_avg"), W.numel(), float(lr), float(alpha),
+                                  float(eps), _stream()))
+
+
+class DenseOptimizer:
+    """The dense torch optimisers of AbstractRecommender._build_optimizer (:48-67) on the native kernels, one
+    state per parameter tensor: 'sgd', 'adam', 'adagrad', 'rmsprop' (torch defaults).  step() consumes and clears g."""
+
+    KINDS = ("sgd", "adam", "adagrad", "rmsprop")
+
+    def __init__(self, kind: str, lr: float):
+        if kind not in self.KINDS:
+            raise ValueError(f"DenseOptimizer: unknown kind {kind!r}")
+        self.kind, self.lr, self.t, self._state = kind, float(lr), 0, {}
+
+    def next_step(self):
+        """Advance the (shared) step count: once per optimizer.step() of the reference."""
+        self.t += 1
+
+    def step(self, W, g):
+        W, g = W.view(-1), g.view(-1)
+        if self.kind == "sgd":
+            return sgd_dense(W, g, self.lr)
+        st = self._state.get(W.data_ptr())
+        if st is None:
+            st = self._state[W.data_ptr()] = tuple(torch.zeros_like(W) for _ in range(2 if self.kind == "adam" else 1))
+        if self.kind == "adam":
+            adam_dense(W, g, st[0], st[1], self.lr, max(self.t, 1))
+        elif self.kind == "adagrad":
+            adagrad_dense(W, g, st[0], self.lr)
+        else:
+            rmsprop_dense(W, g, st[0], self.lr)
+
+
 def _bias_ptrs(biases):
     if biases is None:
         return None, None, None

@@ -275,6 +275,15 @@ int daisy_bpr_item_sgd_apply(daisy_bpr_ctx *ctx, float *Q, float *gQ, float lr, 
 int daisy_adam_dense(float *W, float *g, float *m, float *v, int64_t n, float lr, float beta1,
                      float beta2, float eps, int64_t step, daisy_stream_t stream);
 
+/* torch.optim.Adagrad.step / torch.optim.RMSprop.step with torch's defaults (AbstractRecommender.py:58,60;
+ * Adagrad: lr_decay 0, eps 1e-10; RMSprop: alpha 0.99, eps 1e-8, no momentum), dense like the reference;
+ * g is zeroed.  (optim.SparseAdam, :62, refuses the reference's dense embedding gradients at its first step:
+ * the host mirror raises the same RuntimeError.) */
+int daisy_adagrad_dense(float *W, float *g, float *state_sum, int64_t n, float lr, float eps,
+                        daisy_stream_t stream);
+int daisy_rmsprop_dense(float *W, float *g, float *square_avg, int64_t n, float lr, float alpha, float eps,
+                        daisy_stream_t stream);
+
 /* One whole `zero_grad / calc_loss / backward / SGD.step` on one GPU
  * (AbstractRecommender.py:119-128) for the batch set by daisy_bpr_set_batch*. */
 int daisy_bpr_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t loss_type, float gamma,

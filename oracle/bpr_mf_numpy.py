@@ -180,6 +180,38 @@ class DenseAdam:
         return out
 
 
+class DenseAdagrad:
+    """torch.optim.Adagrad defaults (AbstractRecommender.py:58): lr_decay 0, eps 1e-10, accumulator 0, dense:
+    state_sum += g*g;  w -= lr * g / (sqrt(state_sum) + eps)   (rows with a zero gradient do not move)."""
+
+    def __init__(self, shapes, lr, eps=1e-10, dtype=np.float64):
+        self.lr, self.eps, self.dtype = lr, eps, dtype
+        self.ss = [np.zeros(s, dtype=dtype) for s in shapes]
+
+    def step(self, params, grads):
+        out = []
+        for k, (w, g) in enumerate(zip(params, grads)):
+            self.ss[k] = self.ss[k] + g * g
+            out.append((np.asarray(w, dtype=self.dtype) - self.lr * g / (np.sqrt(self.ss[k]) + self.eps)).astype(np.float32))
+        return out
+
+
+class DenseRMSprop:
+    """torch.optim.RMSprop defaults (AbstractRecommender.py:60): alpha 0.99, eps 1e-8, no momentum, not centered:
+    sq = alpha*sq + (1-alpha)*g*g;  w -= lr * g / (sqrt(sq) + eps)   (sq of EVERY row decays every step)."""
+
+    def __init__(self, shapes, lr, alpha=0.99, eps=1e-8, dtype=np.float64):
+        self.lr, self.alpha, self.eps, self.dtype = lr, alpha, eps, dtype
+        self.sq = [np.zeros(s, dtype=dtype) for s in shapes]
+
+    def step(self, params, grads):
+        out = []
+        for k, (w, g) in enumerate(zip(params, grads)):
+            self.sq[k] = self.alpha * self.sq[k] + (1 - self.alpha) * g * g
+            out.append((np.asarray(w, dtype=self.dtype) - self.lr * g / (np.sqrt(self.sq[k]) + self.eps)).astype(np.float32))
+        return out
+
+
 def mf_rank(P, Q, us, cands, topk):
     """MFRecommender.py:106-123: scores = bmm; argsort(descending); gather ids;
     first topk.  Ties broken by candidate position (stable), ids returned as

@@ -147,6 +147,26 @@ def make_kat_steps():
     print("kat_steps.npz:", names)
 
 
+def make_kat_optimizers():
+    """kat_optimizers.npz: the remaining branches of _build_optimizer (AbstractRecommender.py:56-61) -
+    optim.Adagrad / optim.RMSprop with torch's defaults, and what optim.SparseAdam does on the reference's
+    dense nn.Embedding gradients (it refuses them)."""
+    rng = np.random.default_rng(20220926)
+    out, names = {}, []
+    for (name, opt, lr, ns) in (("bpr_adagrad", "adagrad", 0.01, 4), ("bpr_rmsprop", "rmsprop", 0.001, 4),
+                                ("tl_adagrad", "adagrad", 0.05, 3)):
+        out.update(kat_case(name, 50, 40, 32, 64, "TL" if name.startswith("tl") else "BPR", opt, 1e-3, 1e-3, lr, ns, rng))
+        names.append(name)
+    out["names"] = np.array(names)
+    try:
+        kat_case("x", 10, 10, 8, 4, "BPR", "sparse_adam", 0.0, 0.0, 0.01, 1, rng)
+        out["sparse_adam_error"] = np.array("")
+    except RuntimeError as e:
+        out["sparse_adam_error"] = np.array(str(e))
+    np.savez_compressed(os.path.join(HERE, "kat_optimizers.npz"), **out)
+    print("kat_optimizers.npz:", names, "| sparse_adam:", out["sparse_adam_error"])
+
+
 # ----------------------------------------------------------------------------
 class _TqdmCapture:
     """Stand-in for tqdm inside GeneralRecommender.fit (AbstractRecommender.py:116-129)
@@ -255,3 +275,4 @@ if __name__ == "__main__":  # pragma: no cover
     make_rank_kat()
     make_ml100k()
     make_ml100k(out="ml100k_c1_adam.npz", optimizer="adam", lr=0.001)
+    make_kat_optimizers()

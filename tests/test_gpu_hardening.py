@@ -42,6 +42,46 @@ def test_kat_adam_every_item_mode(ops, kat_steps, mode):
     ctx.close()
 
 
+@pytest.mark.parametrize("mode", ["chunked", "sorted"])
+def test_kat_adagrad_rmsprop(ops, mode):
+    """optim.Adagrad / optim.RMSprop (AbstractRecommender.py:58,60) against the reference's vectors."""
+    import os
+    from conftest import GOLDEN
+    from daisyrec_amd.model.AbstractRecommender import _AdamState
+    g = np.load(os.path.join(GOLDEN, "kat_optimizers.npz"))
+    for name in g["names"]:
+        U, I, d, B, ns = (int(x) for x in g[f"{name}/meta"])
+        lr, r1, r2 = (float(x) for x in g[f"{name}/hyper"])
+        P, Q = _t(g[f"{name}/P0"]), _t(g[f"{name}/Q0"])
+        ctx = ops.BprContext(B, d, U, I)
+        st = _AdamState(P, Q, lr, kind=str(g[f"{name}/optimizer"]))
+        for s in range(ns):
+            ctx.set_batch(_t(g[f"{name}/u"][s]), _t(g[f"{name}/i"][s]), _t(g[f"{name}/j"][s]))
+            st.step(ctx, P, Q, r1, r2, ops.LOSS_IDS[str(g[f"{name}/loss_type"])], ops.ITEM_MODES[mode])
+            ref = float(g[f"{name}/loss"][s])
+            assert abs(float(ctx.stats[7].cpu()) - ref) <= 1e-5 * abs(ref), (name, s)
+            np.testing.assert_allclose(P.cpu().numpy(), g[f"{name}/P"][s], rtol=0, atol=4e-6, err_msg=f"{name} {s}")
+            np.testing.assert_allclose(Q.cpu().numpy(), g[f"{name}/Q"][s], rtol=0, atol=4e-6, err_msg=f"{name} {s}")
+        ctx.close()
+
+
+def test_every_mirror_trains_with_adagrad_and_rmsprop():
+    """the optimiser name travels through MF / FM fit (dense state per tensor)"""
+    from daisyrec_amd.model.FMRecommender import FM
+    from daisyrec_amd.model.MFRecommender import MF
+    from daisyrec_amd.utils.dataset import BasicDataset, get_dataloader
+    rng = np.random.default_rng(4)
+    tri = np.stack([rng.integers(0, 30, 600), rng.integers(0, 20, 600), rng.integers(0, 20, 600)], 1).astype(np.int32)
+    for cls in (MF, FM):
+        for opt in ("adagrad", "rmsprop"):
+            model = cls(mf_config(user_num=30, item_num=20, epochs=3, factors=8, optimizer=opt, lr=0.01))
+            model.fit(get_dataloader(BasicDataset(tri), batch_size=128, shuffle=True, num_workers=0))
+            assert len(model.epoch_losses) == 3 and model.epoch_losses[-1] < model.epoch_losses[0]
+        with pytest.raises(RuntimeError, match="SparseAdam"):
+            cls(mf_config(user_num=30, item_num=20, epochs=1, factors=8, optimizer="sparse_adam")).fit(
+                get_dataloader(BasicDataset(tri), batch_size=128, shuffle=True, num_workers=0))
+
+
 def test_ml100k_c1_adam_through_the_dropin():
     """BASELINE configs[0] with `--optimizer adam --lr 0.001`: 3 epochs of dense Adam through MF.fit against the
     golden reference run (tests/golden/ml100k_c1_adam.npz, make_golden.py)."""

@@ -48,9 +48,11 @@ def test_error_behaviour_matches_reference():
         m._build_criterion(m.loss_type)
     m = MF(mf_config(user_num=5, item_num=7, optimizer="nonsense"))
     assert m._resolve_optimizer() == "adam"           # AbstractRecommender.py:63-65
-    m = MF(mf_config(user_num=5, item_num=7, optimizer="rmsprop"))
-    with pytest.raises(NotImplementedError):
-        m._resolve_optimizer()
+    for name in ("rmsprop", "Adagrad", "SGD", "adam"):         # AbstractRecommender.py:52-61 (case-insensitive)
+        assert MF(mf_config(user_num=5, item_num=7, optimizer=name))._resolve_optimizer() == name.lower()
+    m = MF(mf_config(user_num=5, item_num=7, optimizer="sparse_adam"))
+    with pytest.raises(RuntimeError, match="SparseAdam does not support dense gradients"):
+        m._resolve_optimizer()                        # what optim.SparseAdam.step() says on the reference's dense grads
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no CPU fallback"):
             m.fit(None)

@@ -89,7 +89,8 @@ def test_optimizer_and_loss_names_follow_the_reference():
     from daisyrec_amd.model.FMRecommender import FM
     m = FM(mf_config(user_num=5, item_num=5, factors=8, optimizer="nonsense"))
     assert m._resolve_optimizer() == "adam"                 # unknown -> Adam with a log line (AbstractRecommender.py:63-65)
-    with pytest.raises(NotImplementedError):
-        FM(mf_config(user_num=5, item_num=5, factors=8, optimizer="rmsprop"))._resolve_optimizer()
+    assert FM(mf_config(user_num=5, item_num=5, factors=8, optimizer="rmsprop"))._resolve_optimizer() == "rmsprop"
+    with pytest.raises(RuntimeError, match="SparseAdam"):
+        FM(mf_config(user_num=5, item_num=5, factors=8, optimizer="sparse_adam"))._resolve_optimizer()
     with pytest.raises(NotImplementedError):
         m._build_criterion("XX")

@@ -154,3 +154,26 @@ def test_torch_port_matches_golden(kat_steps):
         assert abs(loss - g[f"{name}/loss"][s]) <= 1e-6 * abs(g[f"{name}/loss"][s])
         np.testing.assert_allclose(m.embed_user.weight.detach().numpy(), g[f"{name}/P"][s], atol=1e-7)
         np.testing.assert_allclose(m.embed_item.weight.detach().numpy(), g[f"{name}/Q"][s], atol=1e-7)
+
+
+def test_adagrad_rmsprop_restatements_match_the_reference():
+    """oracle.DenseAdagrad / DenseRMSprop against optim.Adagrad / optim.RMSprop driven by the reference's MF
+    (tests/golden/kat_optimizers.npz, make_golden.py::make_kat_optimizers); and what the reference's
+    'sparse_adam' branch actually does."""
+    import os
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "kat_optimizers.npz"))
+    assert "SparseAdam does not support dense gradients" in str(g["sparse_adam_error"])
+    for name in g["names"]:
+        U, I, d, B, ns = (int(x) for x in g[f"{name}/meta"])
+        lr, r1, r2 = (float(x) for x in g[f"{name}/hyper"])
+        lt = O.LOSS_IDS[str(g[f"{name}/loss_type"])]
+        cls = O.DenseAdagrad if str(g[f"{name}/optimizer"]) == "adagrad" else O.DenseRMSprop
+        opt = cls([(U, d), (I, d)], lr)
+        P, Q = g[f"{name}/P0"], g[f"{name}/Q0"]
+        for s in range(ns):
+            loss, gP, gQ = O.mf_pair_grad(P, Q, g[f"{name}/u"][s], g[f"{name}/i"][s], g[f"{name}/j"][s], r1, r2, lt)
+            assert abs(loss - float(g[f"{name}/loss"][s])) <= 2e-6 * abs(loss)
+            P, Q = opt.step([P, Q], [gP, gQ])
+            np.testing.assert_allclose(P, g[f"{name}/P"][s], atol=3e-6)
+            np.testing.assert_allclose(Q, g[f"{name}/Q"][s], atol=3e-6)
