@@ -117,9 +117,10 @@ SIGNATURES = {
     "daisy_lgcn_graph_bytes": (_sz, [_p]),
     "daisy_lgcn_graph_read": (C.c_int, [_p, _p, _p, _p, _p]),
     "daisy_lgcn_spmm": (C.c_int, [_p, _p, _p, _i32, _p]),
+    "daisy_lgcn_spmm_rows": (C.c_int, [_p, _p, _p, _i32, _i64, _i64, _p]),
     "daisy_lgcn_propagate": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p]),
     "daisy_lgcn_backprop": (C.c_int, [_p, _p, _i32, _i32, _p, _p, _p]),
-    "daisy_lgcn_reg_grad": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i32, _i32, _f32, _f32, _p, _p, _p]),
+    "daisy_lgcn_reg_grad": (C.c_int, [_p, _p, _p, _p, _i64, _i64, _i64, _i32, _i32, _f32, _f32, _p, _p, _p, _p]),
     "daisy_axpby_f32": (C.c_int, [_p, _f32, _f32, _p, _i64, _i32, _p]),
     "daisy_csr_row_sum": (C.c_int, [_p, _p, _p, _i64, _i32, _p, _p]),
     "daisy_csr_workspace_bytes": (_sz, [_i64]),

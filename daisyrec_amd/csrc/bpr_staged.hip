@@ -1168,8 +1168,9 @@ static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_ty
     UserEdges ed{ctx->edge_vec, ctx->edge_user, ctx->edge_n, ctx->edge_whole};
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
+        static const int tune_ug = getenv("DAISY_STAGED_UGRID") ? atoi(getenv("DAISY_STAGED_UGRID")) : kMaxGrid;
         const int64_t nchunks = (v.B + StagedUserCfg<C>::E - 1) / StagedUserCfg<C>::E;
-        const int gu = grid_for(nchunks, 1, kMaxGrid);
+        const int gu = grid_for(nchunks, 1, tune_ug < kMaxGrid ? tune_ug : kMaxGrid);
         *grid_out = gu;
 #define DAISY_LAUNCH_SU(PM, HP)                                                                                   \
         hipLaunchKernelGGL((k_staged_user<C, PM, HP>), dim3(gu), dim3(kBlock), 0, s, P, Q, v, d, stats, lr, reg_1, \
@@ -1198,7 +1199,8 @@ static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
         const int64_t nchunks = (v.E + StagedItemCfg<C>::E - 1) / StagedItemCfg<C>::E;
-        const dim3 g(grid_for(v.E, StagedItemCfg<C>::E, 16384)), b(kBlock), ge(grid_for(nchunks, C::GROUPS_PER_BLOCK));
+        static const int tune_ig = getenv("DAISY_STAGED_IGRID") ? atoi(getenv("DAISY_STAGED_IGRID")) : 16384;
+        const dim3 g(grid_for(v.E, StagedItemCfg<C>::E, tune_ig)), b(kBlock), ge(grid_for(nchunks, C::GROUPS_PER_BLOCK));
 #define DAISY_LAUNCH_SI(PM, AP)                                                                                   \
         do {                                                                                                     \
             hipLaunchKernelGGL((k_staged_item<C, PM, AP>), g, b, 0, s, ctx->p_stage, ctx->coef, v, d, Qo, cnt_out, \

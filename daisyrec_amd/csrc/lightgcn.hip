@@ -3,6 +3,8 @@
 // The sparse x dense products run on the item pass's segmented-reduction kernel (segsum_rows in
 // bpr_train.hip): random 256-byte row gathers, 16 rows in flight per lane group, single-owner
 // stores - an HBM-bound kernel, no MFMA.  Everything else of a LightGCN step is the MF path.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace daisy {
@@ -113,26 +115,39 @@ __global__ void k_axpby_zero(float *__restrict__ x, float a, float b, float *__r
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_lg_reg(const float *__restrict__ E0, const int32_t *__restrict__ u,
-                                                   const int32_t *__restrict__ i, const int32_t *__restrict__ j,
-                                                   int64_t B, int64_t U, int d, int pointwise, float reg_1,
-                                                   float reg_2, const double *__restrict__ stats,
-                                                   float *__restrict__ dE0) {
+// regulariser gradient on the ego rows of a batch, in two deterministic passes: integer occurrence counts per
+// node (as user | positive item, as negative item), then ONE update per touched row
+//   dE0[row] += n_a * (reg_1*sign(e) + r_a*e) + n_b * (reg_1*sign(e) + r_b*e)
+// (fp32 atomics would add the positive-slot and negative-slot terms of an item in arrival order: the replicas
+// of a multi-GPU training drift apart by an ulp per step)
+__global__ void k_lg_reg_count(const int32_t *__restrict__ u, const int32_t *__restrict__ i,
+                               const int32_t *__restrict__ j, int64_t B, int64_t U, int pointwise,
+                               int32_t *__restrict__ cnt) {
+    for (int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; b < B; b += (int64_t)gridDim.x * blockDim.x) {
+        atomicAdd(cnt + 2 * (int64_t)u[b], 1);
+        atomicAdd(cnt + 2 * (U + i[b]), 1);
+        if (!pointwise) atomicAdd(cnt + 2 * (U + j[b]) + 1, 1);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_lg_reg_apply(const float *__restrict__ E0, int64_t N, int64_t U, int d,
+                                                         float reg_1, float reg_2, const double *__restrict__ stats,
+                                                         int32_t *__restrict__ cnt, float *__restrict__ dE0) {
     const int lane = threadIdx.x % 16, group = threadIdx.x / 16;
     auto inv = [&](double x) { return x > 0.0 ? (float)((double)reg_2 / x) : 0.f; };   // d|X|_F/dX = 0 at X = 0
     const float r_u = inv(stats[DAISY_ST_NORM_U]), r_i = inv(stats[DAISY_ST_NORM_I]), r_j = inv(stats[DAISY_ST_NORM_J]);
     const int64_t gstride = (int64_t)gridDim.x * (kBlock / 16);
-    const int nrows = pointwise ? 2 : 3;
-    for (int64_t t = (int64_t)blockIdx.x * (kBlock / 16) + group; t < B * nrows; t += gstride) {
-        const int64_t b = t / nrows;
-        const int which = (int)(t % nrows);
-        const int64_t row = which == 0 ? (int64_t)u[b] : (U + (which == 1 ? i[b] : j[b]));
-        const float r = which == 0 ? r_u : (which == 1 ? r_i : r_j);
+    for (int64_t row = (int64_t)blockIdx.x * (kBlock / 16) + group; row < N; row += gstride) {
+        const int na = cnt[2 * row], nb = cnt[2 * row + 1];
+        if (na == 0 && nb == 0) continue;
+        const float fa = (float)na, fb = (float)nb;
+        const float ra = row < U ? r_u : r_i;
         for (int c = lane; c < d; c += 16) {
             const float e = E0[row * d + c];
-            const float g = fmaf(r, e, reg_1 * sgn(e));
-            if (g != 0.f) unsafeAtomicAdd(dE0 + row * d + c, g);
+            const float g = fa * fmaf(ra, e, reg_1 * sgn(e)) + fb * fmaf(r_j, e, reg_1 * sgn(e));
+            dE0[row * d + c] += g;
         }
+        if (lane == 0) { cnt[2 * row] = 0; cnt[2 * row + 1] = 0; }      // leave the workspace clean
     }
 }
 
@@ -152,7 +167,22 @@ struct daisy_lgcn_graph {
     int edge_d;
     float *edge_vec, *edge_b;
     int32_t *edge_item, *edge_whole;
+    int64_t *row_ptr_host;   // [N+1] first entry of every row (lazy: daisy_lgcn_spmm_rows)
 };
+
+// row_ptr[r] = first entry e with ekey[e] >= r << 1
+__global__ void k_lg_row_ptr(const uint32_t *__restrict__ ekey, int64_t nnz, int64_t N, int64_t *__restrict__ row_ptr) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r <= N; r += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t target = (uint64_t)r << 1;
+        int64_t lo = 0, hi = nnz;
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((uint64_t)ekey[mid] < target) lo = mid + 1;
+            else hi = mid;
+        }
+        row_ptr[r] = lo;
+    }
+}
 
 // (re)allocate the edge-record scratch of the products for row width d
 static int ensure_edges(daisy_lgcn_graph *g, int d) {
@@ -215,6 +245,7 @@ int daisy_lgcn_graph_create(daisy_lgcn_graph **out, const int32_t *users, const 
     g->U = user_num; g->I = item_num; g->nnz = 2 * m;
     g->reproducible = 0;
     g->edge_arena = nullptr; g->edge_d = 0;
+    g->row_ptr_host = nullptr;
     size_t goff = 0;
     auto gtake = [&](size_t bytes) { size_t o = goff; goff += align_up(bytes); return o; };
     const size_t g_k = gtake((size_t)g->nnz * 4), g_s = gtake((size_t)g->nnz * 8), g_c = gtake((size_t)g->nnz * 8);
@@ -247,6 +278,7 @@ int daisy_lgcn_graph_destroy(daisy_lgcn_graph *g) {
     if (!g) return DAISY_OK;
     if (g->arena) (void)hipFree(g->arena);
     if (g->edge_arena) (void)hipFree(g->edge_arena);
+    if (g->row_ptr_host) free(g->row_ptr_host);
     delete g;
     return DAISY_OK;
 }
@@ -285,6 +317,52 @@ int daisy_lgcn_spmm(const daisy_lgcn_graph *g, const float *X, float *Y, int32_t
     if (rc) return rc;
     return segsum_rows(X, g->coef, g->ekey, g->esu, g->nnz, d, Y, gm->edge_vec, gm->edge_item, gm->edge_b,
                        gm->edge_whole, s);
+}
+
+int daisy_lgcn_spmm_rows(const daisy_lgcn_graph *g, const float *X, float *Yrows, int32_t d, int64_t row_lo,
+                         int64_t row_hi, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(g && X && Yrows && d > 0, "lgcn_spmm_rows: bad argument");
+    const int64_t N = g->U + g->I;
+    DAISY_CHECK_ARG(row_lo >= 0 && row_lo <= row_hi && row_hi <= N, "lgcn_spmm_rows: rows %lld..%lld outside 0..%lld",
+                    (long long)row_lo, (long long)row_hi, (long long)N);
+    hipStream_t s = LS(stream);
+    daisy_lgcn_graph *gm = const_cast<daisy_lgcn_graph *>(g);      // caches and scratch only: the matrix is untouched
+    if (!gm->row_ptr_host) {          // once: the first entry of every row (one host sync)
+        int64_t *dev = nullptr;
+        DAISY_HIP(hipMalloc((void **)&dev, (size_t)(N + 1) * 8));
+        hipLaunchKernelGGL(k_lg_row_ptr, dim3(grid_for(N + 1, kBlock)), dim3(kBlock), 0, s, g->ekey, g->nnz, N, dev);
+        gm->row_ptr_host = (int64_t *)malloc((size_t)(N + 1) * 8);
+        hipError_t e = hipMemcpyAsync(gm->row_ptr_host, dev, (size_t)(N + 1) * 8, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        (void)hipFree(dev);
+        if (e != hipSuccess) {
+            free(gm->row_ptr_host);
+            gm->row_ptr_host = nullptr;
+            set_error("lgcn_spmm_rows: reading the row offsets failed: %s", hipGetErrorString(e));
+            return DAISY_ERR_HIP;
+        }
+    }
+    if (row_hi == row_lo) return DAISY_OK;
+    DAISY_HIP(hipMemsetAsync(Yrows, 0, (size_t)(row_hi - row_lo) * d * 4, s));
+    int64_t e_lo = g->row_ptr_host[row_lo], e_hi = g->row_ptr_host[row_hi];
+    if (e_hi == e_lo) return DAISY_OK;
+    float *base = Yrows - row_lo * (int64_t)d;                     // row r of the product lands in Yrows[r - row_lo]
+    if (g->reproducible) {
+        hipLaunchKernelGGL(k_lg_spmm_owner, dim3(grid_for(e_hi - e_lo, kBlock / 16, kMaxGridSparse)), dim3(kBlock), 0, s,
+                           g->ekey + e_lo, g->esu + e_lo, g->coef + e_lo, e_hi - e_lo, X, (int)d, base);
+        DAISY_LAUNCH_CHECK();
+        return DAISY_OK;
+    }
+    // the segmented reduction takes an even number of entries: borrow one entry of the neighbouring row (its partial
+    // sum lands in the spare row the caller provides before / after Yrows)
+    if ((e_hi - e_lo) & 1) {
+        if (e_hi < g->nnz) ++e_hi;
+        else --e_lo;
+    }
+    int rc = ensure_edges(gm, d);
+    if (rc) return rc;
+    return segsum_rows(X, g->coef, g->ekey + e_lo, g->esu + e_lo, e_hi - e_lo, d, base, gm->edge_vec, gm->edge_item,
+                       gm->edge_b, gm->edge_whole, s);
 }
 
 int daisy_lgcn_propagate(const daisy_lgcn_graph *g, const float *E0, int32_t d, int32_t num_layers,
@@ -345,13 +423,17 @@ int daisy_csr_row_sum(const int64_t *indptr, const int32_t *cols, const float *X
 }
 
 int daisy_lgcn_reg_grad(const float *E0, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B,
-                        int64_t user_num, int32_t d, int32_t pointwise, float reg_1, float reg_2,
-                        const double *stats, float *dE0, daisy_stream_t stream) {
-    DAISY_CHECK_ARG(E0 && u && i && j && stats && dE0 && B > 0 && d > 0, "lgcn_reg_grad: bad argument");
+                        int64_t user_num, int64_t item_num, int32_t d, int32_t pointwise, float reg_1, float reg_2,
+                        const double *stats, int32_t *count_ws, float *dE0, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(E0 && u && i && j && stats && dE0 && count_ws && B > 0 && d > 0 && user_num > 0 && item_num > 0,
+                    "lgcn_reg_grad: bad argument");
     if (reg_1 == 0.f && reg_2 == 0.f) return DAISY_OK;
     hipStream_t s = LS(stream);
-    hipLaunchKernelGGL(k_lg_reg, dim3(grid_for(B * 3, kBlock / 16 * 2)), dim3(kBlock), 0, s, E0, u, i, j, B, user_num,
-                       (int)d, (int)pointwise, reg_1, reg_2, stats, dE0);
+    const int64_t N = user_num + item_num;
+    hipLaunchKernelGGL(k_lg_reg_count, dim3(grid_for(B, kBlock)), dim3(kBlock), 0, s, u, i, j, B, user_num,
+                       (int)pointwise, count_ws);
+    hipLaunchKernelGGL(k_lg_reg_apply, dim3(grid_for(N, kBlock / 16 * 2)), dim3(kBlock), 0, s, E0, N, user_num, (int)d,
+                       reg_1, reg_2, stats, count_ws, dE0);
     DAISY_LAUNCH_CHECK();
     return DAISY_OK;
 }

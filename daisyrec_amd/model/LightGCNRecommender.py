@@ -50,6 +50,11 @@ class LightGCN(GeneralRecommender):
         # round-off; 'sorted' = bitwise reproducible run to run (row-owner products: every row's entries are
         # summed serially, which is slow on graphs with very popular items)
         self.item_mode = str(config.get("item_mode", "chunked")).lower()
+        # multi-GPU (BASELINE configs[4]): 'auto' shards the propagation by node rows over the ranks of an
+        # initialised torch.distributed job (every rank runs the same fit with the same seeds: the batches are
+        # replicated, the sparse products - the bulk of a step - are split); False keeps everything local
+        self.shard_rows = config.get("shard_rows", "auto")
+        self._sharded = None
         self.restore_user_e = None
         self.restore_item_e = None
         self.apply(self._init_weight)
@@ -81,9 +86,23 @@ class LightGCN(GeneralRecommender):
             self._graph.set_reproducible(self.item_mode == "sorted")
         return self._graph
 
+    def _prop(self):
+        """the propagation engine: the local graph, or its row-sharded form over the job's ranks"""
+        g = self._adj()
+        import torch.distributed as dist
+        want = self.shard_rows is True or (self.shard_rows == "auto" and dist.is_available() and dist.is_initialized()
+                                           and dist.get_world_size() > 1)
+        if not want:
+            return g
+        if self._sharded is None:
+            from ..sharding import RowShardedPropagation
+            self._sharded = RowShardedPropagation(g, self.user_num + self.item_num, self.factors, self.device)
+        return self._sharded
+
     def forward(self):
         """:117-129 -> (user_embedding [U,d], item_embedding [I,d])"""
-        out = self._adj().propagate(self._ego(), self.num_layers)
+        E0 = self._ego()
+        out = self._prop().propagate(E0, self.num_layers, out=torch.empty_like(E0))
         return out[:self.user_num], out[self.user_num:]
 
     def _batch_grads(self, ctx, E0, out, G, dE0, u, i, j, loss_id):
@@ -92,7 +111,7 @@ class LightGCN(GeneralRecommender):
         reg = self.reg_1 != 0 or self.reg_2 != 0
         pointwise = loss_id in ops.POINTWISE_LOSSES
         ctx.set_batch(u, i, j)
-        self._adj().propagate(E0, self.num_layers, out=out)
+        self._prop().propagate(E0, self.num_layers, out=out)
         if reg:                       # the regularisers act on the EGO rows (:150-163): their sums first
             ctx.forward(E0[:U], E0[U:], loss_id)
             ego = ctx.stats[1:7].clone()
@@ -108,7 +127,7 @@ class LightGCN(GeneralRecommender):
         else:
             ctx.item_grad_data(out[:U], out[U:], N.ITEM_CHUNKED, gQ=G[U:])
         ctx.user_grad(out[:U], out[U:], 0.0, 0.0, G[:U])
-        self._adj().backprop(G, self.num_layers, dE0)
+        self._prop().backprop(G, self.num_layers, dE0)
         if reg:
             ops.lgcn_reg_grad(E0, u, i, j, U, pointwise, self.reg_1, self.reg_2, ctx.stats, dE0)
 

@@ -702,6 +702,14 @@ class LgcnGraph:
                                   _stream()))
         return Y
 
+    def spmm_rows(self, X, Yrows, row_lo, row_hi):
+        """Yrows[1 + r - row_lo] = (A_hat X)[r] for r in [row_lo, row_hi): `Yrows` is [row_hi-row_lo+2, d] - the
+        block plus one spare row on either side (the segmented reduction may spill a partial neighbour row there)."""
+        assert Yrows.shape[0] >= row_hi - row_lo + 2 and Yrows.is_contiguous()
+        check(lib.daisy_lgcn_spmm_rows(self._h, _ptr(X, torch.float32, "X"), _ptr(Yrows[1:], torch.float32, "Yrows"),
+                                       X.shape[1], int(row_lo), int(row_hi), _stream()))
+        return Yrows[1:1 + row_hi - row_lo]
+
     def propagate(self, E0, num_layers, out=None):
         """LightGCN.forward (LightGCNRecommender.py:117-129): mean_k A_hat^k E0, [N, d]."""
         out = torch.empty_like(E0) if out is None else out
@@ -717,11 +725,19 @@ class LgcnGraph:
                                       _ptr(w, torch.float32, "work"), _ptr(dE0, torch.float32, "dE0"), _stream()))
 
 
+_LGCN_REG_WS = {}
+
+
 def lgcn_reg_grad(E0, u, i, j, user_num, pointwise, reg_1, reg_2, stats, dE0):
+    N = E0.shape[0]
+    key = (E0.device, N)
+    ws = _LGCN_REG_WS.get(key)            # int32 occurrence counts, kept all-zero between calls by the kernels
+    if ws is None:
+        ws = _LGCN_REG_WS[key] = torch.zeros(2 * N, dtype=torch.int32, device=E0.device)
     check(lib.daisy_lgcn_reg_grad(_ptr(E0, torch.float32, "E0"), _ptr(u, torch.int32, "u"), _ptr(i, torch.int32, "i"),
-                                  _ptr(j, torch.int32, "j"), u.numel(), int(user_num), E0.shape[1], int(bool(pointwise)),
-                                  float(reg_1), float(reg_2), _ptr(stats, torch.float64, "stats"),
-                                  _ptr(dE0, torch.float32, "dE0"), _stream()))
+                                  _ptr(j, torch.int32, "j"), u.numel(), int(user_num), int(N - user_num), E0.shape[1],
+                                  int(bool(pointwise)), float(reg_1), float(reg_2), _ptr(stats, torch.float64, "stats"),
+                                  _ptr(ws, torch.int32, "count_ws"), _ptr(dE0, torch.float32, "dE0"), _stream()))
 
 
 def axpby(x, a, b, y, zero_x=False):

@@ -197,3 +197,67 @@ class UserShardedBprTrainer:
             work.wait()
         c.item_sgd_apply(self.Q, self.lr, dense=self.collective)
         return c.stats
+
+
+class RowShardedPropagation:
+    """LightGCN's propagation over the GPUs of one node (BASELINE configs[4]; the reference is single device,
+    LightGCNRecommender.py:117-129).  A_hat is row-sharded by node range: rank r owns rows [r*R, (r+1)*R) of every
+    product Y = A_hat X (R = ceil(N / world)), computes them from the full X it holds, and the ranks all-gather
+    their row blocks (RCCL over xGMI) - one all-gather of N*d floats per layer, forward and backward.  Everything
+    else of the step (batch loss, gradient wrt the propagated rows, regulariser, optimiser) is replicated: it
+    touches 3B rows, the products touch every edge.
+
+    `graph` is a daisyrec_amd.ops.LgcnGraph holding the WHOLE adjacency (4.7 M entries x 20 B for Amazon-Book: the
+    matrix is small, the work is not), or a stand-in with the same `spmm_rows`."""
+
+    def __init__(self, graph, N, d, device, group=None):
+        self.g, self.N, self.d, self.group = graph, int(N), int(d), group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.rows = (self.N + self.world - 1) // self.world
+        self.lo = min(self.rank * self.rows, self.N)
+        self.hi = min(self.lo + self.rows, self.N)
+        self._native = self.world > 1 and dist.get_backend(group) == "nccl"
+        self.block = torch.zeros(self.rows + 2, d, dtype=torch.float32, device=device)     # own rows + 2 spare rows
+        self.full = torch.zeros(self.rows * self.world, d, dtype=torch.float32, device=device)
+        self.work = [torch.empty(self.N, d, dtype=torch.float32, device=device) for _ in range(2)]
+
+    def spmm(self, X, Y):
+        """Y = A_hat X on every rank"""
+        own = self.g.spmm_rows(X, self.block, self.lo, self.hi)
+        if self.world == 1:
+            Y.copy_(own)
+            return Y
+        mine = self.block[1:1 + self.rows]                # padded to R rows (tail rows of the last rank: don't care)
+        if self._native:
+            dist.all_gather_into_tensor(self.full, mine, group=self.group)
+        else:
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            dist.all_gather(parts, mine.clone(), group=self.group)
+            for r, p in enumerate(parts):
+                self.full[r * self.rows:(r + 1) * self.rows].copy_(p)
+        Y.copy_(self.full[:self.N])
+        return Y
+
+    def propagate(self, E0, num_layers, out):
+        """out = mean_k A_hat^k E0  (LightGCNRecommender.py:117-129)"""
+        from . import ops
+        out.copy_(E0)
+        x = E0
+        for k in range(num_layers):
+            y = self.spmm(x, self.work[k & 1])
+            ops.axpby(y, 1.0, 1.0, out)                   # out += E_{k+1}
+            x = y
+        out.mul_(1.0 / (num_layers + 1))
+        return out
+
+    def backprop(self, G, num_layers, dE0):
+        """dE0 += 1/(L+1) sum_k A_hat^k G  (Horner; A_hat is symmetric)"""
+        from . import ops
+        t = G
+        for k in range(num_layers):
+            y = self.spmm(t, self.work[k & 1])
+            ops.axpby(G, 1.0, 1.0, y)                     # T <- G + A_hat T
+            t = y
+        ops.axpby(t, 1.0 / (num_layers + 1), 1.0, dE0)
+        return dE0

@@ -482,6 +482,12 @@ int daisy_lgcn_graph_read(const daisy_lgcn_graph *g, int32_t *row, int32_t *col,
                           daisy_stream_t stream);
 /* Y = A_hat X, X and Y f32[N, d] (Y != X) */
 int daisy_lgcn_spmm(const daisy_lgcn_graph *g, const float *X, float *Y, int32_t d, daisy_stream_t stream);
+/* Rows [row_lo, row_hi) of the same product: Yrows[r - row_lo] = (A_hat X)[r] - the per-rank share of a
+ * row-sharded multi-GPU propagation (BASELINE configs[4]; the ranks all-gather their row blocks per layer).
+ * Yrows must be preceded and followed by one spare row of d floats (they may be overwritten).  The first call
+ * on a graph synchronises the stream once (row offsets). */
+int daisy_lgcn_spmm_rows(const daisy_lgcn_graph *g, const float *X, float *Yrows, int32_t d, int64_t row_lo,
+                         int64_t row_hi, daisy_stream_t stream);
 /* LightGCN.forward (:117-129): out = mean_k A_hat^k E0;  work: f32[2*N*d] scratch */
 int daisy_lgcn_propagate(const daisy_lgcn_graph *g, const float *E0, int32_t d, int32_t num_layers,
                          float *work, float *out, daisy_stream_t stream);
@@ -490,10 +496,13 @@ int daisy_lgcn_backprop(const daisy_lgcn_graph *g, const float *G, int32_t d, in
                         float *dE0, daisy_stream_t stream);
 /* regulariser gradient on the ego rows of one batch (:150-163): for every sample
  * dE0[row] += reg_1*sign(e) + reg_2*e/|rows|_F for row in (u, U+i, U+j [pairwise only]); the three
- * Frobenius norms are stats[DAISY_ST_NORM_U/I/J] of a finalized MF context whose sums were taken on E0 */
+ * Frobenius norms are stats[DAISY_ST_NORM_U/I/J] of a finalized MF context whose sums were taken on E0.
+ * Deterministic: occurrences are counted with integer atomics into count_ws (int32[2*(U+I)], all zero on
+ * entry, left all zero), then every touched row is updated once. */
 int daisy_lgcn_reg_grad(const float *E0, const int32_t *u, const int32_t *i, const int32_t *j, int64_t B,
-                        int64_t user_num, int32_t d, int32_t pointwise, float reg_1, float reg_2,
-                        const double *stats, float *dE0, daisy_stream_t stream);
+                        int64_t user_num, int64_t item_num, int32_t d, int32_t pointwise, float reg_1,
+                        float reg_2, const double *stats, int32_t *count_ws, float *dE0,
+                        daisy_stream_t stream);
 
 /* -------------------------------------------------------------------------
  * Item2Vec (rest of SURVEY.md §8f rank 4; daisy/model/Item2VecRecommender.py:15-112).

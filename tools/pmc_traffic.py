@@ -19,9 +19,11 @@ import os
 import sys
 from collections import defaultdict
 
-STEP_KERNELS = ("k_fwd", "k_reduce_partials", "k_finalize", "k_item_grad_chunked", "k_item_edges", "k_item_grad_sorted",
+STEP_KERNELS = ("k_staged_user_edges", "k_staged_user", "k_staged_item_edges", "k_staged_item", "k_item_apply_counts",
+                "k_fwd", "k_reduce_partials", "k_finalize", "k_item_grad_chunked", "k_item_edges", "k_item_grad_sorted",
                 "k_item_grad_atomic", "k_item_reg", "k_user_chunked", "k_user_edges", "k_user", "k_item_apply",
-                "k_unorm_reduce", "k_unorm", "k_row_sqnorm")
+                "k_unorm_reduce", "k_unorm")
+PLAN_KERNELS = ("k_part_count", "k_part_scatter", "k_invert_perm", "k_plan_keys", "k_plan_entries", "k_run_finish")
 
 
 def load(dirpath, counter):
@@ -37,8 +39,8 @@ def load(dirpath, counter):
     return per_kernel
 
 
-def short(name):
-    for k in STEP_KERNELS:
+def short(name, kernels=STEP_KERNELS):
+    for k in kernels:
         if k + "<" in name or name.startswith("daisy::" + k) or ("::" + k + "(") in name or ("::" + k + "<") in name:
             return k
     return None
@@ -57,11 +59,20 @@ def main():
                 continue
             t = table.setdefault(k, {"launches": cnt, "read_bytes_per_launch": 0.0, "write_bytes_per_launch": 0.0})
             t[f"{key}_bytes_per_launch"] += kib * 1024.0 * corr / max(cnt, 1)
-            if k == "k_fwd":
+            if k in ("k_fwd", "k_staged_user"):
                 steps = cnt
     per_step = sum(v["read_bytes_per_launch"] + v["write_bytes_per_launch"] for v in table.values())
+    # the epoch plan builds of the same run (bytes per build, all kernels of a build summed)
+    plan = {}
+    for src, key, corr in ((rd, "read", 2.0), (wr, "write", 1.0)):
+        for name, (cnt, kib) in src.items():
+            k = short(name, PLAN_KERNELS)
+            if k is not None:
+                t = plan.setdefault(k, {"launches": cnt, "read_bytes": 0.0, "write_bytes": 0.0})
+                t[f"{key}_bytes"] += kib * 1024.0 * corr
+    source = sys.argv[5] if len(sys.argv) > 5 else "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py (see profiles/)"
     res = {"hbm_bytes_per_step": per_step, "batch_per_step": batch, "hbm_bytes_per_interaction": per_step / batch,
-           "steps_profiled": steps, "per_kernel": table,
+           "steps_profiled": steps, "source": source, "per_kernel": table, "plan_kernels_total_bytes": plan,
            "corrections": "FETCH_SIZE KiB x1024 x2 (gfx950 wide-read undercount), WRITE_SIZE KiB x1024 x1; "
                           "fabric-side counters: Infinity-Cache hits included (upper bound of HBM bytes)"}
     json.dump(res, open(out, "w"), indent=1)
