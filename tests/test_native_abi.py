@@ -48,3 +48,19 @@ def test_product_path_never_imports_oracle():
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), os.path.join(dp, f)
                 assert "bpr_mf_numpy" not in txt or f in ("common.h",), os.path.join(dp, f)
+
+
+def test_torch_library_ops_are_registered_without_a_cpu_kernel():
+    """north_star: "surfaced to Python through PyTorch-ROCm custom ops" - torch.ops.daisyrec.* exist with the
+    documented schemas (in-place annotations on the tables) and have NO CPU kernel: host tensors fail in the
+    dispatcher instead of reaching a fallback."""
+    import pytest
+    import torch
+    import daisyrec_amd.torch_ops as t
+    for name in t.OPS:
+        assert hasattr(torch.ops.daisyrec, name)
+    schema = str(torch.ops.daisyrec.bpr_mf_step.default._schema)
+    assert "Tensor(a!) P" in schema and "Tensor(b!) Q" in schema
+    with pytest.raises(NotImplementedError, match="CPU"):
+        torch.ops.daisyrec.mf_predict(torch.zeros(3, 4), torch.zeros(3, 4), torch.zeros(2, dtype=torch.long),
+                                      torch.zeros(2, dtype=torch.long))
