@@ -131,6 +131,7 @@ struct daisy_bpr_ctx {
     daisy::BatchView v;
     daisy::StreamView sv;  // the same batch as the staged step sees it
     int32_t batch_kind;   // layout of the plan the current batch comes from (0: v and sv valid, 1: only sv)
+    int64_t edge_chunks;  // chunks the edge-record arrays hold (two records per chunk)
     float *edge_cnt;      // staged step, edge records of the item pass: [2*nchunks][2] (n_pos, n_neg)
     int32_t pointwise;   // batches set through set_batch* hold (user, item, label) rows
     int last_item_mode;  // mode of the last daisy_bpr_item_grad: the user pass of the same step follows it

@@ -38,9 +38,14 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "bpr_internal.h"
 
 namespace daisy {
+
+constexpr int kStagedUserBlock = 128, kStagedItemBlock = 256;    // threads per workgroup of the two passes (measured:
+                                                                 // user pass 387 -> 360 us at 128, item pass indifferent)
 
 static inline hipStream_t S(daisy_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
@@ -507,18 +512,21 @@ static int plan_build_partitioned(daisy_epoch_plan *p, const daisy_train_index *
 // =============================================================================
 // samples per lane group per chunk in the user pass (3 row gathers each).  Measured at d=64: 4 (128 VGPRs,
 // 4 waves/SIMD) beats 8 (178 VGPRs, 2 waves/SIMD) by 10 % at C2 shapes and ties at C3 shapes.
-template <class C>
+// BLK: threads per workgroup.  A workgroup's waves load together and compute together (the barriers of the
+// run/slot reduction keep them in step), so smaller workgroups interleave memory and VALU phases better
+// across the CU; the price is more chunk boundaries (edge records).
+template <class C, int BLK = kBlock>
 struct StagedUserCfg {
     static constexpr int RUN_BY_REGS = (C::NE <= 8) ? 4 : 2;
     static constexpr int RUN = RUN_BY_REGS < C::LPR ? RUN_BY_REGS : C::LPR;
-    static constexpr int G = C::GROUPS_PER_BLOCK;
+    static constexpr int G = BLK / C::LPR;
     static constexpr int E = G * RUN;
 };
-template <class C>
+template <class C, int BLK = kBlock>
 struct StagedItemCfg {
     static constexpr int RUN_BY_REGS = (C::NE <= 4) ? 16 : ((C::NE <= 8) ? 4 : 2);
     static constexpr int RUN = RUN_BY_REGS < C::LPR ? RUN_BY_REGS : C::LPR;
-    static constexpr int G = C::GROUPS_PER_BLOCK;
+    static constexpr int G = BLK / C::LPR;
     static constexpr int E = G * RUN;
 };
 
@@ -593,12 +601,12 @@ struct UserEdges {
 // (no atomics, fixed summation order: bitwise reproducible).  PREMUL: stage[slot] = dL/dpos * p_u, valid for
 // the losses with dL/dneg = -dL/dpos (BPR, HL); otherwise stage[slot] = p_u and coef[slot] = (dL/dpos, dL/dneg).
 // HAS_POS: the stage slot of a sample comes from the plan (partitioned layout) instead of its position.
-template <class C, bool PREMUL, bool HAS_POS>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 ? 4 : 2, 8))) void k_staged_user(
+template <class C, int BLK, bool PREMUL, bool HAS_POS>
+__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 ? 4 : 2, 8))) void k_staged_user(
     float *__restrict__ P, const float *__restrict__ Q, StreamView v, int d, const double *__restrict__ stats,
     float lr, float reg_1, float reg_2, int loss_type, float gamma, float *__restrict__ stage,
     float2 *__restrict__ coef, float *__restrict__ p_sqnorm, double *__restrict__ partials, UserEdges ed) {
-    constexpr int G = StagedUserCfg<C>::G, RUN = StagedUserCfg<C>::RUN, E = StagedUserCfg<C>::E;
+    constexpr int G = StagedUserCfg<C, BLK>::G, RUN = StagedUserCfg<C, BLK>::RUN, E = StagedUserCfg<C, BLK>::E;
     constexpr int ROWF = C::NE * C::LPR;
     __shared__ float part_acc[2 * G * ROWF];
     __shared__ float part_n[2 * G];
@@ -808,7 +816,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(C::NE <=
         }
         __syncthreads();
     }
-    __shared__ double sm7[kBlock / kWave][8];
+    __shared__ double sm7[BLK / kWave][8];
     const int wave = tid / kWave;
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
@@ -819,7 +827,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(C::NE <=
     if (tid < 7) {
         double t = 0.0;
 #pragma unroll
-        for (int w = 0; w < kBlock / kWave; ++w) t += sm7[w][tid];
+        for (int w = 0; w < BLK / kWave; ++w) t += sm7[w][tid];
         partials[(int64_t)blockIdx.x * 8 + tid] = t;
     }
     if (tid == 7) partials[(int64_t)blockIdx.x * 8 + 7] = 0.0;   // (no FM biases on the staged path)
@@ -891,13 +899,13 @@ __device__ __forceinline__ void item_commit(float *__restrict__ Qo, float *__res
 // Item pass over the staged rows (see the header comment): the run/slot/edge segmented reduction of
 // k_item_grad_chunked<DET> (bpr_train.hip) with the coefficient inside the gathered row and the commit in
 // the owner.  A workgroup takes a chunk of G*RUN consecutive entries, every lane group a run of RUN.
-template <class C, bool PREMUL, bool APPLY>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_staged_item(const float *__restrict__ stage,
+template <class C, int BLK, bool PREMUL, bool APPLY>
+__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_staged_item(const float *__restrict__ stage,
                                                         const float2 *__restrict__ coef, StreamView v, int d,
                                                         float *__restrict__ Qo, float *__restrict__ cnt_out,
                                                         const double *__restrict__ stats, float lr,
                                                         float reg_1, float reg_2, ItemEdges2 ed) {
-    constexpr int G = StagedItemCfg<C>::G, RUN = StagedItemCfg<C>::RUN, E = StagedItemCfg<C>::E;
+    constexpr int G = StagedItemCfg<C, BLK>::G, RUN = StagedItemCfg<C, BLK>::RUN, E = StagedItemCfg<C, BLK>::E;
     constexpr int ROWF = C::NE * C::LPR;
     __shared__ int slot_item[G + 1], slot_shared[G + 1];
     __shared__ int run_first[G], run_last[G];
@@ -1166,25 +1174,37 @@ static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_ty
     const int d = ctx->d;
     const bool premul = premul_loss(loss_type), has_pos = v.s_pos != nullptr;
     UserEdges ed{ctx->edge_vec, ctx->edge_user, ctx->edge_n, ctx->edge_whole};
+    static const int tune_ug = getenv("DAISY_STAGED_UGRID") ? atoi(getenv("DAISY_STAGED_UGRID")) : kMaxGrid;
+    static const int tune_blk = getenv("DAISY_STAGED_UBLK") ? atoi(getenv("DAISY_STAGED_UBLK")) : kStagedUserBlock;
+    int64_t nchunks_out = 0;
+    bool overflow = false;
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
-        static const int tune_ug = getenv("DAISY_STAGED_UGRID") ? atoi(getenv("DAISY_STAGED_UGRID")) : kMaxGrid;
-        const int64_t nchunks = (v.B + StagedUserCfg<C>::E - 1) / StagedUserCfg<C>::E;
-        const int gu = grid_for(nchunks, 1, tune_ug < kMaxGrid ? tune_ug : kMaxGrid);
-        *grid_out = gu;
-#define DAISY_LAUNCH_SU(PM, HP)                                                                                   \
-        hipLaunchKernelGGL((k_staged_user<C, PM, HP>), dim3(gu), dim3(kBlock), 0, s, P, Q, v, d, stats, lr, reg_1, \
-                           reg_2, loss_type, gamma, ctx->p_stage, ctx->coef, ctx->p_sqnorm, ctx->partials, ed)
-        if (premul && has_pos) DAISY_LAUNCH_SU(true, true);
-        else if (premul) DAISY_LAUNCH_SU(true, false);
-        else if (has_pos) DAISY_LAUNCH_SU(false, true);
-        else DAISY_LAUNCH_SU(false, false);
+        auto go = [&](auto blk_tag) {
+            constexpr int BLK = decltype(blk_tag)::value;
+            const int64_t nchunks = (v.B + StagedUserCfg<C, BLK>::E - 1) / StagedUserCfg<C, BLK>::E;
+            if (nchunks > ctx->edge_chunks) { overflow = true; return; }
+            const int gu = grid_for(nchunks, 1, tune_ug < kMaxGrid ? tune_ug : kMaxGrid);
+            *grid_out = gu;
+            nchunks_out = nchunks;
+#define DAISY_LAUNCH_SU(PM, HP)                                                                                         \
+            hipLaunchKernelGGL((k_staged_user<C, BLK, PM, HP>), dim3(gu), dim3(BLK), 0, s, P, Q, v, d, stats, lr, reg_1, \
+                               reg_2, loss_type, gamma, ctx->p_stage, ctx->coef, ctx->p_sqnorm, ctx->partials, ed)
+            if (premul && has_pos) DAISY_LAUNCH_SU(true, true);
+            else if (premul) DAISY_LAUNCH_SU(true, false);
+            else if (has_pos) DAISY_LAUNCH_SU(false, true);
+            else DAISY_LAUNCH_SU(false, false);
 #undef DAISY_LAUNCH_SU
-        hipLaunchKernelGGL((k_staged_user_edges<C>), dim3(grid_for(nchunks, C::GROUPS_PER_BLOCK)), dim3(kBlock), 0, s,
-                           P, nchunks, d, stats, lr, reg_1, reg_2, ed, ctx->p_sqnorm);
+        };
+        if (tune_blk == 128 && C::LPR <= 32) go(std::integral_constant<int, 128>{});
+        else go(std::integral_constant<int, kBlock>{});
+        if (overflow) return DAISY_OK;
+        hipLaunchKernelGGL((k_staged_user_edges<C>), dim3(grid_for(nchunks_out, C::GROUPS_PER_BLOCK)), dim3(kBlock), 0, s,
+                           P, nchunks_out, d, stats, lr, reg_1, reg_2, ed, ctx->p_sqnorm);
         return DAISY_OK;
     });
     if (rc) return rc;
+    if (overflow) { set_error("staged step: the batch needs more edge records than the context holds"); return DAISY_ERR_STATE; }
     DAISY_LAUNCH_CHECK();
     return DAISY_OK;
 }
@@ -1196,26 +1216,33 @@ static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_
     const int d = ctx->d;
     const bool premul = premul_loss(loss_type);
     ItemEdges2 ed{ctx->edge_vec, ctx->edge_user, ctx->edge_cnt, ctx->edge_whole};
+    static const int tune_ig = getenv("DAISY_STAGED_IGRID") ? atoi(getenv("DAISY_STAGED_IGRID")) : 16384;
+    bool overflow = false;
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
-        const int64_t nchunks = (v.E + StagedItemCfg<C>::E - 1) / StagedItemCfg<C>::E;
-        static const int tune_ig = getenv("DAISY_STAGED_IGRID") ? atoi(getenv("DAISY_STAGED_IGRID")) : 16384;
-        const dim3 g(grid_for(v.E, StagedItemCfg<C>::E, tune_ig)), b(kBlock), ge(grid_for(nchunks, C::GROUPS_PER_BLOCK));
+        auto go = [&](auto blk_tag) {
+            constexpr int BLK = decltype(blk_tag)::value;
+            const int64_t nchunks = (v.E + StagedItemCfg<C, BLK>::E - 1) / StagedItemCfg<C, BLK>::E;
+            if (nchunks > ctx->edge_chunks) { overflow = true; return; }
+            const dim3 g(grid_for(v.E, StagedItemCfg<C, BLK>::E, tune_ig)), b(BLK), ge(grid_for(nchunks, C::GROUPS_PER_BLOCK));
 #define DAISY_LAUNCH_SI(PM, AP)                                                                                   \
-        do {                                                                                                     \
-            hipLaunchKernelGGL((k_staged_item<C, PM, AP>), g, b, 0, s, ctx->p_stage, ctx->coef, v, d, Qo, cnt_out, \
-                               stats, lr, reg_1, reg_2, ed);                                                     \
-            hipLaunchKernelGGL((k_staged_item_edges<C, AP>), ge, b, 0, s, ed, nchunks, d, Qo, cnt_out, stats, lr, \
-                               reg_1, reg_2);                                                                    \
-        } while (0)
-        if (premul && apply) DAISY_LAUNCH_SI(true, true);
-        else if (premul) DAISY_LAUNCH_SI(true, false);
-        else if (apply) DAISY_LAUNCH_SI(false, true);
-        else DAISY_LAUNCH_SI(false, false);
+            do {                                                                                                     \
+                hipLaunchKernelGGL((k_staged_item<C, BLK, PM, AP>), g, b, 0, s, ctx->p_stage, ctx->coef, v, d, Qo, cnt_out, \
+                                   stats, lr, reg_1, reg_2, ed);                                                     \
+                hipLaunchKernelGGL((k_staged_item_edges<C, AP>), ge, dim3(kBlock), 0, s, ed, nchunks, d, Qo, cnt_out, stats, lr, \
+                                   reg_1, reg_2);                                                                    \
+            } while (0)
+            if (premul && apply) DAISY_LAUNCH_SI(true, true);
+            else if (premul) DAISY_LAUNCH_SI(true, false);
+            else if (apply) DAISY_LAUNCH_SI(false, true);
+            else DAISY_LAUNCH_SI(false, false);
 #undef DAISY_LAUNCH_SI
+        };
+        go(std::integral_constant<int, kStagedItemBlock>{});
         return DAISY_OK;
     });
     if (rc) return rc;
+    if (overflow) { set_error("staged step: the batch needs more edge records than the context holds"); return DAISY_ERR_STATE; }
     DAISY_LAUNCH_CHECK();
     return DAISY_OK;
 }

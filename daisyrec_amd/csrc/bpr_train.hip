@@ -1479,13 +1479,14 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
         using C = decltype(cfg);
         const size_t cu = ((size_t)max_batch + UserRunCfg<C>::E - 1) / UserRunCfg<C>::E;
         const size_t ci = (2 * (size_t)max_batch + RunCfg<C>::E - 1) / RunCfg<C>::E;
-        const size_t cs = ((size_t)max_batch + C::GROUPS_PER_BLOCK * 2 - 1) / (C::GROUPS_PER_BLOCK * 2);   // staged user pass, RUN >= 2
+        const size_t cs = ((size_t)max_batch + C::GROUPS_PER_BLOCK - 1) / C::GROUPS_PER_BLOCK;   // staged passes: >= 128 threads, RUN >= 2
         max_chunks = (cu > ci ? cu : ci);
         if (cs > max_chunks) max_chunks = cs;
         max_chunks += 2;
         return DAISY_OK;
     });
     const size_t n_edge = 2 * max_chunks;
+    c->edge_chunks = (int64_t)max_chunks;
     const size_t o_ev = take(n_edge * (size_t)d * 4), o_eu = take(n_edge * 4), o_en = take(n_edge * 8);
     const size_t o_ew = take(n_edge * 4);
     const size_t o_ec = take(n_edge * 8);
