@@ -47,7 +47,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=None, help="default: two epochs of full batches")
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=None,
-                    help="interactions per GPU per step (default 2M at N=1, 8M per rank at N>1)")
+                    help="interactions per GPU per step (default 2M at N=1, 16M per rank at N>1: DESIGN.md section 5)")
     ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c3", "tiny"])
     ap.add_argument("--item-mode", default="fused", choices=["fused", "chunked", "atomic", "sorted"])
     ap.add_argument("--plan", default="auto", choices=["auto", "indexed", "sorted"],
@@ -130,7 +130,7 @@ def run_workload(a, rank, world, dev, wl, want_cpu_batches=0):
     else:
         U_loc, I, nnz_loc, scaling = 20_000, 5_000, 1_000_000, "weak"
         name = "tiny smoke workload (NOT a BASELINE config)"
-    B = a.batch if a.batch is not None else ((1 << 21) if world == 1 else (1 << 23))
+    B = a.batch if a.batch is not None else ((1 << 21) if world == 1 else (1 << 24))
     B = min(B, nnz_loc)
     lr, reg = 0.01, a.reg
 

@@ -67,11 +67,45 @@ def run(U, I, nnz, B, modes, tag):
     ctx.close(); plan_i.close(); plan_s.close(); index.close()
 
 
+def rank_share(B):
+    """Per-rank compute of the 8-GPU staged protocol at BASELINE configs[2] (U/8 users, I=1M, nnz/8), collectives
+    replaced by nothing: what is left to overlap or expose the exchange against."""
+    from daisyrec_amd.sharding import UserShardedBprTrainer
+    dev = torch.device("cuda")
+    U, I, nnz, d = 1_250_000, 1_000_000, 62_500_000, 64
+    triples = bench.synth_triples(U, I, nnz, 2022, dev)
+    n = triples.shape[0]
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    Q = torch.empty(I, d, device=dev).normal_(0.0, 0.01, generator=g)
+    P = torch.empty(U, d, device=dev).normal_(0.0, 0.01, generator=g)
+    B = min(B, n)
+    ctx = ops.BprContext(B, d, U, I, device=dev)
+    index = ops.TrainIndex(triples, U, I, user_sorted=True)
+    plan = ops.EpochPlan(n, U, I, device=dev).build_indexed(index, B, order="feistel", seed=1, epoch=0)
+    tr = UserShardedBprTrainer(ctx, P, Q, 0, 0.01, 1e-3, 1e-3)       # world 1, no process group: collectives are no-ops
+    nb = n // B
+    k = [0]
+
+    def step():
+        tr.step_from_plan(plan, k[0] % nb)
+        k[0] += 1
+
+    for _ in range(2):
+        step()
+    ms = ev_time(step, 2 * nb)
+    wire = 2 * 7 / 8 * I * (d + 2) * 4
+    print(f"[c3rank] n={n} B={B}: {ms:.3f} ms/step per rank without collectives ({B / ms / 1e6:.3f} G/s per rank); "
+          f"wire per step and rank 2 x {wire / 2 / 1e6:.0f} MB; at 310 GB/s bus bandwidth {wire / 310e9 * 1e3:.2f} ms")
+
+
 if __name__ == "__main__":
     which = sys.argv[1] if len(sys.argv) > 1 else "c2"
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 21
     modes = [("staged/indexed", "i", "fused"), ("staged/sorted-plan", "s", "fused"), ("chunked (r01)", "s", "chunked")]
-    if which == "c2":
+    if which == "c3rank":      # one rank's share of BASELINE configs[2] on 8 GPUs, through the sharded trainer's phases
+        rank_share(B if len(sys.argv) > 2 else 1 << 24)
+    elif which == "c2":
         run(1_000_000, 100_000, 50_000_000, B, modes, "c2")
     else:
         run(10_000_000, 1_000_000, 200_000_000, B, modes, "c3-200M")
