@@ -50,6 +50,11 @@ struct GemmOp {
     int64_t k_chunk;                      // reduction range per blockIdx.z
     int vec_a, vec_b;                     // set by launch_gemm: operand qualifies for the float4 path
     int bf16;                             // throughput mode: bf16-input MFMA where the tile shape allows it
+    // bf16 STORAGE (precision level 2: activations and a copy of the weights live as bf16 in HBM): when A16 is set the
+    // operands are read through A16 / B16 (same strides, in elements), the gate through G16, and the result goes to
+    // C16 (EPI_BIAS_RELU / EPI_GATE) or, in fp32, to C (EPI_ATOMIC)
+    const uint16_t *A16, *B16, *G16;
+    uint16_t *C16;
 };
 
 template <int WN, int EPI, bool FAST, bool DROP>
@@ -246,6 +251,7 @@ __device__ __forceinline__ uint32_t bf16_rne(float f) {
     uint32_t u = __float_as_uint(f);
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
 
 template <int WN, int EPI, bool DROP>
 __global__ __launch_bounds__(kBlock) void k_gemm_bf16(GemmOp op) {
@@ -354,6 +360,216 @@ __global__ __launch_bounds__(kBlock) void k_gemm_bf16(GemmOp op) {
     gemm_epilogue<WN, EPI, true, DROP>(op, acc, m0, n0, wm, wn, lane);
 }
 
+// bf16-STORAGE variant (precision level 2): both operands are bf16 in HBM, so a tile row of 32 k is 64 bytes -
+// 4 lanes x 16 bytes, copied to LDS as they are (no conversion, half the operand bytes of the fp32-storage
+// kernels above, which is what bounded them).  Operands that are contiguous along their rows instead of k (the
+// weight-gradient GEMM) are read one row x 16 consecutive k per thread with 2-byte loads (a wave instruction
+// still covers 64 consecutive rows = 128 contiguous bytes) and packed k-contiguously on the way into LDS.
+// Epilogues: bias + ReLU (+dropout) or gate with bf16 output (round to nearest even), or fp32 atomics (split-K).
+__device__ __forceinline__ bool bf16_positive(uint16_t h) { return (h & 0x8000u) == 0 && (h & 0x7FFFu) != 0; }
+
+constexpr int kBKH = 32, kLdkH = kBKH + 8;      // k depth of a tile (64 measured no faster on the GEMM and slower on the step:
+                                                // LDS for two stages halves the resident workgroups)
+template <int WN, int EPI, bool DROP, bool AK, bool BK>      // AK / BK: operand A / B is contiguous along k (else along its rows)
+__global__ __launch_bounds__(kBlock) void k_gemm_h(GemmOp op) {
+    constexpr int BM = kGemmBM, BN = 64 * WN;
+    constexpr int LPT = kBKH / 8;                               // lanes per tile row (16 bytes each)
+    constexpr int RPP = kBlock / LPT;                           // tile rows per pass of the workgroup
+    // one LDS block: two stages of the A and B tiles; the output tile of the bf16 epilogues reuses it afterwards
+    constexpr int kStage = 2 * (BM + BN) * kLdkH, kOut = BM * (BN + 8);
+    __shared__ __attribute__((aligned(16))) uint16_t smem[kStage > kOut ? kStage : kOut];
+    uint16_t (*As)[BM * kLdkH] = reinterpret_cast<uint16_t (*)[BM * kLdkH]>(smem);
+    uint16_t (*Bs)[BN * kLdkH] = reinterpret_cast<uint16_t (*)[BN * kLdkH]>(smem + 2 * BM * kLdkH);
+    const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
+    const int wm = wave / 2, wn = wave % 2;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int64_t k_lo = (int64_t)blockIdx.z * op.k_chunk;
+    const int64_t k_hi = (k_lo + op.k_chunk < op.K) ? (k_lo + op.k_chunk) : op.K;
+
+    floatx16 acc[2][WN];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
+
+    // registers of one tile: k-contiguous: Q x uint4; row-contiguous: (ROWS*32/256) halfwords packed in pairs
+    constexpr int NQ = BM / RPP, NS = BM * kBKH / kBlock / 2;
+    uint4 ra[AK ? NQ : 1], rb[BK ? NQ : 1];
+    uint32_t sa[AK ? 1 : NS], sb[BK ? 1 : NS];
+    auto load_op = [&](const uint16_t *__restrict__ P, int64_t srow, int64_t sk, auto kfast_c, int64_t row0, int64_t kt,
+                       auto &r, auto &sr, auto rows_c) {
+        constexpr int ROWS = decltype(rows_c)::value;
+        if constexpr (decltype(kfast_c)::value) {
+            const uint16_t *src = P + (row0 + tid / LPT) * srow + kt + (tid % LPT) * 8;
+#pragma unroll
+            for (int q = 0; q < ROWS / RPP; ++q) r[q] = *reinterpret_cast<const uint4 *>(src + (int64_t)q * RPP * srow);
+        } else {
+            constexpr int KPT = ROWS * kBKH / kBlock;          // consecutive k per thread (16 for 128 rows, 8 for 64)
+            const uint16_t *src = P + row0 + (tid % ROWS) + (kt + (int64_t)(tid / ROWS) * KPT) * sk;
+#pragma unroll
+            for (int q = 0; q < KPT / 2; ++q)
+                sr[q] = (uint32_t)src[(int64_t)(2 * q) * sk] | ((uint32_t)src[(int64_t)(2 * q + 1) * sk] << 16);
+        }
+    };
+    auto store_op = [&](uint16_t *__restrict__ S, auto kfast_c, const auto &r, const auto &sr, auto rows_c) {
+        constexpr int ROWS = decltype(rows_c)::value;
+        if constexpr (decltype(kfast_c)::value) {
+#pragma unroll
+            for (int q = 0; q < ROWS / RPP; ++q)
+                *reinterpret_cast<uint4 *>(S + (tid / LPT + q * RPP) * kLdkH + (tid % LPT) * 8) = r[q];
+        } else {
+            constexpr int KPT = ROWS * kBKH / kBlock;
+            uint16_t *dst = S + (tid % ROWS) * kLdkH + (tid / ROWS) * KPT;
+#pragma unroll
+            for (int q = 0; q < KPT / 8; ++q)
+                *reinterpret_cast<uint4 *>(dst + 8 * q) = make_uint4(sr[4 * q], sr[4 * q + 1], sr[4 * q + 2], sr[4 * q + 3]);
+        }
+    };
+    using RA = std::integral_constant<int, BM>; using RB = std::integral_constant<int, BN>;
+    static_assert(BN <= BM, "tile registers are sized by the A tile");
+
+    if (k_lo < k_hi) {
+        load_op(op.A16, op.sam, op.sak, std::integral_constant<bool, AK>{}, m0, k_lo, ra, sa, RA{});
+        load_op(op.B16, op.sbn, op.sbk, std::integral_constant<bool, BK>{}, (int64_t)n0, k_lo, rb, sb, RB{});
+        store_op(As[0], std::integral_constant<bool, AK>{}, ra, sa, RA{});
+        store_op(Bs[0], std::integral_constant<bool, BK>{}, rb, sb, RB{});
+        __syncthreads();
+        int cur = 0;
+        for (int64_t kt = k_lo; kt < k_hi; kt += kBKH) {
+            const bool more = kt + kBKH < k_hi;
+            if (more) {
+                load_op(op.A16, op.sam, op.sak, std::integral_constant<bool, AK>{}, m0, kt + kBKH, ra, sa, RA{});
+                load_op(op.B16, op.sbn, op.sbk, std::integral_constant<bool, BK>{}, (int64_t)n0, kt + kBKH, rb, sb, RB{});
+            }
+            const uint16_t *as = As[cur] + (wm * 64 + lane % 32) * kLdkH + (lane / 32) * 8;
+            const uint16_t *bs = Bs[cur] + (wn * 32 * WN + lane % 32) * kLdkH + (lane / 32) * 8;
+#pragma unroll
+            for (int ks = 0; ks < kBKH / 16; ++ks) {
+                bf16x8 a[2], b[WN];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+                    a[mi] = *reinterpret_cast<const bf16x8 *>(as + mi * 32 * kLdkH + ks * 16);
+#pragma unroll
+                for (int ni = 0; ni < WN; ++ni)
+                    b[ni] = *reinterpret_cast<const bf16x8 *>(bs + ni * 32 * kLdkH + ks * 16);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < WN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            }
+            if (more) {
+                store_op(As[cur ^ 1], std::integral_constant<bool, AK>{}, ra, sa, RA{});
+                store_op(Bs[cur ^ 1], std::integral_constant<bool, BK>{}, rb, sb, RB{});
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    if constexpr (EPI == EPI_ATOMIC) {
+        gemm_epilogue<WN, EPI, true, DROP>(op, acc, m0, n0, wm, wn, lane);
+    } else {        // bf16 output (interior tiles only: launch_gemm_h checks)
+        // The MFMA result layout gives a lane ONE column and 32 scattered rows: written directly that is 64 two-byte
+        // stores per lane.  So the tile takes a detour through LDS (the operand stages are dead by now) and
+        // leaves as 16-byte stores along its rows.
+        constexpr int LDT = BN + 8;                                       // halfwords per staged row (16-byte multiple)
+        uint16_t *Ts = smem;              // (the last k iteration ended with a barrier: every fragment read is done)
+        const uint16_t *__restrict__ Gt = (EPI == EPI_GATE && op.G16) ? op.G16 + m0 * op.ldg + n0 : nullptr;
+        const int ldg = (int)op.ldg;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) {
+                const int nl = wn * 32 * WN + ni * 32 + lane % 32;
+                float bias = 0.f;
+                if constexpr (EPI == EPI_BIAS_RELU) bias = op.bias[n0 + nl];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int ml = wm * 64 + mi * 32 + (i / 4) * 8 + (lane / 32) * 4 + (i % 4);
+                    float v = acc[mi][ni][i];
+                    if constexpr (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
+                    if constexpr (DROP)
+                        if (op.drop_thresh)
+                            v = drop_keep(op.drop_seed, op.drop_stream,
+                                          (uint64_t)(m0 + ml) * (uint64_t)op.N + (uint64_t)(n0 + nl), op.drop_thresh)
+                                    ? v * op.drop_scale : 0.f;
+                    Ts[ml * LDT + nl] = (uint16_t)bf16_rne(v);
+                }
+            }
+        __syncthreads();
+        constexpr int VPR = BN / 8;                                       // 16-byte vectors per tile row
+        uint16_t *__restrict__ Ct = op.C16 + m0 * op.ldc + n0;
+        for (int e = tid; e < BM * VPR; e += kBlock) {
+            const int row = e / VPR, c8 = (e % VPR) * 8;
+            uint4 v = *reinterpret_cast<const uint4 *>(Ts + row * LDT + c8);
+            if constexpr (EPI == EPI_GATE) {
+                if (Gt) {                                                 // gate: x > 0 of the layer input, 8 columns at a time
+                    const uint4 gq = *reinterpret_cast<const uint4 *>(Gt + (int64_t)row * ldg + c8);
+                    const uint32_t gw[4] = {gq.x, gq.y, gq.z, gq.w};
+                    uint32_t vw[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint16_t g0 = (uint16_t)gw[q], g1 = (uint16_t)(gw[q] >> 16);
+                        float lo = bf16_positive(g0) ? bf16_to_f32((uint16_t)vw[q]) * op.gate_scale : 0.f;
+                        float hi = bf16_positive(g1) ? bf16_to_f32((uint16_t)(vw[q] >> 16)) * op.gate_scale : 0.f;
+                        vw[q] = bf16_rne(lo) | (bf16_rne(hi) << 16);
+                    }
+                    v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
+                }
+            }
+            *reinterpret_cast<uint4 *>(Ct + (int64_t)row * op.ldc + c8) = v;
+        }
+    }
+}
+
+// shapes the bf16-storage kernel takes: whole tiles, k ranges in multiples of 32, 16-byte aligned rows
+static bool gemm_h_ok(const GemmOp &op) {
+    const int bn = (op.N > 64) ? 128 : 64;
+    const int64_t splits = (op.k_chunk < op.K) ? (op.K + op.k_chunk - 1) / op.k_chunk : 1;
+    auto al = [](const uint16_t *p, int64_t srow, int64_t sk) {
+        if (((uintptr_t)p & 15) != 0) return false;
+        return sk == 1 ? (srow % 8 == 0) : (srow == 1);
+    };
+    if (op.sak != 1 && op.sbk == 1) return false;          // (A along rows, B along k) is not a layout of the tower
+    return op.M % kGemmBM == 0 && op.N % bn == 0 && op.K % kBKH == 0 && (splits == 1 || op.k_chunk % kBKH == 0) &&
+           al(op.A16, op.sam, op.sak) && al(op.B16, op.sbn, op.sbk);
+}
+
+template <int EPI>
+static void launch_gemm_h(GemmOp op, hipStream_t s) {
+    const int64_t splits = (op.k_chunk < op.K) ? (op.K + op.k_chunk - 1) / op.k_chunk : 1;
+    if (op.k_chunk >= op.K) op.k_chunk = op.K;
+    const int bn = (op.N > 64) ? 128 : 64;
+    dim3 grid((unsigned)(op.M / kGemmBM), (unsigned)(op.N / bn), (unsigned)splits);
+    constexpr bool can_drop = (EPI == EPI_BIAS_RELU || EPI == EPI_GATE);
+    const bool drop = can_drop && op.drop_thresh != 0;
+    const bool ak = op.sak == 1, bk = op.sbk == 1;
+    auto go = [&](auto wn_c, auto drop_c, auto ak_c, auto bk_c) {
+        hipLaunchKernelGGL((k_gemm_h<decltype(wn_c)::value, EPI, decltype(drop_c)::value, decltype(ak_c)::value,
+                                     decltype(bk_c)::value>), grid, dim3(kBlock), 0, s, op);
+    };
+    using T = std::true_type; using F = std::false_type;
+    using W1 = std::integral_constant<int, 1>; using W2 = std::integral_constant<int, 2>;
+    auto go2 = [&](auto wn_c, auto drop_c) {          // the three operand layouts the tower uses
+        if (ak && bk) go(wn_c, drop_c, T{}, T{});         // forward:          X (k) x W (k)
+        else if (ak) go(wn_c, drop_c, T{}, F{});          // input gradient:   dZ (k) x W^T (rows)
+        else go(wn_c, drop_c, F{}, F{});                  // weight gradient:  dZ^T (rows) x X^T (rows)
+    };
+    if (op.N > 64) {
+        if constexpr (can_drop) { if (drop) go2(W2{}, T{}); else go2(W2{}, F{}); } else go2(W2{}, F{});
+    } else {
+        if constexpr (can_drop) { if (drop) go2(W1{}, T{}); else go2(W1{}, F{}); } else go2(W1{}, F{});
+    }
+}
+
+// fp32 -> bf16 (round to nearest even): the per-step copy of the MLP weights
+__global__ void k_to_bf16(const float *__restrict__ x, int64_t n, uint16_t *__restrict__ y) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        y[e] = (uint16_t)bf16_rne(x[e]);
+}
 // float4 path preconditions: unit stride along one dimension, the other stride and the base 16-byte aligned
 static bool vec_ok(const float *p, int64_t s_row, int64_t s_k, int64_t k_chunk) {
     if (((uintptr_t)p & 15) != 0) return false;
@@ -420,7 +636,8 @@ __device__ __forceinline__ void pair_ids(const PairSrc &s, int64_t r, int64_t &u
 struct L16 { static constexpr int LPR = 16; };
 
 // x0[r] = [uM[user] | iM[item]] (* dropout), g[r] = uG[user]*iG[item]; TRAIN: the ten regulariser sums.
-template <bool TRAIN>
+// H: the activations live as bf16 in HBM (precision level 2)
+template <bool TRAIN, bool H = false>
 __global__ __launch_bounds__(kBlock) void k_nmf_gather(daisy_neumf_params p, PairSrc src, int64_t R, int d,
                                                        int dm, int pointwise, float *__restrict__ X0,
                                                        float *__restrict__ G, uint32_t thresh,
@@ -444,8 +661,14 @@ __global__ __launch_bounds__(kBlock) void k_nmf_gather(daisy_neumf_params p, Pai
                     b = drop_keep(seed, 1, (uint64_t)r * (2 * dm) + dm + c, thresh) ? b * scale : 0.f;
                 }
             }
-            x[c] = a;
-            x[dm + c] = b;
+            if constexpr (H) {
+                uint16_t *xh = reinterpret_cast<uint16_t *>(X0) + r * (int64_t)(2 * dm);
+                xh[c] = (uint16_t)bf16_rne(a);
+                xh[dm + c] = (uint16_t)bf16_rne(b);
+            } else {
+                x[c] = a;
+                x[dm + c] = b;
+            }
         }
         const float *ug = p.uG + user * d, *ig = p.iG + item * d;
         for (int c = lane; c < d; c += 16) {
@@ -474,6 +697,7 @@ __global__ __launch_bounds__(kBlock) void k_nmf_gather(daisy_neumf_params p, Pai
 }
 
 // pred[r] = <Wp[:dg], g[r]> + <Wp[dg:], x_L[r]> + bp      (dg = 0 for model MLP, nl = 0 for model GMF)
+template <bool H = false>
 __global__ __launch_bounds__(kBlock) void k_nmf_predict(const float *__restrict__ G, int dg,
                                                         const float *__restrict__ XL, int nl,
                                                         const float *__restrict__ Wp,
@@ -484,7 +708,12 @@ __global__ __launch_bounds__(kBlock) void k_nmf_predict(const float *__restrict_
     for (int64_t r = (int64_t)blockIdx.x * (kBlock / 16) + group; r < R; r += gstride) {
         float s = 0.f;
         for (int c = lane; c < dg; c += 16) s = fmaf(Wp[c], G[r * (int64_t)dg + c], s);
-        for (int c = lane; c < nl; c += 16) s = fmaf(Wp[dg + c], XL[r * (int64_t)nl + c], s);
+        for (int c = lane; c < nl; c += 16) {
+            float x;
+            if constexpr (H) x = bf16_to_f32(reinterpret_cast<const uint16_t *>(XL)[r * (int64_t)nl + c]);
+            else x = XL[r * (int64_t)nl + c];
+            s = fmaf(Wp[dg + c], x, s);
+        }
         s = group_sum<L16>(s);
         if (lane == 0) pred[r] = s + bp[0];
     }
@@ -532,6 +761,7 @@ __global__ void k_nmf_finalize(double *__restrict__ stats, float reg_1, float re
 }
 
 // dZ_L[r] = dpred[r] * Wp[dg:] gated by x_L[r] > 0;  gWp += sum_r dpred[r]*[g[r] | x_L[r]];  gbp += sum dpred
+template <bool H = false>
 __global__ __launch_bounds__(kBlock) void k_nmf_pred_bwd(const float *__restrict__ dpred,
                                                          const float *__restrict__ G, int dg,
                                                          const float *__restrict__ XL, int nl,
@@ -551,9 +781,13 @@ __global__ __launch_bounds__(kBlock) void k_nmf_pred_bwd(const float *__restrict
                 const int c = c0 + q * 16 + lane;
                 if (c < dg) part[q] = fmaf(dp, G[r * (int64_t)dg + c], part[q]);
                 else if (c < dg + nl) {
-                    const float x = XL[r * (int64_t)nl + (c - dg)];
+                    float x;
+                    if constexpr (H) x = bf16_to_f32(reinterpret_cast<const uint16_t *>(XL)[r * (int64_t)nl + (c - dg)]);
+                    else x = XL[r * (int64_t)nl + (c - dg)];
                     part[q] = fmaf(dp, x, part[q]);
-                    DZ[r * (int64_t)nl + (c - dg)] = (x > 0.f) ? dp * Wp[c] : 0.f;
+                    const float dzv = (x > 0.f) ? dp * Wp[c] : 0.f;
+                    if constexpr (H) reinterpret_cast<uint16_t *>(DZ)[r * (int64_t)nl + (c - dg)] = (uint16_t)bf16_rne(dzv);
+                    else DZ[r * (int64_t)nl + (c - dg)] = dzv;
                 }
             }
         }
@@ -569,8 +803,13 @@ __global__ __launch_bounds__(kBlock) void k_nmf_pred_bwd(const float *__restrict
 
 // out[n] += sum_r X[r*ld + n]: a block takes 64 columns x kColsumRows rows (grid = column tiles x row tiles)
 constexpr int kColsumRows = 512;
+template <bool H = false>
 __global__ __launch_bounds__(kBlock) void k_colsum(const float *__restrict__ X, int64_t R, int N, int64_t ld,
                                                    float *__restrict__ out) {
+    auto at = [&](int64_t idx) -> float {
+        if constexpr (H) return bf16_to_f32(reinterpret_cast<const uint16_t *>(X)[idx]);
+        else return X[idx];
+    };
     __shared__ float sm[4][64];
     const int c = threadIdx.x % 64, rr = threadIdx.x / 64;
     const int n = blockIdx.x * 64 + c;
@@ -579,8 +818,8 @@ __global__ __launch_bounds__(kBlock) void k_colsum(const float *__restrict__ X, 
     float s0 = 0.f, s1 = 0.f;
     if (n < N) {
         int64_t r = r0 + rr;
-        for (; r + 4 < r1; r += 8) { s0 += X[r * ld + n]; s1 += X[(r + 4) * ld + n]; }
-        if (r < r1) s0 += X[r * ld + n];
+        for (; r + 4 < r1; r += 8) { s0 += at(r * ld + n); s1 += at((r + 4) * ld + n); }
+        if (r < r1) s0 += at(r * ld + n);
     }
     sm[rr][c] = s0 + s1;
     __syncthreads();
@@ -588,6 +827,7 @@ __global__ __launch_bounds__(kBlock) void k_colsum(const float *__restrict__ X, 
 }
 
 // embedding gradients of one row r (dense tables, fp32 atomics) + the regulariser gradients
+template <bool H = false>
 __global__ __launch_bounds__(kBlock) void k_nmf_scatter(daisy_neumf_params p, daisy_neumf_params g, PairSrc src,
                                                         int64_t R, int d, int dm, int model, int pointwise,
                                                         const float *__restrict__ dpred,
@@ -612,8 +852,14 @@ __global__ __launch_bounds__(kBlock) void k_nmf_scatter(daisy_neumf_params p, da
         for (int c = lane; c < dm; c += 16) {
             float gu = 0.f, gi = 0.f;
             if (model != DAISY_NEUMF_GMF) {
-                gu = DX0[r * (int64_t)(2 * dm) + c];
-                gi = DX0[r * (int64_t)(2 * dm) + dm + c];
+                if constexpr (H) {
+                    const uint16_t *dx = reinterpret_cast<const uint16_t *>(DX0) + r * (int64_t)(2 * dm);
+                    gu = bf16_to_f32(dx[c]);
+                    gi = bf16_to_f32(dx[dm + c]);
+                } else {
+                    gu = DX0[r * (int64_t)(2 * dm) + c];
+                    gi = DX0[r * (int64_t)(2 * dm) + dm + c];
+                }
             }
             if (reg && first) {
                 const float a = p.uM[user * dm + c], b = p.iM[item * dm + c];
@@ -666,7 +912,8 @@ struct daisy_neumf_ctx {
     size_t arena_bytes;
     float *X[DAISY_NEUMF_MAX_LAYERS + 1];    // X[0] = (dropped) concat input, X[l] = layer outputs
     float *G, *pred, *dpred, *DZ[2];
-    int bf16;                                // daisy_neumf_ctx_set_precision
+    uint16_t *W16[DAISY_NEUMF_MAX_LAYERS];   // bf16 copies of the MLP weights (precision level 2), refreshed per call
+    int bf16;                                // daisy_neumf_ctx_set_precision: 0 fp32, 1 bf16 MFMA inputs, 2 bf16 storage
 };
 
 static inline hipStream_t NS(daisy_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
@@ -677,18 +924,38 @@ static uint32_t drop_threshold(float p) {
     return (t >= 4294967295.0) ? 4294967295u : (uint32_t)t;
 }
 
+// precision level 2 applies when every GEMM of the call is made of whole tiles (else the call runs at level 1)
+static bool neumf_use_h(const daisy_neumf_ctx *ctx, int64_t R) {
+    if (ctx->bf16 != 2 || ctx->model == DAISY_NEUMF_GMF || R % kGemmBM != 0) return false;
+    for (int l = 0; l <= ctx->L; ++l)
+        if (ctx->width[l] % 64 != 0) return false;
+    return true;
+}
+
 // x_L and pred for R pairs starting at src.base (eval: thresh == 0)
 static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p, const PairSrc &src, int64_t R,
                               bool train, int pointwise, uint32_t thresh, float scale, uint64_t seed,
                               double *stats, hipStream_t s) {
     const int d = ctx->d, dm = ctx->dm, L = ctx->L;
     const int grid = grid_for(R, kBlock / 16 * 2);
-    if (train)
-        hipLaunchKernelGGL((k_nmf_gather<true>), dim3(grid), dim3(kBlock), 0, s, *p, src, R, d, dm, pointwise,
-                           ctx->X[0], ctx->G, thresh, scale, seed, stats);
-    else
-        hipLaunchKernelGGL((k_nmf_gather<false>), dim3(grid), dim3(kBlock), 0, s, *p, src, R, d, dm, 0, ctx->X[0],
-                           ctx->G, 0u, 1.f, (uint64_t)0, nullptr);
+    const bool H = neumf_use_h(ctx, R);
+    if (H) {          // bf16 copies of the MLP weights (a few hundred KB)
+        for (int l = 1; l <= L; ++l) {
+            const int64_t nw = (int64_t)ctx->width[l] * ctx->width[l - 1];
+            hipLaunchKernelGGL(k_to_bf16, dim3(grid_for(nw, kBlock * 4)), dim3(kBlock), 0, s, p->W[l - 1], nw, ctx->W16[l - 1]);
+        }
+    }
+    if (train) {
+        if (H) hipLaunchKernelGGL((k_nmf_gather<true, true>), dim3(grid), dim3(kBlock), 0, s, *p, src, R, d, dm, pointwise,
+                                  ctx->X[0], ctx->G, thresh, scale, seed, stats);
+        else hipLaunchKernelGGL((k_nmf_gather<true, false>), dim3(grid), dim3(kBlock), 0, s, *p, src, R, d, dm, pointwise,
+                                ctx->X[0], ctx->G, thresh, scale, seed, stats);
+    } else {
+        if (H) hipLaunchKernelGGL((k_nmf_gather<false, true>), dim3(grid), dim3(kBlock), 0, s, *p, src, R, d, dm, 0, ctx->X[0],
+                                  ctx->G, 0u, 1.f, (uint64_t)0, (double *)nullptr);
+        else hipLaunchKernelGGL((k_nmf_gather<false, false>), dim3(grid), dim3(kBlock), 0, s, *p, src, R, d, dm, 0, ctx->X[0],
+                                ctx->G, 0u, 1.f, (uint64_t)0, (double *)nullptr);
+    }
     DAISY_LAUNCH_CHECK();
     if (ctx->model != DAISY_NEUMF_GMF) {
         for (int l = 1; l <= L; ++l) {
@@ -699,18 +966,28 @@ static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p,
             op.M = R; op.N = ctx->width[l]; op.K = ctx->width[l - 1];
             op.bias = p->b[l - 1];
             op.k_chunk = op.K;
-            op.bf16 = ctx->bf16;
+            op.bf16 = ctx->bf16 ? 1 : 0;
             if (l < L && thresh) {       // the Dropout in front of Linear l+1 acts on this output
                 op.drop_thresh = thresh; op.drop_scale = scale; op.drop_seed = seed; op.drop_stream = (uint32_t)(l + 1);
             }
-            launch_gemm<EPI_BIAS_RELU>(op, s);
+            if (H) {
+                op.A16 = reinterpret_cast<const uint16_t *>(ctx->X[l - 1]);
+                op.B16 = ctx->W16[l - 1];
+                op.C16 = reinterpret_cast<uint16_t *>(ctx->X[l]);
+                if (!gemm_h_ok(op)) { set_error("neumf: layer %d does not tile for the bf16-storage GEMM", l); return DAISY_ERR_STATE; }
+                launch_gemm_h<EPI_BIAS_RELU>(op, s);
+            } else {
+                launch_gemm<EPI_BIAS_RELU>(op, s);
+            }
             DAISY_LAUNCH_CHECK();
         }
     }
     const int dg = (ctx->model == DAISY_NEUMF_MLP) ? 0 : d;
     const int nl = (ctx->model == DAISY_NEUMF_GMF) ? 0 : ctx->width[L];
-    hipLaunchKernelGGL(k_nmf_predict, dim3(grid), dim3(kBlock), 0, s, ctx->G, dg, ctx->X[L], nl, p->Wp, p->bp, R,
-                       ctx->pred);
+    if (H) hipLaunchKernelGGL((k_nmf_predict<true>), dim3(grid), dim3(kBlock), 0, s, ctx->G, dg, ctx->X[L], nl, p->Wp, p->bp, R,
+                              ctx->pred);
+    else hipLaunchKernelGGL((k_nmf_predict<false>), dim3(grid), dim3(kBlock), 0, s, ctx->G, dg, ctx->X[L], nl, p->Wp, p->bp, R,
+                            ctx->pred);
     DAISY_LAUNCH_CHECK();
     return DAISY_OK;
 }
@@ -740,6 +1017,8 @@ int daisy_neumf_ctx_create(daisy_neumf_ctx **out, int64_t max_rows, int32_t fact
     const size_t og = take((size_t)max_rows * factors * 4), op = take((size_t)max_rows * 4),
                  od = take((size_t)max_rows * 4);
     const size_t oz0 = take((size_t)max_rows * c->width[0] * 4), oz1 = take((size_t)max_rows * c->width[0] * 4);
+    size_t ow[DAISY_NEUMF_MAX_LAYERS];
+    for (int l = 1; l <= num_layers; ++l) ow[l - 1] = take((size_t)c->width[l] * c->width[l - 1] * 2);
     c->arena_bytes = off;
     hipError_t e = hipMalloc(&c->arena, off);
     if (e != hipSuccess) {
@@ -751,6 +1030,7 @@ int daisy_neumf_ctx_create(daisy_neumf_ctx **out, int64_t max_rows, int32_t fact
     for (int l = 0; l <= num_layers; ++l) c->X[l] = (float *)(base + ox[l]);
     c->G = (float *)(base + og); c->pred = (float *)(base + op); c->dpred = (float *)(base + od);
     c->DZ[0] = (float *)(base + oz0); c->DZ[1] = (float *)(base + oz1);
+    for (int l = 1; l <= num_layers; ++l) c->W16[l - 1] = (uint16_t *)(base + ow[l - 1]);
     *out = c;
     return DAISY_OK;
 }
@@ -766,7 +1046,8 @@ size_t daisy_neumf_ctx_bytes(const daisy_neumf_ctx *ctx) { return ctx ? ctx->are
 
 int daisy_neumf_ctx_set_precision(daisy_neumf_ctx *ctx, int32_t bf16_gemm) {
     DAISY_CHECK_ARG(ctx != nullptr, "neumf_ctx_set_precision: NULL context");
-    ctx->bf16 = bf16_gemm ? 1 : 0;
+    DAISY_CHECK_ARG(bf16_gemm >= 0 && bf16_gemm <= 2, "neumf_ctx_set_precision: level %d not in 0..2", bf16_gemm);
+    ctx->bf16 = bf16_gemm;
     return DAISY_OK;
 }
 
@@ -816,8 +1097,11 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
     const int dg = (model == DAISY_NEUMF_MLP) ? 0 : d;
     const int nl = (model == DAISY_NEUMF_GMF) ? 0 : ctx->width[L];
     float *dz = ctx->DZ[0], *dz_next = ctx->DZ[1];
-    hipLaunchKernelGGL(k_nmf_pred_bwd, dim3(grid_for(R, kBlock / 16 * 16, 1024)), dim3(kBlock), 0, s, ctx->dpred,
-                       ctx->G, dg, ctx->X[L], nl, p.Wp, R, dz, g.Wp);
+    const bool H = neumf_use_h(ctx, R);
+    if (H) hipLaunchKernelGGL((k_nmf_pred_bwd<true>), dim3(grid_for(R, kBlock / 16 * 16, 1024)), dim3(kBlock), 0, s, ctx->dpred,
+                              ctx->G, dg, ctx->X[L], nl, p.Wp, R, dz, g.Wp);
+    else hipLaunchKernelGGL((k_nmf_pred_bwd<false>), dim3(grid_for(R, kBlock / 16 * 16, 1024)), dim3(kBlock), 0, s, ctx->dpred,
+                            ctx->G, dg, ctx->X[L], nl, p.Wp, R, dz, g.Wp);
     DAISY_LAUNCH_CHECK();
     if (model != DAISY_NEUMF_GMF) {
         for (int l = L; l >= 1; --l) {
@@ -837,29 +1121,62 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
             w.K = R;
             static const int wchunk = getenv("DAISY_WGRAD_CHUNK") ? atoi(getenv("DAISY_WGRAD_CHUNK")) : 2048;
             w.k_chunk = wchunk;
-            w.bf16 = ctx->bf16;
-            launch_gemm<EPI_ATOMIC>(w, s);
-            hipLaunchKernelGGL(k_colsum, dim3((unsigned)((n_out + 63) / 64), (unsigned)((R + kColsumRows - 1) / kColsumRows)),
-                               dim3(kBlock), 0, s, dz, R, n_out, (int64_t)n_out, g.b[l - 1]);
+            w.bf16 = ctx->bf16 ? 1 : 0;
+            const dim3 cs_grid((unsigned)((n_out + 63) / 64), (unsigned)((R + kColsumRows - 1) / kColsumRows));
+            if (H) {
+                w.A16 = reinterpret_cast<const uint16_t *>(w.A);
+                w.B16 = reinterpret_cast<const uint16_t *>(w.B);
+                if (!gemm_h_ok(w)) { set_error("neumf: weight gradient of layer %d does not tile for the bf16-storage GEMM", l); return DAISY_ERR_STATE; }
+                launch_gemm_h<EPI_ATOMIC>(w, s);
+                hipLaunchKernelGGL((k_colsum<true>), cs_grid, dim3(kBlock), 0, s, dz, R, n_out, (int64_t)n_out, g.b[l - 1]);
+            } else {
+                launch_gemm<EPI_ATOMIC>(w, s);
+                hipLaunchKernelGGL((k_colsum<false>), cs_grid, dim3(kBlock), 0, s, dz, R, n_out, (int64_t)n_out, g.b[l - 1]);
+            }
             GemmOp x{};                                   // dZ_{l-1}[R, n_in] = (dZ W_l) gated
             x.A = dz; x.sam = n_out; x.sak = 1;
             x.B = p.W[l - 1]; x.sbn = 1; x.sbk = n_in;
             x.C = dz_next; x.ldc = n_in;
             x.M = R; x.N = n_in; x.K = n_out;
             x.k_chunk = x.K;
-            x.bf16 = ctx->bf16;
+            x.bf16 = ctx->bf16 ? 1 : 0;
             if (l > 1) {                                  // ReLU (and dropout) gate of x_{l-1}
                 x.gate = ctx->X[l - 1]; x.ldg = n_in; x.gate_scale = scale;
             } else if (thresh) {                          // dropout mask of the concat input
                 x.drop_thresh = thresh; x.drop_scale = scale; x.drop_seed = seed; x.drop_stream = 1u;
             }
-            launch_gemm<EPI_GATE>(x, s);
+            if (H) {
+                x.A16 = reinterpret_cast<const uint16_t *>(dz);
+                x.B16 = ctx->W16[l - 1];
+                x.C16 = reinterpret_cast<uint16_t *>(dz_next);
+                x.G16 = (l > 1) ? reinterpret_cast<const uint16_t *>(ctx->X[l - 1]) : nullptr;
+                if (!gemm_h_ok(x)) { set_error("neumf: input gradient of layer %d does not tile for the bf16-storage GEMM", l); return DAISY_ERR_STATE; }
+                launch_gemm_h<EPI_GATE>(x, s);
+            } else {
+                launch_gemm<EPI_GATE>(x, s);
+            }
             DAISY_LAUNCH_CHECK();
             float *t = dz; dz = dz_next; dz_next = t;
         }
     }
-    hipLaunchKernelGGL(k_nmf_scatter, dim3(grid_for(R, kBlock / 16 * 2)), dim3(kBlock), 0, s, p, g, src, R, d, dm,
-                       model, pointwise, ctx->dpred, dz, stats, reg_1, reg_2);
+    if (H) hipLaunchKernelGGL((k_nmf_scatter<true>), dim3(grid_for(R, kBlock / 16 * 2)), dim3(kBlock), 0, s, p, g, src, R, d, dm,
+                              model, pointwise, ctx->dpred, dz, stats, reg_1, reg_2);
+    else hipLaunchKernelGGL((k_nmf_scatter<false>), dim3(grid_for(R, kBlock / 16 * 2)), dim3(kBlock), 0, s, p, g, src, R, d, dm,
+                            model, pointwise, ctx->dpred, dz, stats, reg_1, reg_2);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int daisy_gemm_nt_bf16(const uint16_t *A, const uint16_t *B, uint16_t *C, int64_t M, int32_t N, int32_t K,
+                       daisy_stream_t stream) {
+    DAISY_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "gemm_nt_bf16: bad argument");
+    GemmOp op{};
+    op.A16 = A; op.sam = K; op.sak = 1;
+    op.B16 = B; op.sbn = K; op.sbk = 1;
+    op.C16 = C; op.ldc = N;
+    op.M = M; op.N = N; op.K = K; op.k_chunk = K;
+    DAISY_CHECK_ARG(gemm_h_ok(op), "gemm_nt_bf16: needs M %% 128 == 0, N %% 64 == 0 (128 when N > 64), K %% 32 == 0, 16-byte aligned rows");
+    launch_gemm_h<EPI_GATE>(op, NS(stream));          // no gate tensor: a plain bf16 store
     DAISY_LAUNCH_CHECK();
     return DAISY_OK;
 }

@@ -134,7 +134,7 @@ class NeuMF(GeneralRecommender):
     def _ctx(self, rows):
         ctx = ops.NeumfContext(rows, self.factors, self.num_layers, self.embed_user_GMF.num_embeddings,
                                self.embed_item_GMF.num_embeddings, model=self._native_model, device=self.device)
-        ctx.set_precision(self.precision == "bf16")
+        ctx.set_precision({"fp32": 0, "bf16_inputs": 1, "bf16": 2}.get(self.precision, 0))
         return ctx
 
     # -- reference surface ---------------------------------------------------------------------------

@@ -583,8 +583,9 @@ class NeumfContext:
         return int(lib.daisy_neumf_ctx_bytes(self._h))
 
     def set_precision(self, bf16_gemm):
-        """True: bf16-input MFMA in the MLP tower (throughput mode); False (default): exact fp32."""
-        check(lib.daisy_neumf_ctx_set_precision(self._h, int(bool(bf16_gemm))))
+        """0 / False (default): exact fp32; 1 / True: bf16-input MFMA in the MLP tower (fp32 operands rounded on the way
+        into LDS); 2: activations and a copy of the weights stored as bf16 in HBM too (throughput modes)."""
+        check(lib.daisy_neumf_ctx_set_precision(self._h, int(bf16_gemm)))
 
     def scores(self, params, users, items=None, C_=0, n=None):
         """NeuMF.forward in eval mode: see daisy_neumf_scores for the three pair layouts."""
@@ -634,6 +635,16 @@ def full_topk_from_scores(scores, topk):
     check(lib.daisy_full_topk_from_scores(_ptr(scores.contiguous(), torch.float32, "scores"), I, int(topk),
                                           _ptr(out, torch.int64, "out"), _ptr(ws, torch.uint8, "ws"), ws.numel(),
                                           _stream()))
+    return out
+
+
+def gemm_nt_bf16(A, B):
+    """C = A @ B.T with bf16 storage for A [M,K], B [N,K] and C [M,N] (fp32 accumulation on the MFMA units)."""
+    M, K = A.shape
+    Nn = B.shape[0]
+    out = torch.empty(M, Nn, dtype=torch.bfloat16, device=A.device)
+    check(lib.daisy_gemm_nt_bf16(_ptr(A, torch.bfloat16, "A"), _ptr(B, torch.bfloat16, "B"), _ptr(out, torch.bfloat16, "C"),
+                                 M, Nn, K, _stream()))
     return out
 
 

@@ -414,10 +414,15 @@ int daisy_neumf_ctx_create(daisy_neumf_ctx **out, int64_t max_rows, int32_t fact
                            int32_t model, int64_t user_num, int64_t item_num);
 int daisy_neumf_ctx_destroy(daisy_neumf_ctx *ctx);
 size_t daisy_neumf_ctx_bytes(const daisy_neumf_ctx *ctx);
-/* bf16_gemm != 0: the MLP tower's GEMMs round their fp32 operands to bf16 on the way into LDS and run
+/* bf16_gemm = 1: the MLP tower's GEMMs round their fp32 operands to bf16 on the way into LDS and run
  * v_mfma_f32_32x32x16_bf16 (fp32 accumulate) wherever the tile shape allows (128-row / 64|128-column
- * multiples, K multiple of 32, 16-byte aligned operands; other shapes stay fp32).  Throughput mode:
- * results differ from the fp32 parity mode by bf16 rounding (~3 significant digits).  Default: 0. */
+ * multiples, K multiple of 32, 16-byte aligned operands; other shapes stay fp32).
+ * bf16_gemm = 2 (BASELINE configs[3] "MLP via MFMA bf16"): the activations X_l, the back-propagated dZ_l and a
+ * per-call copy of the MLP weights are STORED as bf16 in HBM as well (half the operand traffic, which is what
+ * bounds level 1); embeddings, GMF branch, weight gradients and the optimiser stay fp32.  Applies to calls
+ * whose row count is a multiple of 128 and whose layer widths are multiples of 64, level 1 otherwise.
+ * Throughput modes: results differ from the fp32 parity mode by bf16 rounding (~3 significant digits).
+ * Default: 0. */
 int daisy_neumf_ctx_set_precision(daisy_neumf_ctx *ctx, int32_t bf16_gemm);
 /* NeuMF.forward in eval mode (:118-137) on n pairs -> out f32[n]; processed in chunks of max_rows.
  * Pairs are given in one of three layouts (the three callers of the reference):
@@ -450,6 +455,10 @@ int daisy_full_topk_from_scores(const float *scores, int64_t item_num, int32_t t
 /* C[M,N] = A[M,K] * B[N,K]^T on the fp32 MFMA tile kernel the MLP tower uses (test / bench hook) */
 int daisy_gemm_nt_f32(const float *A, const float *B, float *C, int64_t M, int32_t N, int32_t K,
                       daisy_stream_t stream);
+/* C[M,N] = A[M,K] * B[N,K]^T with all three matrices stored as bf16 (fp32 accumulate, round to nearest even): the
+ * GEMM of precision level 2 (test / bench hook); M % 128 == 0, N % 64 == 0 (% 128 when N > 64), K % 32 == 0 */
+int daisy_gemm_nt_bf16(const uint16_t *A, const uint16_t *B, uint16_t *C, int64_t M, int32_t N, int32_t K,
+                       daisy_stream_t stream);
 /* same with the precision switch of daisy_neumf_ctx_set_precision */
 int daisy_gemm_nt(const float *A, const float *B, float *C, int64_t M, int32_t N, int32_t K, int32_t bf16,
                   daisy_stream_t stream);

@@ -249,23 +249,72 @@ def test_neumf_bf16_mode_tracks_the_fp32_step():
     p_np = {k: (rng.standard_normal(s) * 0.05).astype(np.float32) for k, s in shapes.items()}
     u, i, j = (torch.as_tensor(rng.integers(0, n, B).astype(np.int32)).to(DEV) for n in (U, I, I))
     res = []
-    for bf16 in (False, True):
+    for level in (0, 1, 2):        # fp32 | bf16 MFMA inputs | bf16 storage of activations and weights as well
         p = _dev(p_np)
         grads = {k: torch.zeros_like(v) for k, v in p.items()}
         ctx = ops.NeumfContext(2 * B, d, L, U, I)
-        ctx.set_precision(bf16)
+        ctx.set_precision(level)
         ctx.step_grads(p, grads, u, i, j, 0, 1e-3, 1e-3)
         res.append((float(ctx.stats[11].cpu()), {k: v.cpu().numpy() for k, v in grads.items()}))
         ctx.close()
-    (l32, g32), (l16, g16) = res
-    assert l32 != l16 and abs(l16 - l32) <= 2e-3 * abs(l32)
-    for k in shapes:
-        # bf16 rounding per product (~0.4 %), accumulated over three layers each way, plus ReLU gates that
-        # flip for activations within rounding of 0: a few per cent in L2, directions unchanged
-        err = np.linalg.norm(g16[k] - g32[k]) / (np.linalg.norm(g32[k]) + 1e-12)
-        cos = float((g16[k] * g32[k]).sum() / (np.linalg.norm(g16[k]) * np.linalg.norm(g32[k]) + 1e-30))
-        if np.linalg.norm(g32[k]) > 0:                  # (bp's gradient is exactly 0 under BPR)
-            assert err < 0.15 and cos > 0.99, (k, err, cos)
+    l32, g32 = res[0]
+    for level, (l16, g16) in ((1, res[1]), (2, res[2])):
+        assert l32 != l16 and abs(l16 - l32) <= 2e-3 * abs(l32), (level, l16, l32)
+        for k in shapes:
+            # bf16 rounding per product (~0.4 %), accumulated over three layers each way, plus ReLU gates that
+            # flip for activations within rounding of 0: a few per cent in L2, directions unchanged
+            err = np.linalg.norm(g16[k] - g32[k]) / (np.linalg.norm(g32[k]) + 1e-12)
+            cos = float((g16[k] * g32[k]).sum() / (np.linalg.norm(g16[k]) * np.linalg.norm(g32[k]) + 1e-30))
+            if np.linalg.norm(g32[k]) > 0:                  # (bp's gradient is exactly 0 under BPR)
+                assert err < (0.15 if level == 1 else 0.25) and cos > (0.99 if level == 1 else 0.97), (level, k, err, cos)
+    assert res[1][0] != res[2][0]                           # level 2 really took the bf16-storage kernels
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (384, 64, 512), (128, 256, 32)])
+def test_mfma_gemm_bf16_storage(M, N, K):
+    """all-bf16-operand GEMM of precision level 2: exact product of the stored bf16 values, fp32 accumulation,
+    result rounded to bf16"""
+    from daisyrec_amd import ops
+    g = torch.Generator(device=DEV)
+    g.manual_seed(M + N + K)
+    A = torch.randn(M, K, device=DEV, generator=g).to(torch.bfloat16)
+    Bm = (torch.randn(N, K, device=DEV, generator=g) * torch.linspace(0.1, 2.0, N, device=DEV)[:, None]).to(torch.bfloat16)
+    got = ops.gemm_nt_bf16(A, Bm)
+    exact = A.double() @ Bm.double().T
+    assert got.dtype == torch.bfloat16 and got.shape == (M, N)
+    assert float((got.double() - exact).abs().max()) <= 1e-2 * float(exact.abs().max())
+    with pytest.raises(ValueError):
+        ops.gemm_nt_bf16(A[:100].contiguous(), Bm)                         # partial row tile
+
+
+def test_neumf_bf16_storage_dropout_and_eval():
+    """level 2 with dropout (masks are functions of (seed, layer, row, column), so the fp32 run of the same seed
+    drops the same elements) and through the scoring entry point"""
+    from daisyrec_amd import ops
+    rng = np.random.default_rng(9)
+    U, I, d, L, B = 200, 150, 64, 2, 256
+    dm = d << (L - 1)
+    shapes = {"uG": (U, d), "iG": (I, d), "uM": (U, dm), "iM": (I, dm), "Wp": (1, 2 * d), "bp": (1,)}
+    w = 2 * dm
+    for l in range(1, L + 1):
+        shapes[f"W{l}"], shapes[f"b{l}"] = (w // 2, w), (w // 2,)
+        w //= 2
+    p_np = {k: (rng.standard_normal(s) * 0.05).astype(np.float32) for k, s in shapes.items()}
+    u, i, j = (torch.as_tensor(rng.integers(0, n, B).astype(np.int32)).to(DEV) for n in (U, I, I))
+    out = []
+    for level in (0, 2):
+        p = _dev(p_np)
+        grads = {k: torch.zeros_like(v) for k, v in p.items()}
+        ctx = ops.NeumfContext(2 * B, d, L, U, I)
+        ctx.set_precision(level)
+        ctx.step_grads(p, grads, u, i, j, 0, 0.0, 0.0, dropout=0.5, seed=77)
+        scores = ctx.scores(p, u.long(), i.long())
+        out.append((float(ctx.stats[11].cpu()), grads["W1"].cpu().numpy(), scores.cpu().numpy()))
+        ctx.close()
+    assert abs(out[1][0] - out[0][0]) <= 5e-3 * abs(out[0][0])
+    cos = float((out[0][1] * out[1][1]).sum() / (np.linalg.norm(out[0][1]) * np.linalg.norm(out[1][1])))
+    assert cos > 0.97
+    assert np.abs(out[0][2] - out[1][2]).max() <= 2e-2 * max(1e-3, np.abs(out[0][2]).max())
 
 
 def test_neumf_argument_errors():
