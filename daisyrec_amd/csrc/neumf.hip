@@ -14,6 +14,8 @@
 //             k_nmf_scatter     embedding gradients (fp32 atomics into the dense gradient tables) +
 //                               the regulariser gradients exactly as NeuMFRecommender.py:149-167 lists them
 // Dropout: x_{l-1} is stored already masked and scaled, so "x > 0" carries mask and ReLU gate at once.
+#include <stdlib.h>
+
 #include "common.h"
 
 #include <type_traits>
@@ -469,7 +471,7 @@ __global__ __launch_bounds__(kBlock) void k_gemm_h(GemmOp op) {
             cur ^= 1;
         }
     }
-    if constexpr (EPI == EPI_ATOMIC) {
+    if (EPI == EPI_ATOMIC || op.C16 == nullptr) {      // fp32 result: split-K atomics, or the tower's input gradient
         gemm_epilogue<WN, EPI, true, DROP>(op, acc, m0, n0, wm, wn, lane);
     } else {        // bf16 output (interior tiles only: launch_gemm_h checks)
         // The MFMA result layout gives a lane ONE column and 32 scattered rows: written directly that is 64 two-byte
@@ -892,6 +894,81 @@ __global__ __launch_bounds__(kBlock) void k_nmf_scatter(daisy_neumf_params p, da
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Embedding gradients without atomics (default): the R rows of a step are sorted by user and by item (two
+// radix sorts of R int32 keys), and each table's gradient is a segmented reduction over the sorted list on the
+// MF item pass's kernel (segsum_rows: single owner per table row, fixed summation order, bitwise reproducible).
+// With ml-1m's 6040 users a batch of 524 288 rows hits every user row ~87 times: the atomic kernel serialises
+// on those addresses.  The regulariser terms are count * f(row) per table row (integer counts).
+// ---------------------------------------------------------------------------------------------
+__global__ void k_nmf_sort_keys(PairSrc src, int64_t R, int32_t *__restrict__ ku, int32_t *__restrict__ ki,
+                                int32_t *__restrict__ val, int pointwise, int32_t *__restrict__ cnt_u,
+                                int32_t *__restrict__ cnt_i, int32_t *__restrict__ cnt_j) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+        int64_t user, item;
+        pair_ids(src, r, user, item);
+        ku[r] = (int32_t)user;
+        ki[r] = (int32_t)item;
+        val[r] = (int32_t)r;
+        if (r < src.B) { atomicAdd(cnt_u + user, 1); atomicAdd(cnt_i + item, 1); }     // regulariser occurrences (:149-167)
+        else if (!pointwise) atomicAdd(cnt_j + item, 1);
+    }
+}
+
+// entry e of a sorted list -> the segmented reduction's view: key = table row << 1, source row = rows_per*r + half
+__global__ void k_nmf_entries(const int32_t *__restrict__ key_sorted, const int32_t *__restrict__ val_sorted, int64_t R,
+                              int64_t n_pad, int rows_per, int half, uint32_t *__restrict__ ekey,
+                              uint2 *__restrict__ esu, float2 *__restrict__ w) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n_pad; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = e < R ? e : R - 1;               // an odd count is padded with a weightless copy of the last entry
+        ekey[e] = (uint32_t)key_sorted[q] << 1;
+        esu[e] = make_uint2((uint32_t)e, (uint32_t)(rows_per * val_sorted[q] + half));
+        w[e] = make_float2(e < R ? 1.f : 0.f, 0.f);
+    }
+}
+
+// GMF branch: per-row gradients  d/d uG[user] = dpred * Wp * iG[item],  d/d iG[item] = dpred * Wp * uG[user]
+__global__ __launch_bounds__(kBlock) void k_nmf_gmf_rows(daisy_neumf_params p, PairSrc src, int64_t R, int d,
+                                                         const float *__restrict__ dpred, float *__restrict__ gu,
+                                                         float *__restrict__ gi) {
+    const int lane = threadIdx.x % 16, group = threadIdx.x / 16;
+    const int64_t gstride = (int64_t)gridDim.x * (kBlock / 16);
+    for (int64_t r = (int64_t)blockIdx.x * (kBlock / 16) + group; r < R; r += gstride) {
+        int64_t user, item;
+        pair_ids(src, r, user, item);
+        const float dp = dpred[r];
+        for (int c = lane; c < d; c += 16) {
+            const float w = dp * p.Wp[c];
+            gu[r * (int64_t)d + c] = w * p.iG[item * d + c];
+            gi[r * (int64_t)d + c] = w * p.uG[user * d + c];
+        }
+    }
+}
+
+// g[row] += sum[row] (clearing sum) + (ca*ia + cb*ib) * w[row] + reg_1*(ca + cb) * sign(w[row]); counts cleared
+__global__ __launch_bounds__(kBlock) void k_nmf_table_commit(float *__restrict__ g, float *__restrict__ sum,
+                                                             const float *__restrict__ w, int64_t rows, int width,
+                                                             int32_t *__restrict__ ca, int ka, int32_t *__restrict__ cb,
+                                                             int kb, float scale_b, const double *__restrict__ stats,
+                                                             float reg_1, float reg_2, int clear_counts) {
+    const int lane = threadIdx.x % 16, group = threadIdx.x / 16;
+    const int64_t gstride = (int64_t)gridDim.x * (kBlock / 16);
+    auto inv = [&](int k) { const double n = stats[DAISY_NST_NORM + k]; return (n > 0.0) ? (float)((double)reg_2 / n) : 0.f; };
+    const float ia = inv(ka), ib = cb ? scale_b * inv(kb) : 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * (kBlock / 16) + group; row < rows; row += gstride) {
+        const float na = (float)ca[row], nb = cb ? (float)cb[row] : 0.f;
+        const float r2 = na * ia + nb * ib, r1 = reg_1 * (na + scale_b * nb);
+        for (int c = lane; c < width; c += 16) {
+            const int64_t x = row * (int64_t)width + c;
+            float v = 0.f;
+            if (sum) { v = sum[x]; sum[x] = 0.f; }
+            if (na + nb > 0.f) { const float e = w[x]; v += fmaf(r2, e, r1 * sgn(e)); }
+            if (v != 0.f) g[x] += v;
+        }
+        if (clear_counts && lane == 0) { ca[row] = 0; if (cb) cb[row] = 0; }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_sgd_dense(float *__restrict__ W, float *__restrict__ g, int64_t n,
                                                       float lr) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
@@ -913,6 +990,13 @@ struct daisy_neumf_ctx {
     float *X[DAISY_NEUMF_MAX_LAYERS + 1];    // X[0] = (dropped) concat input, X[l] = layer outputs
     float *G, *pred, *dpred, *DZ[2];
     uint16_t *W16[DAISY_NEUMF_MAX_LAYERS];   // bf16 copies of the MLP weights (precision level 2), refreshed per call
+    // scratch of the owner-based embedding scatter (allocated at its first use)
+    void *sc_arena;
+    int32_t *sc_ku, *sc_ki, *sc_val, *sc_ks, *sc_vs, *sc_cu, *sc_ci, *sc_cj;
+    uint32_t *sc_ekey; uint2 *sc_esu; float2 *sc_w;
+    float *sc_gu, *sc_gi, *sc_sum, *sc_edge_vec, *sc_edge_b;
+    int32_t *sc_edge_item, *sc_edge_whole;
+    void *sc_tmp; size_t sc_tmp_bytes;
     int bf16;                                // daisy_neumf_ctx_set_precision: 0 fp32, 1 bf16 MFMA inputs, 2 bf16 storage
 };
 
@@ -992,6 +1076,94 @@ static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p,
     return DAISY_OK;
 }
 
+static int neumf_scatter_scratch(daisy_neumf_ctx *c) {
+    if (c->sc_arena) return DAISY_OK;
+    const size_t R = (size_t)c->max_rows + 1, dm = (size_t)c->dm, d = (size_t)c->d;
+    const size_t rows_max = (size_t)(c->U > c->I ? c->U : c->I);
+    size_t chunks = (size_t)segsum_chunks((int64_t)R + 1, c->dm);
+    const size_t ch2 = (size_t)segsum_chunks((int64_t)R + 1, c->d);
+    if (ch2 > chunks) chunks = ch2;
+    chunks += 2;
+    c->sc_tmp_bytes = sort_pairs_i32_temp_bytes((int64_t)R);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
+    const size_t o_ku = take(R * 4), o_ki = take(R * 4), o_val = take(R * 4), o_ks = take(R * 4), o_vs = take(R * 4);
+    const size_t o_cu = take((size_t)c->U * 4), o_ci = take((size_t)c->I * 4), o_cj = take((size_t)c->I * 4);
+    const size_t o_ek = take((R + 1) * 4), o_es = take((R + 1) * 8), o_w = take((R + 1) * 8);
+    const size_t o_gu = take(R * d * 4), o_gi = take(R * d * 4), o_sum = take(rows_max * dm * 4);
+    const size_t o_ev = take(2 * chunks * dm * 4), o_ei = take(2 * chunks * 4), o_eb = take(2 * chunks * 4), o_ew = take(chunks * 4);
+    const size_t o_tmp = take(c->sc_tmp_bytes);
+    hipError_t e = hipMalloc(&c->sc_arena, off);
+    if (e != hipSuccess) {
+        set_error("neumf: hipMalloc(%zu) of the scatter scratch failed: %s", off, hipGetErrorString(e));
+        c->sc_arena = nullptr;
+        return DAISY_ERR_HIP;
+    }
+    char *b = (char *)c->sc_arena;
+    c->sc_ku = (int32_t *)(b + o_ku); c->sc_ki = (int32_t *)(b + o_ki); c->sc_val = (int32_t *)(b + o_val);
+    c->sc_ks = (int32_t *)(b + o_ks); c->sc_vs = (int32_t *)(b + o_vs);
+    c->sc_cu = (int32_t *)(b + o_cu); c->sc_ci = (int32_t *)(b + o_ci); c->sc_cj = (int32_t *)(b + o_cj);
+    c->sc_ekey = (uint32_t *)(b + o_ek); c->sc_esu = (uint2 *)(b + o_es); c->sc_w = (float2 *)(b + o_w);
+    c->sc_gu = (float *)(b + o_gu); c->sc_gi = (float *)(b + o_gi); c->sc_sum = (float *)(b + o_sum);
+    c->sc_edge_vec = (float *)(b + o_ev); c->sc_edge_item = (int32_t *)(b + o_ei); c->sc_edge_b = (float *)(b + o_eb);
+    c->sc_edge_whole = (int32_t *)(b + o_ew);
+    c->sc_tmp = b + o_tmp;
+    // the counts and the row-sum table are kept all-zero between calls by the kernels that consume them
+    e = hipMemset(b + o_cu, 0, o_ek - o_cu);
+    if (e == hipSuccess) e = hipMemset(b + o_sum, 0, rows_max * dm * 4);
+    if (e != hipSuccess) { set_error("neumf: hipMemset of the scatter scratch failed"); return DAISY_ERR_HIP; }
+    return DAISY_OK;
+}
+
+// g.{uG,iG,uM,iM} += the embedding gradients of the step (DX0: fp32 [R, 2*dm] input gradient of the MLP tower)
+static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, const daisy_neumf_params &g,
+                               const PairSrc &src, int64_t R, int pointwise, const float *DX0, const double *stats,
+                               float reg_1, float reg_2, hipStream_t s) {
+    int rc = neumf_scatter_scratch(c);
+    if (rc) return rc;
+    const int d = c->d, dm = c->dm, model = c->model;
+    const int64_t n_pad = R + (R & 1);
+    hipLaunchKernelGGL(k_nmf_sort_keys, dim3(grid_for(R, kBlock * 2)), dim3(kBlock), 0, s, src, R, c->sc_ku, c->sc_ki,
+                       c->sc_val, pointwise, c->sc_cu, c->sc_ci, c->sc_cj);
+    if (model != DAISY_NEUMF_MLP)
+        hipLaunchKernelGGL(k_nmf_gmf_rows, dim3(grid_for(R, kBlock / 16 * 2)), dim3(kBlock), 0, s, p, src, R, d, c->dpred,
+                           c->sc_gu, c->sc_gi);
+    DAISY_LAUNCH_CHECK();
+    for (int side = 0; side < 2; ++side) {            // 0: the user tables, 1: the item tables
+        const int64_t rows = side ? c->I : c->U;
+        rc = sort_pairs_i32(c->sc_tmp, c->sc_tmp_bytes, side ? c->sc_ki : c->sc_ku, c->sc_ks, c->sc_val, c->sc_vs, R,
+                            bits_for(rows), s);
+        if (rc) return rc;
+        const int ge = grid_for(n_pad, kBlock * 2), gt = grid_for(rows, kBlock / 16 * 2);
+        // MLP table: source row = half `side` of DX0[r]
+        if (model != DAISY_NEUMF_GMF) {
+            hipLaunchKernelGGL(k_nmf_entries, dim3(ge), dim3(kBlock), 0, s, c->sc_ks, c->sc_vs, R, n_pad, 2, side, c->sc_ekey,
+                               c->sc_esu, c->sc_w);
+            rc = segsum_rows(DX0, c->sc_w, c->sc_ekey, c->sc_esu, n_pad, dm, c->sc_sum, c->sc_edge_vec, c->sc_edge_item,
+                             c->sc_edge_b, c->sc_edge_whole, s);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(k_nmf_table_commit, dim3(gt), dim3(kBlock), 0, s, side ? g.iM : g.uM,
+                           (model != DAISY_NEUMF_GMF) ? c->sc_sum : (float *)nullptr, side ? p.iM : p.uM, rows, dm,
+                           side ? c->sc_ci : c->sc_cu, side ? 3 : 1, (int32_t *)nullptr, 0, 0.f, stats, reg_1, reg_2, 0);
+        // GMF table: source row = the materialised per-row gradient
+        if (model != DAISY_NEUMF_MLP) {
+            hipLaunchKernelGGL(k_nmf_entries, dim3(ge), dim3(kBlock), 0, s, c->sc_ks, c->sc_vs, R, n_pad, 1, 0, c->sc_ekey,
+                               c->sc_esu, c->sc_w);
+            rc = segsum_rows(side ? c->sc_gi : c->sc_gu, c->sc_w, c->sc_ekey, c->sc_esu, n_pad, d, c->sc_sum, c->sc_edge_vec,
+                             c->sc_edge_item, c->sc_edge_b, c->sc_edge_whole, s);
+            if (rc) return rc;
+        }
+        // (the negative item's GMF rows enter the regulariser twice, NeuMFRecommender.py:158-161)
+        hipLaunchKernelGGL(k_nmf_table_commit, dim3(gt), dim3(kBlock), 0, s, side ? g.iG : g.uG,
+                           (model != DAISY_NEUMF_MLP) ? c->sc_sum : (float *)nullptr, side ? p.iG : p.uG, rows, d,
+                           side ? c->sc_ci : c->sc_cu, side ? 2 : 0, side ? c->sc_cj : (int32_t *)nullptr, 4, 2.f, stats,
+                           reg_1, reg_2, 1);
+        DAISY_LAUNCH_CHECK();
+    }
+    return DAISY_OK;
+}
+
 extern "C" {
 
 int daisy_neumf_ctx_create(daisy_neumf_ctx **out, int64_t max_rows, int32_t factors, int32_t num_layers,
@@ -1008,6 +1180,7 @@ int daisy_neumf_ctx_create(daisy_neumf_ctx **out, int64_t max_rows, int32_t fact
     c->max_rows = max_rows; c->U = user_num; c->I = item_num;
     c->d = factors; c->L = num_layers; c->model = model;
     c->bf16 = 0;
+    c->sc_arena = nullptr;
     c->dm = factors << (num_layers - 1);
     c->width[0] = 2 * c->dm;
     for (int l = 1; l <= num_layers; ++l) c->width[l] = c->width[l - 1] / 2;
@@ -1038,6 +1211,7 @@ int daisy_neumf_ctx_create(daisy_neumf_ctx **out, int64_t max_rows, int32_t fact
 int daisy_neumf_ctx_destroy(daisy_neumf_ctx *ctx) {
     if (!ctx) return DAISY_OK;
     if (ctx->arena) (void)hipFree(ctx->arena);
+    if (ctx->sc_arena) (void)hipFree(ctx->sc_arena);
     delete ctx;
     return DAISY_OK;
 }
@@ -1098,6 +1272,9 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
     const int nl = (model == DAISY_NEUMF_GMF) ? 0 : ctx->width[L];
     float *dz = ctx->DZ[0], *dz_next = ctx->DZ[1];
     const bool H = neumf_use_h(ctx, R);
+    // 1 (default): owner-based, reproducible embedding scatter; 0: the fp32-atomics kernel (kept for A/B measurements)
+    static const int tune_scatter = getenv("DAISY_NMF_SCATTER_OWNER") ? atoi(getenv("DAISY_NMF_SCATTER_OWNER")) : 1;
+    const bool owner_scatter = tune_scatter != 0;
     if (H) hipLaunchKernelGGL((k_nmf_pred_bwd<true>), dim3(grid_for(R, kBlock / 16 * 16, 1024)), dim3(kBlock), 0, s, ctx->dpred,
                               ctx->G, dg, ctx->X[L], nl, p.Wp, R, dz, g.Wp);
     else hipLaunchKernelGGL((k_nmf_pred_bwd<false>), dim3(grid_for(R, kBlock / 16 * 16, 1024)), dim3(kBlock), 0, s, ctx->dpred,
@@ -1148,8 +1325,8 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
             if (H) {
                 x.A16 = reinterpret_cast<const uint16_t *>(dz);
                 x.B16 = ctx->W16[l - 1];
-                x.C16 = reinterpret_cast<uint16_t *>(dz_next);
-                x.G16 = (l > 1) ? reinterpret_cast<const uint16_t *>(ctx->X[l - 1]) : nullptr;
+                x.C16 = (l > 1 || !owner_scatter) ? reinterpret_cast<uint16_t *>(dz_next) : nullptr;   // dX0 in fp32 for the
+                x.G16 = (l > 1) ? reinterpret_cast<const uint16_t *>(ctx->X[l - 1]) : nullptr;          // segmented scatter
                 if (!gemm_h_ok(x)) { set_error("neumf: input gradient of layer %d does not tile for the bf16-storage GEMM", l); return DAISY_ERR_STATE; }
                 launch_gemm_h<EPI_GATE>(x, s);
             } else {
@@ -1159,10 +1336,16 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
             float *t = dz; dz = dz_next; dz_next = t;
         }
     }
-    if (H) hipLaunchKernelGGL((k_nmf_scatter<true>), dim3(grid_for(R, kBlock / 16 * 2)), dim3(kBlock), 0, s, p, g, src, R, d, dm,
-                              model, pointwise, ctx->dpred, dz, stats, reg_1, reg_2);
-    else hipLaunchKernelGGL((k_nmf_scatter<false>), dim3(grid_for(R, kBlock / 16 * 2)), dim3(kBlock), 0, s, p, g, src, R, d, dm,
-                            model, pointwise, ctx->dpred, dz, stats, reg_1, reg_2);
+    if (owner_scatter) {
+        rc = neumf_scatter_owner(ctx, p, g, src, R, pointwise, dz, stats, reg_1, reg_2, s);
+        if (rc) return rc;
+    } else if (H) {
+        hipLaunchKernelGGL((k_nmf_scatter<true>), dim3(grid_for(R, kBlock / 16 * 2)), dim3(kBlock), 0, s, p, g, src, R, d, dm,
+                           model, pointwise, ctx->dpred, dz, stats, reg_1, reg_2);
+    } else {
+        hipLaunchKernelGGL((k_nmf_scatter<false>), dim3(grid_for(R, kBlock / 16 * 2)), dim3(kBlock), 0, s, p, g, src, R, d, dm,
+                           model, pointwise, ctx->dpred, dz, stats, reg_1, reg_2);
+    }
     DAISY_LAUNCH_CHECK();
     return DAISY_OK;
 }

@@ -340,3 +340,35 @@ def test_neumf_argument_errors():
     with pytest.raises(TypeError):                              # host tensor / wrong dtype are refused, no CPU fallback
         ctx.step_grads(p, g, idx[:4].long(), idx[:4], idx[:4])
     ctx.close()
+
+
+@pytest.mark.parametrize("level", [0, 2])
+def test_neumf_step_is_bitwise_reproducible(level):
+    """Hot users and items (every table row hit hundreds of times per step): the embedding gradients are
+    segmented reductions on a single owner per row, so two runs give identical bits (the fp32-atomics kernel
+    kept behind DAISY_NMF_SCATTER_OWNER=0 does not), and they agree with the atomic kernel's sums to round-off
+    - checked through the oracle KATs of this file, which run on the owner kernels by default."""
+    from daisyrec_amd import ops
+    rng = np.random.default_rng(21)
+    U, I, d, L, B = 40, 30, 64, 2, 2048
+    dm = d << (L - 1)
+    shapes = {"uG": (U, d), "iG": (I, d), "uM": (U, dm), "iM": (I, dm), "Wp": (1, 2 * d), "bp": (1,)}
+    w = 2 * dm
+    for l in range(1, L + 1):
+        shapes[f"W{l}"], shapes[f"b{l}"] = (w // 2, w), (w // 2,)
+        w //= 2
+    p_np = {k: (rng.standard_normal(s) * 0.05).astype(np.float32) for k, s in shapes.items()}
+    u, i, j = (torch.as_tensor(rng.integers(0, n, B).astype(np.int32)).to(DEV) for n in (U, I, I))
+    outs = []
+    for _ in range(2):
+        p = _dev(p_np)
+        grads = {k: torch.zeros_like(v) for k, v in p.items()}
+        ctx = ops.NeumfContext(2 * B, d, L, U, I)
+        ctx.set_precision(level)
+        for step in range(2):                      # the second call accumulates on top of the first (contract)
+            ctx.step_grads(p, grads, u, i, j, 0, 1e-3, 1e-3)
+        outs.append({k: grads[k].cpu().numpy() for k in ("uG", "iG", "uM", "iM")})
+        ctx.close()
+    for k in outs[0]:
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+        assert np.abs(outs[0][k]).max() > 0
