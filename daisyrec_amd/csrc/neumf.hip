@@ -372,6 +372,28 @@ __device__ __forceinline__ bool bf16_positive(uint16_t h) { return (h & 0x8000u)
 
 constexpr int kBKH = 32, kLdkH = kBKH + 8;      // k depth of a tile (64 measured no faster on the GEMM and slower on the step:
                                                 // LDS for two stages halves the resident workgroups)
+// Which tile a workgroup computes.  Workgroups go to the 8 XCDs round-robin by their linear id (observed, used for
+// speed only), and each XCD has its own L2: tiles that read the same operand panel are given to workgroups that
+// land on ONE XCD next to each other in time, so the panel comes from HBM once and from that L2 afterwards.
+//   one k range (forward, input gradient): the column tiles of one 128-row panel of A share it;
+//   split-K (weight gradient): all tiles of one k chunk share the chunk's two panels.
+struct TileId { unsigned x, y, z; };
+__device__ __forceinline__ TileId tile_of_block() {
+    const unsigned gx = gridDim.x, gy = gridDim.y, gz = gridDim.z;
+    TileId t{blockIdx.x, blockIdx.y, blockIdx.z};
+    const unsigned lin = t.x + gx * (t.y + gy * t.z), xcd = lin % 8, slot = lin / 8;
+    if (gz > 1) {
+        if (gz % 8 == 0) {
+            const unsigned per = gx * gy, r = slot % per;
+            t.z = (slot / per) * 8 + xcd; t.x = r % gx; t.y = r / gx;
+        }
+    } else if (gx % 8 == 0) {
+        t.y = slot % gy; t.x = (slot / gy) * 8 + xcd;
+    }
+    return t;
+}
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <int WN, int EPI, bool DROP, bool AK, bool BK>      // AK / BK: operand A / B is contiguous along k (else along its rows)
 __global__ __launch_bounds__(kBlock) void k_gemm_h(GemmOp op) {
     constexpr int BM = kGemmBM, BN = 64 * WN;
@@ -384,9 +406,10 @@ __global__ __launch_bounds__(kBlock) void k_gemm_h(GemmOp op) {
     uint16_t (*Bs)[BN * kLdkH] = reinterpret_cast<uint16_t (*)[BN * kLdkH]>(smem + 2 * BM * kLdkH);
     const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
     const int wm = wave / 2, wn = wave % 2;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
-    const int64_t k_lo = (int64_t)blockIdx.z * op.k_chunk;
+    const TileId tile = tile_of_block();
+    const int64_t m0 = (int64_t)tile.x * BM;
+    const int n0 = tile.y * BN;
+    const int64_t k_lo = (int64_t)tile.z * op.k_chunk;
     const int64_t k_hi = (k_lo + op.k_chunk < op.K) ? (k_lo + op.k_chunk) : op.K;
 
     floatx16 acc[2][WN];
@@ -399,7 +422,8 @@ __global__ __launch_bounds__(kBlock) void k_gemm_h(GemmOp op) {
 
     // registers of one tile: k-contiguous: Q x uint4; row-contiguous: (ROWS*32/256) halfwords packed in pairs
     constexpr int NQ = BM / RPP, NS = BM * kBKH / kBlock / 2;
-    uint4 ra[AK ? NQ : 1], rb[BK ? NQ : 1];
+    // (clang's own vector type: arrays of HIP's uint4 class are not split into registers and went through scratch)
+    u32x4 ra[AK ? NQ : 1], rb[BK ? NQ : 1];
     uint32_t sa[AK ? 1 : NS], sb[BK ? 1 : NS];
     auto load_op = [&](const uint16_t *__restrict__ P, int64_t srow, int64_t sk, auto kfast_c, int64_t row0, int64_t kt,
                        auto &r, auto &sr, auto rows_c) {
@@ -407,7 +431,7 @@ __global__ __launch_bounds__(kBlock) void k_gemm_h(GemmOp op) {
         if constexpr (decltype(kfast_c)::value) {
             const uint16_t *src = P + (row0 + tid / LPT) * srow + kt + (tid % LPT) * 8;
 #pragma unroll
-            for (int q = 0; q < ROWS / RPP; ++q) r[q] = *reinterpret_cast<const uint4 *>(src + (int64_t)q * RPP * srow);
+            for (int q = 0; q < ROWS / RPP; ++q) r[q] = *reinterpret_cast<const u32x4 *>(src + (int64_t)q * RPP * srow);
         } else {
             constexpr int KPT = ROWS * kBKH / kBlock;          // consecutive k per thread (16 for 128 rows, 8 for 64)
             const uint16_t *src = P + row0 + (tid % ROWS) + (kt + (int64_t)(tid / ROWS) * KPT) * sk;
@@ -421,13 +445,13 @@ __global__ __launch_bounds__(kBlock) void k_gemm_h(GemmOp op) {
         if constexpr (decltype(kfast_c)::value) {
 #pragma unroll
             for (int q = 0; q < ROWS / RPP; ++q)
-                *reinterpret_cast<uint4 *>(S + (tid / LPT + q * RPP) * kLdkH + (tid % LPT) * 8) = r[q];
+                *reinterpret_cast<u32x4 *>(S + (tid / LPT + q * RPP) * kLdkH + (tid % LPT) * 8) = r[q];
         } else {
             constexpr int KPT = ROWS * kBKH / kBlock;
             uint16_t *dst = S + (tid % ROWS) * kLdkH + (tid / ROWS) * KPT;
 #pragma unroll
             for (int q = 0; q < KPT / 8; ++q)
-                *reinterpret_cast<uint4 *>(dst + 8 * q) = make_uint4(sr[4 * q], sr[4 * q + 1], sr[4 * q + 2], sr[4 * q + 3]);
+                *reinterpret_cast<u32x4 *>(dst + 8 * q) = u32x4{sr[4 * q], sr[4 * q + 1], sr[4 * q + 2], sr[4 * q + 3]};
         }
     };
     using RA = std::integral_constant<int, BM>; using RB = std::integral_constant<int, BN>;
@@ -567,10 +591,16 @@ static void launch_gemm_h(GemmOp op, hipStream_t s) {
     }
 }
 
-// fp32 -> bf16 (round to nearest even): the per-step copy of the MLP weights
-__global__ void k_to_bf16(const float *__restrict__ x, int64_t n, uint16_t *__restrict__ y) {
-    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
-        y[e] = (uint16_t)bf16_rne(x[e]);
+// fp32 -> bf16 (round to nearest even): the per-step copy of the MLP weights, [rows][cols] as stored and (yt)
+// transposed, so that the forward GEMM and the input-gradient GEMM both read W along their k
+__global__ void k_to_bf16(const float *__restrict__ x, int64_t n, int cols, uint16_t *__restrict__ y,
+                          uint16_t *__restrict__ yt) {
+    const int64_t rows = n / cols;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const uint16_t h = (uint16_t)bf16_rne(x[e]);
+        y[e] = h;
+        yt[(e % cols) * rows + e / cols] = h;
+    }
 }
 // float4 path preconditions: unit stride along one dimension, the other stride and the base 16-byte aligned
 static bool vec_ok(const float *p, int64_t s_row, int64_t s_k, int64_t k_chunk) {
@@ -990,6 +1020,7 @@ struct daisy_neumf_ctx {
     float *X[DAISY_NEUMF_MAX_LAYERS + 1];    // X[0] = (dropped) concat input, X[l] = layer outputs
     float *G, *pred, *dpred, *DZ[2];
     uint16_t *W16[DAISY_NEUMF_MAX_LAYERS];   // bf16 copies of the MLP weights (precision level 2), refreshed per call
+    uint16_t *W16T[DAISY_NEUMF_MAX_LAYERS];  // ... and their transposes [n_in][n_out]
     // scratch of the owner-based embedding scatter (allocated at its first use)
     void *sc_arena;
     int32_t *sc_ku, *sc_ki, *sc_val, *sc_ks, *sc_vs, *sc_cu, *sc_ci, *sc_cj;
@@ -1026,7 +1057,8 @@ static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p,
     if (H) {          // bf16 copies of the MLP weights (a few hundred KB)
         for (int l = 1; l <= L; ++l) {
             const int64_t nw = (int64_t)ctx->width[l] * ctx->width[l - 1];
-            hipLaunchKernelGGL(k_to_bf16, dim3(grid_for(nw, kBlock * 4)), dim3(kBlock), 0, s, p->W[l - 1], nw, ctx->W16[l - 1]);
+            hipLaunchKernelGGL(k_to_bf16, dim3(grid_for(nw, kBlock * 4)), dim3(kBlock), 0, s, p->W[l - 1], nw,
+                               ctx->width[l - 1], ctx->W16[l - 1], ctx->W16T[l - 1]);
         }
     }
     if (train) {
@@ -1191,7 +1223,7 @@ int daisy_neumf_ctx_create(daisy_neumf_ctx **out, int64_t max_rows, int32_t fact
                  od = take((size_t)max_rows * 4);
     const size_t oz0 = take((size_t)max_rows * c->width[0] * 4), oz1 = take((size_t)max_rows * c->width[0] * 4);
     size_t ow[DAISY_NEUMF_MAX_LAYERS];
-    for (int l = 1; l <= num_layers; ++l) ow[l - 1] = take((size_t)c->width[l] * c->width[l - 1] * 2);
+    for (int l = 1; l <= num_layers; ++l) ow[l - 1] = take((size_t)c->width[l] * c->width[l - 1] * 2 * 2);
     c->arena_bytes = off;
     hipError_t e = hipMalloc(&c->arena, off);
     if (e != hipSuccess) {
@@ -1203,7 +1235,10 @@ int daisy_neumf_ctx_create(daisy_neumf_ctx **out, int64_t max_rows, int32_t fact
     for (int l = 0; l <= num_layers; ++l) c->X[l] = (float *)(base + ox[l]);
     c->G = (float *)(base + og); c->pred = (float *)(base + op); c->dpred = (float *)(base + od);
     c->DZ[0] = (float *)(base + oz0); c->DZ[1] = (float *)(base + oz1);
-    for (int l = 1; l <= num_layers; ++l) c->W16[l - 1] = (uint16_t *)(base + ow[l - 1]);
+    for (int l = 1; l <= num_layers; ++l) {
+        c->W16[l - 1] = (uint16_t *)(base + ow[l - 1]);
+        c->W16T[l - 1] = c->W16[l - 1] + (size_t)c->width[l] * c->width[l - 1];
+    }
     *out = c;
     return DAISY_OK;
 }
@@ -1324,7 +1359,7 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
             }
             if (H) {
                 x.A16 = reinterpret_cast<const uint16_t *>(dz);
-                x.B16 = ctx->W16[l - 1];
+                x.B16 = ctx->W16T[l - 1]; x.sbn = n_out; x.sbk = 1;        // W^T [n_in][n_out]: both operands along k
                 x.C16 = (l > 1 || !owner_scatter) ? reinterpret_cast<uint16_t *>(dz_next) : nullptr;   // dX0 in fp32 for the
                 x.G16 = (l > 1) ? reinterpret_cast<const uint16_t *>(ctx->X[l - 1]) : nullptr;          // segmented scatter
                 if (!gemm_h_ok(x)) { set_error("neumf: input gradient of layer %d does not tile for the bf16-storage GEMM", l); return DAISY_ERR_STATE; }
