@@ -190,9 +190,9 @@ __global__ __launch_bounds__(kBlock) void k_fwd(const float *__restrict__ P,
 #pragma unroll
             for (int y = 0; y < SUB; ++y) {
                 const int x = x0 + y;
-                p[y].load(P + (int64_t)group_bcast<C>(my_u, x) * d, lane, d);
-                qi[y].load(Q + (int64_t)group_bcast<C>(my_ij.x, x) * d, lane, d);
-                if constexpr (!POINTWISE) qj[y].load(Q + (int64_t)group_bcast<C>(my_ij.y, x) * d, lane, d);
+                p[y].load_clamped(P + (int64_t)group_bcast<C>(my_u, x) * d, lane, d);
+                qi[y].load_clamped(Q + (int64_t)group_bcast<C>(my_ij.x, x) * d, lane, d);
+                if constexpr (!POINTWISE) qj[y].load_clamped(Q + (int64_t)group_bcast<C>(my_ij.y, x) * d, lane, d);
                 else qj[y].zero();                       // point-wise: j is the label, no second row
             }
 #pragma unroll

@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""Staged step at the C2 shapes for several factor counts d (the reference's mf.yaml default is 100):
+python tools/dbg/d_sweep.py [d ...]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import bench  # noqa: E402
+from daisyrec_amd import ops  # noqa: E402
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from probe_staged import ev_time  # noqa: E402
+
+dev = torch.device("cuda")
+U, I, nnz, B = 1_000_000, 100_000, 50_000_000, 1 << 21
+triples = bench.synth_triples(U, I, nnz, 2022, dev)
+n = triples.shape[0]
+index = ops.TrainIndex(triples, U, I, user_sorted=True)
+MODE = os.environ.get("MODE", "fused")
+plan = ops.EpochPlan(n, U, I, device=dev)
+if MODE == "fused":
+    plan.build_indexed(index, B, order="feistel", seed=1, epoch=0)
+else:
+    plan.build(triples, B, order="feistel", seed=1, epoch=0, user_sorted=True)
+for d in [int(x) for x in sys.argv[1:]] or [64, 100, 128, 96, 50, 32, 24, 200, 256]:
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    Q = torch.empty(I, d, device=dev).normal_(0.0, 0.01, generator=g)
+    P = torch.empty(U, d, device=dev).normal_(0.0, 0.01, generator=g)
+    ctx = ops.BprContext(B, d, U, I, device=dev)
+    k = [0]
+
+    def step():
+        ctx.set_batch_from_plan(plan, k[0] % 20)
+        ctx.sgd_step(P, Q, 0.01, 1e-3, 1e-3, item_mode=ops.ITEM_MODES[MODE])
+        k[0] += 1
+
+    for _ in range(3):
+        step()
+    ms = ev_time(step, 20)
+    alg = 24 * d + 12            # bytes per interaction: 6 row touches of 4d bytes + the (u, i, j) record
+    print(f"d={d:4d}  {ms:.4f} ms/step  {B / ms / 1e6:.3f} G inter/s  {alg * B / (ms * 1e-3) / 1e12:.2f} TB/s algorithmic "
+          f"({alg * B / (ms * 1e-3) / 8e12:.3f} of 8 TB/s)", flush=True)
+    ctx.close()
