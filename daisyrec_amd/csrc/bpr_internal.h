@@ -112,13 +112,16 @@ struct daisy_epoch_plan {
     int32_t p_cur;                      // record set holding the finished plan
 };
 
+constexpr int kPreBlocks = 256;   // workgroups (= partial sums) of the staged step's pre-norm pass
+
 struct daisy_bpr_ctx {
     int64_t max_batch, U, I;
     int d;
     void *arena;
     size_t arena_bytes;
     float2 *coef;        // (dL/dpos, dL/dneg) per sample   [max_batch]
-    double *partials;    // per-workgroup sums              [kMaxGrid*8]
+    double *partials;    // per-workgroup sums              [kMaxGrid*8], then [kPreBlocks] of the staged step's
+                         // pre-norm pass (k_unorm), which the user pass reads while it writes the first part
     int32_t *tmp_triples;  // [max_batch*3] staging for daisy_bpr_set_batch
     float *edge_vec;     // [2*nchunks][d] partial user gradients of runs that cross a chunk boundary
     int32_t *edge_user;  // [2*nchunks]    their user (-1: none); [2c] head edge, [2c+1] tail edge
@@ -160,6 +163,59 @@ int small_fit_epoch(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, float *P, 
 int launch_reduce_partials(const double *partials, int nblocks, double *stats, bool finalize, float reg_1,
                            float reg_2, double *epoch_acc, double *step_loss, hipStream_t s);
 // shared device helpers
+// MFRecommender.py:88-89,94-95: loss += reg_1*(L1 terms) + reg_2*(Frobenius terms)
+__device__ __forceinline__ void finalize_stats(double *__restrict__ stats, float reg_1, float reg_2,
+                                               double *__restrict__ epoch_acc,
+                                               double *__restrict__ step_loss) {
+    const double nU = sqrt(stats[DAISY_ST_SQ_U]);
+    const double nI = sqrt(stats[DAISY_ST_SQ_I]);
+    const double nJ = sqrt(stats[DAISY_ST_SQ_J]);
+    const double loss = stats[DAISY_ST_LOSS_DATA] +
+                        (double)reg_1 * (stats[DAISY_ST_L1_I] + stats[DAISY_ST_L1_J]) +
+                        (double)reg_2 * (nI + nJ) + (double)reg_1 * stats[DAISY_ST_L1_U] +
+                        (double)reg_2 * nU;
+    stats[DAISY_ST_LOSS] = loss;
+    stats[DAISY_ST_NORM_U] = nU;
+    stats[DAISY_ST_NORM_I] = nI;
+    stats[DAISY_ST_NORM_J] = nJ;
+    if (epoch_acc) {
+        epoch_acc[0] += loss;
+        if (!(loss == loss) || isinf(loss)) epoch_acc[1] += 1.0;
+    }
+    if (step_loss) *step_loss = loss;
+}
+
+
+// one workgroup of kBlock threads: stats[0..7] = column sums of partials[nblocks][8], in a fixed order
+__device__ __forceinline__ void reduce_partials_block(const double *__restrict__ partials, int nblocks,
+                                                      double *__restrict__ stats, bool finalize, float reg_1,
+                                                      float reg_2, double *__restrict__ epoch_acc,
+                                                      double *__restrict__ step_loss) {
+    __shared__ double sm[kBlock][8];
+    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] += partials[(int64_t)b * 8 + k];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sm[threadIdx.x][k] = t[k];
+    __syncthreads();
+    for (int off = kBlock / 2; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) sm[threadIdx.x][k] += sm[threadIdx.x + off][k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 7) stats[threadIdx.x] = sm[0][threadIdx.x];
+    if (threadIdx.x == 7) stats[DAISY_ST_SUM_COEF] = sm[0][7];
+    if (finalize) {
+        __syncthreads();
+        if (threadIdx.x == 0) finalize_stats(stats, reg_1, reg_2, epoch_acc, step_loss);
+    }
+}
+
+
 __device__ __forceinline__ float inv_or_zero(double n, float reg_2) {
     return (n > 0.0) ? (float)((double)reg_2 / n) : 0.f;  // d|X|_F/dX = 0 at X = 0 (torch)
 }

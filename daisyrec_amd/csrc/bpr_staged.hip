@@ -576,6 +576,18 @@ __global__ __launch_bounds__(kBlock) void k_unorm_reduce(const double *__restric
     if (threadIdx.x == 0) stats[DAISY_ST_SQ_U_PRE] = sm[0];
 }
 
+// Sum |P[u_s]|^2 over the batch as the user pass needs it before its first update.  n_pre == 0: stats holds it (the
+// phase API: the host has all-reduced it over the ranks).  Otherwise the single-GPU step skips k_unorm_reduce and
+// every wave adds k_unorm's n_pre (<= kPreBlocks) partial sums itself - the same loads in the same order in every
+// wave of every workgroup, so all of them see the same bits.
+struct PreNorm { const double *partials; int n; };
+__device__ __forceinline__ double prenorm_sum(const double *__restrict__ stats, PreNorm pre) {
+    if (pre.n == 0) return stats[DAISY_ST_SQ_U_PRE];
+    double t = 0.0;
+    for (int b = threadIdx.x % kWave; b < pre.n; b += kWave) t += pre.partials[b];
+    return wave_sum_f64(t);
+}
+
 template <class C>
 __device__ __forceinline__ void user_finish_row(Row<C> &p, const Row<C> &acc, float n, float lr,
                                                 float reg_1, float rU) {
@@ -605,7 +617,8 @@ template <class C, int BLK, bool PREMUL, bool HAS_POS>
 __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 ? 4 : 2, 8))) void k_staged_user(
     float *__restrict__ P, const float *__restrict__ Q, StreamView v, int d, const double *__restrict__ stats,
     float lr, float reg_1, float reg_2, int loss_type, float gamma, float *__restrict__ stage,
-    float2 *__restrict__ coef, float *__restrict__ p_sqnorm, double *__restrict__ partials, UserEdges ed) {
+    float2 *__restrict__ coef, float *__restrict__ p_sqnorm, double *__restrict__ partials, UserEdges ed,
+    PreNorm pre) {
     constexpr int G = StagedUserCfg<C, BLK>::G, RUN = StagedUserCfg<C, BLK>::RUN, E = StagedUserCfg<C, BLK>::E;
     constexpr int ROWF = C::NE * C::LPR;
     __shared__ float part_acc[2 * G * ROWF];
@@ -619,7 +632,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 
     const int group = tid / C::LPR;
     const int64_t n = v.B;
     const int64_t nchunks = (n + E - 1) / E;
-    const float rU = inv_or_zero(sqrt(stats[DAISY_ST_SQ_U_PRE]), reg_2);
+    const float rU = inv_or_zero(sqrt(prenorm_sum(stats, pre)), reg_2);
     float acc7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
@@ -835,15 +848,33 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 
 
 // chains of edge records: the chunk whose TAIL edge starts a run owns it.  A user whose run crosses a
 // chunk boundary is touched by nobody else in this step, so P[u] is still the pre-step row here.
+// The single-GPU step gives this launch one more workgroup (red.nblocks > 0), which does what k_reduce_partials
+// would do in a launch of its own: the user pass's per-workgroup sums -> stats, norms, loss.
+struct ReduceJob {
+    const double *partials;
+    int nblocks;                 // 0: no reduction rides on this launch
+    double *stats, *epoch_acc, *step_loss;
+};
 template <class C>
 __global__ __launch_bounds__(kBlock) void k_staged_user_edges(float *__restrict__ P, int64_t nchunks, int d,
                                                               const double *__restrict__ stats, float lr,
                                                               float reg_1, float reg_2, UserEdges ed,
-                                                              float *__restrict__ p_sqnorm) {
+                                                              float *__restrict__ p_sqnorm, PreNorm pre,
+                                                              ReduceJob red) {
+    const double sq_pre = prenorm_sum(stats, pre);
+    unsigned nb = gridDim.x;
+    if (red.nblocks > 0) {
+        nb -= 1;
+        if (blockIdx.x == nb) {
+            reduce_partials_block(red.partials, red.nblocks, red.stats, true, reg_1, reg_2, red.epoch_acc, red.step_loss);
+            if (threadIdx.x == 0 && pre.n) red.stats[DAISY_ST_SQ_U_PRE] = sq_pre;
+            return;
+        }
+    }
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
-    const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
-    const float rU = inv_or_zero(sqrt(stats[DAISY_ST_SQ_U_PRE]), reg_2);
+    const int64_t gstride = (int64_t)nb * C::GROUPS_PER_BLOCK;
+    const float rU = inv_or_zero(sqrt(sq_pre), reg_2);
     for (int64_t c = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; c < nchunks; c += gstride) {
         const int uu = ed.user[2 * c + 1];
         if (uu < 0) continue;
@@ -1146,7 +1177,8 @@ static int staged_check(daisy_bpr_ctx *ctx, int loss_type, const char *who) {
     return DAISY_OK;
 }
 
-static int staged_prenorm(daisy_bpr_ctx *ctx, const float *P, double *stats, hipStream_t s) {
+// reduce: also k_unorm_reduce -> stats[SQ_U_PRE] (the phase API); else the consumers add the partial sums themselves
+static int staged_prenorm(daisy_bpr_ctx *ctx, const float *P, double *stats, bool reduce, int *n_pre, hipStream_t s) {
     const StreamView &v = ctx->sv;
     const int d = ctx->d;
     int rc = dispatch_d(d, [&](auto cfg) {
@@ -1159,21 +1191,28 @@ static int staged_prenorm(daisy_bpr_ctx *ctx, const float *P, double *stats, hip
         return DAISY_OK;
     });
     if (rc) return rc;
-    const int gn = grid_for(v.B, kBlock * 4);
-    hipLaunchKernelGGL(k_unorm, dim3(gn), dim3(kBlock), 0, s, ctx->p_sqnorm, v, ctx->partials);
-    hipLaunchKernelGGL(k_unorm_reduce, dim3(1), dim3(kBlock), 0, s, ctx->partials, gn, stats);
+    const int gn = grid_for(v.B, kBlock * 4, kPreBlocks);
+    double *pre = ctx->partials + (size_t)kMaxGrid * 8;        // behind the user pass's own partial sums
+    hipLaunchKernelGGL(k_unorm, dim3(gn), dim3(kBlock), 0, s, ctx->p_sqnorm, v, pre);
+    if (reduce) hipLaunchKernelGGL(k_unorm_reduce, dim3(1), dim3(kBlock), 0, s, pre, gn, stats);
+    if (n_pre) *n_pre = gn;
     DAISY_LAUNCH_CHECK();
     return DAISY_OK;
 }
 
 static inline bool premul_loss(int loss_type) { return loss_type == DAISY_LOSS_BPR || loss_type == DAISY_LOSS_HL; }
 
+// n_pre > 0 (single-GPU step): the pre-norm comes from k_unorm's partial sums and the reduction of this pass's own
+// sums (stats, loss; into epoch_acc / step_loss) rides on the edge launch; n_pre == 0: stats[SQ_U_PRE] is read
+// and the caller reduces
 static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_type, float gamma, float lr,
-                       float reg_1, float reg_2, double *stats, int *grid_out, hipStream_t s) {
+                       float reg_1, float reg_2, double *stats, int *grid_out, int n_pre, double *epoch_acc,
+                       double *step_loss, hipStream_t s) {
     const StreamView &v = ctx->sv;
     const int d = ctx->d;
     const bool premul = premul_loss(loss_type), has_pos = v.s_pos != nullptr;
     UserEdges ed{ctx->edge_vec, ctx->edge_user, ctx->edge_n, ctx->edge_whole};
+    const PreNorm pre{ctx->partials + (size_t)kMaxGrid * 8, n_pre};
     static const int tune_ug = getenv("DAISY_STAGED_UGRID") ? atoi(getenv("DAISY_STAGED_UGRID")) : kMaxGrid;
     static const int tune_blk = getenv("DAISY_STAGED_UBLK") ? atoi(getenv("DAISY_STAGED_UBLK")) : kStagedUserBlock;
     int64_t nchunks_out = 0;
@@ -1189,7 +1228,7 @@ static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_ty
             nchunks_out = nchunks;
 #define DAISY_LAUNCH_SU(PM, HP)                                                                                         \
             hipLaunchKernelGGL((k_staged_user<C, BLK, PM, HP>), dim3(gu), dim3(BLK), 0, s, P, Q, v, d, stats, lr, reg_1, \
-                               reg_2, loss_type, gamma, ctx->p_stage, ctx->coef, ctx->p_sqnorm, ctx->partials, ed)
+                               reg_2, loss_type, gamma, ctx->p_stage, ctx->coef, ctx->p_sqnorm, ctx->partials, ed, pre)
             if (premul && has_pos) DAISY_LAUNCH_SU(true, true);
             else if (premul) DAISY_LAUNCH_SU(true, false);
             else if (has_pos) DAISY_LAUNCH_SU(false, true);
@@ -1199,8 +1238,9 @@ static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_ty
         if (tune_blk == 128 && C::LPR <= 32) go(std::integral_constant<int, 128>{});
         else go(std::integral_constant<int, kBlock>{});
         if (overflow) return DAISY_OK;
-        hipLaunchKernelGGL((k_staged_user_edges<C>), dim3(grid_for(nchunks_out, C::GROUPS_PER_BLOCK)), dim3(kBlock), 0, s,
-                           P, nchunks_out, d, stats, lr, reg_1, reg_2, ed, ctx->p_sqnorm);
+        const ReduceJob red{ctx->partials, n_pre > 0 ? *grid_out : 0, stats, epoch_acc, step_loss};
+        hipLaunchKernelGGL((k_staged_user_edges<C>), dim3(grid_for(nchunks_out, C::GROUPS_PER_BLOCK) + (n_pre > 0 ? 1 : 0)),
+                           dim3(kBlock), 0, s, P, nchunks_out, d, stats, lr, reg_1, reg_2, ed, ctx->p_sqnorm, pre, red);
         return DAISY_OK;
     });
     if (rc) return rc;
@@ -1251,10 +1291,10 @@ int staged_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int loss_type, float
                     float reg_2, double *stats, double *epoch_acc, double *step_loss, hipStream_t s) {
     int rc = staged_check(ctx, loss_type, "sgd_step");
     if (rc) return rc;
-    if ((rc = staged_prenorm(ctx, P, stats, s))) return rc;
-    int gu = 0;
-    if ((rc = staged_user(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, stats, &gu, s))) return rc;
-    if ((rc = launch_reduce_partials(ctx->partials, gu, stats, true, reg_1, reg_2, epoch_acc, step_loss, s))) return rc;
+    // five launches: pre-norm partial sums, user pass, its edges (+ the reduction of its sums), item pass, its edges
+    int gu = 0, n_pre = 0;
+    if ((rc = staged_prenorm(ctx, P, stats, false, &n_pre, s))) return rc;
+    if ((rc = staged_user(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, stats, &gu, n_pre, epoch_acc, step_loss, s))) return rc;
     if ((rc = staged_item(ctx, loss_type, Q, nullptr, true, lr, reg_1, reg_2, stats, s))) return rc;
     ctx->fwd_done = false;
     return DAISY_OK;
@@ -1391,7 +1431,7 @@ int daisy_bpr_ctx_invalidate_cache(daisy_bpr_ctx *ctx) {
 int daisy_bpr_staged_prenorm(daisy_bpr_ctx *ctx, const float *P, double *stats, daisy_stream_t stream) {
     DAISY_CHECK_ARG(ctx && P && stats, "staged_prenorm: NULL argument");
     if (!ctx->batch_set) { set_error("staged_prenorm: no batch set"); return DAISY_ERR_STATE; }
-    return staged_prenorm(ctx, P, stats, S(stream));
+    return staged_prenorm(ctx, P, stats, true, nullptr, S(stream));
 }
 
 int daisy_bpr_staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int32_t loss_type, float gamma, float lr,
@@ -1404,7 +1444,7 @@ int daisy_bpr_staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int32_t 
         return DAISY_ERR_STATE;
     }
     int gu = 0;
-    if ((rc = staged_user(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, stats, &gu, S(stream)))) return rc;
+    if ((rc = staged_user(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, stats, &gu, 0, nullptr, nullptr, S(stream)))) return rc;
     return launch_reduce_partials(ctx->partials, gu, stats, false, 0.f, 0.f, nullptr, nullptr, S(stream));
 }
 

@@ -243,62 +243,15 @@ __global__ __launch_bounds__(kBlock) void k_fwd(const float *__restrict__ P,
     }
 }
 
-__device__ __forceinline__ void finalize_stats(double *__restrict__ stats, float reg_1, float reg_2,
-                                               double *__restrict__ epoch_acc,
-                                               double *__restrict__ step_loss);
-
 // fixed-order reduction of the per-workgroup sums -> stats[0..6]; FINALIZE: also the norms and
-// the loss (single-GPU step: no all-reduce between the two)
+// the loss (single-GPU step: no all-reduce between the two); reduce_partials_block: bpr_internal.h
 template <bool FINALIZE>
 __global__ __launch_bounds__(kBlock) void k_reduce_partials(const double *__restrict__ partials,
                                                             int nblocks, double *__restrict__ stats,
                                                             float reg_1, float reg_2,
                                                             double *__restrict__ epoch_acc,
                                                             double *__restrict__ step_loss) {
-    __shared__ double sm[kBlock][8];
-    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
-#pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] += partials[(int64_t)b * 8 + k];
-    }
-#pragma unroll
-    for (int k = 0; k < 8; ++k) sm[threadIdx.x][k] = t[k];
-    __syncthreads();
-    for (int off = kBlock / 2; off > 0; off >>= 1) {
-        if (threadIdx.x < off) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) sm[threadIdx.x][k] += sm[threadIdx.x + off][k];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x < 7) stats[threadIdx.x] = sm[0][threadIdx.x];
-    if (threadIdx.x == 7) stats[DAISY_ST_SUM_COEF] = sm[0][7];
-    if constexpr (FINALIZE) {
-        __syncthreads();
-        if (threadIdx.x == 0) finalize_stats(stats, reg_1, reg_2, epoch_acc, step_loss);
-    }
-}
-
-// MFRecommender.py:88-89,94-95: loss += reg_1*(L1 terms) + reg_2*(Frobenius terms)
-__device__ __forceinline__ void finalize_stats(double *__restrict__ stats, float reg_1, float reg_2,
-                                               double *__restrict__ epoch_acc,
-                                               double *__restrict__ step_loss) {
-    const double nU = sqrt(stats[DAISY_ST_SQ_U]);
-    const double nI = sqrt(stats[DAISY_ST_SQ_I]);
-    const double nJ = sqrt(stats[DAISY_ST_SQ_J]);
-    const double loss = stats[DAISY_ST_LOSS_DATA] +
-                        (double)reg_1 * (stats[DAISY_ST_L1_I] + stats[DAISY_ST_L1_J]) +
-                        (double)reg_2 * (nI + nJ) + (double)reg_1 * stats[DAISY_ST_L1_U] +
-                        (double)reg_2 * nU;
-    stats[DAISY_ST_LOSS] = loss;
-    stats[DAISY_ST_NORM_U] = nU;
-    stats[DAISY_ST_NORM_I] = nI;
-    stats[DAISY_ST_NORM_J] = nJ;
-    if (epoch_acc) {
-        epoch_acc[0] += loss;
-        if (!(loss == loss) || isinf(loss)) epoch_acc[1] += 1.0;
-    }
-    if (step_loss) *step_loss = loss;
+    reduce_partials_block(partials, nblocks, stats, FINALIZE, reg_1, reg_2, epoch_acc, step_loss);
 }
 
 __global__ void k_finalize(double *__restrict__ stats, float reg_1, float reg_2,
@@ -1471,7 +1424,7 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     const size_t o_coef = take((size_t)max_batch * 8);
-    const size_t o_part = take((size_t)kMaxGrid * 8 * 8);
+    const size_t o_part = take(((size_t)kMaxGrid * 8 + kPreBlocks) * 8);
     const size_t o_tt = take((size_t)max_batch * 12);
     // edge records: two per chunk of the user pass (B samples) or of the item pass (2B entries)
     size_t max_chunks = 0;
