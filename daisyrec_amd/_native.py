@@ -71,6 +71,8 @@ SIGNATURES = {
     "daisy_train_index_destroy": (C.c_int, [_p]),
     "daisy_train_index_bytes": (_sz, [_p]),
     "daisy_epoch_plan_build_indexed": (C.c_int, [_p, _p, _p, _i32, _u64, _u64, _i64, _p]),
+    "daisy_epoch_plan_build_positions": (C.c_int, [_p, _p, _p, _i64, _i64, _p]),
+    "daisy_epoch_plan_batch_rows": (_i64, [_p, _i64]),
     "daisy_bpr_ctx_invalidate_cache": (C.c_int, [_p]),
     "daisy_bpr_staged_prenorm": (C.c_int, [_p, _p, _p, _p]),
     "daisy_bpr_staged_user": (C.c_int, [_p, _p, _p, _i32, _f32, _f32, _f32, _f32, _p, _p]),

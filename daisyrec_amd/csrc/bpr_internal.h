@@ -110,6 +110,11 @@ struct daisy_epoch_plan {
     void *ptemp;                        // rocPRIM scan scratch
     void *parena2;                      // second record set (plans with more than 256 batches: LSD passes ping-pong)
     int32_t p_cur;                      // record set holding the finished plan
+    // daisy_epoch_plan_build_positions: this plan holds a SUBSET of the epoch's rows (one rank's share), batch k =
+    // the held rows whose epoch position lies in [k*B, (k+1)*B): record ranges differ per batch
+    int64_t *h_off;                     // host, [num_batches+1] first record of every batch (NULL: k*batch_size)
+    int64_t *d_off;                     // device scratch of the same
+    int64_t h_off_cap;
 };
 
 constexpr int kPreBlocks = 256;   // workgroups (= partial sums) of the staged step's pre-norm pass

@@ -298,6 +298,30 @@ __global__ void k_invert_perm(const int64_t *__restrict__ perm, int64_t n, uint3
     }
 }
 
+// positions handed in by the caller (daisy_epoch_plan_build_positions): inv[t] = pos[t]; bad |= 2 outside [0, n_total)
+__global__ void k_positions_u32(const int64_t *__restrict__ pos, int64_t n, int64_t n_total, uint32_t *__restrict__ inv,
+                                int *__restrict__ bad) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = pos[t];
+        const bool ok = p >= 0 && p < n_total;
+        if (!ok) atomicOr(bad, 2);
+        inv[t] = ok ? (uint32_t)p : 0u;
+    }
+}
+
+// off[k] = first record of batch k in the partitioned sample records (their batch ids never decrease)
+__global__ void k_batch_offsets(const uint32_t *__restrict__ pos, int64_t n, BatchDiv bd, int64_t nb,
+                                int64_t *__restrict__ off) {
+    for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k <= nb; k += (int64_t)gridDim.x * blockDim.x) {
+        int64_t lo = 0, hi = n;                       // first index whose batch id >= k
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)batch_of(pos[mid], bd) < k) lo = mid + 1; else hi = mid;
+        }
+        off[k] = lo;
+    }
+}
+
 // ---- static index ---------------------------------------------------------------------------------------
 // bad[0] |= 1 when a (user - user_base, item, item) lies outside [0,U) x [0,I) x [0,I)
 __global__ void k_index_entries(const int32_t *__restrict__ triples, int64_t n, int32_t user_base, int64_t U,
@@ -343,10 +367,12 @@ __global__ void k_read_partitioned(StreamView v, int32_t *__restrict__ u, int32_
 }
 
 StreamView plan_stream_view(const daisy_epoch_plan *p, int64_t k) {
-    const int64_t lo = k * p->batch_size;
+    int64_t lo = k * p->batch_size;
     const int c = p->p_cur;
     StreamView v;
     v.B = (p->n - lo < p->batch_size) ? (p->n - lo) : p->batch_size;
+    const uint32_t pos_base = (uint32_t)lo;           // stage slot = epoch position - k*B in both layouts
+    if (p->h_off) { lo = p->h_off[k]; v.B = p->h_off[k + 1] - lo; }      // a rank's share of the epoch
     v.E = 2 * v.B;
     v.s_user = p->p_user[c] + lo;
     v.s_ij = p->p_ij[c] + lo;
@@ -355,7 +381,7 @@ StreamView plan_stream_view(const daisy_epoch_plan *p, int64_t k) {
     v.e_pos = p->p_epos[c] + 2 * lo;
     v.e_stride = 1;
     v.umask = v.imask = 0xFFFFFFFFu;
-    v.pos_base = (uint32_t)lo;
+    v.pos_base = pos_base;
     return v;
 }
 
@@ -419,11 +445,15 @@ static void part_tiling(int64_t n, int64_t &tile_elems, int64_t &ntiles) {
     ntiles = (n + tile_elems - 1) / tile_elems;
 }
 
+// n_total == 0: the index holds the whole epoch (n rows, positions 0..n-1 from `order_mode`).  n_total > 0: it holds
+// a subset and `perm` is not a permutation but the epoch POSITION of every caller row, in [0, n_total): batch k is
+// made of the held rows with position in [k*B, (k+1)*B), so the batches have different sizes (h_off).
 static int plan_build_partitioned(daisy_epoch_plan *p, const daisy_train_index *ix, const int64_t *perm,
                                   int order_mode, uint64_t seed, uint64_t epoch, int64_t batch_size,
-                                  hipStream_t s) {
+                                  int64_t n_total, hipStream_t s) {
     const int64_t n = ix->n;
-    const int64_t nb = (n + batch_size - 1) / batch_size;
+    const bool subset = n_total > 0;
+    const int64_t nb = ((subset ? n_total : n) + batch_size - 1) / batch_size;
     const int bbits = (nb > 1) ? bits_for(nb) : 1;
     const int passes = (bbits + 7) / 8;
     int rc = plan_need_partitioned(p, 0);
@@ -435,7 +465,25 @@ static int plan_build_partitioned(daisy_epoch_plan *p, const daisy_train_index *
     pf.inv = p->p_inv;
     pf.orig = ix->orig;
     pf.n = (uint64_t)n;
-    if (order_mode == DAISY_ORDER_PERM) {
+    int *bad = nullptr;
+    if (subset) {
+        if (p->h_off_cap < nb + 1) {
+            free(p->h_off);
+            if (p->d_off) (void)hipFree(p->d_off);
+            p->h_off = nullptr; p->d_off = nullptr; p->h_off_cap = 0;
+            p->h_off = (int64_t *)malloc((size_t)(nb + 1) * 8);
+            if (!p->h_off || hipMalloc((void **)&p->d_off, (size_t)(nb + 2) * 8) != hipSuccess) {
+                free(p->h_off); p->h_off = nullptr; p->d_off = nullptr;
+                set_error("epoch_plan_build_positions: allocating %lld batch offsets failed", (long long)(nb + 1));
+                return DAISY_ERR_HIP;
+            }
+            p->h_off_cap = nb + 1;
+        }
+        bad = (int *)(p->d_off + nb + 1);
+        DAISY_HIP(hipMemsetAsync(bad, 0, 8, s));
+        hipLaunchKernelGGL(k_positions_u32, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, perm, n, n_total, p->p_inv, bad);
+        DAISY_LAUNCH_CHECK();
+    } else if (order_mode == DAISY_ORDER_PERM) {
         hipLaunchKernelGGL(k_invert_perm, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, perm, n, p->p_inv);
         DAISY_LAUNCH_CHECK();
     }
@@ -501,9 +549,32 @@ static int plan_build_partitioned(daisy_epoch_plan *p, const daisy_train_index *
         }
     }
     p->p_cur = 0;
-    p->n = n; p->batch_size = batch_size; p->num_batches = nb; p->built = true;
+    p->n = n; p->batch_size = batch_size; p->num_batches = nb;
     p->pointwise = 0;
     p->kind = 1;
+    if (subset) {          // where every batch starts: one small copy and one host sync per epoch
+        hipLaunchKernelGGL(k_batch_offsets, dim3(grid_for(nb + 1, kBlock)), dim3(kBlock), 0, s, p->p_pos[0], n, bd, nb,
+                           p->d_off);
+        DAISY_LAUNCH_CHECK();
+        int bad_host[2] = {0, 0};
+        if (hipMemcpyAsync(p->h_off, p->d_off, (size_t)(nb + 1) * 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipMemcpyAsync(bad_host, bad, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {
+            set_error("epoch_plan_build_positions: reading the batch offsets failed");
+            p->built = false;
+            return DAISY_ERR_HIP;
+        }
+        if (bad_host[0]) {
+            set_error("epoch_plan_build_positions: a position lies outside [0, %lld)", (long long)n_total);
+            p->built = false;
+            return DAISY_ERR_ARG;
+        }
+    } else if (p->h_off) {
+        free(p->h_off); p->h_off = nullptr;
+        if (p->d_off) (void)hipFree(p->d_off);
+        p->d_off = nullptr; p->h_off_cap = 0;
+    }
+    p->built = true;
     return DAISY_OK;
 }
 
@@ -1419,7 +1490,26 @@ int daisy_epoch_plan_build_indexed(daisy_epoch_plan *plan, const daisy_train_ind
                     "epoch_plan_build_indexed: bad order_mode %d", order_mode);
     DAISY_CHECK_ARG(order_mode != DAISY_ORDER_PERM || perm != nullptr,
                     "epoch_plan_build_indexed: DAISY_ORDER_PERM needs perm");
-    return plan_build_partitioned(plan, index, perm, order_mode, seed, epoch, batch_size, S(stream));
+    return plan_build_partitioned(plan, index, perm, order_mode, seed, epoch, batch_size, 0, S(stream));
+}
+
+int daisy_epoch_plan_build_positions(daisy_epoch_plan *plan, const daisy_train_index *index, const int64_t *positions,
+                                     int64_t n_total, int64_t batch_size, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(plan && index && positions, "epoch_plan_build_positions: NULL argument");
+    DAISY_CHECK_ARG(index->n <= plan->max_triples && index->U == plan->U && index->I == plan->I,
+                    "epoch_plan_build_positions: the index (n %lld, U %lld, I %lld) does not fit the plan",
+                    (long long)index->n, (long long)index->U, (long long)index->I);
+    DAISY_CHECK_ARG(batch_size > 0 && batch_size < ((int64_t)1 << 31), "epoch_plan_build_positions: bad batch_size");
+    DAISY_CHECK_ARG(n_total >= index->n && n_total < ((int64_t)1 << 32),
+                    "epoch_plan_build_positions: n_total=%lld must be in [n, 2^32)", (long long)n_total);
+    return plan_build_partitioned(plan, index, positions, DAISY_ORDER_PERM, 0, 0, batch_size, n_total, S(stream));
+}
+
+int64_t daisy_epoch_plan_batch_rows(const daisy_epoch_plan *plan, int64_t k) {
+    if (!plan || !plan->built || k < 0 || k >= plan->num_batches) return -1;
+    if (plan->h_off) return plan->h_off[k + 1] - plan->h_off[k];
+    const int64_t lo = k * plan->batch_size;
+    return (plan->n - lo < plan->batch_size) ? (plan->n - lo) : plan->batch_size;
 }
 
 int daisy_bpr_ctx_invalidate_cache(daisy_bpr_ctx *ctx) {

@@ -1114,6 +1114,8 @@ static int plan_free(daisy_epoch_plan *p) {
         if (p->k64[k]) (void)hipFree(p->k64[k]);
     if (p->parena) (void)hipFree(p->parena);
     if (p->parena2) (void)hipFree(p->parena2);
+    if (p->d_off) (void)hipFree(p->d_off);
+    free(p->h_off);
     delete p;
     if (e != hipSuccess) {
         set_error("epoch_plan_destroy: hipFree failed: %s", hipGetErrorString(e));
@@ -1212,6 +1214,8 @@ static int plan_build(daisy_epoch_plan *p, const int32_t *triples, int64_t n, in
     }
     p->ekey = p->k32[1];
     p->eval = p->v64[1];
+    free(p->h_off); p->h_off = nullptr; p->h_off_cap = 0;          // (a plan that held a rank's share before)
+    if (p->d_off) { (void)hipFree(p->d_off); p->d_off = nullptr; }
     p->n = n; p->batch_size = batch_size; p->num_batches = nb; p->built = true;
     p->pointwise = pointwise;
     p->kind = 0;
@@ -1524,6 +1528,11 @@ int daisy_bpr_set_batch_from_plan(daisy_bpr_ctx *ctx, const daisy_epoch_plan *pl
                     "set_batch_from_plan: plan (batch %lld, U %lld, I %lld) does not fit the context",
                     (long long)plan->batch_size, (long long)plan->U, (long long)plan->I);
     if (plan->kind == 1) {            // partitioned layout: only the staged step can read it
+        if (daisy_epoch_plan_batch_rows(plan, k) == 0) {
+            set_error("set_batch_from_plan: batch %lld holds no rows of this plan (a rank's share of the epoch: "
+                      "check daisy_epoch_plan_batch_rows first)", (long long)k);
+            return DAISY_ERR_STATE;
+        }
         ctx->sv = plan_stream_view(plan, k);
         memset(&ctx->v, 0, sizeof(ctx->v));
         ctx->v.B = ctx->sv.B;

@@ -120,6 +120,9 @@ class GeneralRecommender(AbstractRecommender):
         # no upload: the scalable choice, same distribution, different stream)
         self.shuffle_mode = str(config.get("shuffle_mode", "loader")).lower()
         self.seed = int(config.get("seed", 2022))
+        # under torch.distributed (one process per GPU): split the users over the ranks (default) or let every
+        # rank train the whole model
+        self.shard_users = bool(config.get("shard_users", True))
         self.epoch_losses = []
 
     # -- helpers ---------------------------------------------------------------
@@ -148,6 +151,99 @@ class GeneralRecommender(AbstractRecommender):
                 gen = sampler.generator
             return torch.randperm(n, generator=gen)
         return torch.as_tensor(list(iter(sampler)), dtype=torch.int64)
+
+    def _sharded_world(self):
+        """ranks that share this fit: torch.distributed initialised with more than one rank and
+        config['shard_users'] not switched off (the reference is single device, AbstractRecommender.py:99)"""
+        import torch.distributed as dist
+        if not self.shard_users or not dist.is_available() or not dist.is_initialized():
+            return 1
+        world = dist.get_world_size()
+        return world if world > 1 and self.embed_user.weight.shape[0] >= world else 1
+
+    def _epoch_positions(self, train_loader, n, epoch, row_ids):
+        """epoch position of this rank's rows: the order one pass over the DataLoader would use (replayed from the
+        torch RNG exactly like the single-device fit, so every rank draws the same permutation), the keyed device
+        shuffle, or the identity"""
+        from torch.utils.data import SequentialSampler
+        if self.shuffle_mode == "device" and not isinstance(train_loader.sampler, SequentialSampler):
+            return ops.feistel_positions(n, self.seed, epoch, device=row_ids.device)[row_ids].contiguous()
+        perm = self._epoch_order(train_loader, len(train_loader.dataset))
+        if perm is None:
+            return row_ids.clone()
+        perm = perm.to(row_ids.device)
+        if perm.numel() != n:
+            raise NotImplementedError("drop_last with a shuffled loader is not supported on the HIP path "
+                                      "(the dropped rows change per epoch)")
+        inv = torch.empty(n, dtype=torch.int64, device=row_ids.device)
+        inv[perm] = torch.arange(n, dtype=torch.int64, device=row_ids.device)
+        return inv[row_ids].contiguous()
+
+    def _fit_sharded(self, train_loader, triples, n, B, loss_id):
+        """`fit` over the ranks of a torch.distributed job (one process per GPU).  Every rank calls it
+        with the same loader and the same seeds.  Users - with their interactions and their rows of P - are split
+        into contiguous ranges; Q is replicated.  Batch k of rank r = its rows among positions [k*B, (k+1)*B) of
+        the epoch order, so the union over the ranks IS batch k of the single-device fit and the result equals it
+        up to summation order (UserShardedBprTrainer: two small all-reduces, reduce-scatter of the item
+        gradient, all-gather of the updated item rows per step).  At the end every rank holds the whole P."""
+        import torch.distributed as dist
+        from ..sharding import UserShardedBprTrainer, user_range
+        world, rank = dist.get_world_size(), dist.get_rank()
+        P, Q = self.embed_user.weight.data, self.embed_item.weight.data
+        U, I, d = P.shape[0], Q.shape[0], P.shape[1]
+        dist.broadcast(P, 0)               # replicas start from rank 0's tables (same seeds make this a no-op)
+        dist.broadcast(Q, 0)
+        lo, hi = user_range(U, world, rank)
+        u = triples[:n, 0]
+        row_ids = torch.nonzero((u >= lo) & (u < hi)).flatten()        # ascending: CSR order is kept
+        mine = triples[row_ids].contiguous()
+        n_loc = int(mine.shape[0])
+        P_loc = P[lo:hi]
+        ctx = ops.BprContext(B, d, hi - lo, I, device=P.device)        # stage slots are positions inside a GLOBAL batch
+        index = plan = None
+        trainer = UserShardedBprTrainer(ctx, P_loc, Q, lo, self.lr, self.reg_1, self.reg_2, loss_type=loss_id,
+                                        item_mode=ops.ITEM_MODES["fused"])
+        acc = torch.zeros(2, dtype=torch.float64, device=P.device)
+        nb = (n + B - 1) // B
+        last_loss = 0.0
+        try:
+            if n_loc:
+                index = ops.TrainIndex(mine, hi - lo, I, user_base=lo)
+                plan = ops.EpochPlan(n_loc, hi - lo, I, device=P.device)
+            for epoch in range(1, self.epochs + 1):
+                self.train()
+                if n_loc:
+                    plan.build_positions(index, self._epoch_positions(train_loader, n, epoch, row_ids), n, B)
+                else:
+                    self._epoch_positions(train_loader, n, epoch, row_ids)       # keeps the RNG in step with the others
+                acc.zero_()
+                for k in range(nb):
+                    stats = trainer.step_from_plan(plan, k)
+                    loss = stats[ops.N.ST_LOSS]
+                    acc[0] += loss
+                    acc[1] += (~torch.isfinite(loss)).to(torch.float64)
+                host = acc.cpu()
+                current_loss = float(host[0])
+                if float(host[1]) > 0 or current_loss != current_loss:
+                    raise ValueError("Loss=Nan or Infinity: current settings does not fit the recommender")
+                self.epoch_losses.append(current_loss)
+                self.eval()
+                delta_loss = float(current_loss - last_loss)
+                if (abs(delta_loss) < 1e-5) and self.early_stop:       # AbstractRecommender.py:132-137
+                    self.logger.info("Satisfy early stop mechanism")
+                    break
+                last_loss = current_loss
+            for r in range(world):                                     # every rank ends with the whole user table
+                a, b = user_range(U, world, r)
+                if b > a:
+                    dist.broadcast(P[a:b], r)
+        finally:
+            torch.cuda.synchronize()
+            ctx.close()
+            if plan is not None:
+                plan.close()
+            if index is not None:
+                index.close()
 
     def fit(self, train_loader):
         """AbstractRecommender.py:103-137, natively: one enqueue per epoch, one host
@@ -192,6 +288,13 @@ class GeneralRecommender(AbstractRecommender):
         # whole epoch inside one persistent workgroup, csrc/bpr_small.hip)
         staged = (item_mode == ops.ITEM_MODES["fused"] and adam is None and not pointwise and biases is None
                   and B > ops.SMALL_BATCH_MAX)
+        if self._sharded_world() > 1:
+            if item_mode == ops.ITEM_MODES["fused"] and adam is None and not pointwise and biases is None:
+                ctx.close()
+                plan.close()
+                return self._fit_sharded(train_loader, triples, n, B, loss_id)
+            self.logger.info("torch.distributed is initialised, but only SGD + pairwise loss + item_mode 'fused' "
+                             "shards the users over the ranks: every rank trains the whole model")
         if item_mode == ops.ITEM_MODES["fused"] and not staged and B > ops.SMALL_BATCH_MAX:
             item_mode = ops.ITEM_MODES["chunked"]
         index = None

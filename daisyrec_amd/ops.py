@@ -129,6 +129,19 @@ class EpochPlan:
                                                  int(seed), int(epoch), int(batch_size), _stream()))
         return self
 
+    def build_positions(self, index: "TrainIndex", positions, n_total, batch_size):
+        """One rank's share of an epoch over n_total rows: `index` holds this rank's rows, positions[r] (int64,
+        distinct, in [0, n_total)) the place of its row r in the epoch order; batch k = the held rows with position
+        in [k*B, (k+1)*B) - the union over the ranks is batch k of the single-device epoch.  Batches differ in
+        size (`batch_rows`); one host sync."""
+        check(lib.daisy_epoch_plan_build_positions(self._h, index._h, _ptr(positions, torch.int64, "positions"),
+                                                   int(n_total), int(batch_size), _stream()))
+        return self
+
+    def batch_rows(self, k):
+        """rows of batch k held by this plan (host value)"""
+        return int(lib.daisy_epoch_plan_batch_rows(self._h, int(k)))
+
     @property
     def num_batches(self):
         return int(lib.daisy_epoch_plan_num_batches(self._h))

@@ -135,7 +135,12 @@ class UserShardedBprTrainer:
         return self._step()
 
     def step_from_plan(self, plan, k):
-        """One global step on batch k of this rank's epoch plan."""
+        """One global step on batch k of this rank's epoch plan.  A plan that holds a rank's share of a global
+        epoch (`EpochPlan.build_positions`) may have no row of batch k (or `plan` is None: the rank owns no
+        interaction at all): the rank then only takes part in the exchanges."""
+        rows = getattr(plan, "batch_rows", None)
+        if plan is None or (rows is not None and rows(k) == 0):
+            return self._step_empty()
         self.ctx.set_batch_from_plan(plan, k)
         return self._step()
 
@@ -157,6 +162,11 @@ class UserShardedBprTrainer:
         if w0 is not None:
             w0.wait()
         c.finalize(self.reg_1, self.reg_2)               # every rank: the GLOBAL loss and norms
+        return self._exchange_items()
+
+    def _exchange_items(self):
+        """reduce-scatter (gQ, cnt) -> the owner's SGD on its rows of Q -> all-gather of the rows"""
+        c, I = self.ctx, self.Q.shape[0]
         self._reduce_scatter(self.g_own, self.gQ)
         self._reduce_scatter(self.c_own, self.cnt)
         self.gQ.zero_()
@@ -175,6 +185,17 @@ class UserShardedBprTrainer:
                 self._all_gather_rows(self.Q_gather, own)
                 self.Q.copy_(self.Q_gather[:I])
         return c.stats
+
+    def _step_empty(self):
+        """This rank's part of a global step to which it contributes no sample (staged protocol)."""
+        if not self.staged:
+            raise NotImplementedError("an empty local batch is only supported by the staged protocol")
+        c = self.ctx
+        c.stats.zero_()
+        self._all_reduce(c.stats[N.ST_SQ_U_PRE:N.ST_SQ_U_PRE + 1])
+        self._all_reduce(c.stats[:7])
+        c.finalize(self.reg_1, self.reg_2)
+        return self._exchange_items()
 
     def _step_phases(self):
         c = self.ctx

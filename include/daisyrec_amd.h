@@ -172,6 +172,18 @@ size_t daisy_train_index_bytes(const daisy_train_index *index);
 int daisy_epoch_plan_build_indexed(daisy_epoch_plan *plan, const daisy_train_index *index,
                                    const int64_t *perm, int32_t order_mode, uint64_t seed, uint64_t epoch,
                                    int64_t batch_size, daisy_stream_t stream);
+/* ONE RANK'S SHARE of an epoch (multi-GPU fit; the reference iterates one DataLoader on one device,
+ * dataset.py:5-7 + AbstractRecommender.py:117-129).  `index` holds the rows this rank owns (its user range),
+ * positions[r] in [0, n_total) is the place of the caller's row r in the epoch order of ALL n_total rows (distinct
+ * values; int64).  Batch k = the held rows with position in [k*B, (k+1)*B): the union of the ranks' batches k is
+ * exactly batch k of the single-device epoch.  Batches differ in size (possibly 0 rows:
+ * daisy_epoch_plan_batch_rows); num_batches = ceil(n_total / B); one host sync per build.  Contexts that read the
+ * plan need max_batch >= batch_size (stage slots are epoch positions minus k*B). */
+int daisy_epoch_plan_build_positions(daisy_epoch_plan *plan, const daisy_train_index *index,
+                                     const int64_t *positions, int64_t n_total, int64_t batch_size,
+                                     daisy_stream_t stream);
+/* rows of batch k held by this plan (host value; -1: no such batch) */
+int64_t daisy_epoch_plan_batch_rows(const daisy_epoch_plan *plan, int64_t k);
 
 /* The staged step keeps |P[u]|^2 of every row in the context; every entry point that writes P through the
  * context keeps it current or drops it.  A caller that changes P by other means calls this first. */

@@ -1,0 +1,117 @@
+"""`MF.fit` over the ranks of a torch.distributed job (daisyrec_amd/model/AbstractRecommender.py::_fit_sharded):
+three ranks share the one GPU of the test box (gloo), each owning a user range; batch k of a rank is its share of
+batch k of the single-device epoch, so the training must equal the single-process `fit` (same loader order, same
+seeds) up to summation order - epoch losses, both tables, and therefore the ranked lists.  Also: the rank-share
+plan itself against the whole-epoch plan (EpochPlan.build_positions vs build_indexed)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+U, I, D, N_ROWS, B, EPOCHS = 157, 211, 32, 9000, 700, 3          # 13 batches per epoch, the last one partial
+
+
+def _triples():
+    rng = np.random.default_rng(5)
+    u = np.sort(rng.integers(0, U, N_ROWS))
+    u[u == 3] = 4                                    # a user without interactions
+    return np.stack([u, rng.integers(0, I, N_ROWS), rng.integers(0, I, N_ROWS)], 1).astype(np.int32)
+
+
+def _config(shuffle_mode):
+    import logging
+    return {"gpu": "0", "logger": logging.getLogger("t"), "lr": 0.05, "reg_1": 0.001, "reg_2": 0.002,
+            "epochs": EPOCHS, "topk": 10, "user_num": U, "item_num": I, "factors": D, "loss_type": "BPR",
+            "optimizer": "sgd", "init_method": "default", "early_stop": False, "shuffle_mode": shuffle_mode,
+            "progress": False, "seed": 7}
+
+
+def _fit(shuffle_mode, shuffle):
+    from daisyrec_amd.model.MFRecommender import MF
+    from daisyrec_amd.utils.dataset import BasicDataset, get_dataloader
+    torch.manual_seed(123)
+    model = MF(_config(shuffle_mode))
+    loader = get_dataloader(BasicDataset(_triples()), batch_size=B, shuffle=shuffle, num_workers=0)
+    torch.manual_seed(321)                           # the loader's permutations
+    model.fit(loader)
+    return model
+
+
+def _worker(rank, world, port, out_dir, shuffle_mode, shuffle):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _fit(shuffle_mode, shuffle)
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), P=model.embed_user.weight.data.cpu().numpy(),
+             Q=model.embed_item.weight.data.cpu().numpy(), losses=np.array(model.epoch_losses))
+    dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("shuffle_mode,shuffle", [("loader", True), ("device", True), ("loader", False)])
+def test_fit_over_three_ranks_equals_the_single_process_fit(tmp_path, shuffle_mode, shuffle):
+    world = 3
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), shuffle_mode, shuffle), nprocs=world, join=True)
+    ref = _fit(shuffle_mode, shuffle)                # no process group here: the single-device path
+    P, Q = ref.embed_user.weight.data.cpu().numpy(), ref.embed_item.weight.data.cpu().numpy()
+    assert len(ref.epoch_losses) == EPOCHS
+    for r in range(world):
+        o = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        np.testing.assert_allclose(o["losses"], ref.epoch_losses, rtol=1e-6)
+        np.testing.assert_allclose(o["Q"], Q, atol=2e-6)
+        np.testing.assert_allclose(o["P"], P, atol=2e-6)          # every rank ends with the WHOLE user table
+
+
+def test_rank_share_plans_tile_the_epoch_plan():
+    from daisyrec_amd import ops
+    from daisyrec_amd.sharding import user_range
+    dev = torch.device("cuda")
+    tr = torch.from_numpy(_triples()).to(dev)
+    n = tr.shape[0]
+    pos = ops.feistel_positions(n, 7, 2, device=dev)
+    whole = ops.EpochPlan(n, U, I, device=dev).build_indexed(ops.TrainIndex(tr, U, I), B, order="feistel", seed=7, epoch=2)
+    nb = whole.num_batches
+    got = [[] for _ in range(nb)]
+    world = 4
+    for r in range(world):
+        lo, hi = user_range(U, world, r)
+        ids = torch.nonzero((tr[:, 0] >= lo) & (tr[:, 0] < hi)).flatten()
+        mine = tr[ids].contiguous()
+        index = ops.TrainIndex(mine, hi - lo, I, user_base=lo)
+        plan = ops.EpochPlan(mine.shape[0], hi - lo, I, device=dev).build_positions(index, pos[ids].contiguous(), n, B)
+        assert plan.num_batches == nb
+        assert sum(plan.batch_rows(k) for k in range(nb)) == mine.shape[0]
+        for k in range(nb):
+            if plan.batch_rows(k) == 0:
+                continue
+            u, i, j, ei, es, _ = plan.read_batch(k, B)
+            assert u.shape[0] == plan.batch_rows(k)
+            got[k].append(torch.stack([u + lo, i, j], 1).cpu().numpy())
+            # entries: sorted by item, their stage slots are the positions of the samples inside the GLOBAL batch
+            assert bool((ei[1:] >= ei[:-1]).all())
+            slots = (es & 0x7FFFFFFF).cpu().numpy()
+            assert slots.min() >= 0 and slots.max() < B
+        plan.close(); index.close()
+    for k in range(nb):
+        u, i, j, *_ = whole.read_batch(k, B)
+        want = torch.stack([u, i, j], 1).cpu().numpy()
+        have = np.concatenate(got[k])
+        assert have.shape == want.shape
+        key = lambda a: a[np.lexsort((a[:, 2], a[:, 1], a[:, 0]))]
+        np.testing.assert_array_equal(key(have), key(want))        # the ranks' batches k are a partition of batch k
+    with pytest.raises(ValueError, match="outside"):
+        bad = pos.clone(); bad[0] = n + 5
+        ops.EpochPlan(n, U, I, device=dev).build_positions(ops.TrainIndex(tr, U, I), bad, n, B)

@@ -1,9 +1,9 @@
 #!/usr/bin/env python
-"""bf16-storage GEMM alone (for rocprofv3 PMC passes): python tools/dbg/gemm_only.py [M N K reps]"""
+"""bf16-storage GEMM alone (for rocprofv3 PMC passes): python tools/gemm_only.py [M N K reps]"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
 from daisyrec_amd import ops

@@ -1,4 +1,4 @@
-# per-kernel time of a command: bash tools/dbg/kstats.sh <n rows> <cmd...>
+# per-kernel time of a command: bash tools/kstats.sh <n rows> <cmd...>
 cd /tmp && export TMPDIR=/tmp
 N=$1; shift
 rm -rf /tmp/ks; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o p -- "$@" > /tmp/ks.log 2>&1

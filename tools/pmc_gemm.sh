@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 run() { n=$1; shift
-  rm -rf /tmp/pmc_$n; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_$n -o p -- python $R/tools/dbg/gemm_only.py > /tmp/pmc_$n.log 2>&1
+  rm -rf /tmp/pmc_$n; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_$n -o p -- python $R/tools/gemm_only.py > /tmp/pmc_$n.log 2>&1
   python - <<PY
 import csv, glob, collections
 agg = collections.defaultdict(float); cnt = collections.Counter()

@@ -7,7 +7,7 @@ import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from daisyrec_amd import ops  # noqa: E402
 
 U, I, n, B = 943, 1152, 78363, int(sys.argv[1]) if len(sys.argv) > 1 else 256

@@ -1,13 +1,13 @@
 #!/usr/bin/env python
 """Whole epochs through daisy_bpr_fit_epoch_sgd (the loop MF.fit runs, in C) at the C2 shapes for several batch sizes:
-python tools/dbg/b_sweep.py [B ...]"""
+python tools/sweep_batch.py [B ...]"""
 import os
 import sys
 import time
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from daisyrec_amd import ops  # noqa: E402
 

@@ -1,16 +1,16 @@
 #!/usr/bin/env python
 """Staged step at the C2 shapes for several factor counts d (the reference's mf.yaml default is 100):
-python tools/dbg/d_sweep.py [d ...]"""
+python tools/sweep_factors.py [d ...]"""
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 from daisyrec_amd import ops  # noqa: E402
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from probe_staged import ev_time  # noqa: E402
 
 dev = torch.device("cuda")
