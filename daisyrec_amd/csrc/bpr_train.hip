@@ -386,7 +386,7 @@ struct ItemEdges {
     int32_t *whole;      // [nchunks]       the head edge's segment also runs on into the next chunk
 };
 
-template <class C, int RUN_OVERRIDE = 0, bool DET = false>
+template <class C, int RUN_OVERRIDE = 0, bool DET = false, bool XH = false>      // XH: the gathered rows are bf16
 __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__restrict__ P,
                                                               const float2 *__restrict__ coef,
                                                               BatchView v, int d,
@@ -452,14 +452,16 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
 #pragma unroll
             for (int x = 0; x < RUN; ++x) {
                 const uint32_t ux = group_bcast<C>(my_su.y, x);
-                p[x].load(P + (int64_t)ux * d, lane, d);
+                if constexpr (XH) p[x].load_bf16(reinterpret_cast<const uint16_t *>(P) + (int64_t)ux * d, lane, d);
+                else p[x].load(P + (int64_t)ux * d, lane, d);
             }
         } else {
 #pragma unroll
             for (int x = 0; x < RUN; ++x) {
                 const uint32_t ux = group_bcast<C>(my_su.y, x);
-                if (x < cnt) p[x].load(P + (int64_t)ux * d, lane, d);
-                else p[x].zero();
+                if (x >= cnt) p[x].zero();
+                else if constexpr (XH) p[x].load_bf16(reinterpret_cast<const uint16_t *>(P) + (int64_t)ux * d, lane, d);
+                else p[x].load(P + (int64_t)ux * d, lane, d);
             }
         }
         __syncthreads();
@@ -1283,7 +1285,7 @@ int64_t segsum_chunks(int64_t n_entries, int d) {
 
 int segsum_rows(const float *X, const float2 *coef, const uint32_t *ekey, const uint2 *esu, int64_t n_entries,
                 int d, float *out, float *edge_vec, int32_t *edge_item, float *edge_b, int32_t *edge_whole,
-                hipStream_t s) {
+                hipStream_t s, bool x_bf16) {
     if (n_entries <= 0) return DAISY_OK;
     if (n_entries & 1) { set_error("segsum_rows: odd entry count %lld", (long long)n_entries); return DAISY_ERR_ARG; }
     BatchView v{};
@@ -1295,8 +1297,12 @@ int segsum_rows(const float *X, const float2 *coef, const uint32_t *ekey, const 
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
         const int64_t nchunks = (n_entries + RunCfg<C>::E - 1) / RunCfg<C>::E;
-        hipLaunchKernelGGL((k_item_grad_chunked<C, 0, true>), dim3(grid_for(n_entries, RunCfg<C>::E, 16384)),
-                           dim3(kBlock), 0, s, X, coef, v, d, out, ed);
+        if (x_bf16)
+            hipLaunchKernelGGL((k_item_grad_chunked<C, 0, true, true>), dim3(grid_for(n_entries, RunCfg<C>::E, 16384)),
+                               dim3(kBlock), 0, s, X, coef, v, d, out, ed);
+        else
+            hipLaunchKernelGGL((k_item_grad_chunked<C, 0, true>), dim3(grid_for(n_entries, RunCfg<C>::E, 16384)),
+                               dim3(kBlock), 0, s, X, coef, v, d, out, ed);
         hipLaunchKernelGGL((k_item_edges<C>), dim3(grid_for(nchunks, C::GROUPS_PER_BLOCK)), dim3(kBlock), 0, s, ed,
                            nchunks, d, out, (float *)nullptr);
         return DAISY_OK;

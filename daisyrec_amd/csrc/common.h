@@ -115,6 +115,21 @@ struct Row {
             }
         }
     }
+    // the same fragment from a row stored as bf16 (NeuMF's back-propagated tower-input gradient at precision level 2)
+    __device__ __forceinline__ void load_bf16(const uint16_t *__restrict__ row, int lane, int d) {
+#pragma unroll
+        for (int c = 0; c < C::NV; ++c) {
+            const int e = (c * C::LPR + lane) * C::VEC;
+            if constexpr (C::VEC == 4) {
+                uint2 t = make_uint2(0u, 0u);
+                if (C::EXACT || e < d) t = *reinterpret_cast<const uint2 *>(row + e);
+                v[c * 4 + 0] = __uint_as_float(t.x << 16); v[c * 4 + 1] = __uint_as_float(t.x & 0xFFFF0000u);
+                v[c * 4 + 2] = __uint_as_float(t.y << 16); v[c * 4 + 3] = __uint_as_float(t.y & 0xFFFF0000u);
+            } else {
+                v[c] = (C::EXACT || e < d) ? __uint_as_float((uint32_t)row[e] << 16) : 0.f;
+            }
+        }
+    }
     __device__ __forceinline__ void load_clamped(const float *__restrict__ row, int lane, int d) {
 #pragma unroll
         for (int c = 0; c < C::NV; ++c) {
@@ -441,8 +456,9 @@ __device__ __forceinline__ void pair_coef(int loss_type, float pos, float neg, f
 // edge_* are scratch for segsum_chunks(n_entries, d) chunks: vec f32[2*chunks*d], item i32[2*chunks],
 // b f32[2*chunks], whole i32[chunks]
 int64_t segsum_chunks(int64_t n_entries, int d);
+// x_bf16: X holds bf16 rows (uint16_t [rows][d]) instead of fp32
 int segsum_rows(const float *X, const float2 *coef, const uint32_t *ekey, const uint2 *esu, int64_t n_entries,
                 int d, float *out, float *edge_vec, int32_t *edge_item, float *edge_b, int32_t *edge_whole,
-                hipStream_t s);
+                hipStream_t s, bool x_bf16 = false);
 
 }  // namespace daisy

@@ -1149,8 +1149,8 @@ static int neumf_scatter_scratch(daisy_neumf_ctx *c) {
 
 // g.{uG,iG,uM,iM} += the embedding gradients of the step (DX0: fp32 [R, 2*dm] input gradient of the MLP tower)
 static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, const daisy_neumf_params &g,
-                               const PairSrc &src, int64_t R, int pointwise, const float *DX0, const double *stats,
-                               float reg_1, float reg_2, hipStream_t s) {
+                               const PairSrc &src, int64_t R, int pointwise, const float *DX0, bool dx0_bf16,
+                               const double *stats, float reg_1, float reg_2, hipStream_t s) {
     int rc = neumf_scatter_scratch(c);
     if (rc) return rc;
     const int d = c->d, dm = c->dm, model = c->model;
@@ -1172,7 +1172,7 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
             hipLaunchKernelGGL(k_nmf_entries, dim3(ge), dim3(kBlock), 0, s, c->sc_ks, c->sc_vs, R, n_pad, 2, side, c->sc_ekey,
                                c->sc_esu, c->sc_w);
             rc = segsum_rows(DX0, c->sc_w, c->sc_ekey, c->sc_esu, n_pad, dm, c->sc_sum, c->sc_edge_vec, c->sc_edge_item,
-                             c->sc_edge_b, c->sc_edge_whole, s);
+                             c->sc_edge_b, c->sc_edge_whole, s, dx0_bf16);
             if (rc) return rc;
         }
         hipLaunchKernelGGL(k_nmf_table_commit, dim3(gt), dim3(kBlock), 0, s, side ? g.iM : g.uM,
@@ -1360,8 +1360,8 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
             if (H) {
                 x.A16 = reinterpret_cast<const uint16_t *>(dz);
                 x.B16 = ctx->W16T[l - 1]; x.sbn = n_out; x.sbk = 1;        // W^T [n_in][n_out]: both operands along k
-                x.C16 = (l > 1 || !owner_scatter) ? reinterpret_cast<uint16_t *>(dz_next) : nullptr;   // dX0 in fp32 for the
-                x.G16 = (l > 1) ? reinterpret_cast<const uint16_t *>(ctx->X[l - 1]) : nullptr;          // segmented scatter
+                x.C16 = reinterpret_cast<uint16_t *>(dz_next);        // bf16 like every other stored gradient of this level
+                x.G16 = (l > 1) ? reinterpret_cast<const uint16_t *>(ctx->X[l - 1]) : nullptr;
                 if (!gemm_h_ok(x)) { set_error("neumf: input gradient of layer %d does not tile for the bf16-storage GEMM", l); return DAISY_ERR_STATE; }
                 launch_gemm_h<EPI_GATE>(x, s);
             } else {
@@ -1372,7 +1372,7 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
         }
     }
     if (owner_scatter) {
-        rc = neumf_scatter_owner(ctx, p, g, src, R, pointwise, dz, stats, reg_1, reg_2, s);
+        rc = neumf_scatter_owner(ctx, p, g, src, R, pointwise, dz, H, stats, reg_1, reg_2, s);
         if (rc) return rc;
     } else if (H) {
         hipLaunchKernelGGL((k_nmf_scatter<true>), dim3(grid_for(R, kBlock / 16 * 2)), dim3(kBlock), 0, s, p, g, src, R, d, dm,

@@ -104,7 +104,12 @@ class GeneralRecommender(AbstractRecommender):
 
     def __init__(self, config):
         super().__init__()
-        os.environ["CUDA_VISIBLE_DEVICES"] = config["gpu"]          # AbstractRecommender.py:99
+        # AbstractRecommender.py:99.  Under a one-process-per-GPU launcher (torchrun sets LOCAL_RANK, or the caller
+        # has initialised torch.distributed) the launcher has given this process its device: hiding all GPUs but
+        # config['gpu'] here would put every rank on the same one.
+        import torch.distributed as _dist
+        if "LOCAL_RANK" not in os.environ and not (_dist.is_available() and _dist.is_initialized()):
+            os.environ["CUDA_VISIBLE_DEVICES"] = config["gpu"]
         self.device = "cuda" if torch.cuda.is_available() else "cpu"
         self.logger = config.get("logger") or logging.getLogger("daisyrec_amd")
         # knobs of the native path (absent from the reference config: defaults keep its behaviour)

@@ -42,11 +42,15 @@ def _fit(shuffle_mode, shuffle):
     return model
 
 
-def _worker(rank, world, port, out_dir, shuffle_mode, shuffle):
+def _worker(rank, world, port, out_dir, shuffle_mode, shuffle, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":                            # one rank per GPU over RCCL
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     model = _fit(shuffle_mode, shuffle)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), P=model.embed_user.weight.data.cpu().numpy(),
              Q=model.embed_item.weight.data.cpu().numpy(), losses=np.array(model.epoch_losses))
@@ -61,10 +65,7 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("shuffle_mode,shuffle", [("loader", True), ("device", True), ("loader", False)])
-def test_fit_over_three_ranks_equals_the_single_process_fit(tmp_path, shuffle_mode, shuffle):
-    world = 3
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), shuffle_mode, shuffle), nprocs=world, join=True)
+def _compare(tmp_path, world, shuffle_mode, shuffle):
     ref = _fit(shuffle_mode, shuffle)                # no process group here: the single-device path
     P, Q = ref.embed_user.weight.data.cpu().numpy(), ref.embed_item.weight.data.cpu().numpy()
     assert len(ref.epoch_losses) == EPOCHS
@@ -73,6 +74,20 @@ def test_fit_over_three_ranks_equals_the_single_process_fit(tmp_path, shuffle_mo
         np.testing.assert_allclose(o["losses"], ref.epoch_losses, rtol=1e-6)
         np.testing.assert_allclose(o["Q"], Q, atol=2e-6)
         np.testing.assert_allclose(o["P"], P, atol=2e-6)          # every rank ends with the WHOLE user table
+
+
+@pytest.mark.parametrize("shuffle_mode,shuffle", [("loader", True), ("device", True), ("loader", False)])
+def test_fit_over_three_ranks_equals_the_single_process_fit(tmp_path, shuffle_mode, shuffle):
+    world = 3
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), shuffle_mode, shuffle), nprocs=world, join=True)
+    _compare(tmp_path, world, shuffle_mode, shuffle)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_fit_over_rccl_ranks_equals_the_single_process_fit(tmp_path):
+    world = min(torch.cuda.device_count(), 8)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "loader", True, "nccl"), nprocs=world, join=True)
+    _compare(tmp_path, world, "loader", True)
 
 
 def test_rank_share_plans_tile_the_epoch_plan():
