@@ -10,9 +10,15 @@
 
 namespace daisy {
 
+// rocPRIM's default sends every sort of up to 1 M items to its merge sort, which ignores end_bit: ~18 launches of
+// ~6 us for the 524 288 13-bit keys of a NeuMF step, where Onesweep needs a histogram and two digit passes.
+// The id sorts here know their key width, so Onesweep takes over above 262 144 items (measured: merge sort still wins at 131 072 and below).
+using IdSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                rocprim::default_config, 262144>;
+
 size_t sort_pairs_i32_temp_bytes(int64_t n) {
     size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const int32_t *)nullptr, (int32_t *)nullptr,
+    (void)rocprim::radix_sort_pairs<IdSortConfig>(nullptr, bytes, (const int32_t *)nullptr, (int32_t *)nullptr,
                                     (const int32_t *)nullptr, (int32_t *)nullptr, (size_t)n, 0, 32);
     return bytes;
 }
@@ -20,7 +26,7 @@ size_t sort_pairs_i32_temp_bytes(int64_t n) {
 int sort_pairs_i32(void *temp, size_t temp_bytes, const int32_t *kin, int32_t *kout,
                    const int32_t *vin, int32_t *vout, int64_t n, int end_bit, hipStream_t s) {
     // keys are non-negative ids, so unsigned ordering == signed ordering
-    DAISY_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, reinterpret_cast<const uint32_t *>(kin),
+    DAISY_HIP(rocprim::radix_sort_pairs<IdSortConfig>(temp, temp_bytes, reinterpret_cast<const uint32_t *>(kin),
                                         reinterpret_cast<uint32_t *>(kout), vin, vout, (size_t)n, 0,
                                         (unsigned)end_bit, s));
     return DAISY_OK;
@@ -70,7 +76,7 @@ int exclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32
 
 size_t sort_pairs_u32_u64_temp_bytes(int64_t n) {
     size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
+    (void)rocprim::radix_sort_pairs<IdSortConfig>(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
                                     (const uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)n, 0, 32);
     return bytes;
 }
@@ -78,14 +84,14 @@ size_t sort_pairs_u32_u64_temp_bytes(int64_t n) {
 int sort_pairs_u32_u64(void *temp, size_t temp_bytes, const uint32_t *kin, uint32_t *kout,
                        const uint64_t *vin, uint64_t *vout, int64_t n, int begin_bit, int end_bit,
                        hipStream_t s) {
-    DAISY_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)n,
+    DAISY_HIP(rocprim::radix_sort_pairs<IdSortConfig>(temp, temp_bytes, kin, kout, vin, vout, (size_t)n,
                                         (unsigned)begin_bit, (unsigned)end_bit, s));
     return DAISY_OK;
 }
 
 size_t sort_pairs_u64_u64_temp_bytes(int64_t n) {
     size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+    (void)rocprim::radix_sort_pairs<IdSortConfig>(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
                                     (const uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)n, 0, 64);
     return bytes;
 }
@@ -93,49 +99,49 @@ size_t sort_pairs_u64_u64_temp_bytes(int64_t n) {
 int sort_pairs_u64_u64(void *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout,
                        const uint64_t *vin, uint64_t *vout, int64_t n, int begin_bit, int end_bit,
                        hipStream_t s) {
-    DAISY_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)n,
+    DAISY_HIP(rocprim::radix_sort_pairs<IdSortConfig>(temp, temp_bytes, kin, kout, vin, vout, (size_t)n,
                                         (unsigned)begin_bit, (unsigned)end_bit, s));
     return DAISY_OK;
 }
 
 size_t sort_pairs_u64_i32_temp_bytes(int64_t n) {
     size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+    (void)rocprim::radix_sort_pairs<IdSortConfig>(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
                                     (const int32_t *)nullptr, (int32_t *)nullptr, (size_t)n, 0, 64);
     return bytes;
 }
 
 int sort_pairs_u64_i32(void *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout,
                        const int32_t *vin, int32_t *vout, int64_t n, int end_bit, hipStream_t s) {
-    DAISY_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)n, 0,
+    DAISY_HIP(rocprim::radix_sort_pairs<IdSortConfig>(temp, temp_bytes, kin, kout, vin, vout, (size_t)n, 0,
                                         (unsigned)end_bit, s));
     return DAISY_OK;
 }
 
 size_t sort_pairs_u64_i64_temp_bytes(int64_t n) {
     size_t bytes = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+    (void)rocprim::radix_sort_pairs<IdSortConfig>(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
                                     (const int64_t *)nullptr, (int64_t *)nullptr, (size_t)n, 0, 64);
     return bytes;
 }
 
 int sort_pairs_u64_i64(void *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout,
                        const int64_t *vin, int64_t *vout, int64_t n, int end_bit, hipStream_t s) {
-    DAISY_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, kin, kout, vin, vout, (size_t)n, 0,
+    DAISY_HIP(rocprim::radix_sort_pairs<IdSortConfig>(temp, temp_bytes, kin, kout, vin, vout, (size_t)n, 0,
                                         (unsigned)end_bit, s));
     return DAISY_OK;
 }
 
 size_t sort_keys_u64_temp_bytes(int64_t n) {
     size_t bytes = 0;
-    (void)rocprim::radix_sort_keys(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+    (void)rocprim::radix_sort_keys<IdSortConfig>(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
                                    (size_t)n, 0, 64);
     return bytes;
 }
 
 int sort_keys_u64(void *temp, size_t temp_bytes, const uint64_t *kin, uint64_t *kout, int64_t n,
                   int end_bit, hipStream_t s) {
-    DAISY_HIP(rocprim::radix_sort_keys(temp, temp_bytes, kin, kout, (size_t)n, 0, (unsigned)end_bit,
+    DAISY_HIP(rocprim::radix_sort_keys<IdSortConfig>(temp, temp_bytes, kin, kout, (size_t)n, 0, (unsigned)end_bit,
                                        s));
     return DAISY_OK;
 }
