@@ -365,13 +365,10 @@ __global__ __launch_bounds__(kBlock) void k_gemm_bf16(GemmOp op) {
 // bf16-STORAGE variant (precision level 2): both operands are bf16 in HBM, so a tile row of 32 k is 64 bytes -
 // 4 lanes x 16 bytes, copied to LDS as they are (no conversion, half the operand bytes of the fp32-storage
 // kernels above, which is what bounded them).  Operands that are contiguous along their rows instead of k (the
-// weight-gradient GEMM) are read one row x 16 consecutive k per thread with 2-byte loads (a wave instruction
-// still covers 64 consecutive rows = 128 contiguous bytes) and packed k-contiguously on the way into LDS.
+// weight-gradient GEMM) keep that layout in LDS and are transposed by the fragment read (lds_frag_tr below).
 // Epilogues: bias + ReLU (+dropout) or gate with bf16 output (round to nearest even), or fp32 atomics (split-K).
 __device__ __forceinline__ bool bf16_positive(uint16_t h) { return (h & 0x8000u) == 0 && (h & 0x7FFFu) != 0; }
 
-constexpr int kBKH = 32, kLdkH = kBKH + 8;      // k depth of a tile (64 measured no faster on the GEMM and slower on the step:
-                                                // LDS for two stages halves the resident workgroups)
 // Which tile a workgroup computes.  Workgroups go to the 8 XCDs round-robin by their linear id (observed, used for
 // speed only), and each XCD has its own L2: tiles that read the same operand panel are given to workgroups that
 // land on ONE XCD next to each other in time, so the panel comes from HBM once and from that L2 afterwards.
@@ -394,16 +391,38 @@ __device__ __forceinline__ TileId tile_of_block() {
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kBKH = 32, kLdkH = kBKH + 8;      // k depth of a tile (64 measured no faster on the GEMM and slower on the step:
+                                                // LDS for two stages halves the resident workgroups)
+// An operand that is contiguous along its ROWS instead of k (both operands of the weight-gradient GEMM: dZ^T and
+// X^T with k = the batch row) is copied to LDS as it lies in memory - [k][row] tiles, 16-byte loads along the rows -
+// and the MFMA fragment (8 consecutive k of one row per lane) comes out of gfx950's transposing LDS read:
+// ds_read_b64_tr_b16 hands lane i of a 16-lane group column i of the [4 k][16 rows] block whose 16 four-element
+// pieces the lanes address (measured: result[i][j] = piece[4j + i/4][i%4]), two of them per fragment.  The first
+// version read such operands with 2-byte global loads and packed them in registers: 265 TFLOP/s on the weight
+// gradients against 430-600 on the k-contiguous GEMMs.  Pitch rows + 32 halfwords: the 8 k rows one instruction
+// touches fall on 4 distinct 16-bank offsets, twice - the two LDS cycles its 512 bytes need anyway.
+constexpr int kPadT = 32;
+typedef short short4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ bf16x8 lds_frag_tr(const uint16_t *p, int pitch) {
+    typedef __attribute__((address_space(3))) short4v *lds_v4;
+    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)p);
+    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p + 4 * pitch));
+    typedef short short8v __attribute__((ext_vector_type(8)));
+    const short8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 template <int WN, int EPI, bool DROP, bool AK, bool BK>      // AK / BK: operand A / B is contiguous along k (else along its rows)
 __global__ __launch_bounds__(kBlock) void k_gemm_h(GemmOp op) {
     constexpr int BM = kGemmBM, BN = 64 * WN;
-    constexpr int LPT = kBKH / 8;                               // lanes per tile row (16 bytes each)
-    constexpr int RPP = kBlock / LPT;                           // tile rows per pass of the workgroup
+    constexpr int LPT = kBKH / 8;                               // k-contiguous: lanes per tile row (16 bytes each)
+    constexpr int RPP = kBlock / LPT;                           //               tile rows per pass of the workgroup
+    constexpr int PTA = BM + kPadT, PTB = BN + kPadT;           // row-contiguous: halfwords per k row of the LDS tile
+    constexpr int kTileA = AK ? BM * kLdkH : kBKH * PTA, kTileB = BK ? BN * kLdkH : kBKH * PTB;
     // one LDS block: two stages of the A and B tiles; the output tile of the bf16 epilogues reuses it afterwards
-    constexpr int kStage = 2 * (BM + BN) * kLdkH, kOut = BM * (BN + 8);
+    constexpr int kStage = 2 * (kTileA + kTileB), kOut = BM * (BN + 8);
     __shared__ __attribute__((aligned(16))) uint16_t smem[kStage > kOut ? kStage : kOut];
-    uint16_t (*As)[BM * kLdkH] = reinterpret_cast<uint16_t (*)[BM * kLdkH]>(smem);
-    uint16_t (*Bs)[BN * kLdkH] = reinterpret_cast<uint16_t (*)[BN * kLdkH]>(smem + 2 * BM * kLdkH);
+    uint16_t *const As0 = smem, *const Bs0 = smem + 2 * kTileA;
     const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
     const int wm = wave / 2, wn = wave % 2;
     const TileId tile = tile_of_block();
@@ -420,67 +439,74 @@ __global__ __launch_bounds__(kBlock) void k_gemm_h(GemmOp op) {
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mi][ni][i] = 0.f;
 
-    // registers of one tile: k-contiguous: Q x uint4; row-contiguous: (ROWS*32/256) halfwords packed in pairs
-    constexpr int NQ = BM / RPP, NS = BM * kBKH / kBlock / 2;
+    // registers of one tile: 16 bytes per load in both layouts (BM*32*2 / 256 threads = 2 loads for 128 rows)
     // (clang's own vector type: arrays of HIP's uint4 class are not split into registers and went through scratch)
-    u32x4 ra[AK ? NQ : 1], rb[BK ? NQ : 1];
-    uint32_t sa[AK ? 1 : NS], sb[BK ? 1 : NS];
+    constexpr int NQ = BM * kBKH / 8 / kBlock;
+    u32x4 ra[NQ], rb[NQ];
     auto load_op = [&](const uint16_t *__restrict__ P, int64_t srow, int64_t sk, auto kfast_c, int64_t row0, int64_t kt,
-                       auto &r, auto &sr, auto rows_c) {
+                       auto &r, auto rows_c) {
         constexpr int ROWS = decltype(rows_c)::value;
         if constexpr (decltype(kfast_c)::value) {
             const uint16_t *src = P + (row0 + tid / LPT) * srow + kt + (tid % LPT) * 8;
 #pragma unroll
             for (int q = 0; q < ROWS / RPP; ++q) r[q] = *reinterpret_cast<const u32x4 *>(src + (int64_t)q * RPP * srow);
         } else {
-            constexpr int KPT = ROWS * kBKH / kBlock;          // consecutive k per thread (16 for 128 rows, 8 for 64)
-            const uint16_t *src = P + row0 + (tid % ROWS) + (kt + (int64_t)(tid / ROWS) * KPT) * sk;
+            constexpr int VPR = ROWS / 8, KPP = kBlock / VPR;      // 16-byte vectors per k row; k rows per pass
+            const uint16_t *src = P + row0 + (tid % VPR) * 8 + (kt + tid / VPR) * sk;
 #pragma unroll
-            for (int q = 0; q < KPT / 2; ++q)
-                sr[q] = (uint32_t)src[(int64_t)(2 * q) * sk] | ((uint32_t)src[(int64_t)(2 * q + 1) * sk] << 16);
+            for (int q = 0; q < kBKH / KPP; ++q) r[q] = *reinterpret_cast<const u32x4 *>(src + (int64_t)q * KPP * sk);
         }
     };
-    auto store_op = [&](uint16_t *__restrict__ S, auto kfast_c, const auto &r, const auto &sr, auto rows_c) {
+    auto store_op = [&](uint16_t *__restrict__ S, auto kfast_c, const auto &r, auto rows_c) {
         constexpr int ROWS = decltype(rows_c)::value;
         if constexpr (decltype(kfast_c)::value) {
 #pragma unroll
             for (int q = 0; q < ROWS / RPP; ++q)
                 *reinterpret_cast<u32x4 *>(S + (tid / LPT + q * RPP) * kLdkH + (tid % LPT) * 8) = r[q];
         } else {
-            constexpr int KPT = ROWS * kBKH / kBlock;
-            uint16_t *dst = S + (tid % ROWS) * kLdkH + (tid / ROWS) * KPT;
+            constexpr int VPR = ROWS / 8, KPP = kBlock / VPR, PT = ROWS + kPadT;
 #pragma unroll
-            for (int q = 0; q < KPT / 8; ++q)
-                *reinterpret_cast<u32x4 *>(dst + 8 * q) = u32x4{sr[4 * q], sr[4 * q + 1], sr[4 * q + 2], sr[4 * q + 3]};
+            for (int q = 0; q < kBKH / KPP; ++q)
+                *reinterpret_cast<u32x4 *>(S + (tid / VPR + q * KPP) * PT + (tid % VPR) * 8) = r[q];
         }
     };
     using RA = std::integral_constant<int, BM>; using RB = std::integral_constant<int, BN>;
+    using KA = std::integral_constant<bool, AK>; using KB = std::integral_constant<bool, BK>;
     static_assert(BN <= BM, "tile registers are sized by the A tile");
 
     if (k_lo < k_hi) {
-        load_op(op.A16, op.sam, op.sak, std::integral_constant<bool, AK>{}, m0, k_lo, ra, sa, RA{});
-        load_op(op.B16, op.sbn, op.sbk, std::integral_constant<bool, BK>{}, (int64_t)n0, k_lo, rb, sb, RB{});
-        store_op(As[0], std::integral_constant<bool, AK>{}, ra, sa, RA{});
-        store_op(Bs[0], std::integral_constant<bool, BK>{}, rb, sb, RB{});
+        load_op(op.A16, op.sam, op.sak, KA{}, m0, k_lo, ra, RA{});
+        load_op(op.B16, op.sbn, op.sbk, KB{}, (int64_t)n0, k_lo, rb, RB{});
+        store_op(As0, KA{}, ra, RA{});
+        store_op(Bs0, KB{}, rb, RB{});
         __syncthreads();
         int cur = 0;
         for (int64_t kt = k_lo; kt < k_hi; kt += kBKH) {
             const bool more = kt + kBKH < k_hi;
             if (more) {
-                load_op(op.A16, op.sam, op.sak, std::integral_constant<bool, AK>{}, m0, kt + kBKH, ra, sa, RA{});
-                load_op(op.B16, op.sbn, op.sbk, std::integral_constant<bool, BK>{}, (int64_t)n0, kt + kBKH, rb, sb, RB{});
+                load_op(op.A16, op.sam, op.sak, KA{}, m0, kt + kBKH, ra, RA{});
+                load_op(op.B16, op.sbn, op.sbk, KB{}, (int64_t)n0, kt + kBKH, rb, RB{});
             }
-            const uint16_t *as = As[cur] + (wm * 64 + lane % 32) * kLdkH + (lane / 32) * 8;
-            const uint16_t *bs = Bs[cur] + (wn * 32 * WN + lane % 32) * kLdkH + (lane / 32) * 8;
+            const uint16_t *At = As0 + cur * kTileA, *Bt = Bs0 + cur * kTileB;
+            // k-contiguous tile: lane -> row lane%32, k half lane/32.  [k][row] tile: the address of this lane's piece
+            // of the transposing read (k row 8*(lane/32) + (lane%16)/4, rows 16*((lane%32)/16) + 4*(lane%4) ...)
+            const uint16_t *as = AK ? At + (wm * 64 + lane % 32) * kLdkH + (lane / 32) * 8
+                                    : At + (8 * (lane / 32) + (lane % 16) / 4) * PTA + wm * 64 + 16 * ((lane % 32) / 16) + 4 * (lane % 4);
+            const uint16_t *bs = BK ? Bt + (wn * 32 * WN + lane % 32) * kLdkH + (lane / 32) * 8
+                                    : Bt + (8 * (lane / 32) + (lane % 16) / 4) * PTB + wn * 32 * WN + 16 * ((lane % 32) / 16) + 4 * (lane % 4);
 #pragma unroll
             for (int ks = 0; ks < kBKH / 16; ++ks) {
                 bf16x8 a[2], b[WN];
 #pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-                    a[mi] = *reinterpret_cast<const bf16x8 *>(as + mi * 32 * kLdkH + ks * 16);
+                for (int mi = 0; mi < 2; ++mi) {
+                    if constexpr (AK) a[mi] = *reinterpret_cast<const bf16x8 *>(as + mi * 32 * kLdkH + ks * 16);
+                    else a[mi] = lds_frag_tr(as + ks * 16 * PTA + mi * 32, PTA);
+                }
 #pragma unroll
-                for (int ni = 0; ni < WN; ++ni)
-                    b[ni] = *reinterpret_cast<const bf16x8 *>(bs + ni * 32 * kLdkH + ks * 16);
+                for (int ni = 0; ni < WN; ++ni) {
+                    if constexpr (BK) b[ni] = *reinterpret_cast<const bf16x8 *>(bs + ni * 32 * kLdkH + ks * 16);
+                    else b[ni] = lds_frag_tr(bs + ks * 16 * PTB + ni * 32, PTB);
+                }
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -488,8 +514,8 @@ __global__ __launch_bounds__(kBlock) void k_gemm_h(GemmOp op) {
                         acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
             }
             if (more) {
-                store_op(As[cur ^ 1], std::integral_constant<bool, AK>{}, ra, sa, RA{});
-                store_op(Bs[cur ^ 1], std::integral_constant<bool, BK>{}, rb, sb, RB{});
+                store_op(As0 + (cur ^ 1) * kTileA, KA{}, ra, RA{});
+                store_op(Bs0 + (cur ^ 1) * kTileB, KB{}, rb, RB{});
             }
             __syncthreads();
             cur ^= 1;
@@ -557,7 +583,7 @@ static bool gemm_h_ok(const GemmOp &op) {
     const int64_t splits = (op.k_chunk < op.K) ? (op.K + op.k_chunk - 1) / op.k_chunk : 1;
     auto al = [](const uint16_t *p, int64_t srow, int64_t sk) {
         if (((uintptr_t)p & 15) != 0) return false;
-        return sk == 1 ? (srow % 8 == 0) : (srow == 1);
+        return sk == 1 ? (srow % 8 == 0) : (srow == 1 && sk % 8 == 0);     // 16-byte loads along k / along the rows
     };
     if (op.sak != 1 && op.sbk == 1) return false;          // (A along rows, B along k) is not a layout of the tower
     return op.M % kGemmBM == 0 && op.N % bn == 0 && op.K % kBKH == 0 && (splits == 1 || op.k_chunk % kBKH == 0) &&
