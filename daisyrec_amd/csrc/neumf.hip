@@ -859,6 +859,61 @@ __global__ __launch_bounds__(kBlock) void k_nmf_pred_bwd(const float *__restrict
     for (int c = threadIdx.x; c < dg + nl; c += kBlock) unsafeAtomicAdd(gWp + c, col[c]);
 }
 
+// the same for dg == nl == d <= 64, d % 4 == 0 (every NeuMF tower: the last layer is `factors` wide like the GMF
+// product): 16 lanes per row, each lane 4 consecutive columns of g[r] and of x_L[r] with one vector load each
+template <bool H>
+__global__ __launch_bounds__(kBlock) void k_nmf_pred_bwd_v(const float *__restrict__ dpred,
+                                                           const float *__restrict__ G, int d,
+                                                           const float *__restrict__ XL,
+                                                           const float *__restrict__ Wp, int64_t R,
+                                                           float *__restrict__ DZ, float *__restrict__ gWp) {
+    __shared__ float col[128];
+    if (threadIdx.x < 128) col[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x % 16, group = threadIdx.x / 16;
+    const bool on = 4 * lane < d;
+    const int c4 = on ? 4 * lane : 0;
+    const int64_t gstride = (int64_t)gridDim.x * (kBlock / 16);
+    const float4 wp = *reinterpret_cast<const float4 *>(Wp + d + c4);
+    float pg[4] = {0.f, 0.f, 0.f, 0.f}, px[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t r = (int64_t)blockIdx.x * (kBlock / 16) + group; r < R; r += gstride) {
+        const float dp = dpred[r];
+        const float4 g4 = *reinterpret_cast<const float4 *>(G + r * d + c4);
+        float x[4];
+        if constexpr (H) {
+            const uint2 q = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint16_t *>(XL) + r * d + c4);
+            x[0] = __uint_as_float(q.x << 16); x[1] = __uint_as_float(q.x & 0xFFFF0000u);
+            x[2] = __uint_as_float(q.y << 16); x[3] = __uint_as_float(q.y & 0xFFFF0000u);
+        } else {
+            const float4 q = *reinterpret_cast<const float4 *>(XL + r * d + c4);
+            x[0] = q.x; x[1] = q.y; x[2] = q.z; x[3] = q.w;
+        }
+        pg[0] = fmaf(dp, g4.x, pg[0]); pg[1] = fmaf(dp, g4.y, pg[1]);
+        pg[2] = fmaf(dp, g4.z, pg[2]); pg[3] = fmaf(dp, g4.w, pg[3]);
+        const float w4[4] = {wp.x, wp.y, wp.z, wp.w};
+        float dz[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            px[k] = fmaf(dp, x[k], px[k]);
+            dz[k] = (x[k] > 0.f) ? dp * w4[k] : 0.f;
+        }
+        if (on) {
+            if constexpr (H)
+                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(DZ) + r * d + c4) =
+                    make_uint2(bf16_rne(dz[0]) | (bf16_rne(dz[1]) << 16), bf16_rne(dz[2]) | (bf16_rne(dz[3]) << 16));
+            else
+                *reinterpret_cast<float4 *>(DZ + r * d + c4) = make_float4(dz[0], dz[1], dz[2], dz[3]);
+        }
+    }
+    if (on) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { atomicAdd(&col[c4 + k], pg[k]); atomicAdd(&col[64 + c4 + k], px[k]); }
+    }
+    __syncthreads();
+    if (threadIdx.x < d) unsafeAtomicAdd(gWp + threadIdx.x, col[threadIdx.x]);
+    else if (threadIdx.x >= 64 && threadIdx.x < 64 + d) unsafeAtomicAdd(gWp + d + (threadIdx.x - 64), col[threadIdx.x]);
+}
+
 // out[n] += sum_r X[r*ld + n]: a block takes 64 columns x kColsumRows rows (grid = column tiles x row tiles)
 constexpr int kColsumRows = 512;
 template <bool H = false>
@@ -882,6 +937,45 @@ __global__ __launch_bounds__(kBlock) void k_colsum(const float *__restrict__ X, 
     sm[rr][c] = s0 + s1;
     __syncthreads();
     if (rr == 0 && n < N) unsafeAtomicAdd(out + n, (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]));
+}
+
+// the same for a bf16 matrix whose rows are whole 16-byte vectors (N % 8 == 0, N <= 2048, ld == N): a thread owns
+// 8 consecutive columns and reads them with one 16-byte load per row; a block takes kColsumRowsH rows
+constexpr int kColsumRowsH = 512;
+__global__ __launch_bounds__(kBlock) void k_colsum_h(const uint16_t *__restrict__ X, int64_t R, int N,
+                                                     float *__restrict__ out) {
+    __shared__ float sm[kBlock][9];
+    const int vpr = N / 8;                            // vectors per row (a divisor of kBlock or a multiple: see the launch)
+    const int cv = threadIdx.x % vpr, rr = threadIdx.x / vpr, rpp = kBlock / vpr;
+    const int64_t r0 = (int64_t)blockIdx.x * kColsumRowsH;
+    const int64_t r1 = (r0 + kColsumRowsH < R) ? r0 + kColsumRowsH : R;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto add = [&](const uint4 &q) {
+        const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            acc[2 * k] += __uint_as_float(w[k] << 16);
+            acc[2 * k + 1] += __uint_as_float(w[k] & 0xFFFF0000u);
+        }
+    };
+    const uint16_t *col = X + cv * 8;
+    int64_t r = r0 + rr;
+    for (; r + 3 * rpp < r1; r += 4 * rpp) {          // four rows in flight per thread
+        const uint4 q0 = *reinterpret_cast<const uint4 *>(col + r * N);
+        const uint4 q1 = *reinterpret_cast<const uint4 *>(col + (r + rpp) * N);
+        const uint4 q2 = *reinterpret_cast<const uint4 *>(col + (r + 2 * rpp) * N);
+        const uint4 q3 = *reinterpret_cast<const uint4 *>(col + (r + 3 * rpp) * N);
+        add(q0); add(q1); add(q2); add(q3);
+    }
+    for (; r < r1; r += rpp) add(*reinterpret_cast<const uint4 *>(col + r * N));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) sm[threadIdx.x][k] = acc[k];
+    __syncthreads();
+    for (int c = threadIdx.x; c < N; c += kBlock) {   // column c: vector c/8, element c%8, summed over the row groups
+        float t = 0.f;
+        for (int g = 0; g < rpp; ++g) t += sm[g * vpr + c / 8][c % 8];
+        unsafeAtomicAdd(out + c, t);
+    }
 }
 
 // embedding gradients of one row r (dense tables, fp32 atomics) + the regulariser gradients
@@ -1336,7 +1430,13 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
     // 1 (default): owner-based, reproducible embedding scatter; 0: the fp32-atomics kernel (kept for A/B measurements)
     static const int tune_scatter = getenv("DAISY_NMF_SCATTER_OWNER") ? atoi(getenv("DAISY_NMF_SCATTER_OWNER")) : 1;
     const bool owner_scatter = tune_scatter != 0;
-    if (H) hipLaunchKernelGGL((k_nmf_pred_bwd<true>), dim3(grid_for(R, kBlock / 16 * 16, 1024)), dim3(kBlock), 0, s, ctx->dpred,
+    const bool vec_pred = dg == nl && dg > 0 && dg <= 64 && dg % 4 == 0;          // NeuMF proper (not the GMF / MLP ablations)
+    const int pb_grid = grid_for(R, kBlock / 16 * 8, 512);         // few workgroups: each ends with 2d global atomics
+    if (vec_pred && H) hipLaunchKernelGGL((k_nmf_pred_bwd_v<true>), dim3(pb_grid), dim3(kBlock), 0, s, ctx->dpred, ctx->G, dg,
+                                          ctx->X[L], p.Wp, R, dz, g.Wp);
+    else if (vec_pred) hipLaunchKernelGGL((k_nmf_pred_bwd_v<false>), dim3(pb_grid), dim3(kBlock), 0, s, ctx->dpred, ctx->G, dg,
+                                          ctx->X[L], p.Wp, R, dz, g.Wp);
+    else if (H) hipLaunchKernelGGL((k_nmf_pred_bwd<true>), dim3(grid_for(R, kBlock / 16 * 16, 1024)), dim3(kBlock), 0, s, ctx->dpred,
                               ctx->G, dg, ctx->X[L], nl, p.Wp, R, dz, g.Wp);
     else hipLaunchKernelGGL((k_nmf_pred_bwd<false>), dim3(grid_for(R, kBlock / 16 * 16, 1024)), dim3(kBlock), 0, s, ctx->dpred,
                             ctx->G, dg, ctx->X[L], nl, p.Wp, R, dz, g.Wp);
@@ -1366,7 +1466,11 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
                 w.B16 = reinterpret_cast<const uint16_t *>(w.B);
                 if (!gemm_h_ok(w)) { set_error("neumf: weight gradient of layer %d does not tile for the bf16-storage GEMM", l); return DAISY_ERR_STATE; }
                 launch_gemm_h<EPI_ATOMIC>(w, s);
-                hipLaunchKernelGGL((k_colsum<true>), cs_grid, dim3(kBlock), 0, s, dz, R, n_out, (int64_t)n_out, g.b[l - 1]);
+                if (n_out % 8 == 0 && kBlock % (n_out / 8) == 0)
+                    hipLaunchKernelGGL(k_colsum_h, dim3((unsigned)((R + kColsumRowsH - 1) / kColsumRowsH)), dim3(kBlock), 0, s,
+                                       reinterpret_cast<const uint16_t *>(dz), R, n_out, g.b[l - 1]);
+                else
+                    hipLaunchKernelGGL((k_colsum<true>), cs_grid, dim3(kBlock), 0, s, dz, R, n_out, (int64_t)n_out, g.b[l - 1]);
             } else {
                 launch_gemm<EPI_ATOMIC>(w, s);
                 hipLaunchKernelGGL((k_colsum<false>), cs_grid, dim3(kBlock), 0, s, dz, R, n_out, (int64_t)n_out, g.b[l - 1]);
