@@ -1294,17 +1294,21 @@ int segsum_rows(const float *X, const float2 *coef, const uint32_t *ekey, const 
     v.imask = 0xFFFFFFFFu;
     v.B = n_entries / 2;
     ItemEdges ed{edge_vec, edge_item, edge_b, edge_whole};
+    static const int tune_run = getenv("DAISY_SEGSUM_RUN") ? atoi(getenv("DAISY_SEGSUM_RUN")) : 4;
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
-        const int64_t nchunks = (n_entries + RunCfg<C>::E - 1) / RunCfg<C>::E;
-        if (x_bf16)
-            hipLaunchKernelGGL((k_item_grad_chunked<C, 0, true, true>), dim3(grid_for(n_entries, RunCfg<C>::E, 16384)),
-                               dim3(kBlock), 0, s, X, coef, v, d, out, ed);
-        else
-            hipLaunchKernelGGL((k_item_grad_chunked<C, 0, true>), dim3(grid_for(n_entries, RunCfg<C>::E, 16384)),
-                               dim3(kBlock), 0, s, X, coef, v, d, out, ed);
-        hipLaunchKernelGGL((k_item_edges<C>), dim3(grid_for(nchunks, C::GROUPS_PER_BLOCK)), dim3(kBlock), 0, s, ed,
-                           nchunks, d, out, (float *)nullptr);
+        auto go = [&](auto ro_tag) {
+            // wide rows (d > 128: 16 floats per lane) default to 2 rows in flight per lane group; 4 measured faster
+            // for the NeuMF tables (fewer, longer chunks: 3 barriers per chunk)
+            constexpr int RO = decltype(ro_tag)::value;
+            const int64_t nchunks = (n_entries + RunCfg<C, RO>::E - 1) / RunCfg<C, RO>::E;
+            const dim3 g(grid_for(n_entries, RunCfg<C, RO>::E, 16384)), ge(grid_for(nchunks, C::GROUPS_PER_BLOCK));
+            if (x_bf16) hipLaunchKernelGGL((k_item_grad_chunked<C, RO, true, true>), g, dim3(kBlock), 0, s, X, coef, v, d, out, ed);
+            else hipLaunchKernelGGL((k_item_grad_chunked<C, RO, true>), g, dim3(kBlock), 0, s, X, coef, v, d, out, ed);
+            hipLaunchKernelGGL((k_item_edges<C>), ge, dim3(kBlock), 0, s, ed, nchunks, d, out, (float *)nullptr);
+        };
+        if (C::NE == 16 && tune_run == 4) go(std::integral_constant<int, 4>{});
+        else go(std::integral_constant<int, 0>{});
         return DAISY_OK;
     });
     if (rc) return rc;
