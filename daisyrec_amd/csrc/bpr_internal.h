@@ -198,7 +198,15 @@ __device__ __forceinline__ void reduce_partials_block(const double *__restrict__
                                                       double *__restrict__ step_loss) {
     __shared__ double sm[kBlock][8];
     double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int b = threadIdx.x; b < nblocks; b += kBlock) {
+    int b = threadIdx.x;
+    for (; b + kBlock < nblocks; b += 2 * kBlock) {          // two rows (16 loads) in flight per thread
+        double a0[8], a1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { a0[k] = partials[(int64_t)b * 8 + k]; a1[k] = partials[(int64_t)(b + kBlock) * 8 + k]; }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = (t[k] + a0[k]) + a1[k];
+    }
+    for (; b < nblocks; b += kBlock) {
 #pragma unroll
         for (int k = 0; k < 8; ++k) t[k] += partials[(int64_t)b * 8 + k];
     }

@@ -933,20 +933,20 @@ __global__ __launch_bounds__(kBlock) void k_staged_user_edges(float *__restrict_
                                                               float *__restrict__ p_sqnorm, PreNorm pre,
                                                               ReduceJob red) {
     const double sq_pre = prenorm_sum(stats, pre);
-    unsigned nb = gridDim.x;
-    if (red.nblocks > 0) {
-        nb -= 1;
-        if (blockIdx.x == nb) {
+    unsigned nb = gridDim.x, bid = blockIdx.x;
+    if (red.nblocks > 0) {            // workgroup 0 (dispatched first: its chain of dependent loads is the longest)
+        if (bid == 0) {
             reduce_partials_block(red.partials, red.nblocks, red.stats, true, reg_1, reg_2, red.epoch_acc, red.step_loss);
             if (threadIdx.x == 0 && pre.n) red.stats[DAISY_ST_SQ_U_PRE] = sq_pre;
             return;
         }
+        nb -= 1; bid -= 1;
     }
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)nb * C::GROUPS_PER_BLOCK;
     const float rU = inv_or_zero(sqrt(sq_pre), reg_2);
-    for (int64_t c = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; c < nchunks; c += gstride) {
+    for (int64_t c = (int64_t)bid * C::GROUPS_PER_BLOCK + group; c < nchunks; c += gstride) {
         const int uu = ed.user[2 * c + 1];
         if (uu < 0) continue;
         Row<C> acc, t;
@@ -1262,23 +1262,27 @@ static int staged_prenorm(daisy_bpr_ctx *ctx, const float *P, double *stats, boo
         return DAISY_OK;
     });
     if (rc) return rc;
-    const int gn = grid_for(v.B, kBlock * 4, kPreBlocks);
-    double *pre = ctx->partials + (size_t)kMaxGrid * 8;        // behind the user pass's own partial sums
+    // Batches up to kPreBlocks workgroups of pre-norm work: the consumers add the partial sums themselves (one launch
+    // less; what bounds a step of that size).  Larger ones: a full grid and k_unorm_reduce - every workgroup of the
+    // user pass re-adding thousands of partial sums measured slower than the launch it saves.
+    int gn = grid_for(v.B, kBlock * 4);
+    const bool fold = !reduce && gn <= kPreBlocks / 2;
+    double *pre = fold ? ctx->partials + (size_t)kMaxGrid * 8 : ctx->partials;   // fold: behind the user pass's own sums
     hipLaunchKernelGGL(k_unorm, dim3(gn), dim3(kBlock), 0, s, ctx->p_sqnorm, v, pre);
-    if (reduce) hipLaunchKernelGGL(k_unorm_reduce, dim3(1), dim3(kBlock), 0, s, pre, gn, stats);
-    if (n_pre) *n_pre = gn;
+    if (!fold) hipLaunchKernelGGL(k_unorm_reduce, dim3(1), dim3(kBlock), 0, s, pre, gn, stats);
+    if (n_pre) *n_pre = fold ? gn : 0;
     DAISY_LAUNCH_CHECK();
     return DAISY_OK;
 }
 
 static inline bool premul_loss(int loss_type) { return loss_type == DAISY_LOSS_BPR || loss_type == DAISY_LOSS_HL; }
 
-// n_pre > 0 (single-GPU step): the pre-norm comes from k_unorm's partial sums and the reduction of this pass's own
-// sums (stats, loss; into epoch_acc / step_loss) rides on the edge launch; n_pre == 0: stats[SQ_U_PRE] is read
-// and the caller reduces
+// n_pre > 0: the pre-norm comes from k_unorm's partial sums, else from stats[SQ_U_PRE].  ride_reduce (single-GPU
+// step): the reduction of this pass's own sums (stats, loss; into epoch_acc / step_loss) rides on the edge
+// launch; else the caller reduces
 static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_type, float gamma, float lr,
-                       float reg_1, float reg_2, double *stats, int *grid_out, int n_pre, double *epoch_acc,
-                       double *step_loss, hipStream_t s) {
+                       float reg_1, float reg_2, double *stats, int *grid_out, int n_pre, bool ride_reduce,
+                       double *epoch_acc, double *step_loss, hipStream_t s) {
     const StreamView &v = ctx->sv;
     const int d = ctx->d;
     const bool premul = premul_loss(loss_type), has_pos = v.s_pos != nullptr;
@@ -1309,8 +1313,8 @@ static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_ty
         if (tune_blk == 128 && C::LPR <= 32) go(std::integral_constant<int, 128>{});
         else go(std::integral_constant<int, kBlock>{});
         if (overflow) return DAISY_OK;
-        const ReduceJob red{ctx->partials, n_pre > 0 ? *grid_out : 0, stats, epoch_acc, step_loss};
-        hipLaunchKernelGGL((k_staged_user_edges<C>), dim3(grid_for(nchunks_out, C::GROUPS_PER_BLOCK) + (n_pre > 0 ? 1 : 0)),
+        const ReduceJob red{ctx->partials, ride_reduce ? *grid_out : 0, stats, epoch_acc, step_loss};
+        hipLaunchKernelGGL((k_staged_user_edges<C>), dim3(grid_for(nchunks_out, C::GROUPS_PER_BLOCK) + (ride_reduce ? 1 : 0)),
                            dim3(kBlock), 0, s, P, nchunks_out, d, stats, lr, reg_1, reg_2, ed, ctx->p_sqnorm, pre, red);
         return DAISY_OK;
     });
@@ -1362,10 +1366,11 @@ int staged_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int loss_type, float
                     float reg_2, double *stats, double *epoch_acc, double *step_loss, hipStream_t s) {
     int rc = staged_check(ctx, loss_type, "sgd_step");
     if (rc) return rc;
-    // five launches: pre-norm partial sums, user pass, its edges (+ the reduction of its sums), item pass, its edges
+    // five launches (six for large batches, see staged_prenorm): pre-norm partial sums, user pass, its edges (+ the
+    // reduction of its sums), item pass, its edges
     int gu = 0, n_pre = 0;
     if ((rc = staged_prenorm(ctx, P, stats, false, &n_pre, s))) return rc;
-    if ((rc = staged_user(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, stats, &gu, n_pre, epoch_acc, step_loss, s))) return rc;
+    if ((rc = staged_user(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, stats, &gu, n_pre, true, epoch_acc, step_loss, s))) return rc;
     if ((rc = staged_item(ctx, loss_type, Q, nullptr, true, lr, reg_1, reg_2, stats, s))) return rc;
     ctx->fwd_done = false;
     return DAISY_OK;
@@ -1534,7 +1539,7 @@ int daisy_bpr_staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int32_t 
         return DAISY_ERR_STATE;
     }
     int gu = 0;
-    if ((rc = staged_user(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, stats, &gu, 0, nullptr, nullptr, S(stream)))) return rc;
+    if ((rc = staged_user(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, stats, &gu, 0, false, nullptr, nullptr, S(stream)))) return rc;
     return launch_reduce_partials(ctx->partials, gu, stats, false, 0.f, 0.f, nullptr, nullptr, S(stream));
 }
 

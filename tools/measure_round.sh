@@ -16,6 +16,14 @@ python $R/bench.py --no-cpu-baseline --dist zipf > $O/bench_c2_zipf.json 2>/dev/
 python $R/bench.py --no-cpu-baseline --reg 0 > $O/bench_c2_reg0.json 2>/dev/null
 python $R/bench.py --no-cpu-baseline --item-mode chunked > $O/bench_c2_chunked.json 2>/dev/null
 python $R/bench.py --gpus 2 --backend gloo --workload c2 --batch 2097152 --no-ref > $O/bench_c2_gloo2.json 2> $O/bench_gloo2.err
+python $R/tools/sweep_batch.py > $O/batch_sweep.txt 2>/dev/null
+python $R/tools/sweep_factors.py > $O/factor_sweep.txt 2>/dev/null
+MODE=chunked python $R/tools/sweep_factors.py 64 100 128 200 256 > $O/factor_sweep_chunked.txt 2>/dev/null
+python $R/tools/small_epoch.py > $O/small_epoch.txt 2>/dev/null
+python $R/tools/bench_neumf.py > $O/bench_neumf.txt 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_neumf -o nmf -- python $R/tools/neumf_steps.py 2 262144 > /dev/null 2>&1
+python $R/tools/rocprof_summary.py $O/prof_neumf > $O/neumf_kernel_summary.txt 2>/dev/null
+python $R/tools/bench_lightgcn.py > $O/bench_lightgcn.txt 2>/dev/null
 cd $R
 head -14 $O/mf_kernel_summary.txt | cut -c1-64,100-170
 for f in $O/bench_*.json; do echo "$f: $(python -c "
