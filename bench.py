@@ -310,7 +310,7 @@ def main():
             except Exception:
                 traffic = None
         if r["staged"]:
-            chain = ("one SGD step = k_unorm + k_staged_user (+edges) + k_reduce_partials + k_staged_item (+edges)"
+            chain = ("one SGD step = k_unorm (+reduce) + k_staged_user + its edge kernel (which also reduces the batch sums) + k_staged_item (+edges)"
                      + (" + RCCL reduce-scatter / k_item_apply_counts / all-gather" if world > 1 else ""))
         else:
             chain = "one SGD step = k_fwd + k_reduce_partials + k_item_grad_" + a.item_mode + " + k_user + k_item_apply"
