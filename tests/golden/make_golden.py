@@ -186,13 +186,14 @@ class _TqdmCapture:
         _TqdmCapture.epoch_losses.append(float(loss))
 
 
-def make_ml100k(epochs=3, out="ml100k_c1.npz", **over):
+def make_ml100k(epochs=3, out="ml100k_c1.npz", factors=32, num_ng=1, **over):
     """`over`: config overrides (e.g. optimizer='adam', lr=0.001 -> ml100k_c1_adam.npz: the same run with
-    torch.optim.Adam, AbstractRecommender.py:54)"""
+    torch.optim.Adam, AbstractRecommender.py:54).  factors=100, num_ng=4 -> ml100k_default.npz: what
+    `python run_examples/test.py` runs when nothing is overridden (mf.yaml:1, basic.yaml:22-24)."""
     cwd = os.getcwd()
     os.chdir(REF)                        # data_path is relative ('data/'); nothing is written
     try:
-        cfg = base_config(factors=32, num_ng=1, epochs=epochs, early_stop=False,
+        cfg = base_config(factors=factors, num_ng=num_ng, epochs=epochs, early_stop=False,
                           algo_name="mf", dataset="ml-100k", **over)
         seed_all(cfg["seed"])            # config.py:21-42 (CPU part)
         df = RawDataReader(cfg).get_data()
@@ -233,7 +234,7 @@ def make_ml100k(epochs=3, out="ml100k_c1.npz", **over):
         os.path.join(HERE, out),
         user_num=np.int64(cfg["user_num"]), item_num=np.int64(cfg["item_num"]),
         hyper=np.array([cfg["lr"], cfg["reg_1"], cfg["reg_2"]], dtype=np.float64),
-        factors=np.int64(32), batch_size=np.int64(cfg["batch_size"]), epochs=np.int64(epochs),
+        factors=np.int64(factors), batch_size=np.int64(cfg["batch_size"]), epochs=np.int64(epochs),
         topk=np.int64(cfg["topk"]), seed=np.int64(cfg["seed"]),
         train_users=train_users, train_items=train_items,
         samples=samples.astype(np.int32), P0=P0, Q0=Q0,
@@ -275,4 +276,5 @@ if __name__ == "__main__":  # pragma: no cover
     make_rank_kat()
     make_ml100k()
     make_ml100k(out="ml100k_c1_adam.npz", optimizer="adam", lr=0.001)
+    make_ml100k(epochs=2, out="ml100k_default.npz", factors=100, num_ng=4)
     make_kat_optimizers()

@@ -2,6 +2,8 @@
 (a) the golden vectors produced by the real reference and (b) the CPU oracle on seeded
 inputs.  Tolerances: integer/index work bit-exact; fp32 tables within fp32 round-off of
 the reference; loss within 1e-5 relative (north_star); ranked top-N identical."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -308,6 +310,33 @@ def test_ml100k_c1_through_the_dropin(ml100k):
                           cfg["reg_1"], cfg["reg_2"])[0]
     got = float(model.calc_loss([torch.from_numpy(b[:, k].copy()) for k in range(3)]).cpu())
     assert abs(got - want) <= 1e-5 * abs(want)
+
+
+def test_ml100k_default_run_through_the_dropin():
+    """What `python run_examples/test.py` trains when nothing is overridden: ml-100k, factors = 100 (mf.yaml:1),
+    num_ng = 4 and batch_size = 256 (basic.yaml:22-24), SGD, BPR - 313 452 triples, 1225 steps per epoch, rows that
+    do not fill their lanes.  Fixture generated from the reference by tests/golden/make_golden.py."""
+    from daisyrec_amd.model.MFRecommender import MF
+    from daisyrec_amd.utils.dataset import BasicDataset, CandidatesDataset, get_dataloader
+    from conftest import GOLDEN
+    g = np.load(os.path.join(GOLDEN, "ml100k_default.npz"))
+    assert int(g["factors"]) == 100 and int(g["batch_size"]) == 256 and g["samples"].shape[0] == 313452
+    cfg = mf_config(user_num=int(g["user_num"]), item_num=int(g["item_num"]), epochs=int(g["epochs"]),
+                    factors=100, num_ng=4)
+    torch.manual_seed(int(g["seed"]))
+    model = MF(cfg)
+    np.testing.assert_array_equal(model.embed_user.weight.detach().numpy(), g["P0"])
+    loader = get_dataloader(BasicDataset(g["samples"]), batch_size=256, shuffle=True, num_workers=0)
+    torch.set_rng_state(torch.from_numpy(g["rng_state_before_fit"]))
+    model.fit(loader)
+    for got, ref in zip(model.epoch_losses, g["epoch_losses"]):
+        assert abs(got - ref) <= 1e-5 * abs(ref), (got, ref)
+    np.testing.assert_allclose(model.embed_user.weight.detach().cpu().numpy(), g["P1"], atol=5e-4)
+    np.testing.assert_allclose(model.embed_item.weight.detach().cpu().numpy(), g["Q1"], atol=5e-4)
+    ucands = [[int(u), c] for u, c in zip(g["test_u"], g["cands"])]
+    preds = model.rank(get_dataloader(CandidatesDataset(ucands), batch_size=128, shuffle=False, num_workers=0))
+    same = (preds == g["preds"]).all(1).mean()
+    assert same >= 0.97, same          # 2450 steps amplify summation-order differences; top-50 lists of >= 97 % of the users identical
 
 
 def test_ml100k_atomic_mode_and_adam_run(ml100k):
