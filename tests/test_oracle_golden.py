@@ -83,6 +83,29 @@ def test_ml100k_end_to_end(ml100k):
     np.testing.assert_array_equal(full, g["full_rank16"])
 
 
+def test_ml100k_default_run_end_to_end():
+    """The run test.py does when nothing is overridden (factors 100, num_ng 4, B=256; mf.yaml, basic.yaml):
+    the oracle over the reference's own triples / init / batch order."""
+    from conftest import GOLDEN
+    import os
+    g = np.load(os.path.join(GOLDEN, "ml100k_default.npz"))
+    samples, B = g["samples"], int(g["batch_size"])
+    lr, r1, r2 = g["hyper"]
+    P, Q = g["P0"].copy(), g["Q0"].copy()
+    for ep, perm in enumerate(ml100k_epoch_orders(g)):
+        tot = 0.0
+        for s in range(0, len(samples), B):
+            idx = perm[s:s + B]
+            loss, P, Q = O.mf_sgd_step(P, Q, samples[idx, 0], samples[idx, 1], samples[idx, 2], lr, r1, r2)
+            tot += loss
+        ref = g["epoch_losses"][ep]
+        assert abs(tot - ref) <= 1e-5 * abs(ref)
+    np.testing.assert_allclose(P, g["P1"], atol=5e-4)
+    np.testing.assert_allclose(Q, g["Q1"], atol=5e-4)
+    pred, _ = O.mf_rank(P, Q, g["test_u"], g["cands"], int(g["topk"]))
+    assert (pred == g["preds"]).all(1).mean() >= 0.97
+
+
 # ---- sampler -----------------------------------------------------------------
 def test_philox_known_answers():
     """Random123 kat_vectors for philox4x32-10."""
