@@ -15,7 +15,10 @@
 //      user side, same phase: the group at the head of a user's run sums over the STAGED item rows and writes
 //      P[u] in place - nobody reads the tables during this phase, only the pre-step copies in LDS.
 //      (d too wide for three staged rows per sample: the user rows stay in global memory, and the user side
-//      waits behind one more barrier for the item side to finish reading them.)
+//      waits behind one more barrier for the item side to finish reading them.  Wider still - the reference's
+//      default d = 100 at B = 256 - only the USER rows are staged: the user side runs first and reads its item
+//      rows from the table, which nobody has written yet; after a barrier the item side reads the staged user
+//      rows and the pre-step row of its own item from the table.)
 //
 // Global traffic per step = the 3B gathered rows + one write per distinct row; the index arrays of step k+1
 // are fetched while step k computes.  Every sum runs in plan order on a single owner: bitwise reproducible.
@@ -64,12 +67,17 @@ __device__ __forceinline__ void lds_load_row(Row<C> &r, const float *src, int la
 #pragma unroll
     for (int c = 0; c < C::NV; ++c) {
         const int e = (c * C::LPR + lane) * C::VEC;
+        const bool in = C::EXACT || e < d;                 // lanes past d read the row's start and drop the value:
+        const int ec = in ? e : 0;                         // no LDS read behind a branch
 #pragma unroll
-        for (int k = 0; k < C::VEC; ++k) r.v[c * C::VEC + k] = (C::EXACT || e < d) ? src[e + k] : 0.f;
+        for (int k = 0; k < C::VEC; ++k) {
+            const float t = src[ec + k];
+            r.v[c * C::VEC + k] = in ? t : 0.f;
+        }
     }
 }
 
-template <class C, bool STAGE_P>
+template <class C, int MODE>      // rows staged in LDS per sample: 3 = q_i, q_j, p_u; 2 = q_i, q_j; 1 = p_u only
 __global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
     float *__restrict__ P, float *__restrict__ Q, SmallPlan pl, int d, int dpad, int loss_type, float gamma, float lr,
     float reg_1, float reg_2, double *__restrict__ stats, double *__restrict__ epoch_acc,
@@ -78,7 +86,8 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
     constexpr int NW = kSmallThreads / kWave;
     constexpr int UN = (C::NE <= 4) ? 2 : 1;            // samples whose 3 row gathers are issued together per lane group
     constexpr int PT = (3 * kSmallBatchMax + kSmallThreads - 1) / kSmallThreads;   // metadata words per thread
-    extern __shared__ float s_rows[];                  // [B][dpad] q_i | [B][dpad] q_j | (STAGE_P: [B][dpad] p_u)
+    constexpr bool STAGE_P = MODE != 2, STAGE_Q = MODE != 1;
+    extern __shared__ float s_rows[];                  // MODE 3/2: [B][dpad] q_i | [B][dpad] q_j | (3: [B][dpad] p_u);  MODE 1: [B][dpad] p_u
     __shared__ SmallMeta s_meta[2];
     __shared__ float2 s_coef[kSmallBatchMax];          // (dL/dpos, dL/dneg)
     __shared__ double s_part[NW][8];
@@ -90,7 +99,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
     const int wave = tid / kWave;
     float *const s_qi = s_rows;
     float *const s_qj = s_rows + (size_t)pl.B * dpad;
-    float *const s_p = s_rows + 2 * (size_t)pl.B * dpad;
+    float *const s_p = STAGE_Q ? s_rows + 2 * (size_t)pl.B * dpad : s_rows;
     double acc_epoch = 0.0, nan_epoch = 0.0;           // thread 0 only
 
     // element x of a step's metadata: x < B samples, then 2B entries
@@ -141,17 +150,19 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
                 const int s = s0 + y * G;
                 if (s < Bk) {
                     const int2 it = m.ij[s];
-                    p[y].load(P + (int64_t)m.ukey[s] * d, lane, d);
-                    qi[y].load(Q + (int64_t)it.x * d, lane, d);
-                    qj[y].load(Q + (int64_t)it.y * d, lane, d);
+                    p[y].load_clamped(P + (int64_t)m.ukey[s] * d, lane, d);
+                    qi[y].load_clamped(Q + (int64_t)it.x * d, lane, d);
+                    qj[y].load_clamped(Q + (int64_t)it.y * d, lane, d);
                 }
             }
 #pragma unroll
             for (int y = 0; y < UN; ++y) {
                 const int s = s0 + y * G;
                 if (s < Bk) {
-                    lds_store_row<C>(s_qi + (size_t)s * dpad, qi[y], lane, d);
-                    lds_store_row<C>(s_qj + (size_t)s * dpad, qj[y], lane, d);
+                    if constexpr (STAGE_Q) {
+                        lds_store_row<C>(s_qi + (size_t)s * dpad, qi[y], lane, d);
+                        lds_store_row<C>(s_qj + (size_t)s * dpad, qj[y], lane, d);
+                    }
                     if constexpr (STAGE_P) lds_store_row<C>(s_p + (size_t)s * dpad, p[y], lane, d);
                     const float pos = row_dot<C>(p[y], qi[y]);
                     const float neg = row_dot<C>(p[y], qj[y]);
@@ -203,62 +214,84 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
 
         // ---- B, item side: entries sorted by item; the head of a run owns Q[item]
         const int nE = 2 * Bk;
-        for (int e = group; e < nE; e += G) {
-            const uint32_t r = m.item[e];
-            if (e > 0 && m.item[e - 1] == r) continue;
-            const uint32_t s_head = m.su[e].x;
-            Row<C> a, qr;          // the pre-step Q[r] is the staged q of the head entry's own sample
-            lds_load_row<C>(qr, ((s_head & kNegBit) ? s_qj : s_qi) + (size_t)(s_head & ~kNegBit) * dpad, lane, d);
-            a.zero();
-            float np = 0.f, nn = 0.f;
-            for (int q = e; q < nE && m.item[q] == r; ++q) {
-                const uint2 su = m.su[q];
-                const bool is_neg = (su.x & kNegBit) != 0;
-                const float2 c2 = s_coef[su.x & ~kNegBit];
-                const float c = is_neg ? c2.y : c2.x;
-                np += is_neg ? 0.f : 1.f;
-                nn += is_neg ? 1.f : 0.f;
-                Row<C> pr;
-                if constexpr (STAGE_P) lds_load_row<C>(pr, s_p + (size_t)(su.x & ~kNegBit) * dpad, lane, d);
-                else pr.load(P + (int64_t)su.y * d, lane, d);
+        auto item_side = [&]() {
+            for (int e = group; e < nE; e += G) {
+                const uint32_t r = m.item[e];
+                if (e > 0 && m.item[e - 1] == r) continue;
+                const uint32_t s_head = m.su[e].x;
+                Row<C> a, qr;      // the pre-step Q[r]: the staged q of the head entry's own sample, or (MODE 1) the table row
+                if constexpr (STAGE_Q)
+                    lds_load_row<C>(qr, ((s_head & kNegBit) ? s_qj : s_qi) + (size_t)(s_head & ~kNegBit) * dpad, lane, d);
+                else qr.load_clamped(Q + (int64_t)r * d, lane, d);
+                a.zero();
+                float np = 0.f, nn = 0.f;
+                for (int q = e; q < nE && m.item[q] == r; ++q) {
+                    const uint2 su = m.su[q];
+                    const bool is_neg = (su.x & kNegBit) != 0;
+                    const float2 c2 = s_coef[su.x & ~kNegBit];
+                    const float c = is_neg ? c2.y : c2.x;
+                    np += is_neg ? 0.f : 1.f;
+                    nn += is_neg ? 1.f : 0.f;
+                    Row<C> pr;
+                    if constexpr (STAGE_P) lds_load_row<C>(pr, s_p + (size_t)(su.x & ~kNegBit) * dpad, lane, d);
+                    else pr.load(P + (int64_t)su.y * d, lane, d);
 #pragma unroll
-                for (int x = 0; x < C::NE; ++x) a.v[x] = fmaf(c, pr.v[x], a.v[x]);
-            }
-            const float w1 = reg_1 * (np + nn), w2 = np * rI + nn * rJ;
+                    for (int x = 0; x < C::NE; ++x) a.v[x] = fmaf(c, pr.v[x], a.v[x]);
+                }
+                const float w1 = reg_1 * (np + nn), w2 = np * rI + nn * rJ;
 #pragma unroll
-            for (int x = 0; x < C::NE; ++x) {
-                const float g = a.v[x] + fmaf(w2, qr.v[x], w1 * sgn(qr.v[x]));
-                qr.v[x] = fmaf(-lr, g, qr.v[x]);
+                for (int x = 0; x < C::NE; ++x) {
+                    const float g = a.v[x] + fmaf(w2, qr.v[x], w1 * sgn(qr.v[x]));
+                    qr.v[x] = fmaf(-lr, g, qr.v[x]);
+                }
+                qr.store(Q + (int64_t)r * d, lane, d);      // nobody reads Q before the next step's phase A
             }
-            qr.store(Q + (int64_t)r * d, lane, d);      // nobody reads Q before the next step's phase A
-        }
-        if constexpr (!STAGE_P) __syncthreads();        // the item side read P from global memory
-
+        };
         // ---- B, user side: samples grouped by user; the head of a run owns P[u]
-        for (int s = group; s < Bk; s += G) {
-            const uint32_t uu = m.ukey[s];
-            if (s > 0 && m.ukey[s - 1] == uu) continue;
-            Row<C> p, a;
-            if constexpr (STAGE_P) lds_load_row<C>(p, s_p + (size_t)s * dpad, lane, d);
-            else p.load(P + (int64_t)uu * d, lane, d);
-            a.zero();
-            float cnt = 0.f;
-            for (int q = s; q < Bk && m.ukey[q] == uu; ++q) {
-                const float2 c = s_coef[q];
-                Row<C> qi, qj;
-                lds_load_row<C>(qi, s_qi + (size_t)q * dpad, lane, d);
-                lds_load_row<C>(qj, s_qj + (size_t)q * dpad, lane, d);
+        auto user_side = [&]() {
+            for (int s = group; s < Bk; s += G) {
+                const uint32_t uu = m.ukey[s];
+                if (s > 0 && m.ukey[s - 1] == uu) continue;
+                Row<C> p, a;
+                if constexpr (STAGE_P) lds_load_row<C>(p, s_p + (size_t)s * dpad, lane, d);
+                else p.load(P + (int64_t)uu * d, lane, d);
+                a.zero();
+                float cnt = 0.f;
+                for (int q = s; q < Bk && m.ukey[q] == uu; ++q) {
+                    const float2 c = s_coef[q];
+                    Row<C> qi, qj;
+                    if constexpr (STAGE_Q) {
+                        lds_load_row<C>(qi, s_qi + (size_t)q * dpad, lane, d);
+                        lds_load_row<C>(qj, s_qj + (size_t)q * dpad, lane, d);
+                    } else {                                // MODE 1: the item side has not run yet, Q is pre-step
+                        const int2 it = m.ij[q];
+                        qi.load_clamped(Q + (int64_t)it.x * d, lane, d);
+                        qj.load_clamped(Q + (int64_t)it.y * d, lane, d);
+                    }
 #pragma unroll
-                for (int x = 0; x < C::NE; ++x) a.v[x] = fmaf(c.x, qi.v[x], fmaf(c.y, qj.v[x], a.v[x]));
-                cnt += 1.f;
-            }
-            const float w1 = reg_1 * cnt, w2 = rU * cnt;
+                    for (int x = 0; x < C::NE; ++x) a.v[x] = fmaf(c.x, qi.v[x], fmaf(c.y, qj.v[x], a.v[x]));
+                    cnt += 1.f;
+                }
+                const float w1 = reg_1 * cnt, w2 = rU * cnt;
 #pragma unroll
-            for (int x = 0; x < C::NE; ++x) {
-                const float g = a.v[x] + fmaf(w2, p.v[x], w1 * sgn(p.v[x]));
-                p.v[x] = fmaf(-lr, g, p.v[x]);
+                for (int x = 0; x < C::NE; ++x) {
+                    const float g = a.v[x] + fmaf(w2, p.v[x], w1 * sgn(p.v[x]));
+                    p.v[x] = fmaf(-lr, g, p.v[x]);
+                }
+                p.store(P + (int64_t)uu * d, lane, d);
             }
-            p.store(P + (int64_t)uu * d, lane, d);
+        };
+        if constexpr (MODE == 3) {            // both sides read only the staged pre-step rows
+            item_side();
+            user_side();
+        } else if constexpr (MODE == 2) {     // the item side reads P from the table: the user side writes it afterwards
+            item_side();
+            __syncthreads();
+            user_side();
+        } else {                              // the user side reads Q from the table: the item side writes it afterwards
+            user_side();
+            __syncthreads();
+            item_side();
         }
         if (k + 1 < pl.nb) stash(k + 1);
         __syncthreads();
@@ -273,7 +306,7 @@ bool small_epoch_supported(const daisy_bpr_ctx *ctx, const daisy_epoch_plan *pla
     static const int enabled = getenv("DAISY_SMALL_EPOCH") ? atoi(getenv("DAISY_SMALL_EPOCH")) : 1;
     return enabled && plan->kind == 0 && !plan->pointwise && plan->batch_size <= kSmallBatchMax && !ctx->bu &&
            loss_type >= DAISY_LOSS_BPR && loss_type <= DAISY_LOSS_TL && plan->batch_size <= ctx->max_batch &&
-           2 * (size_t)plan->batch_size * small_dpad(ctx->d) * sizeof(float) <= kSmallLdsRows;
+           (size_t)plan->batch_size * small_dpad(ctx->d) * sizeof(float) <= kSmallLdsRows;      // at least the user rows
 }
 
 int small_fit_epoch(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, float *P, float *Q, int loss_type, float gamma,
@@ -288,8 +321,8 @@ int small_fit_epoch(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, float *P, 
     pl.n = plan->n; pl.B = plan->batch_size; pl.nb = plan->num_batches;
     const int d = ctx->d, dpad = small_dpad(d);
     const size_t row_bytes = (size_t)plan->batch_size * dpad * sizeof(float);
-    const bool stage_p = 3 * row_bytes <= kSmallLdsRows;
-    const size_t shmem = (stage_p ? 3 : 2) * row_bytes;
+    const int mode = (3 * row_bytes <= kSmallLdsRows) ? 3 : ((2 * row_bytes <= kSmallLdsRows) ? 2 : 1);
+    const size_t shmem = (size_t)mode * row_bytes;
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
         auto launch = [&](auto kern) -> int {
@@ -299,7 +332,9 @@ int small_fit_epoch(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, float *P, 
                                reg_1, reg_2, stats, epoch_acc, step_losses);
             return DAISY_OK;
         };
-        return stage_p ? launch(k_small_epoch<C, true>) : launch(k_small_epoch<C, false>);
+        if (mode == 3) return launch(k_small_epoch<C, 3>);
+        if (mode == 2) return launch(k_small_epoch<C, 2>);
+        return launch(k_small_epoch<C, 1>);
     });
     if (rc) return rc;
     DAISY_LAUNCH_CHECK();

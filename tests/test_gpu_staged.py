@@ -215,7 +215,8 @@ def test_partitioned_plan_refused_by_phase_kernels():
     ctx.close(); plan.close(); index.close()
 
 
-@pytest.mark.parametrize("d,B,loss", [(32, 256, "BPR"), (64, 256, "HL"), (20, 100, "TL"), (128, 100, "BPR"), (8, 1, "BPR"), (256, 50, "BPR"), (100, 77, "BPR")])
+@pytest.mark.parametrize("d,B,loss", [(32, 256, "BPR"), (64, 256, "HL"), (20, 100, "TL"), (128, 100, "BPR"), (8, 1, "BPR"), (256, 50, "BPR"), (100, 77, "BPR"),
+                                      (100, 256, "BPR"), (128, 256, "HL"), (72, 256, "TL")])      # only the user rows fit the LDS
 def test_small_batch_epoch_in_one_workgroup(d, B, loss):
     """B <= 256 over the sorted plan: fit_epoch_sgd runs every step of the epoch inside one persistent
     workgroup (csrc/bpr_small.hip).  Same users and items recur from step to step, so a stale cache line
