@@ -112,6 +112,7 @@ SIGNATURES = {
     "daisy_full_topk_from_scores": (C.c_int, [_p, _i64, _i32, _p, _p, _sz, _p]),
     "daisy_gemm_nt_f32": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _p]),
     "daisy_gemm_nt_bf16": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _p]),
+    "daisy_gemm_tn_bf16": (C.c_int, [_p, _p, _p, _i64, _i32, _i64, _i64, _p]),
     "daisy_gemm_nt": (C.c_int, [_p, _p, _p, _i64, _i32, _i32, _i32, _p]),
     "daisy_lgcn_graph_create": (C.c_int, [C.POINTER(_p), _p, _p, _i64, _i64, _i64, _p]),
     "daisy_lgcn_graph_destroy": (C.c_int, [_p]),

@@ -1529,6 +1529,21 @@ int daisy_gemm_nt_bf16(const uint16_t *A, const uint16_t *B, uint16_t *C, int64_
     return DAISY_OK;
 }
 
+int daisy_gemm_tn_bf16(const uint16_t *At, const uint16_t *Bt, float *C, int64_t M, int32_t N, int64_t K,
+                       int64_t k_chunk, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(At && Bt && C && M > 0 && N > 0 && K > 0 && k_chunk > 0, "gemm_tn_bf16: bad argument");
+    GemmOp op{};                         // the weight-gradient layout: both operands [K][rows], rows contiguous
+    op.A16 = At; op.sam = 1; op.sak = M;
+    op.B16 = Bt; op.sbn = 1; op.sbk = N;
+    op.C = C; op.ldc = N;
+    op.M = M; op.N = N; op.K = K; op.k_chunk = k_chunk;
+    DAISY_CHECK_ARG(gemm_h_ok(op), "gemm_tn_bf16: needs M %% 128 == 0, N %% 64 == 0 (128 when N > 64), K and k_chunk %% 32 == 0, "
+                                   "M and N %% 8 == 0, 16-byte aligned operands");
+    launch_gemm_h<EPI_ATOMIC>(op, NS(stream));
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
 int daisy_sgd_dense(float *W, float *g, int64_t n, float lr, daisy_stream_t stream) {
     DAISY_CHECK_ARG(W && g && n > 0, "sgd_dense: bad argument");
     hipLaunchKernelGGL(k_sgd_dense, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, NS(stream), W, g, n, lr);

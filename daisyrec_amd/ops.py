@@ -661,6 +661,17 @@ def gemm_nt_bf16(A, B):
     return out
 
 
+def gemm_tn_bf16(At, Bt, k_chunk=2048):
+    """C = At.T @ Bt for bf16 At [K,M], Bt [K,N] (the weight-gradient layout of NeuMF's precision level 2), fp32
+    result, the reduction cut into k_chunk slices (fp32 atomics)."""
+    K, M = At.shape
+    Nn = Bt.shape[1]
+    out = torch.zeros(M, Nn, dtype=torch.float32, device=At.device)
+    check(lib.daisy_gemm_tn_bf16(_ptr(At, torch.bfloat16, "At"), _ptr(Bt, torch.bfloat16, "Bt"),
+                                 _ptr(out, torch.float32, "C"), M, Nn, K, int(k_chunk), _stream()))
+    return out
+
+
 def gemm_nt(A, B, bf16=False):
     """C = A @ B.T on the MFMA tile kernels of the NeuMF tower (test / bench hook)."""
     M, K = A.shape

@@ -471,6 +471,12 @@ int daisy_gemm_nt_f32(const float *A, const float *B, float *C, int64_t M, int32
  * GEMM of precision level 2 (test / bench hook); M % 128 == 0, N % 64 == 0 (% 128 when N > 64), K % 32 == 0 */
 int daisy_gemm_nt_bf16(const uint16_t *A, const uint16_t *B, uint16_t *C, int64_t M, int32_t N, int32_t K,
                        daisy_stream_t stream);
+/* C[M,N] (fp32, accumulated into: zero it first) += At[K,M]^T * Bt[K,N] with both operands stored as bf16 and
+ * contiguous along their rows, the reduction over K cut into k_chunk slices that add with fp32 atomics: the
+ * weight-gradient GEMM of precision level 2, gW = dZ^T X (NeuMFRecommender.py:139-169 through autograd; test / bench
+ * hook); M % 128 == 0, N % 64 == 0 (% 128 when N > 64), K % 32 == 0, k_chunk % 32 == 0 */
+int daisy_gemm_tn_bf16(const uint16_t *At, const uint16_t *Bt, float *C, int64_t M, int32_t N, int64_t K,
+                       int64_t k_chunk, daisy_stream_t stream);
 /* same with the precision switch of daisy_neumf_ctx_set_precision */
 int daisy_gemm_nt(const float *A, const float *B, float *C, int64_t M, int32_t N, int32_t K, int32_t bf16,
                   daisy_stream_t stream);

@@ -270,7 +270,24 @@ def test_neumf_bf16_mode_tracks_the_fp32_step():
     assert res[1][0] != res[2][0]                           # level 2 really took the bf16-storage kernels
 
 
-@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (384, 64, 512), (128, 256, 32)])
+@pytest.mark.parametrize("M,N,K,chunk", [(256, 512, 4096, 2048), (128, 64, 96, 32), (512, 256, 16384, 2048),
+                                          (128, 128, 640, 64), (256, 64, 1024, 1024)])
+def test_mfma_gemm_tn_bf16_weight_gradient_layout(M, N, K, chunk):
+    """gW = dZ^T X with both operands stored [K][rows] as bf16: the fragments come out of the transposing LDS read
+    (ds_read_b64_tr_b16).  Against the exact product of the bf16 operands; k slices that are (16384/2048 = 8) and
+    are not a multiple of the 8 XCDs (the tile order differs), one and several tiles per slice."""
+    from daisyrec_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M + N + K)
+    At = torch.randn(K, M, device=DEV, generator=g).to(torch.bfloat16)
+    Bt = torch.randn(K, N, device=DEV, generator=g).to(torch.bfloat16)
+    got = ops.gemm_tn_bf16(At, Bt, k_chunk=chunk).double().cpu()
+    want = At.double().cpu().T @ Bt.double().cpu()
+    assert (got - want).abs().max() <= 2e-5 * float(K) ** 0.5 * 4 + 1e-6 * want.abs().max()
+    with pytest.raises(ValueError, match="gemm_tn_bf16"):
+        ops.gemm_tn_bf16(At[:, :100].contiguous(), Bt)
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (384, 64, 512), (128, 256, 32), (1024, 256, 512), (2048, 128, 64)])
 def test_mfma_gemm_bf16_storage(M, N, K):
     """all-bf16-operand GEMM of precision level 2: exact product of the stored bf16 values, fp32 accumulation,
     result rounded to bf16"""
