@@ -15,21 +15,23 @@ U, I, D, B, STEPS = 40, 30, 16, 96, 3
 LR, R1, R2 = 0.05, 0.01, 0.02
 
 
-def _data():
+def _data(lopsided=False):
     rng = np.random.default_rng(9)
     P0 = (rng.standard_normal((U, D)) * 0.2).astype(np.float32)
     Q0 = (rng.standard_normal((I, D)) * 0.2).astype(np.float32)
     batches = [np.stack([rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)], 1)
                .astype(np.int32) for _ in range(STEPS)]
+    if lopsided:                              # step 1: every sample belongs to the first rank's users
+        batches[1][:, 0] = rng.integers(0, U // 4, B)
     return P0, Q0, batches
 
 
-def _worker(rank, world, port, out_dir, mode):
+def _worker(rank, world, port, out_dir, mode, lopsided=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from daisyrec_amd.sharding import UserShardedBprTrainer, shard_triples, user_range
     from oracle_backend import OracleContext
-    P0, Q0, batches = _data()
+    P0, Q0, batches = _data(lopsided)
     lo, hi = user_range(U, world, rank)
     P = torch.from_numpy(P0[lo:hi].copy())
     Q = torch.from_numpy(Q0.copy())
@@ -41,7 +43,10 @@ def _worker(rank, world, port, out_dir, mode):
     losses = []
     for b in batches:
         mine = shard_triples(b, U, world, rank)
-        stats = tr.step_from_triples(torch.from_numpy(mine))
+        if len(mine) == 0:                    # this rank owns no sample of the step: it only joins the exchanges
+            stats = tr.step_from_plan(None, 0)
+        else:
+            stats = tr.step_from_triples(torch.from_numpy(mine))
         losses.append(float(stats[7]))
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), P=P.numpy(), Q=Q.numpy(), lo=lo, hi=hi,
              losses=np.array(losses), acc=float(ctx.epoch_acc[0]))
@@ -79,6 +84,24 @@ def test_user_sharding_equals_single_process(tmp_path, mode, world):
         assert abs(float(o["acc"]) - sum(ref_losses)) < 1e-6
     for o in outs[1:]:
         np.testing.assert_array_equal(outs[0]["Q"], o["Q"])
+
+
+def test_ranks_without_samples_in_a_step_only_join_the_exchanges(tmp_path):
+    """a rank's share of a global batch can be empty (MF.fit over ranks: EpochPlan.build_positions)"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    world = 4
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "fused", True), nprocs=world, join=True)
+    P, Q, batches = _data(True)
+    ref_losses = []
+    for b in batches:
+        loss, P, Q = O.mf_sgd_step(P, Q, b[:, 0], b[:, 1], b[:, 2], LR, R1, R2)
+        ref_losses.append(loss)
+    for r in range(world):
+        o = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
+        np.testing.assert_allclose(o["losses"], ref_losses, rtol=1e-9)
+        np.testing.assert_allclose(o["Q"], Q, atol=2e-6)
+        np.testing.assert_allclose(o["P"], P[int(o["lo"]):int(o["hi"])], atol=2e-6)
 
 
 def test_user_range_partition():
