@@ -60,6 +60,9 @@ def parse():
                     help="build the next epoch's plan on a side stream (two plans in ping-pong; measured slower "
                          "with the partitioned plan)")
     ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--slices", type=int, default=1,
+                    help="N>1: cut the item pass into this many item ranges and exchange a finished range on a side "
+                         "stream while the next one is reduced (1: one exchange after the whole pass)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 code path on one GPU)")
     return ap.parse_args()
@@ -144,7 +147,7 @@ def run_workload(a, rank, world, dev, wl, want_cpu_batches=0):
     P = torch.empty(U_loc, d, device=dev).normal_(0.0, 0.01, generator=g)
     ctx = ops.BprContext(B, d, U_loc, I, device=dev)
     item_mode = ops.ITEM_MODES[a.item_mode]
-    trainer = UserShardedBprTrainer(ctx, P, Q, 0, lr, reg, reg, item_mode=item_mode) if world > 1 else None
+    trainer = UserShardedBprTrainer(ctx, P, Q, 0, lr, reg, reg, item_mode=item_mode, slices=a.slices) if world > 1 else None
     user_sorted = ops.triples_user_sorted(triples)      # synthetic triples are generated in CSR order
     plan_kind = a.plan if a.plan != "auto" else ("indexed" if a.item_mode == "fused" else "sorted")
     index = ops.TrainIndex(triples, U_loc, I, user_sorted=user_sorted) if plan_kind == "indexed" else None
@@ -323,6 +326,7 @@ def main():
                        "optimizer": "sgd", "lr": r["lr"], "reg_1": r["reg"], "reg_2": r["reg"], "loss": "BPR",
                        "item_mode": a.item_mode, "id_distribution": a.dist, "interactions_per_gpu": r["n"],
                        "parallelism": f"user-sharded dp{world}" if world > 1 else "single GPU",
+                       "exchange_slices": a.slices if world > 1 else None,
                        "plan_layout": r["plan_kind"], "plan_bytes": r["plan_bytes"], "index_bytes": r["index_bytes"],
                        "plan_bytes_per_interaction": r["plan_bytes"] / r["n"], "plan_overlapped": bool(a.overlap_plan),
                        "semantics": "batch-synchronous (autograd + SGD.step equivalent), shuffle=True (device Feistel permutation per epoch)"},

@@ -78,6 +78,8 @@ SIGNATURES = {
     "daisy_bpr_staged_user": (C.c_int, [_p, _p, _p, _i32, _f32, _f32, _f32, _f32, _p, _p]),
     "daisy_bpr_staged_item": (C.c_int, [_p, _i32, _p, _p, _p, _f32, _f32, _f32, _p, _p]),
     "daisy_item_apply_counts": (C.c_int, [_p, _p, _p, _i64, _i32, _f32, _f32, _f32, _p, _p]),
+    "daisy_bpr_staged_item_slices": (C.c_int, [_p, _p, _i32, _p]),
+    "daisy_bpr_staged_item_slice": (C.c_int, [_p, _i32, _p, _p, _i32, _f32, _f32, _f32, _p, _p]),
     "daisy_bpr_forward": (C.c_int, [_p, _p, _p, _i32, _f32, _p, _p]),
     "daisy_bpr_finalize": (C.c_int, [_p, _p, _f32, _f32, _p, _p, _p]),
     "daisy_bpr_item_grad": (C.c_int, [_p, _p, _p, _p, _f32, _f32, _p, _i32, _p]),

@@ -117,6 +117,7 @@ struct daisy_epoch_plan {
     int64_t h_off_cap;
 };
 
+constexpr int kMaxItemSlices = 16;  // daisy_bpr_staged_item_slices
 constexpr int kPreBlocks = 256;   // workgroups (= partial sums) of the staged step's pre-norm pass
 
 struct daisy_bpr_ctx {
@@ -141,6 +142,8 @@ struct daisy_bpr_ctx {
     int32_t batch_kind;   // layout of the plan the current batch comes from (0: v and sv valid, 1: only sv)
     int64_t edge_chunks;  // chunks the edge-record arrays hold (two records per chunk)
     float *edge_cnt;      // staged step, edge records of the item pass: [2*nchunks][2] (n_pos, n_neg)
+    int64_t *slice_rng;   // staged step in item slices (multi-GPU pipelining): entry range of slice s = [slice_rng[s], slice_rng[s+1])
+    int32_t n_slices;     //   of the current batch (0: not prepared)
     int32_t pointwise;   // batches set through set_batch* hold (user, item, label) rows
     int last_item_mode;  // mode of the last daisy_bpr_item_grad: the user pass of the same step follows it
     float *bu, *bi, *b0, *g_bu, *g_bi, *g_b0;   // FM bias parameters (daisy_bpr_ctx_set_bias); bu == nullptr: MF

@@ -1006,8 +1006,18 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                                                         const float2 *__restrict__ coef, StreamView v, int d,
                                                         float *__restrict__ Qo, float *__restrict__ cnt_out,
                                                         const double *__restrict__ stats, float lr,
-                                                        float reg_1, float reg_2, ItemEdges2 ed) {
+                                                        float reg_1, float reg_2, ItemEdges2 ed,
+                                                        const int64_t *__restrict__ erange) {
     constexpr int G = StagedItemCfg<C, BLK>::G, RUN = StagedItemCfg<C, BLK>::RUN, E = StagedItemCfg<C, BLK>::E;
+    // erange: only the entries [erange[0], erange[1]) - an item range of the batch (the entries are sorted by item, so
+    // no segment crosses the cut and the piece is reduced exactly like a whole batch).  Multi-GPU steps cut the item
+    // pass into such slices so that a finished slice can be exchanged while the next one is reduced.
+    if (erange) {
+        const int64_t lo = erange[0];
+        v.e_key += lo;
+        v.e_pos += lo * v.e_stride;
+        v.E = erange[1] - lo;
+    }
     constexpr int ROWF = C::NE * C::LPR;
     __shared__ int slot_item[G + 1], slot_shared[G + 1];
     __shared__ int run_first[G], run_last[G];
@@ -1176,7 +1186,9 @@ template <class C, bool APPLY>
 __global__ __launch_bounds__(kBlock) void k_staged_item_edges(ItemEdges2 ed, int64_t nchunks, int d,
                                                               float *__restrict__ Qo, float *__restrict__ cnt_out,
                                                               const double *__restrict__ stats, float lr,
-                                                              float reg_1, float reg_2) {
+                                                              float reg_1, float reg_2,
+                                                              const int64_t *__restrict__ erange, int chunk_entries) {
+    if (erange) nchunks = (erange[1] - erange[0] + chunk_entries - 1) / chunk_entries;      // chunks of the slice
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
@@ -1225,6 +1237,20 @@ __global__ __launch_bounds__(kBlock) void k_item_apply_counts(float *__restrict_
         z.store(g + r * d, lane, d);
         if (lane == 0) { cnt[2 * r] = 0.f; cnt[2 * r + 1] = 0.f; }
     }
+}
+
+// rng[s] = first entry of the batch whose item is >= bounds.b[s]  (s = 0..S; the entries are sorted by item)
+struct SliceBounds { int32_t b[kMaxItemSlices + 1]; };
+__global__ void k_slice_ranges(StreamView v, SliceBounds bounds, int S, int64_t *__restrict__ rng) {
+    const int s = threadIdx.x;
+    if (s > S) return;
+    int64_t lo = 0, hi = v.E;
+    const uint32_t want = (uint32_t)bounds.b[s];
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (((v.e_key[mid] & v.imask) >> 1) < want) lo = mid + 1; else hi = mid;
+    }
+    rng[s] = lo;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1325,8 +1351,10 @@ static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_ty
 }
 
 // apply != 0: Qo = Q, updated in place; else Qo = gQ (data term), cnt_out f32[I][2]
+// slice >= 0: only the entries of item slice `slice` (daisy_bpr_staged_item_slices has run for this batch)
 static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_out, bool apply, float lr,
-                       float reg_1, float reg_2, const double *stats, hipStream_t s) {
+                       float reg_1, float reg_2, const double *stats, hipStream_t s, int slice = -1) {
+    const int64_t *erange = (slice >= 0) ? ctx->slice_rng + slice : nullptr;
     const StreamView &v = ctx->sv;
     const int d = ctx->d;
     const bool premul = premul_loss(loss_type);
@@ -1343,9 +1371,9 @@ static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_
 #define DAISY_LAUNCH_SI(PM, AP)                                                                                   \
             do {                                                                                                     \
                 hipLaunchKernelGGL((k_staged_item<C, BLK, PM, AP>), g, b, 0, s, ctx->p_stage, ctx->coef, v, d, Qo, cnt_out, \
-                                   stats, lr, reg_1, reg_2, ed);                                                     \
+                                   stats, lr, reg_1, reg_2, ed, erange);                                             \
                 hipLaunchKernelGGL((k_staged_item_edges<C, AP>), ge, dim3(kBlock), 0, s, ed, nchunks, d, Qo, cnt_out, stats, lr, \
-                                   reg_1, reg_2);                                                                    \
+                                   reg_1, reg_2, erange, StagedItemCfg<C, BLK>::E);                                  \
             } while (0)
             if (premul && apply) DAISY_LAUNCH_SI(true, true);
             else if (premul) DAISY_LAUNCH_SI(true, false);
@@ -1550,6 +1578,34 @@ int daisy_bpr_staged_item(daisy_bpr_ctx *ctx, int32_t loss_type, float *Q, float
     int rc = staged_check(ctx, loss_type, "staged_item");
     if (rc) return rc;
     return staged_item(ctx, loss_type, Q ? Q : gQ, cnt, Q != nullptr, lr, reg_1, reg_2, stats, S(stream));
+}
+
+int daisy_bpr_staged_item_slices(daisy_bpr_ctx *ctx, const int32_t *item_bounds, int32_t n_slices, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(ctx && item_bounds && n_slices >= 1 && n_slices <= kMaxItemSlices,
+                    "staged_item_slices: 1..%d slices", kMaxItemSlices);
+    if (!ctx->batch_set) { set_error("staged_item_slices: no batch set"); return DAISY_ERR_STATE; }
+    SliceBounds sb;
+    for (int k = 0; k <= n_slices; ++k) {
+        DAISY_CHECK_ARG(item_bounds[k] >= 0 && (k == 0 || item_bounds[k] >= item_bounds[k - 1]),
+                        "staged_item_slices: the item bounds must not decrease");
+        sb.b[k] = item_bounds[k];
+    }
+    DAISY_CHECK_ARG(item_bounds[0] == 0 && item_bounds[n_slices] >= ctx->I,
+                    "staged_item_slices: the slices must cover the items 0..%lld", (long long)ctx->I);
+    hipLaunchKernelGGL(k_slice_ranges, dim3(1), dim3(64), 0, S(stream), ctx->sv, sb, (int)n_slices, ctx->slice_rng);
+    DAISY_LAUNCH_CHECK();
+    ctx->n_slices = n_slices;
+    return DAISY_OK;
+}
+
+int daisy_bpr_staged_item_slice(daisy_bpr_ctx *ctx, int32_t loss_type, float *gQ, float *cnt, int32_t slice, float lr,
+                                float reg_1, float reg_2, const double *stats, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(ctx && gQ && cnt && stats, "staged_item_slice: NULL argument");
+    int rc = staged_check(ctx, loss_type, "staged_item_slice");
+    if (rc) return rc;
+    DAISY_CHECK_ARG(slice >= 0 && slice < ctx->n_slices, "staged_item_slice: slice %d of %d (daisy_bpr_staged_item_slices first)",
+                    slice, ctx->n_slices);
+    return staged_item(ctx, loss_type, gQ, cnt, false, lr, reg_1, reg_2, stats, S(stream), slice);
 }
 
 int daisy_item_apply_counts(float *Q, float *g, float *cnt, int64_t rows, int32_t d, float lr, float reg_1,

@@ -1457,6 +1457,7 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
     const size_t o_ev = take(n_edge * (size_t)d * 4), o_eu = take(n_edge * 4), o_en = take(n_edge * 8);
     const size_t o_ew = take(n_edge * 4);
     const size_t o_ec = take(n_edge * 8);
+    const size_t o_sr = take((kMaxItemSlices + 1) * 8);
     const size_t o_ps = take((size_t)max_batch * (size_t)d * 4);
     const size_t o_pn = take((size_t)user_num * 4);
     c->arena_bytes = off;
@@ -1475,6 +1476,8 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
     c->edge_n = (float *)(base + o_en);
     c->edge_whole = (int32_t *)(base + o_ew);
     c->edge_cnt = (float *)(base + o_ec);
+    c->slice_rng = (int64_t *)(base + o_sr);
+    c->n_slices = 0;
     c->batch_kind = 0;
     c->p_stage = (float *)(base + o_ps);
     c->p_sqnorm = (float *)(base + o_pn);
@@ -1553,7 +1556,7 @@ int daisy_bpr_set_batch_from_plan(daisy_bpr_ctx *ctx, const daisy_epoch_plan *pl
         ctx->batch_kind = 0;
         view_bias(ctx);
     }
-    ctx->batch_set = true; ctx->fwd_done = false;
+    ctx->batch_set = true; ctx->fwd_done = false; ctx->n_slices = 0;
     return DAISY_OK;
 }
 
@@ -1576,7 +1579,7 @@ int daisy_bpr_set_batch_from_triples(daisy_bpr_ctx *ctx, const int32_t *triples,
     ctx->sv = stream_view_of(ctx->v);
     ctx->batch_kind = 0;
     view_bias(ctx);
-    ctx->batch_set = true; ctx->fwd_done = false;
+    ctx->batch_set = true; ctx->fwd_done = false; ctx->n_slices = 0;
     return DAISY_OK;
 }
 

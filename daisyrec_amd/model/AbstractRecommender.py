@@ -128,6 +128,7 @@ class GeneralRecommender(AbstractRecommender):
         # under torch.distributed (one process per GPU): split the users over the ranks (default) or let every
         # rank train the whole model
         self.shard_users = bool(config.get("shard_users", True))
+        self.exchange_slices = int(config.get("exchange_slices", 1))     # > 1: pipeline the item exchange (sharding.py)
         self.epoch_losses = []
 
     # -- helpers ---------------------------------------------------------------
@@ -207,7 +208,7 @@ class GeneralRecommender(AbstractRecommender):
         ctx = ops.BprContext(B, d, hi - lo, I, device=P.device)        # stage slots are positions inside a GLOBAL batch
         index = plan = None
         trainer = UserShardedBprTrainer(ctx, P_loc, Q, lo, self.lr, self.reg_1, self.reg_2, loss_type=loss_id,
-                                        item_mode=ops.ITEM_MODES["fused"])
+                                        item_mode=ops.ITEM_MODES["fused"], slices=self.exchange_slices)
         acc = torch.zeros(2, dtype=torch.float64, device=P.device)
         nb = (n + B - 1) // B
         last_loss = 0.0

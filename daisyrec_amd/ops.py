@@ -239,6 +239,17 @@ class BprContext:
                                         float(lr), float(reg_1), float(reg_2),
                                         _ptr(self.stats, torch.float64, "stats"), _stream()))
 
+    def staged_item_slices(self, item_bounds):
+        """Cut the item pass of the current batch at the given items (host ints, bounds[0] = 0, bounds[-1] >= item_num,
+        at most 16 slices): `staged_item_slice(s, ...)` then reduces the entries of items [bounds[s], bounds[s+1])."""
+        b = (C.c_int32 * len(item_bounds))(*[int(x) for x in item_bounds])
+        check(lib.daisy_bpr_staged_item_slices(self._h, b, len(item_bounds) - 1, _stream()))
+
+    def staged_item_slice(self, s, lr, reg_1, reg_2, gQ, cnt, loss_type=N.LOSS_BPR):
+        check(lib.daisy_bpr_staged_item_slice(self._h, int(loss_type), _ptr(gQ, torch.float32, "gQ"),
+                                              _ptr(cnt, torch.float32, "cnt"), int(s), float(lr), float(reg_1),
+                                              float(reg_2), _ptr(self.stats, torch.float64, "stats"), _stream()))
+
     def item_apply_counts(self, Q_rows, g_rows, cnt_rows, lr, reg_1, reg_2):
         """The row owner's SGD step of a multi-GPU staged step: Q_rows -= lr*(g_rows + regulariser from the
         reduced entry counts and the finalized global norms); clears g_rows and cnt_rows."""

@@ -31,6 +31,11 @@ reduce-scatter + all-gather pair a ring all-reduce is made of:
 Per step and rank at d=64: 2*(N-1)/N * I * 264 B on the wire (I=1M, N=8: 2 x 231 MB), against
 B_local interactions of compute; DESIGN.md section 5 has the budget.
 
+`slices=S` (> 1, opt-in): the item rows are cut into S ranges, the item pass runs range by range
+(daisy_bpr_staged_item_slice; the entries are sorted by item) and the exchange of a finished range - reduce-scatter,
+owner update, all-gather - runs on a side stream while the next range is reduced.  Ownership then interleaves: rank
+r owns the r-th block of every range.  Every rank must use the same S.
+
 PHASE protocol (item modes 'chunked' / 'sorted', or a backend without the staged phases):
 forward -> all_reduce(stats) -> item_grad -> all_reduce(gQ) overlapped with user_sgd -> dense
 item_sgd_apply.  Kept for the modes the staged step does not cover.
@@ -64,7 +69,7 @@ class UserShardedBprTrainer:
     table; both are updated in place."""
 
     def __init__(self, ctx, P_local, Q, user_lo, lr, reg_1, reg_2, loss_type=N.LOSS_BPR,
-                 gamma=1e-10, item_mode=N.ITEM_FUSED, group=None, overlap=True, always_collective=False):
+                 gamma=1e-10, item_mode=N.ITEM_FUSED, group=None, overlap=True, always_collective=False, slices=1):
         self.ctx, self.P, self.Q = ctx, P_local, Q
         self.user_lo = int(user_lo)
         self.lr, self.reg_1, self.reg_2 = float(lr), float(reg_1), float(reg_2)
@@ -87,16 +92,22 @@ class UserShardedBprTrainer:
         # collectives the backend lacks are emulated with the ones it has (gloo: no reduce_scatter);
         # "nccl" (= RCCL on ROCm) runs the real ones
         self._native_rs = self.collective and dist.get_backend(group) == "nccl"
+        self.slices = min(16, max(1, int(slices))) if self.staged and hasattr(ctx, "staged_item_slice") else 1
+        self.side = None
         if self.staged:
             I, d = Q.shape
-            self.rows = (I + self.world - 1) // self.world          # item rows per owner
-            Ipad = self.rows * self.world
+            S = self.slices
+            # item rows per owner AND slice; slice s = rows [s*world*rows, (s+1)*world*rows), its r-th block is rank r's
+            self.rows = (I + self.world * S - 1) // (self.world * S)
+            Ipad = self.rows * self.world * S
+            self.bounds = [min(s_ * self.world * self.rows, I) for s_ in range(S)] + [Ipad]
+            self.side = torch.cuda.Stream(device=Q.device) if (S > 1 and Q.is_cuda) else None
             self.gQ = torch.zeros(Ipad, d, dtype=torch.float32, device=Q.device)
             self.cnt = torch.zeros(Ipad, 2, dtype=torch.float32, device=Q.device)
             self.g_own = torch.zeros(self.rows, d, dtype=torch.float32, device=Q.device)
             self.c_own = torch.zeros(self.rows, 2, dtype=torch.float32, device=Q.device)
             self.Q_gather = Q if Ipad == I else torch.zeros(Ipad, d, dtype=torch.float32, device=Q.device)
-            self.own_lo = self.rank * self.rows
+            self.own_lo = self.rank * self.rows                     # (of slice 0; slice s: + s*world*rows)
             self.own_hi = min(self.own_lo + self.rows, I)
 
     # -- collectives -----------------------------------------------------------------------------
@@ -106,9 +117,10 @@ class UserShardedBprTrainer:
         return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
 
     def _reduce_scatter(self, out, full):
-        """out[rows] = sum over ranks of full[rank*rows:(rank+1)*rows]"""
+        """out[rows] = sum over ranks of full[rank*rows:(rank+1)*rows]  (`full`: world*rows rows - the whole padded
+        table, or one slice of it)"""
         if not self.collective:
-            out.copy_(full)
+            out.copy_(full[self.rank * self.rows:(self.rank + 1) * self.rows])
         elif self._native_rs:
             dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=self.group)
         else:
@@ -157,34 +169,70 @@ class UserShardedBprTrainer:
         self._all_reduce(c.stats[N.ST_SQ_U_PRE:N.ST_SQ_U_PRE + 1])
         c.staged_user(self.P, self.Q, self.lr, self.reg_1, self.reg_2, self.loss_type, self.gamma)
         w0 = self._all_reduce(c.stats[:7], async_op=self.overlap)
-        c.staged_item(self.lr, self.reg_1, self.reg_2, gQ=self.gQ[:I], cnt=self.cnt[:I],
-                      loss_type=self.loss_type)          # overlaps the 56-byte all-reduce
-        if w0 is not None:
-            w0.wait()
-        c.finalize(self.reg_1, self.reg_2)               # every rank: the GLOBAL loss and norms
-        return self._exchange_items()
+        if self.slices == 1:
+            c.staged_item(self.lr, self.reg_1, self.reg_2, gQ=self.gQ[:I], cnt=self.cnt[:I],
+                          loss_type=self.loss_type)      # overlaps the 56-byte all-reduce
+            if w0 is not None:
+                w0.wait()
+            c.finalize(self.reg_1, self.reg_2)           # every rank: the GLOBAL loss and norms
+            return self._exchange_items()
+        # item pass range by range; the exchange of range s runs on the side stream under the pass over range s+1
+        c.staged_item_slices(self.bounds)
+        fin = None
+        for s_ in range(self.slices):
+            c.staged_item_slice(s_, self.lr, self.reg_1, self.reg_2, self.gQ[:I], self.cnt[:I], loss_type=self.loss_type)
+            if s_ == 0:
+                if w0 is not None:
+                    w0.wait()
+                c.finalize(self.reg_1, self.reg_2)
+            self._exchange_slice(s_)
+        self._join_side()
+        return c.stats
+
+    def _on_side(self):
+        """context: the side stream, ordered behind everything queued on the current stream so far"""
+        import contextlib
+        if self.side is None:
+            return contextlib.nullcontext()
+        self.side.wait_stream(torch.cuda.current_stream(self.Q.device))
+        return torch.cuda.stream(self.side)
+
+    def _join_side(self):
+        if self.side is not None:
+            torch.cuda.current_stream(self.Q.device).wait_stream(self.side)
+
+    def _exchange_slice(self, s_):
+        """reduce-scatter (gQ, cnt) of item slice s_ -> the owner's SGD on its block -> all-gather of the slice's rows"""
+        c, I = self.ctx, self.Q.shape[0]
+        w = self.world * self.rows
+        a = s_ * w                                        # first row of the slice (padded numbering)
+        with self._on_side():
+            self._reduce_scatter(self.g_own, self.gQ[a:a + w])
+            self._reduce_scatter(self.c_own, self.cnt[a:a + w])
+            self.gQ[a:a + w].zero_()
+            self.cnt[a:a + w].zero_()
+            lo = a + self.rank * self.rows
+            hi = min(lo + self.rows, I)
+            n_own = max(hi - lo, 0)
+            if n_own > 0:
+                c.item_apply_counts(self.Q[lo:hi], self.g_own[:n_own], self.c_own[:n_own], self.lr, self.reg_1, self.reg_2)
+            if self.collective:
+                if self.Q_gather is self.Q:
+                    self._all_gather_rows(self.Q[a:a + w], self.Q[lo:lo + self.rows])
+                else:                                    # I not a multiple of world*slices: padded staging
+                    own = self.Q_gather[lo:lo + self.rows]
+                    if n_own > 0:
+                        own[:n_own].copy_(self.Q[lo:hi])
+                    self._all_gather_rows(self.Q_gather[a:a + w], own)
+                    top = min(a + w, I)
+                    if top > a:
+                        self.Q[a:top].copy_(self.Q_gather[a:top])
 
     def _exchange_items(self):
-        """reduce-scatter (gQ, cnt) -> the owner's SGD on its rows of Q -> all-gather of the rows"""
-        c, I = self.ctx, self.Q.shape[0]
-        self._reduce_scatter(self.g_own, self.gQ)
-        self._reduce_scatter(self.c_own, self.cnt)
-        self.gQ.zero_()
-        self.cnt.zero_()
-        n_own = self.own_hi - self.own_lo
-        if n_own > 0:
-            q_own = self.Q[self.own_lo:self.own_hi]
-            c.item_apply_counts(q_own, self.g_own[:n_own], self.c_own[:n_own], self.lr, self.reg_1, self.reg_2)
-        if self.collective:
-            if self.Q_gather is self.Q:
-                self._all_gather_rows(self.Q, self.Q[self.own_lo:self.own_lo + self.rows])
-            else:                                        # I not a multiple of the world size: padded staging
-                own = self.Q_gather[self.own_lo:self.own_lo + self.rows]
-                if n_own > 0:
-                    own[:n_own].copy_(self.Q[self.own_lo:self.own_hi])
-                self._all_gather_rows(self.Q_gather, own)
-                self.Q.copy_(self.Q_gather[:I])
-        return c.stats
+        for s_ in range(self.slices):
+            self._exchange_slice(s_)
+        self._join_side()
+        return self.ctx.stats
 
     def _step_empty(self):
         """This rank's part of a global step to which it contributes no sample (staged protocol)."""

@@ -182,6 +182,16 @@ int daisy_epoch_plan_build_indexed(daisy_epoch_plan *plan, const daisy_train_ind
 int daisy_epoch_plan_build_positions(daisy_epoch_plan *plan, const daisy_train_index *index,
                                      const int64_t *positions, int64_t n_total, int64_t batch_size,
                                      daisy_stream_t stream);
+/* The item pass of a multi-GPU step in item slices, so that the exchange of a finished slice (reduce-scatter, owner
+ * update, all-gather) runs while the next slice is reduced.  item_bounds[0..n_slices] (host; item_bounds[0] = 0,
+ * non-decreasing, item_bounds[n_slices] >= item_num; at most 16 slices) cut the items; _slices locates the cuts in
+ * the current batch's item-sorted entries (one tiny kernel), _slice(s) writes gQ / cnt of the items of slice s like
+ * daisy_bpr_staged_item(gQ, cnt).  Same counts; same gQ up to the order in which the partial sums of a long segment
+ * meet (the cuts move workgroup boundaries); the same cuts give the same bits on every rank and in every run. */
+int daisy_bpr_staged_item_slices(daisy_bpr_ctx *ctx, const int32_t *item_bounds, int32_t n_slices,
+                                 daisy_stream_t stream);
+int daisy_bpr_staged_item_slice(daisy_bpr_ctx *ctx, int32_t loss_type, float *gQ, float *cnt, int32_t slice,
+                                float lr, float reg_1, float reg_2, const double *stats, daisy_stream_t stream);
 /* rows of batch k held by this plan (host value; -1: no such batch) */
 int64_t daisy_epoch_plan_batch_rows(const daisy_epoch_plan *plan, int64_t k);
 

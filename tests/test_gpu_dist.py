@@ -27,7 +27,7 @@ def _data():
     return P0, Q0, batches
 
 
-def _worker(rank, world, port, out_dir, use_plan, mode, backend="gloo"):
+def _worker(rank, world, port, out_dir, use_plan, mode, backend="gloo", slices=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from daisyrec_amd import ops
@@ -43,7 +43,8 @@ def _worker(rank, world, port, out_dir, use_plan, mode, backend="gloo"):
     P = torch.from_numpy(P0[lo:hi].copy()).to(dev)
     Q = torch.from_numpy(Q0.copy()).to(dev)
     ctx = ops.BprContext(B, D, hi - lo, I, device=dev)
-    tr = UserShardedBprTrainer(ctx, P, Q, lo, LR, R1, R2, item_mode=ops.ITEM_MODES[mode])
+    tr = UserShardedBprTrainer(ctx, P, Q, lo, LR, R1, R2, item_mode=ops.ITEM_MODES[mode], slices=slices)
+    assert tr.slices == (slices if mode == "fused" else 1)
     assert tr.staged == (mode == "fused")
     losses = []
     for b in batches:
@@ -101,6 +102,14 @@ def _check(tmp_path, world):
 def test_two_ranks_on_one_gpu_equal_the_single_process_step(tmp_path, use_plan, mode):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), use_plan, mode), nprocs=world, join=True)
+    _check(tmp_path, world)
+
+
+@pytest.mark.parametrize("world,slices", [(2, 4), (3, 5)])
+def test_item_pass_in_slices_with_the_exchange_on_a_side_stream(tmp_path, world, slices):
+    """slices > 1: the item pass range by range, each range's reduce-scatter / owner update / all-gather queued on a
+    side stream behind it; ownership interleaves per range; 300 items are not divisible by 3 x 5 (padded staging)"""
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True, "fused", "gloo", slices), nprocs=world, join=True)
     _check(tmp_path, world)
 
 

@@ -425,11 +425,12 @@ def test_sharded_trainer_on_rccl_world1(ops):
         Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
         tri = np.stack([rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)], 1).astype(np.int32)
         loss, Pn, Qn = O.mf_sgd_step(P0, Q0, tri[:, 0], tri[:, 1], tri[:, 2], 0.01, 1e-3, 1e-3)
-        for overlap, mode in ((True, "fused"), (False, "fused"), (True, "chunked"), (False, "sorted")):
+        for overlap, mode, slices in ((True, "fused", 1), (False, "fused", 1), (True, "chunked", 1), (False, "sorted", 1),
+                                      (True, "fused", 4), (True, "fused", 7)):        # 7: 300 items need padding
             P, Q = _t(P0), _t(Q0)
             ctx = ops.BprContext(B, d, U, I)
             tr = UserShardedBprTrainer(ctx, P, Q, 0, 0.01, 1e-3, 1e-3, overlap=overlap,
-                                       item_mode=ops.ITEM_MODES[mode], always_collective=True)
+                                       item_mode=ops.ITEM_MODES[mode], always_collective=True, slices=slices)
             assert tr.collective and tr.staged == (mode == "fused")
             stats = tr.step_from_triples(_t(tri))
             torch.cuda.synchronize()

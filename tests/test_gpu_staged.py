@@ -177,6 +177,54 @@ def test_staged_phases_equal_single_call():
     assert np.abs(res[0][0] - Pn).max() < 3e-6 and np.abs(res[0][1] - Qn).max() < 3e-6
 
 
+@pytest.mark.parametrize("loss", ["BPR", "TL"])
+def test_item_pass_in_slices_equals_the_whole_pass(loss):
+    """daisy_bpr_staged_item_slices / _slice: the item pass cut at item boundaries (what a multi-GPU step pipelines
+    its exchange under) writes the same counts and the same gQ up to the order in which a long segment's partial sums
+    meet (the cuts move the workgroup boundaries) - even cuts, cuts at popular items, empty slices."""
+    from daisyrec_amd import ops
+    U, I, d, B = 400, 257, 64, 20000
+    rng = np.random.default_rng(3)
+    tri = np.stack([rng.integers(0, U, B), (rng.zipf(1.3, B) % I), rng.integers(0, I, B)], 1).astype(np.int32)
+    tri[:, 1][tri[:, 1] >= 200] = 7                         # nothing positive in [200, 257); item 7 very popular
+    P0, Q0 = _tables(U, I, d, 9)
+    u, i, j = (torch.from_numpy(tri[:, c].copy()).to(DEV) for c in range(3))
+    lid = ops.LOSS_IDS[loss]
+    P, Q = torch.from_numpy(P0).to(DEV), torch.from_numpy(Q0).to(DEV)
+    ctx = ops.BprContext(B, d, U, I)
+    ctx.set_batch(u, i, j)
+    ctx.staged_prenorm(P)
+    ctx.staged_user(P, Q, 0.02, 1e-3, 1e-3, lid)
+    ctx.finalize(1e-3, 1e-3)
+    g0, c0 = torch.zeros(I, d, device=DEV), torch.zeros(I, 2, device=DEV)
+    ctx.staged_item(0.02, 1e-3, 1e-3, gQ=g0, cnt=c0, loss_type=lid)
+    for bounds in ([0, I], [0, 64, 128, 192, I], [0, 7, 8, 8, 100, 300], list(range(0, 16 * 17, 17))[:16] + [I],
+                   [0, 1, 2, 3, I + 5]):
+        g1, c1 = torch.zeros(I, d, device=DEV), torch.zeros(I, 2, device=DEV)
+        ctx.staged_item_slices(bounds)
+        for s_ in reversed(range(len(bounds) - 1)):         # any order
+            ctx.staged_item_slice(s_, 0.02, 1e-3, 1e-3, g1, c1, loss_type=lid)
+        torch.cuda.synchronize()
+        assert torch.equal(c0, c1), bounds
+        scale = float(g0.abs().max().cpu())
+        assert float((g0 - g1).abs().max().cpu()) <= 2e-6 * scale, bounds
+        if len(bounds) == 2:
+            assert torch.equal(g0, g1)                      # one slice = the whole pass
+        # a slice touches only its own rows
+        g2, c2 = torch.zeros(I, d, device=DEV), torch.zeros(I, 2, device=DEV)
+        ctx.staged_item_slice(0, 0.02, 1e-3, 1e-3, g2, c2, loss_type=lid)
+        torch.cuda.synchronize()
+        hi = min(bounds[1], I)
+        assert float(g2[hi:].abs().max().cpu() if hi < I else 0.0) == 0.0
+        assert float((g2[:hi] - g0[:hi]).abs().max().cpu()) <= 2e-6 * scale
+    with pytest.raises(ValueError, match="cover"):
+        ctx.staged_item_slices([0, 10, 20])
+    with pytest.raises(ValueError, match="slice"):
+        ctx.set_batch(u, i, j)
+        ctx.staged_item_slice(0, 0.02, 1e-3, 1e-3, g0, c0)
+    ctx.close()
+
+
 def test_norm_cache_follows_torch_side_edits():
     """P changed by a torch op between two staged steps: the wrapper sees the version counter move and the
     row-norm cache is rebuilt (a stale cache would put the wrong |P[u]|_F into the user update)."""

@@ -83,7 +83,8 @@ def rank_share(B):
     ctx = ops.BprContext(B, d, U, I, device=dev)
     index = ops.TrainIndex(triples, U, I, user_sorted=True)
     plan = ops.EpochPlan(n, U, I, device=dev).build_indexed(index, B, order="feistel", seed=1, epoch=0)
-    tr = UserShardedBprTrainer(ctx, P, Q, 0, 0.01, 1e-3, 1e-3)       # world 1, no process group: collectives are no-ops
+    slices = int(os.environ.get("SLICES", "1"))
+    tr = UserShardedBprTrainer(ctx, P, Q, 0, 0.01, 1e-3, 1e-3, slices=slices)       # world 1, no process group: collectives are no-ops
     nb = n // B
     k = [0]
 
@@ -95,7 +96,7 @@ def rank_share(B):
         step()
     ms = ev_time(step, 2 * nb)
     wire = 2 * 7 / 8 * I * (d + 2) * 4
-    print(f"[c3rank] n={n} B={B}: {ms:.3f} ms/step per rank without collectives ({B / ms / 1e6:.3f} G/s per rank); "
+    print(f"[c3rank] slices={slices} n={n} B={B}: {ms:.3f} ms/step per rank without collectives ({B / ms / 1e6:.3f} G/s per rank); "
           f"wire per step and rank 2 x {wire / 2 / 1e6:.0f} MB; at 310 GB/s bus bandwidth {wire / 310e9 * 1e3:.2f} ms")
 
 
