@@ -130,3 +130,45 @@ def test_rank_share_plans_tile_the_epoch_plan():
     with pytest.raises(ValueError, match="outside"):
         bad = pos.clone(); bad[0] = n + 5
         ops.EpochPlan(n, U, I, device=dev).build_positions(ops.TrainIndex(tr, U, I), bad, n, B)
+
+
+def test_rank_shares_at_baseline_scale_tile_the_epoch():
+    """BASELINE configs[1] shapes (1 M users x 100 K items, 2 M-sample batches) cut for 8 ranks: size-independent
+    properties of the rank-share plans - every row lands in exactly one (rank, batch), the batches of the ranks add
+    up to the global batch sizes, every batch is grouped by user and its entries sorted by item, stage slots are
+    distinct positions inside the global batch."""
+    import bench
+    from daisyrec_amd import ops
+    from daisyrec_amd.sharding import user_range
+    dev = torch.device("cuda")
+    U_, I_, n_, B_ = 1_000_000, 100_000, 20_000_000, 1 << 21
+    tr = bench.synth_triples(U_, I_, n_, 2022, dev)
+    n = tr.shape[0]
+    pos = ops.feistel_positions(n, 5, 1, device=dev)
+    nb = (n + B_ - 1) // B_
+    total = torch.zeros(nb, dtype=torch.int64)
+    seen = torch.zeros(n, dtype=torch.int32, device=dev)
+    world = 8
+    for r in range(world):
+        lo, hi = user_range(U_, world, r)
+        ids = torch.nonzero((tr[:, 0] >= lo) & (tr[:, 0] < hi)).flatten()
+        mine = tr[ids].contiguous()
+        index = ops.TrainIndex(mine, hi - lo, I_, user_base=lo, user_sorted=True)
+        plan = ops.EpochPlan(mine.shape[0], hi - lo, I_, device=dev).build_positions(index, pos[ids].contiguous(), n, B_)
+        assert plan.num_batches == nb
+        rows = torch.tensor([plan.batch_rows(k) for k in range(nb)])
+        assert int(rows.sum()) == mine.shape[0]
+        total += rows
+        for k in (0, nb // 2, nb - 1):
+            u, i, j, ei, es, _ = plan.read_batch(k, B_)
+            assert bool((u[1:] >= u[:-1]).all()) and bool((ei[1:] >= ei[:-1]).all())
+            slots = (es & 0x7FFFFFFF).to(torch.int64)
+            assert int(slots.min()) >= 0 and int(slots.max()) < B_
+            pos_slots = slots[::1].unique()
+            assert pos_slots.numel() == u.shape[0]           # two entries per sample, one slot per sample
+            seen.index_add_(0, (pos_slots + k * B_).clamp_(max=n - 1), torch.ones_like(pos_slots, dtype=torch.int32))
+        plan.close(); index.close()
+    want = torch.full((nb,), B_, dtype=torch.int64)
+    want[-1] = n - (nb - 1) * B_
+    assert torch.equal(total, want)                          # the ranks' batches k add up to the global batch k
+    assert int(seen.max()) <= 1                              # no epoch position claimed twice
