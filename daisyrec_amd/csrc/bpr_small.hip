@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
         }
 #pragma unroll
         for (int q = 0; q < 7; ++q) {
-            const double w = wave_sum_f64((double)acc[q]);
+            const double w = (double)wave_sum_f32_dpp(acc[q]);     // fp32 inside the wave (64 terms), fp64 across the waves
             if ((tid % kWave) == 0) s_part[wave][q] = w;
         }
         __syncthreads();

@@ -245,6 +245,23 @@ __device__ __forceinline__ double wave_sum_f64(double x) {
     return x;
 }
 
+// Sum over the 64 lanes of a wave in fp32 without touching the LDS crossbar: four DPP steps inside each 16-lane row
+// (every lane of a row then holds the row's sum), then the four row sums through v_readlane.  Fixed order; the
+// result is the same in every lane.  (wave_sum_f64 costs twelve ds_bpermute per sum: with seven sums in sixteen
+// waves that storm was 2-3 us of the small-batch step.)
+__device__ __forceinline__ float wave_sum_f32_dpp(float x) {
+    x += dpp_f32<kDppQuadXor1>(x);
+    x += dpp_f32<kDppQuadXor2>(x);
+    x += dpp_f32<kDppHalfMirror>(x);
+    x += dpp_f32<kDppMirror>(x);
+    const int xi = __builtin_bit_cast(int, x);
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(xi, 48));
+    return (r0 + r1) + (r2 + r3);
+}
+
 // Pick the fragment shape for a runtime d.  F is a generic lambda taking a RowCfg tag.
 template <class F>
 inline int dispatch_d(int d, F &&f) {
