@@ -92,6 +92,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
     __shared__ float2 s_coef[kSmallBatchMax];          // (dL/dpos, dL/dneg)
     __shared__ double s_part[NW][8];
     __shared__ double s_stats[DAISY_STATS_LEN];
+    __shared__ float s_inv[3];                         // reg_2 / |P[u]|_F, / |Q[i]|_F, / |Q[j]|_F of the step
 
     const int tid = threadIdx.x;
     const int lane = tid % C::LPR;
@@ -195,10 +196,12 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
 #pragma unroll
             for (int w = 0; w < NW; ++w) t += s_part[w][tid];
             s_stats[tid] = t;
+            // reg_2 / |X|_F once, by the thread that holds the sum (an fp64 sqrt and divide per THREAD was a
+            // measurable part of the step)
+            if (tid >= DAISY_ST_SQ_U) s_inv[tid - DAISY_ST_SQ_U] = inv_or_zero(sqrt(t), reg_2);
         }
         __syncthreads();
-        const float rU = inv_or_zero(sqrt(s_stats[DAISY_ST_SQ_U]), reg_2), rI = inv_or_zero(sqrt(s_stats[DAISY_ST_SQ_I]), reg_2),
-                    rJ = inv_or_zero(sqrt(s_stats[DAISY_ST_SQ_J]), reg_2);
+        const float rU = s_inv[0], rI = s_inv[1], rJ = s_inv[2];
         if (tid == 0) {       // MFRecommender.py:88-89,94-95 (slots 7..10 are written here and read by nobody until the end)
             const double nU = sqrt(s_stats[DAISY_ST_SQ_U]), nI = sqrt(s_stats[DAISY_ST_SQ_I]),
                          nJ = sqrt(s_stats[DAISY_ST_SQ_J]);
