@@ -303,13 +303,20 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
     if (tid == 0 && epoch_acc) { epoch_acc[0] += acc_epoch; epoch_acc[1] += nan_epoch; }
 }
 
-static inline int small_dpad(int d) { return (d + 3) / 4 * 4; }     // float4-aligned rows (a lane group reads one row per LDS cycle: no padding needed)
+// floats per staged row: float4-aligned; rows that are a multiple of 128 bytes get one float4 of padding when three
+// row sets still fit (every row would start on the same banks otherwise: measured 11.3 vs 7.x us per step at d = 32
+// with four-lane groups)
+static inline int small_dpad(int d, int64_t B = kSmallBatchMax) {
+    const int p = (d + 3) / 4 * 4;
+    if (p % 32 == 0 && 3 * (size_t)B * (p + 4) * sizeof(float) <= kSmallLdsRows) return p + 4;
+    return p;
+}
 
 bool small_epoch_supported(const daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, int loss_type) {
     static const int enabled = getenv("DAISY_SMALL_EPOCH") ? atoi(getenv("DAISY_SMALL_EPOCH")) : 1;
     return enabled && plan->kind == 0 && !plan->pointwise && plan->batch_size <= kSmallBatchMax && !ctx->bu &&
            loss_type >= DAISY_LOSS_BPR && loss_type <= DAISY_LOSS_TL && plan->batch_size <= ctx->max_batch &&
-           (size_t)plan->batch_size * small_dpad(ctx->d) * sizeof(float) <= kSmallLdsRows;      // at least the user rows
+           (size_t)plan->batch_size * small_dpad(ctx->d, plan->batch_size) * sizeof(float) <= kSmallLdsRows;      // at least the user rows
 }
 
 int small_fit_epoch(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, float *P, float *Q, int loss_type, float gamma,
@@ -322,11 +329,27 @@ int small_fit_epoch(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, float *P, 
     pl.esu = reinterpret_cast<const uint2 *>(plan->eval);
     pl.umask = plan->umask; pl.imask = plan->imask;
     pl.n = plan->n; pl.B = plan->batch_size; pl.nb = plan->num_batches;
-    const int d = ctx->d, dpad = small_dpad(d);
+    const int d = ctx->d, dpad = small_dpad(d, plan->batch_size);
     const size_t row_bytes = (size_t)plan->batch_size * dpad * sizeof(float);
     const int mode = (3 * row_bytes <= kSmallLdsRows) ? 3 : ((2 * row_bytes <= kSmallLdsRows) ? 2 : 1);
     const size_t shmem = (size_t)mode * row_bytes;
-    int rc = dispatch_d(d, [&](auto cfg) {
+    // Lane groups half as wide as dispatch_d's (a lane then holds two float4 of a row instead of one): twice as
+    // many groups share the serial part of phase B - the run heads each group works through one after the other,
+    // a chain of dependent LDS reads - which is what bounds a step here, not bytes.  Measured at B=256: d=32 8.9 ->
+    // see profiles/r02_small_epoch.txt.
+    static const int tune_narrow = getenv("DAISY_SMALL_NARROW") ? atoi(getenv("DAISY_SMALL_NARROW")) : 1;
+    auto dispatch_small = [&](auto &&f) -> int {
+        if (tune_narrow && d % 4 == 0 && d <= 128) {
+            if (d == 32) return f(RowCfg<4, 4, 2, true>{});
+            if (d == 64) return f(RowCfg<8, 4, 2, true>{});
+            if (d == 128) return f(RowCfg<8, 4, 4, true>{});
+            if (d <= 32) return f(RowCfg<4, 4, 2>{});
+            if (d <= 64) return f(RowCfg<8, 4, 2>{});
+            return f(RowCfg<8, 4, 4>{});
+        }
+        return dispatch_d(d, f);
+    };
+    int rc = dispatch_small([&](auto cfg) {
         using C = decltype(cfg);
         auto launch = [&](auto kern) -> int {
             DAISY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
