@@ -198,18 +198,20 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
             s_stats[tid] = t;
             // reg_2 / |X|_F once, by the thread that holds the sum (an fp64 sqrt and divide per THREAD was a
             // measurable part of the step)
-            if (tid >= DAISY_ST_SQ_U) s_inv[tid - DAISY_ST_SQ_U] = inv_or_zero(sqrt(t), reg_2);
+            if (tid >= DAISY_ST_SQ_U) {
+                const double nrm = sqrt(t);
+                s_stats[DAISY_ST_NORM_U + (tid - DAISY_ST_SQ_U)] = nrm;
+                s_inv[tid - DAISY_ST_SQ_U] = inv_or_zero(nrm, reg_2);
+            }
         }
         __syncthreads();
         const float rU = s_inv[0], rI = s_inv[1], rJ = s_inv[2];
         if (tid == 0) {       // MFRecommender.py:88-89,94-95 (slots 7..10 are written here and read by nobody until the end)
-            const double nU = sqrt(s_stats[DAISY_ST_SQ_U]), nI = sqrt(s_stats[DAISY_ST_SQ_I]),
-                         nJ = sqrt(s_stats[DAISY_ST_SQ_J]);
+            const double nU = s_stats[DAISY_ST_NORM_U], nI = s_stats[DAISY_ST_NORM_I], nJ = s_stats[DAISY_ST_NORM_J];
             const double loss = s_stats[DAISY_ST_LOSS_DATA] +
                                 (double)reg_1 * (s_stats[DAISY_ST_L1_I] + s_stats[DAISY_ST_L1_J]) +
                                 (double)reg_2 * (nI + nJ) + (double)reg_1 * s_stats[DAISY_ST_L1_U] + (double)reg_2 * nU;
             s_stats[DAISY_ST_LOSS] = loss;
-            s_stats[DAISY_ST_NORM_U] = nU; s_stats[DAISY_ST_NORM_I] = nI; s_stats[DAISY_ST_NORM_J] = nJ;
             acc_epoch += loss;
             if (!(loss == loss) || isinf(loss)) nan_epoch += 1.0;
             if (step_losses) step_losses[k] = loss;
