@@ -904,7 +904,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 
     const int wave = tid / kWave;
 #pragma unroll
     for (int k = 0; k < 7; ++k) {
-        const double w = wave_sum_f64((double)acc7[k]);
+        const double w = (double)wave_sum_f32_dpp(acc7[k]);     // fp32 inside the wave, fp64 across waves and workgroups
         if ((tid % kWave) == 0) sm7[wave][k] = w;
     }
     __syncthreads();
