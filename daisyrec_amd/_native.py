@@ -67,6 +67,7 @@ SIGNATURES = {
     "daisy_bpr_ctx_validate_batch": (C.c_int, [_p, _p]),
     "daisy_epoch_plan_read_batch": (C.c_int, [_p, _i64, _p, _p, _p, _p, _p, _p, C.POINTER(_i64), _p]),
     "daisy_feistel_positions": (C.c_int, [_i64, _u64, _u64, _p, _p]),
+    "daisy_feistel_positions_at": (C.c_int, [_p, _i64, _i64, _u64, _u64, _p, _p]),
     "daisy_train_index_create": (C.c_int, [C.POINTER(_p), _p, _i64, _i64, _i64, _i32, _i32, _p]),
     "daisy_train_index_destroy": (C.c_int, [_p]),
     "daisy_train_index_bytes": (_sz, [_p]),

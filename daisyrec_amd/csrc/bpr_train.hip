@@ -141,6 +141,15 @@ __global__ void k_unpack_batch(BatchView v, int32_t *__restrict__ u, int32_t *__
     }
 }
 
+// out[k] = position of triple ids[k] (a rank's rows of a multi-GPU fit)
+__global__ void k_feistel_at(const int64_t *__restrict__ ids, int64_t m, int64_t n, FeistelKey fk,
+                             int64_t *__restrict__ out) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < m; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t t = ids[e];
+        out[e] = (t >= 0 && t < n) ? (int64_t)feistel_position((uint64_t)t, (uint64_t)n, fk) : -1;
+    }
+}
+
 __global__ void k_feistel_perm(int64_t n, FeistelKey fk, int64_t *__restrict__ out) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
          e += (int64_t)gridDim.x * blockDim.x)
@@ -1417,6 +1426,15 @@ int daisy_feistel_positions(int64_t n, uint64_t seed, uint64_t epoch, int64_t *o
     DAISY_CHECK_ARG(out && n > 0 && n <= ((int64_t)1 << 30), "feistel_positions: n must be in 1..2^30");
     FeistelKey fk = make_feistel_key((uint64_t)n, seed, epoch);
     hipLaunchKernelGGL(k_feistel_perm, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, S(stream), n, fk, out);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int daisy_feistel_positions_at(const int64_t *ids, int64_t n_ids, int64_t n, uint64_t seed, uint64_t epoch,
+                               int64_t *out, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(ids && out && n_ids > 0 && n > 0 && n <= ((int64_t)1 << 30), "feistel_positions_at: bad argument");
+    FeistelKey fk = make_feistel_key((uint64_t)n, seed, epoch);
+    hipLaunchKernelGGL(k_feistel_at, dim3(grid_for(n_ids, kBlock)), dim3(kBlock), 0, S(stream), ids, n_ids, n, fk, out);
     DAISY_LAUNCH_CHECK();
     return DAISY_OK;
 }

@@ -173,7 +173,7 @@ class GeneralRecommender(AbstractRecommender):
         shuffle, or the identity"""
         from torch.utils.data import SequentialSampler
         if self.shuffle_mode == "device" and not isinstance(train_loader.sampler, SequentialSampler):
-            return ops.feistel_positions(n, self.seed, epoch, device=row_ids.device)[row_ids].contiguous()
+            return ops.feistel_positions_at(row_ids, n, self.seed, epoch)
         perm = self._epoch_order(train_loader, len(train_loader.dataset))
         if perm is None:
             return row_ids.clone()

@@ -145,6 +145,10 @@ int daisy_epoch_plan_read_batch(const daisy_epoch_plan *plan, int64_t k, int32_t
 /* out[t] = position of triple t in the DAISY_ORDER_FEISTEL order of (seed, epoch) */
 int daisy_feistel_positions(int64_t n, uint64_t seed, uint64_t epoch, int64_t *out,
                             daisy_stream_t stream);
+/* the same for a subset of the triples: out[k] = position of triple ids[k] among all n (-1 for an id outside 0..n-1):
+ * what a rank of a multi-GPU fit needs for its rows (daisy_epoch_plan_build_positions) */
+int daisy_feistel_positions_at(const int64_t *ids, int64_t n_ids, int64_t n, uint64_t seed, uint64_t epoch,
+                               int64_t *out, daisy_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Static index of a training set + the PARTITIONED epoch plan (ABI 3).

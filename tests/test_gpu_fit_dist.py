@@ -97,6 +97,8 @@ def test_rank_share_plans_tile_the_epoch_plan():
     tr = torch.from_numpy(_triples()).to(dev)
     n = tr.shape[0]
     pos = ops.feistel_positions(n, 7, 2, device=dev)
+    some = torch.tensor([0, 5, n - 1, 17, 5], device=dev)
+    assert torch.equal(ops.feistel_positions_at(some, n, 7, 2), pos[some])
     whole = ops.EpochPlan(n, U, I, device=dev).build_indexed(ops.TrainIndex(tr, U, I), B, order="feistel", seed=7, epoch=2)
     nb = whole.num_batches
     got = [[] for _ in range(nb)]
