@@ -217,7 +217,7 @@ __device__ __forceinline__ void reduce_partials_block(const double *__restrict__
     for (int k = 0; k < 8; ++k) sm[threadIdx.x][k] = t[k];
     __syncthreads();
     for (int off = kBlock / 2; off > 0; off >>= 1) {
-        if (threadIdx.x < off) {
+        if ((int)threadIdx.x < off) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) sm[threadIdx.x][k] += sm[threadIdx.x + off][k];
         }

@@ -641,7 +641,7 @@ __global__ __launch_bounds__(kBlock) void k_unorm_reduce(const double *__restric
     sm[threadIdx.x] = t;
     __syncthreads();
     for (int off = kBlock / 2; off > 0; off >>= 1) {
-        if (threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+        if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
         __syncthreads();
     }
     if (threadIdx.x == 0) stats[DAISY_ST_SQ_U_PRE] = sm[0];

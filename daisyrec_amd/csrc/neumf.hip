@@ -910,8 +910,9 @@ __global__ __launch_bounds__(kBlock) void k_nmf_pred_bwd_v(const float *__restri
         for (int k = 0; k < 4; ++k) { atomicAdd(&col[c4 + k], pg[k]); atomicAdd(&col[64 + c4 + k], px[k]); }
     }
     __syncthreads();
-    if (threadIdx.x < d) unsafeAtomicAdd(gWp + threadIdx.x, col[threadIdx.x]);
-    else if (threadIdx.x >= 64 && threadIdx.x < 64 + d) unsafeAtomicAdd(gWp + d + (threadIdx.x - 64), col[threadIdx.x]);
+    const int t = (int)threadIdx.x;
+    if (t < d) unsafeAtomicAdd(gWp + t, col[t]);
+    else if (t >= 64 && t < 64 + d) unsafeAtomicAdd(gWp + d + (t - 64), col[t]);
 }
 
 // out[n] += sum_r X[r*ld + n]: a block takes 64 columns x kColsumRows rows (grid = column tiles x row tiles)
