@@ -11,8 +11,12 @@ from __future__ import annotations
 import importlib
 
 
-def install(sampler=False):
-    """Patch `daisy.model.MFRecommender.MF` (and optionally the sampler) in place."""
+def install(sampler=False, front_end=False):
+    """Patch `daisy.model.MFRecommender.MF` (and the other mirrored recommenders) in place.
+    sampler: also the negative sampler (device generator: same distribution, different stream than MT19937).
+    front_end: also `daisy.utils.utils.get_ur / get_ir` (same dicts, built from one sort instead of a Python row
+    loop) and `build_candidates_set` (device generator) - what makes the drivers usable beyond ml-100k sizes
+    (SURVEY.md section 8f rank 1).  Call before the driver module is imported (it binds these names at import)."""
     from .model.MFRecommender import MF
     from .model.FMRecommender import FM
 
@@ -37,4 +41,10 @@ def install(sampler=False):
 
         ref_s = importlib.import_module("daisy.utils.sampler")
         ref_s.BasicNegtiveSampler = BasicNegtiveSampler
+    if front_end:
+        from .utils import utils as U
+
+        ref_u = importlib.import_module("daisy.utils.utils")
+        ref_u.get_ur, ref_u.get_ir = U.get_ur, U.get_ir
+        ref_u.build_candidates_set = U.build_candidates_set
     return MF

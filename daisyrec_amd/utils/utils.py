@@ -1,15 +1,43 @@
 """Device-side replacements for the two host loops of daisy/utils/utils.py that sit either side
 of the MF hot path at scale:
 
-* ``get_ur``               utils.py:19-34  (Python iterrows loop)       -> ``user_csr``
+* ``get_ur``               utils.py:19-34  (Python iterrows loop)       -> ``user_csr`` (device CSR), and ``get_ur`` /
+                                                                          ``get_ir`` with the reference's return type
+                                                                          (dict of sets) built without the row loop
 * ``build_candidates_set`` utils.py:53-85  (O(U*I) np.setdiff1d loop)   -> same name, same return
 """
 from __future__ import annotations
+
+from collections import defaultdict
 
 import numpy as np
 import torch
 
 from .. import ops
+
+
+def _grouped_sets(keys, vals):
+    out = defaultdict(set)
+    keys, vals = np.asarray(keys).astype(np.int64), np.asarray(vals).astype(np.int64)
+    if keys.size == 0:
+        return out
+    order = np.argsort(keys, kind="stable")
+    ks, vs = keys[order], vals[order]
+    cuts = np.flatnonzero(ks[1:] != ks[:-1]) + 1
+    for k, chunk in zip(ks[np.r_[0, cuts]].tolist(), np.split(vs, cuts)):
+        out[k] = set(chunk.tolist())
+    return out
+
+
+def get_ur(df):
+    """utils.py:19-34: {user: set(items)} as a defaultdict(set) with int keys - the same object the reference's
+    row loop builds (1.9 s per 100 k rows there), from one sort (host numpy: this dict is host data by contract)."""
+    return _grouped_sets(df["user"].to_numpy(), df["item"].to_numpy())
+
+
+def get_ir(df):
+    """utils.py:36-51: {item: set(users)}"""
+    return _grouped_sets(df["item"].to_numpy(), df["user"].to_numpy())
 
 
 def user_csr(df_or_pairs, user_num, device="cuda"):

@@ -65,3 +65,39 @@ def test_ops_reject_host_tensors():
                        torch.zeros(2, dtype=torch.int64))
     with pytest.raises(NotImplementedError):
         ops.loss_id("CLX")
+
+
+def test_get_ur_get_ir_build_the_reference_dicts(ml100k):
+    """utils.py:19-51 without the row loop: same keys, same sets, same container type; on the ml-100k train set and
+    on edge cases (empty frame, duplicate rows, one user).  Where the reference checkout is reachable, its own
+    functions are the judge; everywhere, a literal restatement of its loop."""
+    import importlib
+    import os
+    import sys
+    from collections import defaultdict
+    import pandas as pd
+    from daisyrec_amd.utils.utils import get_ir, get_ur
+
+    def loop(df, a, b):                       # utils.py:29-32 / 46-49 as written
+        out = defaultdict(set)
+        for _, row in df.iterrows():
+            out[int(row[a])].add(int(row[b]))
+        return out
+
+    g = ml100k
+    big = pd.DataFrame({"user": g["train_users"][:20000], "item": g["train_items"][:20000], "rating": 1.0})
+    frames = [big, big.iloc[:0], pd.DataFrame({"user": [3, 3, 3], "item": [7, 7, 1], "rating": 1.0}),
+              pd.DataFrame({"user": [5], "item": [0], "rating": 1.0})]
+    for df in frames:
+        ur, ir = get_ur(df), get_ir(df)
+        assert type(ur) is defaultdict and ur == loop(df, "user", "item") and ir == loop(df, "item", "user")
+        assert all(type(k) is int for k in ur) and all(type(i) is int for s in ur.values() for i in s)
+    ref = os.environ.get("DAISY_REFERENCE", "/root/reference")
+    if os.path.isdir(os.path.join(ref, "daisy")):
+        sys.path.insert(0, ref)
+        sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden", "_shims"))
+        try:
+            U = importlib.import_module("daisy.utils.utils")
+            assert get_ur(big) == U.get_ur(big) and get_ir(big) == U.get_ir(big)
+        finally:
+            sys.path.remove(ref)

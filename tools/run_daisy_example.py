@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--daisy", required=True, help="checkout of AmazingDD/daisyRec (contains daisy/, run_examples/, data/)")
     ap.add_argument("--script", default="run_examples/test.py")
     ap.add_argument("--native-sampler", action="store_true", help="also rebind daisy.utils.sampler.BasicNegtiveSampler")
+    ap.add_argument("--native-front-end", action="store_true",
+                    help="also rebind daisy.utils.utils.get_ur / get_ir / build_candidates_set (no Python row loops)")
     ap.add_argument("rest", nargs=argparse.REMAINDER)
     a = ap.parse_args()
     rest = a.rest[1:] if a.rest[:1] == ["--"] else a.rest
@@ -49,7 +51,7 @@ def main():
     sys.path.insert(0, os.path.abspath(a.daisy))
 
     import daisyrec_amd.dropin as dropin
-    dropin.install(sampler=a.native_sampler)
+    dropin.install(sampler=a.native_sampler, front_end=a.native_front_end)
 
     os.chdir(os.path.abspath(a.daisy))                      # data_path etc. are relative (basic.yaml)
     sys.argv = [a.script] + rest
