@@ -708,33 +708,48 @@ __global__ __launch_bounds__(kBlock) void k_nmf_gather(daisy_neumf_params p, Pai
         int64_t user, item;
         pair_ids(src, r, user, item);
         const bool first = !TRAIN || r < src.B;            // rows r >= B repeat the users with the negatives
+        // a lane takes 4 consecutive columns: 16-byte table reads, 16-byte (fp32) or 8-byte (bf16) stores - the
+        // first version moved one element per lane and stored bf16 two bytes at a time (363 us per 524 288 rows)
         const float *um = p.uM + user * dm, *im = p.iM + item * dm;
         float *x = X0 + r * (int64_t)(2 * dm);
-        for (int c = lane; c < dm; c += 16) {
-            float a = um[c], b = im[c];
+        uint16_t *xh = reinterpret_cast<uint16_t *>(X0) + r * (int64_t)(2 * dm);
+        for (int c = 4 * lane; c < dm; c += 64) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(um + c), b4 = *reinterpret_cast<const float4 *>(im + c);
+            float a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
             if (TRAIN) {
-                if (first) { s1[1] += fabsf(a); s2[1] = fmaf(a, a, s2[1]); s1[3] += fabsf(b); s2[3] = fmaf(b, b, s2[3]); }
-                if (thresh) {
-                    a = drop_keep(seed, 1, (uint64_t)r * (2 * dm) + c, thresh) ? a * scale : 0.f;
-                    b = drop_keep(seed, 1, (uint64_t)r * (2 * dm) + dm + c, thresh) ? b * scale : 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (first) {
+                        s1[1] += fabsf(a[k]); s2[1] = fmaf(a[k], a[k], s2[1]);
+                        s1[3] += fabsf(b[k]); s2[3] = fmaf(b[k], b[k], s2[3]);
+                    }
+                    if (thresh) {
+                        a[k] = drop_keep(seed, 1, (uint64_t)r * (2 * dm) + c + k, thresh) ? a[k] * scale : 0.f;
+                        b[k] = drop_keep(seed, 1, (uint64_t)r * (2 * dm) + dm + c + k, thresh) ? b[k] * scale : 0.f;
+                    }
                 }
             }
             if constexpr (H) {
-                uint16_t *xh = reinterpret_cast<uint16_t *>(X0) + r * (int64_t)(2 * dm);
-                xh[c] = (uint16_t)bf16_rne(a);
-                xh[dm + c] = (uint16_t)bf16_rne(b);
+                *reinterpret_cast<uint2 *>(xh + c) =
+                    make_uint2(bf16_rne(a[0]) | (bf16_rne(a[1]) << 16), bf16_rne(a[2]) | (bf16_rne(a[3]) << 16));
+                *reinterpret_cast<uint2 *>(xh + dm + c) =
+                    make_uint2(bf16_rne(b[0]) | (bf16_rne(b[1]) << 16), bf16_rne(b[2]) | (bf16_rne(b[3]) << 16));
             } else {
-                x[c] = a;
-                x[dm + c] = b;
+                *reinterpret_cast<float4 *>(x + c) = make_float4(a[0], a[1], a[2], a[3]);
+                *reinterpret_cast<float4 *>(x + dm + c) = make_float4(b[0], b[1], b[2], b[3]);
             }
         }
         const float *ug = p.uG + user * d, *ig = p.iG + item * d;
-        for (int c = lane; c < d; c += 16) {
-            const float a = ug[c], b = ig[c];
-            G[r * (int64_t)d + c] = a * b;
+        for (int c = 4 * lane; c < d; c += 64) {
+            const float4 a4 = *reinterpret_cast<const float4 *>(ug + c), b4 = *reinterpret_cast<const float4 *>(ig + c);
+            const float a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+            *reinterpret_cast<float4 *>(G + r * (int64_t)d + c) = make_float4(a[0] * b[0], a[1] * b[1], a[2] * b[2], a[3] * b[3]);
             if (TRAIN) {
-                if (first) { s1[0] += fabsf(a); s2[0] = fmaf(a, a, s2[0]); s1[2] += fabsf(b); s2[2] = fmaf(b, b, s2[2]); }
-                else if (!pointwise) { s1[4] += fabsf(b); s2[4] = fmaf(b, b, s2[4]); }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (first) { s1[0] += fabsf(a[k]); s2[0] = fmaf(a[k], a[k], s2[0]); s1[2] += fabsf(b[k]); s2[2] = fmaf(b[k], b[k], s2[2]); }
+                    else if (!pointwise) { s1[4] += fabsf(b[k]); s2[4] = fmaf(b[k], b[k], s2[4]); }
+                }
             }
         }
     }
