@@ -1103,10 +1103,13 @@ __global__ __launch_bounds__(kBlock) void k_nmf_gmf_rows(daisy_neumf_params p, P
         int64_t user, item;
         pair_ids(src, r, user, item);
         const float dp = dpred[r];
-        for (int c = lane; c < d; c += 16) {
-            const float w = dp * p.Wp[c];
-            gu[r * (int64_t)d + c] = w * p.iG[item * d + c];
-            gi[r * (int64_t)d + c] = w * p.uG[user * d + c];
+        for (int c = 4 * lane; c < d; c += 64) {              // 4 consecutive columns per lane (d % 4 == 0)
+            const float4 wp = *reinterpret_cast<const float4 *>(p.Wp + c);
+            const float4 ig = *reinterpret_cast<const float4 *>(p.iG + item * d + c);
+            const float4 ug = *reinterpret_cast<const float4 *>(p.uG + user * d + c);
+            const float w0 = dp * wp.x, w1 = dp * wp.y, w2 = dp * wp.z, w3 = dp * wp.w;
+            *reinterpret_cast<float4 *>(gu + r * (int64_t)d + c) = make_float4(w0 * ig.x, w1 * ig.y, w2 * ig.z, w3 * ig.w);
+            *reinterpret_cast<float4 *>(gi + r * (int64_t)d + c) = make_float4(w0 * ug.x, w1 * ug.y, w2 * ug.z, w3 * ug.w);
         }
     }
 }
