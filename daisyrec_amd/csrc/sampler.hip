@@ -71,6 +71,25 @@ __global__ void k_sample_per_user(const int64_t *__restrict__ indptr,
     }
 }
 
+// out[r][col0 + c] = smallest item i with cdf[i] > x * cdf[I-1], x uniform in [0,1) from Philox(seed, stream, r*k + c):
+// np.random.choice(np.arange(I), size=k, p=prob) of sampler.py:76-80 (inverse CDF; the user's positives are NOT
+// excluded there either)
+__global__ void k_sample_categorical(const double *__restrict__ cdf, int64_t I, int64_t rows, int k, uint64_t seed,
+                                     uint64_t stream, int32_t *__restrict__ out, int ld, int col0) {
+    const int64_t n = rows * k;
+    const double total = cdf[I - 1];
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t x = philox_u64(seed, stream, (uint64_t)e);
+        const double t = (double)(x >> 11) * (1.0 / 9007199254740992.0) * total;     // 53 random bits
+        int64_t lo = 0, hi = I - 1;                      // the last item catches t == total after rounding
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (cdf[mid] > t) hi = mid; else lo = mid + 1;
+        }
+        out[(e / k) * ld + col0 + (e % k)] = (int32_t)lo;
+    }
+}
+
 __global__ void k_expand_triples(const int32_t *__restrict__ users, const int32_t *__restrict__ items,
                                  int64_t n, const int32_t *__restrict__ js, int num_ng,
                                  int32_t *__restrict__ triples) {
@@ -156,6 +175,16 @@ int daisy_sample_neg_per_user(const int64_t *indptr, const int32_t *csr_items, i
     DAISY_CHECK_ARG(epoch < kStreamPerm, "sample_neg_per_user: epoch out of range");
     hipLaunchKernelGGL(k_sample_per_user, dim3(grid_for(user_num * num_ng, kBlock)), dim3(kBlock), 0,
                        S(stream), indptr, csr_items, user_num, item_num, (int)num_ng, seed, epoch, js);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int daisy_sample_categorical(const double *cdf, int64_t item_num, int64_t rows, int32_t k, uint64_t seed,
+                             uint64_t stream_id, int32_t *out, int32_t ld, int32_t col0, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(cdf && out && item_num > 0 && rows > 0 && k > 0 && ld >= col0 + k && col0 >= 0,
+                    "sample_categorical: bad argument");
+    hipLaunchKernelGGL(k_sample_categorical, dim3(grid_for(rows * k, kBlock)), dim3(kBlock), 0, S(stream), cdf, item_num,
+                       rows, (int)k, seed, stream_id, out, (int)ld, (int)col0);
     DAISY_LAUNCH_CHECK();
     return DAISY_OK;
 }

@@ -520,6 +520,19 @@ def sample_neg_per_user(indptr, csr_items, item_num, num_ng, seed, epoch=0):
     return js
 
 
+POP_STREAM = 1 << 62          # Philox stream of the popularity-weighted draws (the uniform ones use `epoch`)
+
+
+def sample_categorical(cdf, rows, k, seed, stream_id, out=None, col0=0):
+    """k draws per row from the categorical distribution with inclusive cumulative sums `cdf` (float64 [I], device):
+    the 'high-pop' / 'low-pop' share of sampler.py:76-80.  Written into out[:, col0:col0+k] (int32 [rows, ld])."""
+    if out is None:
+        out = torch.empty(rows, k, dtype=torch.int32, device=cdf.device)
+    check(lib.daisy_sample_categorical(_ptr(cdf, torch.float64, "cdf"), cdf.numel(), int(rows), int(k), int(seed),
+                                       int(stream_id), _ptr(out, torch.int32, "out"), out.shape[1], int(col0), _stream()))
+    return out
+
+
 def expand_triples(users, items, js):
     n, num_ng = users.numel(), js.shape[1]
     out = torch.empty(n * num_ng, 3, dtype=torch.int32, device=users.device)

@@ -48,9 +48,18 @@ class BasicNegtiveSampler(AbstractSampler):
         assert self.sample_method in ["uniform", "low-pop", "high-pop"], \
             f"Invalid sampling method: {self.sample_method}"
         assert 0 <= self.sample_ratio <= 1, "Invalid sample ratio value"
-        if self.sample_method != "uniform" and self.sample_ratio > 0:
-            raise NotImplementedError("popularity-mixed negative sampling is outside the uniform hot path")
         self.df = df
+        self.pop_prob = None
+        if self.sample_method in ("high-pop", "low-pop"):                     # sampler.py:44-54
+            pop = df.groupby(self.iid_name).size()
+            pop = pop / pop.sum()
+            if self.sample_method == "high-pop":
+                norm_pop = np.zeros(self.item_num)
+                norm_pop[pop.index] = pop.values
+            else:
+                norm_pop = np.ones(self.item_num)
+                norm_pop[pop.index] = 1 - pop.values
+            self.pop_prob = norm_pop / norm_pop.sum()
 
     def _train_pairs(self):
         """(users, items) that define each user's positives: config['train_ur'] when the
@@ -79,7 +88,18 @@ class BasicNegtiveSampler(AbstractSampler):
         pu, pi = self._train_pairs()
         indptr, csr = ops.build_user_csr(torch.from_numpy(pu).to(self.device),
                                          torch.from_numpy(pi).to(self.device), self.user_num)
-        js = ops.sample_neg_per_user(indptr, csr, self.item_num, self.num_ng, self.seed, self.epoch)
+        # sampler.py:65-81: with 'high-pop' / 'low-pop', int(sample_ratio * num_ng) of a user's negatives are drawn
+        # from the popularity distribution over ALL items (positives not excluded, as in the reference), the rest
+        # uniformly from the complement of the user's row; columns in that order
+        other_num = int(self.sample_ratio * self.num_ng) if self.pop_prob is not None else 0
+        uniform_num = self.num_ng - other_num
+        js = torch.empty(self.user_num, self.num_ng, dtype=torch.int32, device=self.device)
+        if uniform_num > 0:
+            js[:, :uniform_num] = ops.sample_neg_per_user(indptr, csr, self.item_num, uniform_num, self.seed, self.epoch)
+        if other_num > 0:
+            cdf = torch.from_numpy(np.cumsum(self.pop_prob.astype(np.float64))).to(self.device)
+            ops.sample_categorical(cdf, self.user_num, other_num, self.seed, ops.POP_STREAM | self.epoch, out=js,
+                                   col0=uniform_num)
         if bool((js < 0).any().item()):
             # a user who has interacted with every item: np.random.choice(np.setdiff1d(...)) on an empty
             # array in the reference (sampler.py:84-89)

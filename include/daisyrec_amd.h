@@ -376,6 +376,12 @@ int daisy_build_user_csr(const int32_t *users, const int32_t *items, int64_t n, 
 int daisy_sample_neg_per_user(const int64_t *indptr, const int32_t *csr_items, int64_t user_num,
                               int64_t item_num, int32_t num_ng, uint64_t seed, uint64_t epoch,
                               int32_t *js, daisy_stream_t stream);
+/* sampler.py:76-80, the 'high-pop' / 'low-pop' share of a user's negatives: k draws per row from the categorical
+ * distribution whose inclusive cumulative sums are cdf[0..item_num) (float64, any positive total), by inverse CDF on
+ * Philox(seed, stream_id, row*k + c); written to out[row*ld + col0 + c].  Like np.random.choice(p=...) in the
+ * reference, the draws do not exclude the user's positives. */
+int daisy_sample_categorical(const double *cdf, int64_t item_num, int64_t rows, int32_t k, uint64_t seed,
+                             uint64_t stream_id, int32_t *out, int32_t ld, int32_t col0, daisy_stream_t stream);
 /* df.explode('neg_set') (sampler.py:91,100-101): triples int32 [n*num_ng][3] in
  * train-set row order, each interaction repeated num_ng times. */
 int daisy_expand_triples(const int32_t *users, const int32_t *items, int64_t n, const int32_t *js,

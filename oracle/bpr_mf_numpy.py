@@ -300,6 +300,21 @@ def sample_uniform_neg_per_user(indptr, items, item_num, num_ng, seed, epoch=0):
     return out
 
 
+def sample_categorical(cdf, rows, k, seed, stream):
+    """k draws per row from the categorical distribution with inclusive cumulative sums `cdf` (float64): inverse CDF
+    on 53 Philox bits, index = row*k + c (np.random.choice(np.arange(I), size=k, p=prob) of sampler.py:76-80;
+    numpy's own choice is the same inverse-CDF search on its MT19937 uniforms)."""
+    cdf = np.asarray(cdf, dtype=np.float64)
+    out = np.empty((rows, k), dtype=np.int32)
+    total = cdf[-1]
+    for r in range(rows):
+        for c in range(k):
+            x = _draw_u64(seed, stream, r * k + c)
+            t = float(x >> 11) * (1.0 / 9007199254740992.0) * total
+            out[r, c] = min(int(np.searchsorted(cdf, t, side="right")), len(cdf) - 1)
+    return out
+
+
 def sample_uniform_neg_per_interaction(indptr, items, users, item_num, num_ng, seed, epoch=0):
     """Per-interaction variant (one draw per (interaction, k)); stream = epoch | 1<<63."""
     n = len(users)

@@ -274,6 +274,49 @@ def test_sampler_mirror_interface(ops, ml100k):
     np.testing.assert_array_equal(BasicNegtiveSampler(df, cfg2).sampling(), tri)
 
 
+def test_popularity_mixed_sampling(ops, ml100k):
+    """sampler.py:44-54,65-81 ('high-pop' / 'low-pop' with sample_ratio > 0): int(ratio * num_ng) of a user's
+    negatives from the popularity distribution over all items, the rest uniform from the complement; the device
+    draws bit-exact against the oracle's inverse-CDF restatement, the empirical distribution against pop_prob."""
+    import pandas as pd
+    from daisyrec_amd.utils.sampler import BasicNegtiveSampler
+    g = ml100k
+    U, I = int(g["user_num"]), int(g["item_num"])
+    df = pd.DataFrame({"user": g["train_users"], "item": g["train_items"], "rating": 1})
+    ur = {}
+    for u, i in zip(g["train_users"], g["train_items"]):
+        ur.setdefault(int(u), set()).add(int(i))
+    for u in range(U):
+        ur.setdefault(u, set())
+    for method in ("high-pop", "low-pop"):
+        cfg = mf_config(user_num=U, item_num=I, num_ng=5, sample_method=method, sample_ratio=0.5, train_ur=ur)
+        smp = BasicNegtiveSampler(df, cfg)
+        tri = smp.sampling()
+        assert tri.shape == (len(df) * 5, 3) and tri.dtype == np.int32
+        js = tri[:, 2].reshape(-1, 5)
+        users = g["train_users"]
+        # columns 0..2 uniform from the complement (never a positive), columns 3..4 from the popularity distribution
+        assert all(int(j) not in ur[int(u)] for u, row in zip(users[::37], js[::37]) for j in row[:3])
+        cdf = np.cumsum(smp.pop_prob.astype(np.float64))
+        want = O.sample_categorical(cdf, 40, 2, int(cfg["seed"]), (1 << 62) | 0)
+        first_row_of_user = {int(u): k for k, u in reversed(list(enumerate(users)))}
+        for u in range(40):
+            if u in first_row_of_user:
+                np.testing.assert_array_equal(js[first_row_of_user[u], 3:], want[u])
+        # distribution of many draws: chi-square against pop_prob on the items with a non-negligible expectation
+        draws = ops.sample_categorical(torch.from_numpy(cdf).to(DEV), 4000, 50, 11, 5).cpu().numpy().ravel()
+        cnt = np.bincount(draws, minlength=I).astype(np.float64)
+        exp = smp.pop_prob * draws.size
+        keep = exp >= 5
+        chi2 = ((cnt[keep] - exp[keep]) ** 2 / exp[keep]).sum()
+        dof = int(keep.sum()) - 1
+        assert abs(chi2 - dof) < 6 * np.sqrt(2 * dof), (method, chi2, dof)
+        if method == "high-pop":
+            assert cnt[smp.pop_prob == 0].sum() == 0         # items nobody interacted with are never drawn
+    cfg = mf_config(user_num=U, item_num=I, num_ng=4, sample_method="high-pop", sample_ratio=1.0, train_ur=ur)
+    assert BasicNegtiveSampler(df, cfg).sampling().shape == (len(df) * 4, 3)      # no uniform share at all
+
+
 # ------------------------------------------------------------------ BASELINE config C1 end to end
 def test_ml100k_c1_through_the_dropin(ml100k):
     """ml-100k, d=32, num_ng=1, SGD, B=256 (BASELINE.json configs[0]) through MF.fit/MF.rank with
