@@ -133,6 +133,7 @@ SIGNATURES = {
     "daisy_csr_workspace_bytes": (_sz, [_i64]),
     "daisy_build_user_csr": (C.c_int, [_p, _p, _i64, _i64, _p, _p, _p, _sz, _p]),
     "daisy_sample_neg_per_user": (C.c_int, [_p, _p, _i64, _i64, _i32, _u64, _u64, _p, _p]),
+    "daisy_skipgram_samples": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _p, _i64, _u64, _u64, _p, _p, _p]),
     "daisy_sample_categorical": (C.c_int, [_p, _i64, _i64, _i32, _u64, _u64, _p, _i32, _i32, _p]),
     "daisy_expand_triples": (C.c_int, [_p, _p, _i64, _p, _i32, _p, _p]),
     "daisy_resample_neg_per_interaction": (C.c_int, [_p, _p, _i64, _p, _i64, _u64, _u64, _p]),

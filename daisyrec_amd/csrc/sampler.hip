@@ -90,6 +90,40 @@ __global__ void k_sample_categorical(const double *__restrict__ cdf, int64_t I, 
     }
 }
 
+// SkipGramNegativeSampler.sampling (sampler.py:133-155): for the element at position p of user u's sequence
+// (the user's items in train-set order) the (target, context, 1) rows of its window [p-w, p+w] in window order,
+// then as many (target, negative, 0) rows, negatives uniform from the complement of the user's row.  One thread per
+// sequence element; rows [off[e], off[e+1]) of `out` are its own (off = exclusive scan of 2 * window size).
+__global__ void k_skipgram_fill(const int32_t *__restrict__ seq_items, const int32_t *__restrict__ seq_user,
+                                const int64_t *__restrict__ seq_ptr, const int64_t *__restrict__ off, int64_t n, int w,
+                                const int64_t *__restrict__ ur_ptr, const int32_t *__restrict__ ur_items, int64_t I,
+                                uint64_t seed, uint64_t stream, int32_t *__restrict__ out, int *__restrict__ bad) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t u = seq_user[e], target = seq_items[e];
+        const int64_t a = seq_ptr[u], b = seq_ptr[u + 1], p = e - a;
+        int64_t o = off[e];
+        const int64_t first = o;
+        for (int64_t j = (p - w > 0 ? p - w : 0); j <= p + w && j < b - a; ++j) {
+            if (j == p) continue;
+            out[3 * o] = target; out[3 * o + 1] = seq_items[a + j]; out[3 * o + 2] = 1;
+            ++o;
+        }
+        const int64_t c = o - first;                                    // = (off[e+1] - off[e]) / 2
+        const int64_t lo = ur_ptr[u], deg = ur_ptr[u + 1] - lo, free_ = I - deg;
+        for (int64_t k = 0; k < c; ++k) {
+            int32_t neg = -1;
+            if (free_ > 0) {
+                const uint64_t x = philox_u64(seed, stream, (uint64_t)(first / 2 + k));
+                neg = kth_in_complement(ur_items + lo, deg, (int64_t)__umul64hi(x, (uint64_t)free_));
+            } else {
+                atomicOr(bad, 1);
+            }
+            out[3 * o] = target; out[3 * o + 1] = neg; out[3 * o + 2] = 0;
+            ++o;
+        }
+    }
+}
+
 __global__ void k_expand_triples(const int32_t *__restrict__ users, const int32_t *__restrict__ items,
                                  int64_t n, const int32_t *__restrict__ js, int num_ng,
                                  int32_t *__restrict__ triples) {
@@ -175,6 +209,18 @@ int daisy_sample_neg_per_user(const int64_t *indptr, const int32_t *csr_items, i
     DAISY_CHECK_ARG(epoch < kStreamPerm, "sample_neg_per_user: epoch out of range");
     hipLaunchKernelGGL(k_sample_per_user, dim3(grid_for(user_num * num_ng, kBlock)), dim3(kBlock), 0,
                        S(stream), indptr, csr_items, user_num, item_num, (int)num_ng, seed, epoch, js);
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int daisy_skipgram_samples(const int32_t *seq_items, const int32_t *seq_user, const int64_t *seq_ptr,
+                           const int64_t *row_offsets, int64_t n, int32_t context_window, const int64_t *ur_indptr,
+                           const int32_t *ur_items, int64_t item_num, uint64_t seed, uint64_t stream_id, int32_t *out,
+                           int32_t *bad_flag, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(seq_items && seq_user && seq_ptr && row_offsets && ur_indptr && ur_items && out && bad_flag &&
+                        n > 0 && context_window > 0 && item_num > 0, "skipgram_samples: bad argument");
+    hipLaunchKernelGGL(k_skipgram_fill, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, S(stream), seq_items, seq_user, seq_ptr,
+                       row_offsets, n, (int)context_window, ur_indptr, ur_items, item_num, seed, stream_id, out, bad_flag);
     DAISY_LAUNCH_CHECK();
     return DAISY_OK;
 }

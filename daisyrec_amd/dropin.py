@@ -39,8 +39,11 @@ def install(sampler=False, front_end=False):
     if sampler:
         from .utils.sampler import BasicNegtiveSampler
 
+        from .utils.sampler import SkipGramNegativeSampler
+
         ref_s = importlib.import_module("daisy.utils.sampler")
         ref_s.BasicNegtiveSampler = BasicNegtiveSampler
+        ref_s.SkipGramNegativeSampler = SkipGramNegativeSampler
     if front_end:
         from .utils import utils as U
 

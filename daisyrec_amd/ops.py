@@ -533,6 +533,31 @@ def sample_categorical(cdf, rows, k, seed, stream_id, out=None, col0=0):
     return out
 
 
+def skipgram_samples(seq_items, seq_user, seq_ptr, context_window, ur_indptr, ur_items, item_num, seed, stream_id=0):
+    """SkipGramNegativeSampler.sampling (sampler.py:133-155) on the device: int32 [rows, 3] (target, context, label)
+    rows, element by element of the user sequences - window positives, then as many uniform negatives."""
+    dev = seq_items.device
+    n = seq_items.numel()
+    pos = torch.arange(n, device=dev, dtype=torch.int64) - seq_ptr[seq_user.long()]
+    length = (seq_ptr[1:] - seq_ptr[:-1])[seq_user.long()]
+    w = int(context_window)
+    cnt = torch.clamp(pos, max=w) + torch.clamp(length - 1 - pos, max=w)                 # window size of every element
+    off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    off[1:] = torch.cumsum(2 * cnt, 0)
+    rows = int(off[-1].item())
+    out = torch.empty(rows, 3, dtype=torch.int32, device=dev)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    if rows:
+        check(lib.daisy_skipgram_samples(_ptr(seq_items, torch.int32, "seq_items"), _ptr(seq_user, torch.int32, "seq_user"),
+                                         _ptr(seq_ptr, torch.int64, "seq_ptr"), _ptr(off, torch.int64, "row_offsets"), n, w,
+                                         _ptr(ur_indptr, torch.int64, "ur_indptr"), _ptr(ur_items, torch.int32, "ur_items"),
+                                         int(item_num), int(seed), int(stream_id), _ptr(out, torch.int32, "out"),
+                                         _ptr(bad, torch.int32, "bad"), _stream()))
+    if int(bad.item()):
+        raise ValueError("'a' cannot be empty unless no samples are taken")      # np.random.choice on an empty complement
+    return out
+
+
 def expand_triples(users, items, js):
     n, num_ng = users.numel(), js.shape[1]
     out = torch.empty(n * num_ng, 3, dtype=torch.int32, device=users.device)

@@ -118,3 +118,48 @@ class BasicNegtiveSampler(AbstractSampler):
     def sampling(self):
         """np.int32 (N*num_ng, 3) like sampler.py:100-101."""
         return self.sampling_device().cpu().numpy()
+
+
+class SkipGramNegativeSampler(AbstractSampler):
+    """sampler.py:105-160 (Item2Vec): (target, context, label) rows from windows over the user sequences, with as many
+    uniform negatives per target as it has context items.  Same constructor, same `sampling()` return value layout
+    (np.int array [rows, 3], user by user in `groupby` order, element by element: positives in window order, then
+    the negatives); the positives are the reference's exactly, the negatives come from the device generator
+    (Philox keyed by config['seed']) instead of MT19937 - same distribution, never one of the user's train items."""
+
+    STREAM = 1 << 61
+
+    def __init__(self, df, config, discard=False):
+        super().__init__(config)
+        self.context_window = config["context_window"]
+        self.user_num = config["user_num"]
+        self.seed = int(config.get("seed", 2022))
+        self.epoch = int(config.get("sampler_epoch", 0))
+        self.device = config.get("device", "cuda")
+        if discard:                                                           # sampler.py:123-130 (host, vectorised there too)
+            word_frequecy = df[self.iid_name].value_counts()
+            prob_discard = 1 - np.sqrt(config["rho"] / word_frequecy)
+            rnd_p = np.random.uniform(low=0.0, high=1.0, size=len(df))
+            df = df[rnd_p >= df[self.iid_name].map(prob_discard).values]
+        self.df = df
+
+    def sampling_device(self):
+        if not torch.cuda.is_available():
+            raise RuntimeError("daisyrec_amd sampler needs a HIP device (no CPU fallback)")
+        users = self.df[self.uid_name].to_numpy().astype(np.int64)
+        items = self.df[self.iid_name].to_numpy().astype(np.int32)
+        order = np.argsort(users, kind="stable")                              # groupby(user)[item].agg(list): train-set order kept
+        seq_user = torch.from_numpy(users[order].astype(np.int32)).to(self.device)
+        seq_items = torch.from_numpy(items[order]).to(self.device)
+        seq_ptr = torch.zeros(self.user_num + 1, dtype=torch.int64, device=self.device)
+        seq_ptr[1:] = torch.cumsum(torch.bincount(seq_user.long(), minlength=self.user_num), 0)
+        us = np.fromiter((u for u, s in self.ur.items() for _ in s), dtype=np.int32)
+        it = np.fromiter((i for _, s in self.ur.items() for i in s), dtype=np.int32)
+        ur_ptr, ur_items = ops.build_user_csr(torch.from_numpy(us).to(self.device), torch.from_numpy(it).to(self.device),
+                                              self.user_num)
+        return ops.skipgram_samples(seq_items, seq_user, seq_ptr, self.context_window, ur_ptr, ur_items, self.item_num,
+                                    self.seed, self.STREAM | self.epoch)
+
+    def sampling(self):
+        return self.sampling_device().cpu().numpy().astype(np.int64)           # np.array(list of python ints) is int64
+

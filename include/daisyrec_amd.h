@@ -376,6 +376,16 @@ int daisy_build_user_csr(const int32_t *users, const int32_t *items, int64_t n, 
 int daisy_sample_neg_per_user(const int64_t *indptr, const int32_t *csr_items, int64_t user_num,
                               int64_t item_num, int32_t num_ng, uint64_t seed, uint64_t epoch,
                               int32_t *js, daisy_stream_t stream);
+/* SkipGramNegativeSampler.sampling (sampler.py:133-155, Item2Vec's sampler): the user sequences (items in train-set
+ * order, seq_items[n] with seq_ptr[U+1] and the owner seq_user[n] of every element), the window half-width, the
+ * users' train rows as a CSR with sorted distinct items.  Element e writes rows [row_offsets[e], row_offsets[e+1]) of
+ * out (int32 [rows][3]): its (target, context, 1) rows in window order, then as many (target, negative, 0) rows with
+ * negatives uniform from the complement of its user's row (Philox(seed, stream_id, row/2 + k)); row_offsets = the
+ * exclusive scan of 2 * (window size of e).  bad_flag |= 1 when a user has no negative to draw. */
+int daisy_skipgram_samples(const int32_t *seq_items, const int32_t *seq_user, const int64_t *seq_ptr,
+                           const int64_t *row_offsets, int64_t n, int32_t context_window, const int64_t *ur_indptr,
+                           const int32_t *ur_items, int64_t item_num, uint64_t seed, uint64_t stream_id, int32_t *out,
+                           int32_t *bad_flag, daisy_stream_t stream);
 /* sampler.py:76-80, the 'high-pop' / 'low-pop' share of a user's negatives: k draws per row from the categorical
  * distribution whose inclusive cumulative sums are cdf[0..item_num) (float64, any positive total), by inverse CDF on
  * Philox(seed, stream_id, row*k + c); written to out[row*ld + col0 + c].  Like np.random.choice(p=...) in the

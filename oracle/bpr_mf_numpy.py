@@ -315,6 +315,29 @@ def sample_categorical(cdf, rows, k, seed, stream):
     return out
 
 
+def skipgram_samples(seqs, ur_rows, item_num, context_window, seed, stream):
+    """SkipGramNegativeSampler.sampling (sampler.py:133-155) restated with the Philox draws of the device path:
+    `seqs` = list of (user, [items in train order]) in groupby order, `ur_rows[u]` = sorted distinct train items of u.
+    Element by element: (target, context, 1) for the window, then as many (target, negative, 0); the k-th negative of
+    an element whose rows start at `first` uses index first/2 + k."""
+    out = []
+    for u, seq in seqs:
+        row = ur_rows[u]
+        free = item_num - len(row)
+        for i in range(len(seq)):
+            first = len(out)
+            j = i - context_window
+            while j <= i + context_window and j < len(seq):
+                if j >= 0 and j != i:
+                    out.append([seq[i], seq[j], 1])
+                j += 1
+            c = len(out) - first
+            for k in range(c):
+                x = _draw_u64(seed, stream, first // 2 + k)
+                out.append([seq[i], kth_in_complement(row, (x * free) >> 64), 0])
+    return np.array(out, dtype=np.int64).reshape(-1, 3)
+
+
 def sample_uniform_neg_per_interaction(indptr, items, users, item_num, num_ng, seed, epoch=0):
     """Per-interaction variant (one draw per (interaction, k)); stream = epoch | 1<<63."""
     n = len(users)

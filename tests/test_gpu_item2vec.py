@@ -90,3 +90,53 @@ def test_item2vec_ml100k_through_the_dropin(kat_i2v):
     loss = float(model.calc_loss([torch.from_numpy(b[:, k].copy()) for k in range(3)]).cpu())
     want, _ = IV.item2vec_grad(model.shared_embedding.weight.detach().cpu().numpy(), b[:, 0], b[:, 1], b[:, 2])
     assert abs(loss - want) <= 1e-5 * abs(want)
+
+
+def test_skipgram_sampler_on_the_device():
+    """SkipGramNegativeSampler (sampler.py:105-160) mirror: bit-exact against the oracle's restatement (same Philox
+    draws); the (target, context, 1) rows are what the reference's window loop emits, in its order; negatives are
+    never one of the user's train items; users with short sequences, a user without rows, window larger than a
+    sequence."""
+    import pandas as pd
+    from daisyrec_amd.utils.sampler import SkipGramNegativeSampler
+    from oracle import bpr_mf_numpy as O
+    rng = np.random.default_rng(4)
+    U, I, w = 30, 50, 3
+    users = rng.integers(0, U, 400)
+    users[users == 7] = 8                                    # user 7 has no rows
+    users[:2] = 29                                           # a two-element sequence
+    items = rng.integers(0, I, 400)
+    df = pd.DataFrame({"user": users, "item": items, "rating": 1})
+    ur = {u: set() for u in range(U)}
+    for u, i in zip(users, items):
+        ur[int(u)].add(int(i))
+    cfg = {"UID_NAME": "user", "IID_NAME": "item", "item_num": I, "user_num": U, "train_ur": ur, "context_window": w,
+           "rho": 1e-5, "seed": 2022}
+    smp = SkipGramNegativeSampler(df, cfg)
+    got = smp.sampling()
+    seqs = [(int(u), [int(x) for x in g_]) for u, g_ in df.groupby("user")["item"].agg(list).items()]
+    rows = {u: np.array(sorted(s), dtype=np.int32) for u, s in ur.items()}
+    want = O.skipgram_samples(seqs, rows, I, w, 2022, SkipGramNegativeSampler.STREAM)
+    assert got.dtype == np.int64 and got.shape == want.shape
+    np.testing.assert_array_equal(got, want)
+    # the reference's own loop for the positives (sampler.py:139-149), and the negative property
+    ref_pos = []
+    for u, seq in seqs:
+        for i in range(len(seq)):
+            j = i - w
+            while j <= i + w and j < len(seq):
+                if j >= 0 and j != i:
+                    ref_pos.append([seq[i], seq[j], 1])
+                j += 1
+    np.testing.assert_array_equal(got[got[:, 2] == 1], np.array(ref_pos))
+    assert (got[:, 2] == 0).sum() == (got[:, 2] == 1).sum()
+    # every negative row follows its target's positives and avoids the user's items
+    k = 0
+    for u, seq in seqs:
+        for i in range(len(seq)):
+            c = min(i, w) + min(len(seq) - 1 - i, w)
+            blk = got[k:k + 2 * c]
+            assert (blk[:, 0] == seq[i]).all() and (blk[:c, 2] == 1).all() and (blk[c:, 2] == 0).all()
+            assert not (set(blk[c:, 1].tolist()) & ur[u])
+            k += 2 * c
+    assert k == len(got)
