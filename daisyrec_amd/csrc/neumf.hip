@@ -391,8 +391,14 @@ __device__ __forceinline__ TileId tile_of_block() {
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-constexpr int kBKH = 32, kLdkH = kBKH + 8;      // k depth of a tile (64 measured no faster on the GEMM and slower on the step:
-                                                // LDS for two stages halves the resident workgroups)
+constexpr int kBKH = 32, kLdkH = kBKH;          // k depth of a tile (64 measured no faster on the GEMM and slower on the step:
+                                                // LDS for two stages halves the resident workgroups).  k-contiguous tiles
+                                                // are unpadded (64-byte rows); the four 16-byte chunks of row r sit at
+                                                // position chunk ^ ((r / 4) % 4): the fragment reads (ds_read_b128: 16 rows
+                                                // per LDS cycle) and the tile writes (two rows per 8-lane group) are then
+                                                // both conflict-free; the first version's 80-byte pitch left 31 % of the LDS
+                                                // cycles in bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)
+__device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
 // An operand that is contiguous along its ROWS instead of k (both operands of the weight-gradient GEMM: dZ^T and
 // X^T with k = the batch row) is copied to LDS as it lies in memory - [k][row] tiles, 16-byte loads along the rows -
 // and the MFMA fragment (8 consecutive k of one row per lane) comes out of gfx950's transposing LDS read:
@@ -461,8 +467,10 @@ __global__ __launch_bounds__(kBlock) void k_gemm_h(GemmOp op) {
         constexpr int ROWS = decltype(rows_c)::value;
         if constexpr (decltype(kfast_c)::value) {
 #pragma unroll
-            for (int q = 0; q < ROWS / RPP; ++q)
-                *reinterpret_cast<u32x4 *>(S + (tid / LPT + q * RPP) * kLdkH + (tid % LPT) * 8) = r[q];
+            for (int q = 0; q < ROWS / RPP; ++q) {
+                const int row = tid / LPT + q * RPP;
+                *reinterpret_cast<u32x4 *>(S + row * kLdkH + swz_chunk(row, tid % LPT) * 8) = r[q];
+            }
         } else {
             constexpr int VPR = ROWS / 8, KPP = kBlock / VPR, PT = ROWS + kPadT;
 #pragma unroll
@@ -490,21 +498,24 @@ __global__ __launch_bounds__(kBlock) void k_gemm_h(GemmOp op) {
             const uint16_t *At = As0 + cur * kTileA, *Bt = Bs0 + cur * kTileB;
             // k-contiguous tile: lane -> row lane%32, k half lane/32.  [k][row] tile: the address of this lane's piece
             // of the transposing read (k row 8*(lane/32) + (lane%16)/4, rows 16*((lane%32)/16) + 4*(lane%4) ...)
-            const uint16_t *as = AK ? At + (wm * 64 + lane % 32) * kLdkH + (lane / 32) * 8
+            // (the row offsets wm*64 + mi*32 and wn*32*WN + ni*32 are multiples of 32: the swizzle of a lane's row
+            // depends on lane % 32 only)
+            const int sw = ((lane % 32) >> 2) & 3, half = lane / 32;
+            const uint16_t *as = AK ? At + (wm * 64 + lane % 32) * kLdkH
                                     : At + (8 * (lane / 32) + (lane % 16) / 4) * PTA + wm * 64 + 16 * ((lane % 32) / 16) + 4 * (lane % 4);
-            const uint16_t *bs = BK ? Bt + (wn * 32 * WN + lane % 32) * kLdkH + (lane / 32) * 8
+            const uint16_t *bs = BK ? Bt + (wn * 32 * WN + lane % 32) * kLdkH
                                     : Bt + (8 * (lane / 32) + (lane % 16) / 4) * PTB + wn * 32 * WN + 16 * ((lane % 32) / 16) + 4 * (lane % 4);
 #pragma unroll
             for (int ks = 0; ks < kBKH / 16; ++ks) {
                 bf16x8 a[2], b[WN];
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {
-                    if constexpr (AK) a[mi] = *reinterpret_cast<const bf16x8 *>(as + mi * 32 * kLdkH + ks * 16);
+                    if constexpr (AK) a[mi] = *reinterpret_cast<const bf16x8 *>(as + mi * 32 * kLdkH + ((2 * ks + half) ^ sw) * 8);
                     else a[mi] = lds_frag_tr(as + ks * 16 * PTA + mi * 32, PTA);
                 }
 #pragma unroll
                 for (int ni = 0; ni < WN; ++ni) {
-                    if constexpr (BK) b[ni] = *reinterpret_cast<const bf16x8 *>(bs + ni * 32 * kLdkH + ks * 16);
+                    if constexpr (BK) b[ni] = *reinterpret_cast<const bf16x8 *>(bs + ni * 32 * kLdkH + ((2 * ks + half) ^ sw) * 8);
                     else b[ni] = lds_frag_tr(bs + ks * 16 * PTB + ni * 32, PTB);
                 }
 #pragma unroll
