@@ -20,6 +20,10 @@
 
 #include <type_traits>
 
+#ifndef DAISY_BKH
+#define DAISY_BKH 32        // k depth of the bf16-storage GEMM's tiles (32 or 64; -DDAISY_BKH=64 to try the other)
+#endif
+
 namespace daisy {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -391,14 +395,16 @@ __device__ __forceinline__ TileId tile_of_block() {
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-constexpr int kBKH = 32, kLdkH = kBKH;          // k depth of a tile (64 measured no faster on the GEMM and slower on the step:
-                                                // LDS for two stages halves the resident workgroups).  k-contiguous tiles
+constexpr int kBKH = DAISY_BKH, kLdkH = kBKH;          // k depth of a tile (64: 587 vs 610 TFLOP/s on the forward shape, step equal -
+                                                // 64 KB of LDS per workgroup halve the resident workgroups).  k-contiguous tiles
                                                 // are unpadded (64-byte rows); the four 16-byte chunks of row r sit at
                                                 // position chunk ^ ((r / 4) % 4): the fragment reads (ds_read_b128: 16 rows
                                                 // per LDS cycle) and the tile writes (two rows per 8-lane group) are then
                                                 // both conflict-free; the first version's 80-byte pitch left 31 % of the LDS
                                                 // cycles in bank conflicts (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE)
-__device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ ((row >> 2) & 3); }
+// (32-deep tiles: 4 chunks per 64-byte row, chunk ^ ((r / 4) % 4); 64-deep: 8 chunks per 128-byte row, chunk ^ ((r / 2) % 8))
+__device__ __forceinline__ int swz_of_row(int row) { return kBKH == 32 ? ((row >> 2) & 3) : ((row >> 1) & 7); }
+__device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ swz_of_row(row); }
 // An operand that is contiguous along its ROWS instead of k (both operands of the weight-gradient GEMM: dZ^T and
 // X^T with k = the batch row) is copied to LDS as it lies in memory - [k][row] tiles, 16-byte loads along the rows -
 // and the MFMA fragment (8 consecutive k of one row per lane) comes out of gfx950's transposing LDS read:
@@ -500,7 +506,7 @@ __global__ __launch_bounds__(kBlock) void k_gemm_h(GemmOp op) {
             // of the transposing read (k row 8*(lane/32) + (lane%16)/4, rows 16*((lane%32)/16) + 4*(lane%4) ...)
             // (the row offsets wm*64 + mi*32 and wn*32*WN + ni*32 are multiples of 32: the swizzle of a lane's row
             // depends on lane % 32 only)
-            const int sw = ((lane % 32) >> 2) & 3, half = lane / 32;
+            const int sw = swz_of_row(lane % 32), half = lane / 32;
             const uint16_t *as = AK ? At + (wm * 64 + lane % 32) * kLdkH
                                     : At + (8 * (lane / 32) + (lane % 16) / 4) * PTA + wm * 64 + 16 * ((lane % 32) / 16) + 4 * (lane % 4);
             const uint16_t *bs = BK ? Bt + (wn * 32 * WN + lane % 32) * kLdkH
