@@ -258,6 +258,15 @@ __device__ __forceinline__ uint32_t bf16_rne(float f) {
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+// two floats -> two bf16 (round to nearest even) in one dword, lo in bits 0..15: gfx950's v_cvt_pk_bf16_f32 - one
+// instruction where the integer form above takes five per value (the epilogue of a 128x128 tile converts 64 values
+// per lane: that was more VALU work than the tile's MFMAs at K = 128)
+__device__ __forceinline__ uint32_t bf16_pack2(float lo, float hi) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
 
 template <int WN, int EPI, bool DROP>
 __global__ __launch_bounds__(kBlock) void k_gemm_bf16(GemmOp op) {
@@ -303,7 +312,7 @@ __global__ __launch_bounds__(kBlock) void k_gemm_bf16(GemmOp op) {
             for (int q = 0; q < 4 * Q; ++q) r[q] = src[(int64_t)q * sk];
         }
     };
-    auto pack2 = [](float lo, float hi) { return bf16_rne(lo) | (bf16_rne(hi) << 16); };
+    auto pack2 = [](float lo, float hi) { return bf16_pack2(lo, hi); };
     auto store_op = [&](uint16_t *__restrict__ S, bool kfast, auto &r, auto rows_c, auto q_c) {
         constexpr int ROWS = decltype(rows_c)::value, Q = decltype(q_c)::value;
         if (kfast) {
@@ -556,16 +565,22 @@ __global__ __launch_bounds__(kBlock) void k_gemm_h(GemmOp op) {
                 float bias = 0.f;
                 if constexpr (EPI == EPI_BIAS_RELU) bias = op.bias[n0 + nl];
 #pragma unroll
-                for (int i = 0; i < 16; ++i) {
+                for (int i = 0; i < 16; i += 2) {                       // rows ml, ml + 1 of column nl: one packed conversion
                     const int ml = wm * 64 + mi * 32 + (i / 4) * 8 + (lane / 32) * 4 + (i % 4);
-                    float v = acc[mi][ni][i];
-                    if constexpr (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
-                    if constexpr (DROP)
-                        if (op.drop_thresh)
-                            v = drop_keep(op.drop_seed, op.drop_stream,
-                                          (uint64_t)(m0 + ml) * (uint64_t)op.N + (uint64_t)(n0 + nl), op.drop_thresh)
-                                    ? v * op.drop_scale : 0.f;
-                    Ts[ml * LDT + nl] = (uint16_t)bf16_rne(v);
+                    float v[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        v[h] = acc[mi][ni][i + h];
+                        if constexpr (EPI == EPI_BIAS_RELU) v[h] = fmaxf(v[h] + bias, 0.f);
+                        if constexpr (DROP)
+                            if (op.drop_thresh)
+                                v[h] = drop_keep(op.drop_seed, op.drop_stream,
+                                                 (uint64_t)(m0 + ml + h) * (uint64_t)op.N + (uint64_t)(n0 + nl), op.drop_thresh)
+                                           ? v[h] * op.drop_scale : 0.f;
+                    }
+                    const uint32_t pk = bf16_pack2(v[0], v[1]);
+                    Ts[ml * LDT + nl] = (uint16_t)pk;
+                    Ts[(ml + 1) * LDT + nl] = (uint16_t)(pk >> 16);
                 }
             }
         __syncthreads();
@@ -584,7 +599,7 @@ __global__ __launch_bounds__(kBlock) void k_gemm_h(GemmOp op) {
                         const uint16_t g0 = (uint16_t)gw[q], g1 = (uint16_t)(gw[q] >> 16);
                         float lo = bf16_positive(g0) ? bf16_to_f32((uint16_t)vw[q]) * op.gate_scale : 0.f;
                         float hi = bf16_positive(g1) ? bf16_to_f32((uint16_t)(vw[q] >> 16)) * op.gate_scale : 0.f;
-                        vw[q] = bf16_rne(lo) | (bf16_rne(hi) << 16);
+                        vw[q] = bf16_pack2(lo, hi);
                     }
                     v = make_uint4(vw[0], vw[1], vw[2], vw[3]);
                 }
@@ -748,9 +763,9 @@ __global__ __launch_bounds__(kBlock) void k_nmf_gather(daisy_neumf_params p, Pai
             }
             if constexpr (H) {
                 *reinterpret_cast<uint2 *>(xh + c) =
-                    make_uint2(bf16_rne(a[0]) | (bf16_rne(a[1]) << 16), bf16_rne(a[2]) | (bf16_rne(a[3]) << 16));
+                    make_uint2(bf16_pack2(a[0], a[1]), bf16_pack2(a[2], a[3]));
                 *reinterpret_cast<uint2 *>(xh + dm + c) =
-                    make_uint2(bf16_rne(b[0]) | (bf16_rne(b[1]) << 16), bf16_rne(b[2]) | (bf16_rne(b[3]) << 16));
+                    make_uint2(bf16_pack2(b[0], b[1]), bf16_pack2(b[2], b[3]));
             } else {
                 *reinterpret_cast<float4 *>(x + c) = make_float4(a[0], a[1], a[2], a[3]);
                 *reinterpret_cast<float4 *>(x + dm + c) = make_float4(b[0], b[1], b[2], b[3]);
@@ -932,7 +947,7 @@ __global__ __launch_bounds__(kBlock) void k_nmf_pred_bwd_v(const float *__restri
         if (on) {
             if constexpr (H)
                 *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(DZ) + r * d + c4) =
-                    make_uint2(bf16_rne(dz[0]) | (bf16_rne(dz[1]) << 16), bf16_rne(dz[2]) | (bf16_rne(dz[3]) << 16));
+                    make_uint2(bf16_pack2(dz[0], dz[1]), bf16_pack2(dz[2], dz[3]));
             else
                 *reinterpret_cast<float4 *>(DZ + r * d + c4) = make_float4(dz[0], dz[1], dz[2], dz[3]);
         }
