@@ -1315,7 +1315,7 @@ static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_ty
     UserEdges ed{ctx->edge_vec, ctx->edge_user, ctx->edge_n, ctx->edge_whole};
     const PreNorm pre{ctx->partials + (size_t)kMaxGrid * 8, n_pre};
     static const int tune_ug = getenv("DAISY_STAGED_UGRID") ? atoi(getenv("DAISY_STAGED_UGRID")) : kMaxGrid;
-    static const int tune_blk = getenv("DAISY_STAGED_UBLK") ? atoi(getenv("DAISY_STAGED_UBLK")) : kStagedUserBlock;
+    static const int tune_blk = getenv("DAISY_STAGED_UBLK") ? atoi(getenv("DAISY_STAGED_UBLK")) : 0;     // 0: by row shape
     int64_t nchunks_out = 0;
     bool overflow = false;
     int rc = dispatch_d(d, [&](auto cfg) {
@@ -1336,7 +1336,12 @@ static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_ty
             else DAISY_LAUNCH_SU(false, false);
 #undef DAISY_LAUNCH_SU
         };
-        if (tune_blk == 128 && C::LPR <= 32) go(std::integral_constant<int, 128>{});
+        // workgroup size of the user pass: 128 threads; ONE wave (its barriers are free) for rows of two float4 per
+        // lane (64 < d <= 128: 1.40 -> 1.27 ms per 2M-sample step at d=128; slower at d <= 64 (0.60 -> 0.71), and
+        // rows of four float4 per lane would need more edge records than the context holds)
+        const int blk = tune_blk ? tune_blk : ((C::NE == 8 && C::LPR == 16) ? 64 : kStagedUserBlock);
+        if (blk == 64 && C::NE == 8 && C::LPR == 16) go(std::integral_constant<int, 64>{});
+        else if (blk <= 128 && C::LPR <= 32) go(std::integral_constant<int, 128>{});
         else go(std::integral_constant<int, kBlock>{});
         if (overflow) return DAISY_OK;
         const ReduceJob red{ctx->partials, ride_reduce ? *grid_out : 0, stats, epoch_acc, step_loss};
