@@ -595,7 +595,14 @@ struct StagedUserCfg {
 };
 template <class C, int BLK = kBlock>
 struct StagedItemCfg {
-    static constexpr int RUN_BY_REGS = (C::NE <= 4) ? 16 : ((C::NE <= 8) ? 4 : 2);
+#ifndef DAISY_ITEM_RUN8
+#define DAISY_ITEM_RUN8 8
+#endif
+#ifndef DAISY_ITEM_RUN16
+#define DAISY_ITEM_RUN16 4
+#endif
+    // staged rows in flight per lane group: 64 row registers in every shape (16 x 4 floats, 8 x 8, 4 x 16)
+    static constexpr int RUN_BY_REGS = (C::NE <= 4) ? 16 : ((C::NE <= 8) ? DAISY_ITEM_RUN8 : DAISY_ITEM_RUN16);
     static constexpr int RUN = RUN_BY_REGS < C::LPR ? RUN_BY_REGS : C::LPR;
     static constexpr int G = BLK / C::LPR;
     static constexpr int E = G * RUN;
