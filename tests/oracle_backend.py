@@ -109,6 +109,22 @@ class OracleContext:
         gQ += torch.from_numpy(g.astype(np.float32))
         cnt += torch.from_numpy(c.astype(np.float32))
 
+    def staged_item_slices(self, item_bounds):
+        """ops.BprContext.staged_item_slices: the item ranges a sliced step reduces one after the other"""
+        self._bounds = [int(b) for b in item_bounds]
+
+    def staged_item_slice(self, s, lr, reg_1, reg_2, gQ, cnt, loss_type=0):
+        lo, hi = self._bounds[s], self._bounds[s + 1]
+        g = np.zeros((self.item_num, self.d))
+        c = np.zeros((self.item_num, 2))
+        mi, mj = (self.i >= lo) & (self.i < hi), (self.j >= lo) & (self.j < hi)
+        np.add.at(g, self.i[mi], self.cp[mi, None] * self.pu_pre[mi])
+        np.add.at(g, self.j[mj], self.cn[mj, None] * self.pu_pre[mj])
+        np.add.at(c[:, 0], self.i[mi], 1.0)
+        np.add.at(c[:, 1], self.j[mj], 1.0)
+        gQ += torch.from_numpy(g.astype(np.float32))
+        cnt += torch.from_numpy(c.astype(np.float32))
+
     def item_apply_counts(self, Q_rows, g_rows, cnt_rows, lr, reg_1, reg_2):
         nI, nJ = float(self.stats[9]), float(self.stats[10])
         q = Q_rows.numpy().astype(np.float64)

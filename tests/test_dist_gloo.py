@@ -26,7 +26,7 @@ def _data(lopsided=False):
     return P0, Q0, batches
 
 
-def _worker(rank, world, port, out_dir, mode, lopsided=False):
+def _worker(rank, world, port, out_dir, mode, lopsided=False, slices=1):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from daisyrec_amd.sharding import UserShardedBprTrainer, shard_triples, user_range
@@ -38,8 +38,8 @@ def _worker(rank, world, port, out_dir, mode, lopsided=False):
     from daisyrec_amd import _native as N
     ctx = OracleContext(B, D, hi - lo, I)
     tr = UserShardedBprTrainer(ctx, P, Q, lo, LR, R1, R2, overlap=(rank % 2 == 0),
-                               item_mode={"fused": N.ITEM_FUSED, "chunked": N.ITEM_CHUNKED}[mode])
-    assert tr.staged == (mode == "fused")
+                               item_mode={"fused": N.ITEM_FUSED, "chunked": N.ITEM_CHUNKED}[mode], slices=slices)
+    assert tr.staged == (mode == "fused") and tr.slices == (slices if mode == "fused" else 1)
     losses = []
     for b in batches:
         mine = shard_triples(b, U, world, rank)
@@ -102,6 +102,28 @@ def test_ranks_without_samples_in_a_step_only_join_the_exchanges(tmp_path):
         np.testing.assert_allclose(o["losses"], ref_losses, rtol=1e-9)
         np.testing.assert_allclose(o["Q"], Q, atol=2e-6)
         np.testing.assert_allclose(o["P"], P[int(o["lo"]):int(o["hi"])], atol=2e-6)
+
+
+@pytest.mark.parametrize("world,slices", [(2, 3), (4, 5)])
+def test_sliced_exchange_equals_single_process(tmp_path, world, slices):
+    """slices > 1 (sharding.py: item pass range by range, each range's exchange right behind it, rank r owning the
+    r-th block of every range): 30 items over world x slices blocks needs padding in both cases; one step has
+    ranks without samples"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "fused", True, slices), nprocs=world, join=True)
+    P, Q, batches = _data(True)
+    ref_losses = []
+    for b in batches:
+        loss, P, Q = O.mf_sgd_step(P, Q, b[:, 0], b[:, 1], b[:, 2], LR, R1, R2)
+        ref_losses.append(loss)
+    outs = [np.load(os.path.join(str(tmp_path), f"r{r}.npz")) for r in range(world)]
+    for o in outs:
+        np.testing.assert_allclose(o["losses"], ref_losses, rtol=1e-9)
+        np.testing.assert_allclose(o["Q"], Q, atol=2e-6)
+        np.testing.assert_allclose(o["P"], P[int(o["lo"]):int(o["hi"])], atol=2e-6)
+    for o in outs[1:]:
+        np.testing.assert_array_equal(outs[0]["Q"], o["Q"])
 
 
 def test_user_range_partition():
