@@ -1393,7 +1393,9 @@ static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_
             else DAISY_LAUNCH_SI(false, false);
 #undef DAISY_LAUNCH_SI
         };
-        go(std::integral_constant<int, kStagedItemBlock>{});
+        static const int tune_iblk = getenv("DAISY_STAGED_IBLK") ? atoi(getenv("DAISY_STAGED_IBLK")) : 0;
+        if (tune_iblk == 128 && C::NE == 4 && C::LPR == 16) go(std::integral_constant<int, 128>{});      // (A/B knob, d = 64 only)
+        else go(std::integral_constant<int, kStagedItemBlock>{});
         return DAISY_OK;
     });
     if (rc) return rc;
