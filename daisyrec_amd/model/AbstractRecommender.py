@@ -204,6 +204,11 @@ class GeneralRecommender(AbstractRecommender):
         row_ids = torch.nonzero((u >= lo) & (u < hi)).flatten()        # ascending: CSR order is kept
         mine = triples[row_ids].contiguous()
         n_loc = int(mine.shape[0])
+        held = torch.tensor([n_loc], dtype=torch.int64, device=P.device)
+        dist.all_reduce(held)
+        if int(held.item()) != n:          # a user id outside [0, user_num) belongs to no rank: what the index would report
+            raise ValueError(f"index out of range in the training triples: need 0 <= user < {U} "
+                             "(the reference raises IndexError in nn.Embedding, MFRecommender.py:64-65)")
         P_loc = P[lo:hi]
         ctx = ops.BprContext(B, d, hi - lo, I, device=P.device)        # stage slots are positions inside a GLOBAL batch
         index = plan = None
