@@ -90,6 +90,10 @@ SIGNATURES = {
     "daisy_bpr_user_grad": (C.c_int, [_p, _p, _p, _p, _f32, _f32, _p, _p]),
     "daisy_bpr_item_sgd_apply": (C.c_int, [_p, _p, _p, _f32, _i32, _p]),
     "daisy_adam_dense": (C.c_int, [_p, _p, _p, _p, _i64, _f32, _f32, _f32, _f32, _i64, _p]),
+    "daisy_adam_lazy_table": (C.c_int, [_f32, _f32, _f32, _i64, _p]),
+    "daisy_adam_lazy_catchup": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f32, _f32, _f32, _i64, _p]),
+    "daisy_adam_lazy_step": (C.c_int, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _f32, _f32, _f32, _i64, _p]),
+    "daisy_adam_lazy_flush": (C.c_int, [_p, _p, _p, _p, _i64, _i32, _p, _f32, _f32, _f32, _i64, _p]),
     "daisy_adagrad_dense": (C.c_int, [_p, _p, _p, _i64, _f32, _f32, _p]),
     "daisy_rmsprop_dense": (C.c_int, [_p, _p, _p, _i64, _f32, _f32, _f32, _p]),
     "daisy_bpr_sgd_step": (C.c_int, [_p, _p, _p, _i32, _f32, _f32, _f32, _f32, _p, _p, _p, _p,

@@ -1035,6 +1035,95 @@ __global__ __launch_bounds__(kBlock) void k_adam_dense(float *__restrict__ W, fl
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Dense Adam without touching every row in every step.  torch's Adam moves every element in every step (the moments
+// decay without a gradient), which at table sizes beyond the batch is most of the step's traffic.  But a row's
+// update sequence depends on nothing but its own gradients: a row without gradient in steps a+1..b can be brought
+// from its state after step a to its state after step b in registers (b - a zero-gradient updates, the very
+// expressions of k_adam_dense with g = 0) whenever it is next needed - before the step that reads it, or at a flush.
+// last[r] = the step row r has been updated to.  table[s] = (lr / (1 - beta1^s), sqrt(1 - beta2^s)) as the dense
+// entry point computes them on the host, so the replay uses the same bits.  Result: identical to daisy_adam_dense
+// in every step (tested bit for bit), HBM traffic proportional to the rows a step touches.
+// ---------------------------------------------------------------------------------------------------------
+template <class C>
+__device__ __forceinline__ void adam_row(Row<C> &w, Row<C> &m, Row<C> &v, const Row<C> &g, float step_size, float bc2_sqrt,
+                                         float beta1, float beta2, float eps) {
+    const float w1 = 1.f - beta1, w2 = 1.f - beta2;
+#pragma unroll
+    for (int k = 0; k < C::NE; ++k) {
+        const float gg = g.v[k];
+        const float mm = fmaf(w1, gg - m.v[k], m.v[k]);
+        const float vv = fmaf(w2 * gg, gg, beta2 * v.v[k]);
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        w.v[k] = w.v[k] - step_size * (mm / denom);
+        m.v[k] = mm;
+        v.v[k] = vv;
+    }
+}
+
+struct AdamTable { float *W, *g, *m, *v; int32_t *last; };
+struct AdamHyper { const float2 *table; float beta1, beta2, eps; int32_t t; };
+
+// the lane group that raises last[row] from below `upto` wins the row: it replays the zero-gradient steps
+// last+1 .. upto-1 (catch-up, WITH_G = false: upto = t, the row is then current for step t's forward) or applies step
+// t itself with the row's gradient and clears it (WITH_G: upto = t + 1)
+template <class C, bool WITH_G>
+__device__ __forceinline__ void adam_claim_row(const AdamTable &T, int64_t row, int d, const AdamHyper &h, int lane) {
+    const int32_t target = WITH_G ? h.t : h.t - 1;
+    int32_t old = 0;
+    if (lane == 0) old = atomicMax(T.last + row, target);
+    old = group_bcast<C>(old, 0);
+    if (old >= target) return;
+    Row<C> w, m, v, g;
+    w.load(T.W + row * d, lane, d); m.load(T.m + row * d, lane, d); v.load(T.v + row * d, lane, d);
+    g.zero();
+    for (int32_t s = old + 1; s < (WITH_G ? h.t : h.t); ++s) {           // zero-gradient steps old+1 .. t-1
+        const float2 c = h.table[s];
+        adam_row<C>(w, m, v, g, c.x, c.y, h.beta1, h.beta2, h.eps);
+    }
+    if constexpr (WITH_G) {
+        g.load(T.g + row * d, lane, d);
+        const float2 c = h.table[h.t];
+        adam_row<C>(w, m, v, g, c.x, c.y, h.beta1, h.beta2, h.eps);
+        g.zero();
+        g.store(T.g + row * d, lane, d);
+    }
+    w.store(T.W + row * d, lane, d); m.store(T.m + row * d, lane, d); v.store(T.v + row * d, lane, d);
+}
+
+// every row reference of the current batch: user of sample s, its item(s)
+template <class C, bool WITH_G>
+__global__ __launch_bounds__(kBlock) void k_adam_batch_rows(BatchView v, int d, AdamTable TP, AdamTable TQ, AdamHyper h) {
+    const int lane = threadIdx.x % C::LPR, group = threadIdx.x / C::LPR;
+    const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
+    for (int64_t s = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; s < v.B; s += gstride) {
+        const int2 ij = v.ij[s];
+        adam_claim_row<C, WITH_G>(TP, (int64_t)(v.ukey[s] & v.umask), d, h, lane);
+        adam_claim_row<C, WITH_G>(TQ, (int64_t)ij.x, d, h, lane);
+        if (!v.pointwise) adam_claim_row<C, WITH_G>(TQ, (int64_t)ij.y, d, h, lane);
+    }
+}
+
+// all rows up to step t (end of an epoch, before the tables are read by anything but a step)
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_adam_flush(AdamTable T, int64_t rows, int d, AdamHyper h) {
+    const int lane = threadIdx.x % C::LPR, group = threadIdx.x / C::LPR;
+    const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
+    for (int64_t r = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; r < rows; r += gstride) {
+        const int32_t old = T.last[r];
+        if (old >= h.t) continue;
+        Row<C> w, m, v, g;
+        w.load(T.W + r * d, lane, d); m.load(T.m + r * d, lane, d); v.load(T.v + r * d, lane, d);
+        g.zero();
+        for (int32_t s = old + 1; s <= h.t; ++s) {
+            const float2 c = h.table[s];
+            adam_row<C>(w, m, v, g, c.x, c.y, h.beta1, h.beta2, h.eps);
+        }
+        w.store(T.W + r * d, lane, d); m.store(T.m + r * d, lane, d); v.store(T.v + r * d, lane, d);
+        if (lane == 0) T.last[r] = h.t;
+    }
+}
+
 // torch.optim.Adagrad single-tensor math (defaults): state_sum.addcmul_(g, g); w.addcdiv_(g, sqrt(state_sum) + eps, -lr)
 __global__ __launch_bounds__(kBlock) void k_adagrad_dense(float *__restrict__ W, float *__restrict__ g,
                                                           float *__restrict__ ss, int64_t n, float lr, float eps) {
@@ -1864,6 +1953,71 @@ int daisy_adam_dense(float *W, float *g, float *m, float *v, int64_t n, float lr
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     hipLaunchKernelGGL(k_adam_dense, dim3(grid_for(n, kBlock * 4)), dim3(kBlock), 0, S(stream), W, g, m,
                        v, n, (float)((double)lr / bc1), beta1, beta2, eps, (float)sqrt(bc2));
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int daisy_adam_lazy_table(float lr, float beta1, float beta2, int64_t n_steps, float *table_host) {
+    DAISY_CHECK_ARG(table_host && n_steps >= 1, "adam_lazy_table: bad argument");
+    table_host[0] = table_host[1] = 0.f;                              // step 0 does not exist
+    for (int64_t s = 1; s <= n_steps; ++s) {                          // the host arithmetic of daisy_adam_dense
+        const double bc1 = 1.0 - pow((double)beta1, (double)s), bc2 = 1.0 - pow((double)beta2, (double)s);
+        table_host[2 * s] = (float)((double)lr / bc1);
+        table_host[2 * s + 1] = (float)sqrt(bc2);
+    }
+    return DAISY_OK;
+}
+
+static int adam_lazy_batch(daisy_bpr_ctx *ctx, bool with_g, float *P, float *gP, float *mP, float *vP, int32_t *lastP,
+                           float *Q, float *gQ, float *mQ, float *vQ, int32_t *lastQ, const float *table, float beta1,
+                           float beta2, float eps, int64_t step, hipStream_t s) {
+    if (!ctx->batch_set || ctx->batch_kind != 0) {
+        set_error("adam_lazy: needs a batch of the sorted plan layout / daisy_bpr_set_batch*");
+        return DAISY_ERR_STATE;
+    }
+    const BatchView &v = ctx->v;
+    const AdamTable TP{P, gP, mP, vP, lastP}, TQ{Q, gQ, mQ, vQ, lastQ};
+    const AdamHyper h{reinterpret_cast<const float2 *>(table), beta1, beta2, eps, (int32_t)step};
+    int rc = dispatch_d(ctx->d, [&](auto cfg) {
+        using C = decltype(cfg);
+        const dim3 g(grid_for(v.B, C::GROUPS_PER_BLOCK, 8192));
+        if (with_g) hipLaunchKernelGGL((k_adam_batch_rows<C, true>), g, dim3(kBlock), 0, s, v, ctx->d, TP, TQ, h);
+        else hipLaunchKernelGGL((k_adam_batch_rows<C, false>), g, dim3(kBlock), 0, s, v, ctx->d, TP, TQ, h);
+        return DAISY_OK;
+    });
+    if (rc) return rc;
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int daisy_adam_lazy_catchup(daisy_bpr_ctx *ctx, float *P, float *mP, float *vP, int32_t *lastP, float *Q, float *mQ,
+                            float *vQ, int32_t *lastQ, const float *table, float beta1, float beta2, float eps,
+                            int64_t step, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(ctx && P && mP && vP && lastP && Q && mQ && vQ && lastQ && table && step >= 1, "adam_lazy_catchup: bad argument");
+    return adam_lazy_batch(ctx, false, P, nullptr, mP, vP, lastP, Q, nullptr, mQ, vQ, lastQ, table, beta1, beta2, eps, step,
+                           S(stream));
+}
+
+int daisy_adam_lazy_step(daisy_bpr_ctx *ctx, float *P, float *gP, float *mP, float *vP, int32_t *lastP, float *Q,
+                         float *gQ, float *mQ, float *vQ, int32_t *lastQ, const float *table, float beta1, float beta2,
+                         float eps, int64_t step, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(ctx && P && gP && mP && vP && lastP && Q && gQ && mQ && vQ && lastQ && table && step >= 1,
+                    "adam_lazy_step: bad argument");
+    return adam_lazy_batch(ctx, true, P, gP, mP, vP, lastP, Q, gQ, mQ, vQ, lastQ, table, beta1, beta2, eps, step, S(stream));
+}
+
+int daisy_adam_lazy_flush(float *W, float *m, float *v, int32_t *last, int64_t rows, int32_t d, const float *table,
+                          float beta1, float beta2, float eps, int64_t step, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(W && m && v && last && table && rows > 0 && step >= 0, "adam_lazy_flush: bad argument");
+    const AdamTable T{W, nullptr, m, v, last};
+    const AdamHyper h{reinterpret_cast<const float2 *>(table), beta1, beta2, eps, (int32_t)step};
+    int rc = dispatch_d(d, [&](auto cfg) {
+        using C = decltype(cfg);
+        hipLaunchKernelGGL((k_adam_flush<C>), dim3(grid_for(rows, C::GROUPS_PER_BLOCK * 2)), dim3(kBlock), 0, S(stream), T,
+                           rows, (int)d, h);
+        return DAISY_OK;
+    });
+    if (rc) return rc;
     DAISY_LAUNCH_CHECK();
     return DAISY_OK;
 }

@@ -442,6 +442,58 @@ class DenseOptimizer:
             rmsprop_dense(W, g, st[0], self.lr)
 
 
+class LazyAdam:
+    """torch.optim.Adam (defaults) on the two MF tables with traffic proportional to the rows a step touches, and the
+    same bits as the dense form: rows without a gradient are replayed in registers when next needed
+    (csrc/bpr_train.hip: k_adam_batch_rows / k_adam_flush).  Usage per step: `catchup(ctx)` before the forward
+    pass, `step(ctx, gP, gQ)` after the gradients; `flush()` before anything else reads the tables."""
+
+    BETA1, BETA2, EPS = 0.9, 0.999, 1e-8
+
+    def __init__(self, P, Q, lr, max_steps):
+        self.P, self.Q, self.lr, self.t = P, Q, float(lr), 0
+        self.m = [torch.zeros_like(P), torch.zeros_like(Q)]
+        self.v = [torch.zeros_like(P), torch.zeros_like(Q)]
+        self.last = [torch.zeros(P.shape[0], dtype=torch.int32, device=P.device),
+                     torch.zeros(Q.shape[0], dtype=torch.int32, device=Q.device)]
+        self._table_steps = 0
+        self._table = None
+        self._grow(max(int(max_steps), 1))
+
+    def _grow(self, n_steps):
+        host = (C.c_float * (2 * (n_steps + 1)))()
+        check(lib.daisy_adam_lazy_table(self.lr, self.BETA1, self.BETA2, n_steps, host))
+        self._table = torch.frombuffer(host, dtype=torch.float32).clone().to(self.P.device)
+        self._table_steps = n_steps
+
+    def catchup(self, ctx):
+        self.t += 1
+        if self.t > self._table_steps:
+            self._grow(2 * self.t)
+        f = torch.float32
+        check(lib.daisy_adam_lazy_catchup(
+            ctx._h, _ptr(self.P, f, "P"), _ptr(self.m[0], f, "mP"), _ptr(self.v[0], f, "vP"),
+            _ptr(self.last[0], torch.int32, "lastP"), _ptr(self.Q, f, "Q"), _ptr(self.m[1], f, "mQ"),
+            _ptr(self.v[1], f, "vQ"), _ptr(self.last[1], torch.int32, "lastQ"), _ptr(self._table, f, "table"),
+            self.BETA1, self.BETA2, self.EPS, self.t, _stream()))
+
+    def step(self, ctx, gP, gQ):
+        f = torch.float32
+        check(lib.daisy_adam_lazy_step(
+            ctx._h, _ptr(self.P, f, "P"), _ptr(gP, f, "gP"), _ptr(self.m[0], f, "mP"), _ptr(self.v[0], f, "vP"),
+            _ptr(self.last[0], torch.int32, "lastP"), _ptr(self.Q, f, "Q"), _ptr(gQ, f, "gQ"), _ptr(self.m[1], f, "mQ"),
+            _ptr(self.v[1], f, "vQ"), _ptr(self.last[1], torch.int32, "lastQ"), _ptr(self._table, f, "table"),
+            self.BETA1, self.BETA2, self.EPS, self.t, _stream()))
+
+    def flush(self):
+        f = torch.float32
+        for W, m, v, last in ((self.P, self.m[0], self.v[0], self.last[0]), (self.Q, self.m[1], self.v[1], self.last[1])):
+            check(lib.daisy_adam_lazy_flush(_ptr(W, f, "W"), _ptr(m, f, "m"), _ptr(v, f, "v"),
+                                            _ptr(last, torch.int32, "last"), W.shape[0], W.shape[1],
+                                            _ptr(self._table, f, "table"), self.BETA1, self.BETA2, self.EPS, self.t,
+                                            _stream()))
+
+
 def _bias_ptrs(biases):
     if biases is None:
         return None, None, None

@@ -301,6 +301,27 @@ int daisy_bpr_item_sgd_apply(daisy_bpr_ctx *ctx, float *Q, float *gQ, float lr, 
 int daisy_adam_dense(float *W, float *g, float *m, float *v, int64_t n, float lr, float beta1,
                      float beta2, float eps, int64_t step, daisy_stream_t stream);
 
+/* The same optimiser without moving every row in every step (MF tables; same result bit for bit).  A row's Adam
+ * sequence depends only on its own gradients, so rows without a gradient are left behind and replayed in registers
+ * when they are next needed: last[r] (int32, zero-initialised) = the step row r has been updated to.
+ *   daisy_adam_lazy_table    host: table[2*s], table[2*s+1] = lr/(1-beta1^s), sqrt(1-beta2^s) for s = 1..n_steps
+ *                            (float[2*(n_steps+1)], the host arithmetic of daisy_adam_dense); upload it once.
+ *   daisy_adam_lazy_catchup  before the forward pass of step `step`: every row the current batch references is
+ *                            brought to step-1 (zero-gradient steps replayed).
+ *   daisy_adam_lazy_step     after the gradients: the referenced rows take step `step` with gP / gQ (cleared).
+ *   daisy_adam_lazy_flush    all rows of one table to `step` (end of an epoch / of fit, before anything else reads
+ *                            the table).
+ * The batch is the context's current one (sorted plan layout or daisy_bpr_set_batch*). */
+int daisy_adam_lazy_table(float lr, float beta1, float beta2, int64_t n_steps, float *table_host);
+int daisy_adam_lazy_catchup(daisy_bpr_ctx *ctx, float *P, float *mP, float *vP, int32_t *lastP, float *Q, float *mQ,
+                            float *vQ, int32_t *lastQ, const float *table, float beta1, float beta2, float eps,
+                            int64_t step, daisy_stream_t stream);
+int daisy_adam_lazy_step(daisy_bpr_ctx *ctx, float *P, float *gP, float *mP, float *vP, int32_t *lastP, float *Q,
+                         float *gQ, float *mQ, float *vQ, int32_t *lastQ, const float *table, float beta1, float beta2,
+                         float eps, int64_t step, daisy_stream_t stream);
+int daisy_adam_lazy_flush(float *W, float *m, float *v, int32_t *last, int64_t rows, int32_t d, const float *table,
+                          float beta1, float beta2, float eps, int64_t step, daisy_stream_t stream);
+
 /* torch.optim.Adagrad.step / torch.optim.RMSprop.step with torch's defaults (AbstractRecommender.py:58,60;
  * Adagrad: lr_decay 0, eps 1e-10; RMSprop: alpha 0.99, eps 1e-8, no momentum), dense like the reference;
  * g is zeroed.  (optim.SparseAdam, :62, refuses the reference's dense embedding gradients at its first step:

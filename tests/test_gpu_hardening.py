@@ -218,3 +218,43 @@ def test_rank_truncates_topk_to_the_candidate_count(ops):
     want, _ = O.mf_rank(P.cpu().numpy(), Q.cpu().numpy(), us.cpu().numpy(), cands.cpu().numpy(), 6)
     np.testing.assert_array_equal(ids.cpu().numpy().astype(np.float32), want)
     assert ops.mf_full_rank(P, Q, 2, 100).numel() == 30
+
+
+def test_lazy_adam_equals_dense_adam_bit_for_bit():
+    """ops.LazyAdam (rows without a gradient replayed in registers when next needed) against the dense optimiser
+    that rewrites every row in every step: tables and both moments identical after every flush - batches that touch
+    a small part of large tables, rows touched in consecutive steps, rows never touched, d that does not fill its
+    lanes, more steps than the table was sized for."""
+    from daisyrec_amd import ops
+    from daisyrec_amd.model.AbstractRecommender import _AdamState
+    rng = np.random.default_rng(8)
+    for d, U, I, B, steps in ((64, 5000, 3000, 300, 25), (100, 400, 300, 700, 12), (20, 50, 40, 64, 40)):
+        P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+        Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+        batches = [tuple(torch.from_numpy(rng.integers(0, hi, B).astype(np.int32)).to("cuda") for hi in (U, I, I))
+                   for _ in range(steps)]
+        res = []
+        for lazy in (False, True):
+            P, Q = torch.from_numpy(P0).to("cuda"), torch.from_numpy(Q0).to("cuda")
+            ctx = ops.BprContext(B, d, U, I)
+            st = _AdamState(P, Q, 0.01, None, kind="adam", max_steps=5, lazy=lazy)      # 5: the table must grow
+            snaps = []
+            for k, (u, i, j) in enumerate(batches):
+                ctx.set_batch(u, i, j)
+                st.step(ctx, P, Q, 1e-3, 2e-3, 0, ops.ITEM_MODES["chunked"])
+                if k % 7 == 6 or k == steps - 1:
+                    st.flush()
+                    torch.cuda.synchronize()
+                    snaps.append((P.clone(), Q.clone()))
+            if lazy:
+                mom = (st.lazy.m[0], st.lazy.v[0], st.lazy.m[1], st.lazy.v[1])
+                assert int(st.lazy.last[0].min()) == steps and int(st.lazy.last[1].min()) == steps
+            else:
+                sP, sQ = st.opt._state[P.view(-1).data_ptr()], st.opt._state[Q.view(-1).data_ptr()]
+                mom = (sP[0].view(U, d), sP[1].view(U, d), sQ[0].view(I, d), sQ[1].view(I, d))
+            res.append((snaps, [m.clone() for m in mom]))
+            ctx.close()
+        for (Pa, Qa), (Pb, Qb) in zip(res[0][0], res[1][0]):
+            assert torch.equal(Pa, Pb) and torch.equal(Qa, Qb), (d, U, I, B)
+        for a, b in zip(res[0][1], res[1][1]):
+            assert torch.equal(a, b), (d, U, I, B)
