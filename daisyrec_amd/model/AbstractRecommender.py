@@ -382,14 +382,15 @@ class _AdamState:
     """Dense optimiser state (torch.optim.Adam by default; Adagrad / RMSprop through `kind`) for the two tables
     and, for FM, the three bias tensors (AbstractRecommender.py:54-61)."""
 
-    def __init__(self, P, Q, lr, biases=None, kind="adam", max_steps=0, lazy=True):
+    def __init__(self, P, Q, lr, biases=None, kind="adam", max_steps=0, lazy=False):
         self.opt = ops.DenseOptimizer(kind, lr)
         self.gP = torch.zeros_like(P)
         # FM: gradient buffers of (u_bias, i_bias, bias_)
         self.w = [] if biases is None else [b.view(-1) for b in biases]
         self.g = [torch.zeros_like(b) for b in self.w]
-        # Adam on the two tables alone (MF): the exact lazy form - rows without a gradient are replayed when they are
-        # next needed instead of being rewritten in every step (ops.LazyAdam: same bits as the dense optimiser)
+        # lazy=True, Adam on the two tables alone (MF): the exact lazy form - rows without a gradient are replayed when
+        # they are next needed instead of being rewritten in every step (ops.LazyAdam: same bits as the dense
+        # optimiser); between flush() calls only the rows of the batches seen so far are current
         self.lazy = ops.LazyAdam(P, Q, lr, max_steps) if (lazy and kind == "adam" and biases is None) else None
 
     def step(self, ctx, P, Q, reg_1, reg_2, loss_id, item_mode):
