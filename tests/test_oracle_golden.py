@@ -200,3 +200,51 @@ def test_adagrad_rmsprop_restatements_match_the_reference():
             P, Q = opt.step([P, Q], [gP, gQ])
             np.testing.assert_allclose(P, g[f"{name}/P"][s], atol=3e-6)
             np.testing.assert_allclose(Q, g[f"{name}/Q"][s], atol=3e-6)
+
+
+def test_lazy_adam_replay_is_the_dense_sequence():
+    """The idea behind ops.LazyAdam, on the oracle's DenseAdam: a row's Adam sequence depends only on its own gradients,
+    so leaving rows without a gradient behind and replaying their zero-gradient steps later (per-step constants
+    lr/(1-b1^s), sqrt(1-b2^s)) gives exactly the dense optimiser's tables and moments - same operations in the same
+    order per row, hence bit-identical in any precision."""
+    rng = np.random.default_rng(3)
+    U, d, steps, lr, b1, b2, eps = 40, 5, 30, 0.01, 0.9, 0.999, 1e-8
+    W0 = rng.standard_normal((U, d)).astype(np.float32)
+    touched = [rng.choice(U, size=6, replace=False) for _ in range(steps)]
+    grads = [rng.standard_normal((6, d)).astype(np.float32) for _ in range(steps)]
+
+    def one(w, m, v, g, s):                                 # one row, one step (float32 like the kernels)
+        f = np.float32
+        m = f(b1) * m + f(1 - b1) * g                       # (the exact expression does not matter, only that both
+        v = f(b2) * v + f(1 - b2) * g * g                   #  paths use the same one)
+        denom = np.sqrt(v) / f(np.sqrt(1.0 - b2 ** s)) + f(eps)
+        return (w - f(lr / (1.0 - b1 ** s)) * (m / denom)).astype(f), m.astype(f), v.astype(f)
+
+    # dense: every row every step
+    Wd, Md, Vd = W0.copy(), np.zeros_like(W0), np.zeros_like(W0)
+    for s in range(1, steps + 1):
+        G = np.zeros_like(W0)
+        G[touched[s - 1]] = grads[s - 1]
+        for r in range(U):
+            Wd[r], Md[r], Vd[r] = one(Wd[r], Md[r], Vd[r], G[r], s)
+    # lazy: touched rows catch up, take the step; flush at the end
+    Wl, Ml, Vl, last = W0.copy(), np.zeros_like(W0), np.zeros_like(W0), np.zeros(U, dtype=np.int64)
+    zero = np.zeros(d, dtype=np.float32)
+    for s in range(1, steps + 1):
+        for k, r in enumerate(touched[s - 1]):
+            for q in range(last[r] + 1, s):
+                Wl[r], Ml[r], Vl[r] = one(Wl[r], Ml[r], Vl[r], zero, q)
+            Wl[r], Ml[r], Vl[r] = one(Wl[r], Ml[r], Vl[r], grads[s - 1][k], s)
+            last[r] = s
+    for r in range(U):
+        for q in range(last[r] + 1, steps + 1):
+            Wl[r], Ml[r], Vl[r] = one(Wl[r], Ml[r], Vl[r], zero, q)
+    assert np.array_equal(Wd, Wl) and np.array_equal(Md, Ml) and np.array_equal(Vd, Vl)
+    # and the dense restatement the goldens pin agrees with this row-wise form to round-off
+    opt = O.DenseAdam([W0.shape], lr)
+    W = W0.copy()
+    for s in range(1, steps + 1):
+        G = np.zeros_like(W0)
+        G[touched[s - 1]] = grads[s - 1]
+        (W,) = opt.step([W], [G])
+    np.testing.assert_allclose(W, Wd, rtol=0, atol=2e-6)
