@@ -347,17 +347,23 @@ int daisy_lgcn_spmm_rows(const daisy_lgcn_graph *g, const float *X, float *Yrows
     int64_t e_lo = g->row_ptr_host[row_lo], e_hi = g->row_ptr_host[row_hi];
     if (e_hi == e_lo) return DAISY_OK;
     float *base = Yrows - row_lo * (int64_t)d;                     // row r of the product lands in Yrows[r - row_lo]
-    if (g->reproducible) {
+    // The segmented reduction takes an even number of entries: an odd range borrows one entry of the ADJACENT row, whose
+    // partial sum lands in the spare row the caller provides before / after Yrows.  The entry next to the range belongs
+    // to the next NON-EMPTY row, which is the adjacent one only if that row has entries (isolated nodes are common:
+    // user_num / item_num come from the full dataset, the graph from the train split) - otherwise its partial sum would
+    // land far outside the block, so such a block is summed by the row owners instead.
+    bool owner = g->reproducible != 0;
+    if (!owner && ((e_hi - e_lo) & 1)) {
+        const int64_t *rp = g->row_ptr_host;
+        if (row_hi < N && rp[row_hi + 1] > e_hi) ++e_hi;                  // first entry of row_hi
+        else if (row_lo > 0 && rp[row_lo - 1] < e_lo) --e_lo;             // last entry of row_lo - 1
+        else owner = true;
+    }
+    if (owner) {
         hipLaunchKernelGGL(k_lg_spmm_owner, dim3(grid_for(e_hi - e_lo, kBlock / 16, kMaxGridSparse)), dim3(kBlock), 0, s,
                            g->ekey + e_lo, g->esu + e_lo, g->coef + e_lo, e_hi - e_lo, X, (int)d, base);
         DAISY_LAUNCH_CHECK();
         return DAISY_OK;
-    }
-    // the segmented reduction takes an even number of entries: borrow one entry of the neighbouring row (its partial
-    // sum lands in the spare row the caller provides before / after Yrows)
-    if ((e_hi - e_lo) & 1) {
-        if (e_hi < g->nnz) ++e_hi;
-        else --e_lo;
     }
     int rc = ensure_edges(gm, d);
     if (rc) return rc;

@@ -16,6 +16,7 @@
 //                                                                           daisy_bpr_set_batch + daisy_bpr_sgd_step
 //                                                                           AbstractRecommender.py:119-128
 #include <ATen/ATen.h>
+#include <c10/core/DeviceGuard.h>
 #include <c10/hip/HIPStream.h>
 #include <torch/library.h>
 
@@ -33,6 +34,14 @@ void need(const at::Tensor &t, at::ScalarType dt, const char *name) {
     TORCH_CHECK(t.is_contiguous(), name, ": tensor must be contiguous");
 }
 
+// every tensor of an op lives on the device of its first one; that device becomes the current one for the call, so
+// the library's allocations (contexts), at::empty workspaces and kernel launches all land there
+void same_device(const at::Tensor &first, std::initializer_list<const at::Tensor *> rest, const char *op) {
+    for (const at::Tensor *t : rest)
+        TORCH_CHECK(t->device() == first.device(), op, ": all tensors must be on one device (", first.device(), " vs ",
+                    t->device(), ")");
+}
+
 void ok(int rc) { TORCH_CHECK(rc == DAISY_OK, "daisyrec: ", daisy_last_error()); }
 
 daisy_stream_t stream_of(const at::Tensor &t) {
@@ -42,6 +51,8 @@ daisy_stream_t stream_of(const at::Tensor &t) {
 at::Tensor mf_predict(const at::Tensor &P, const at::Tensor &Q, const at::Tensor &u, const at::Tensor &i) {
     need(P, at::kFloat, "P"); need(Q, at::kFloat, "Q"); need(u, at::kLong, "u"); need(i, at::kLong, "i");
     TORCH_CHECK(P.dim() == 2 && Q.dim() == 2 && P.size(1) == Q.size(1) && u.numel() == i.numel(), "mf_predict: shapes");
+    same_device(P, {&Q, &u, &i}, "mf_predict");
+    const c10::OptionalDeviceGuard guard(P.device());
     at::Tensor out = at::empty({u.numel()}, P.options());
     if (u.numel() == 0) return out;
     ok(daisy_mf_predict(P.data_ptr<float>(), Q.data_ptr<float>(), (int32_t)P.size(1), u.data_ptr<int64_t>(),
@@ -53,6 +64,8 @@ at::Tensor mf_rank_topk(const at::Tensor &P, const at::Tensor &Q, const at::Tens
                         int64_t topk) {
     need(P, at::kFloat, "P"); need(Q, at::kFloat, "Q"); need(us, at::kLong, "us"); need(cands, at::kLong, "cands");
     TORCH_CHECK(cands.dim() == 2 && us.numel() == cands.size(0), "mf_rank_topk: cands must be [len(us), C]");
+    same_device(P, {&Q, &us, &cands}, "mf_rank_topk");
+    const c10::OptionalDeviceGuard guard(P.device());
     const int64_t B = cands.size(0), C = cands.size(1);
     topk = topk < C ? topk : C;                                  // rank_list[:, :topk] truncates
     at::Tensor out = at::empty({B, topk}, cands.options());
@@ -66,6 +79,8 @@ at::Tensor mf_rank_topk(const at::Tensor &P, const at::Tensor &Q, const at::Tens
 
 at::Tensor mf_full_rank(const at::Tensor &P, const at::Tensor &Q, int64_t u, int64_t topk) {
     need(P, at::kFloat, "P"); need(Q, at::kFloat, "Q");
+    same_device(P, {&Q}, "mf_full_rank");
+    const c10::OptionalDeviceGuard guard(P.device());
     const int64_t I = Q.size(0);
     topk = topk < I ? topk : I;
     at::Tensor out = at::empty({topk}, P.options().dtype(at::kLong));
@@ -79,6 +94,8 @@ at::Tensor mf_full_rank(const at::Tensor &P, const at::Tensor &Q, int64_t u, int
 at::Tensor sample_uniform_neg(const at::Tensor &indptr, const at::Tensor &items, int64_t item_num, int64_t num_ng,
                               int64_t seed, int64_t epoch) {
     need(indptr, at::kLong, "indptr"); need(items, at::kInt, "items");
+    same_device(items, {&indptr}, "sample_uniform_neg");
+    const c10::OptionalDeviceGuard guard(items.device());
     const int64_t U = indptr.numel() - 1;
     at::Tensor js = at::empty({U, num_ng}, items.options());
     ok(daisy_sample_neg_per_user(indptr.data_ptr<int64_t>(), items.data_ptr<int32_t>(), U, item_num, (int32_t)num_ng,
@@ -101,6 +118,8 @@ at::Tensor bpr_mf_step(at::Tensor P, at::Tensor Q, const at::Tensor &u, const at
     TORCH_CHECK(P.dim() == 2 && Q.dim() == 2 && P.size(1) == Q.size(1), "bpr_mf_step: tables must be [rows, d]");
     const int64_t B = u.numel();
     TORCH_CHECK(B > 0 && i.numel() == B && j.numel() == B, "bpr_mf_step: u, i, j must have the same length");
+    same_device(P, {&Q, &u, &i, &j}, "bpr_mf_step");
+    const c10::OptionalDeviceGuard guard(P.device());
     int64_t cap = 256;
     while (cap < B) cap *= 2;
     CtxEntry *e;

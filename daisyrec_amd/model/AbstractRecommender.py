@@ -26,6 +26,29 @@ NATIVE_OPTIMIZERS = ("sgd", "adam", "adagrad", "rmsprop")
 KNOWN_OPTIMIZERS = ("adam", "sgd", "adagrad", "rmsprop", "sparse_adam")
 
 
+# 'auto' picks the lazy Adam only when the tables are large enough for the dense pass to matter: below this many
+# table bytes (ml-100k scale: 2.6 k rows) the dense optimiser is one trivial launch and the lazy form only adds two
+# launches per step plus serial replays at every catch-up / flush
+LAZY_ADAM_MIN_TABLE_BYTES = 64 << 20
+
+
+def _parse_lazy_adam(value):
+    """config['lazy_adam']: True / False / 'auto' (yaml and CLI strings included); anything else is an error -
+    bool('false') would silently be True"""
+    if isinstance(value, bool):
+        return value
+    if isinstance(value, (int, float)) and value in (0, 1):
+        return bool(value)
+    key = str(value).strip().lower()
+    if key == "auto":
+        return "auto"
+    if key in ("true", "1", "yes", "on"):
+        return True
+    if key in ("false", "0", "no", "off"):
+        return False
+    raise ValueError(f"config['lazy_adam'] must be True, False or 'auto', got {value!r}")
+
+
 class AbstractRecommender(nn.Module):
     """Reference: AbstractRecommender.py:10-93."""
 
@@ -111,6 +134,13 @@ class GeneralRecommender(AbstractRecommender):
         if "LOCAL_RANK" not in os.environ and not (_dist.is_available() and _dist.is_initialized()):
             os.environ["CUDA_VISIBLE_DEVICES"] = config["gpu"]
         self.device = "cuda" if torch.cuda.is_available() else "cpu"
+        # torchrun exports LOCAL_RANK but neither narrows CUDA_VISIBLE_DEVICES nor selects a device: without this every
+        # rank would allocate on GPU 0 and RCCL would refuse the duplicate device.  'cuda' then means the current
+        # device, i.e. this rank's own (a caller that already chose another device keeps it).
+        if self.device == "cuda" and "LOCAL_RANK" in os.environ and torch.cuda.device_count() > 1:
+            local_rank = int(os.environ["LOCAL_RANK"])
+            if torch.cuda.current_device() == 0 and 0 < local_rank < torch.cuda.device_count():
+                torch.cuda.set_device(local_rank)
         self.logger = config.get("logger") or logging.getLogger("daisyrec_amd")
         # knobs of the native path (absent from the reference config: defaults keep its behaviour)
         # 'fused' (default): the staged step over the partitioned epoch plan (forward fused into the user
@@ -132,7 +162,7 @@ class GeneralRecommender(AbstractRecommender):
         # MF + Adam: the exact lazy row updates of ops.LazyAdam.  'auto': when a step references fewer rows than the
         # tables have (3B < U + I; measured: 1.55x at 10M x 1M with B = 2M, but 0.9x at 1M x 100K with B = 1M, where
         # every step touches most rows anyway and the dense streaming pass is cheaper than row-wise claims)
-        self.lazy_adam = config.get("lazy_adam", "auto")
+        self.lazy_adam = _parse_lazy_adam(config.get("lazy_adam", "auto"))
         self.epoch_losses = []
 
     # -- helpers ---------------------------------------------------------------
@@ -197,6 +227,7 @@ class GeneralRecommender(AbstractRecommender):
         up to summation order (UserShardedBprTrainer: two small all-reduces, reduce-scatter of the item
         gradient, all-gather of the updated item rows per step).  At the end every rank holds the whole P."""
         import torch.distributed as dist
+        from torch.utils.data import SequentialSampler
         from ..sharding import UserShardedBprTrainer, user_range
         world, rank = dist.get_world_size(), dist.get_rank()
         P, Q = self.embed_user.weight.data, self.embed_item.weight.data
@@ -229,8 +260,10 @@ class GeneralRecommender(AbstractRecommender):
                 self.train()
                 if n_loc:
                     plan.build_positions(index, self._epoch_positions(train_loader, n, epoch, row_ids), n, B)
-                else:
-                    self._epoch_positions(train_loader, n, epoch, row_ids)       # keeps the RNG in step with the others
+                elif not (self.shuffle_mode == "device" and not isinstance(train_loader.sampler, SequentialSampler)):
+                    # a rank without rows: the replayed DataLoader pass draws from the torch RNG, which has to stay in
+                    # step with the other ranks; the device shuffle draws nothing (and has no rows to place here)
+                    self._epoch_order(train_loader, len(train_loader.dataset))
                 acc.zero_()
                 for k in range(nb):
                     stats = trainer.step_from_plan(plan, k)
@@ -292,7 +325,9 @@ class GeneralRecommender(AbstractRecommender):
         plan = ops.EpochPlan(n, P.shape[0], Q.shape[0], device=P.device)
         biases = self._biases() if hasattr(self, "_biases") else None     # FM: (u_bias, i_bias, bias_)
         adam = (_AdamState(P, Q, self.lr, biases, kind=opt, max_steps=self.epochs * ((n + B - 1) // B),
-                           lazy=(3 * B < P.shape[0] + Q.shape[0]) if self.lazy_adam == "auto" else bool(self.lazy_adam))
+                           lazy=((3 * B < P.shape[0] + Q.shape[0]
+                                  and (P.numel() + Q.numel()) * 4 >= LAZY_ADAM_MIN_TABLE_BYTES)
+                                 if self.lazy_adam == "auto" else self.lazy_adam))
                 if opt != "sgd" else None)                                                # any dense optimiser but SGD
         if biases is not None:
             g_i_bias = adam.g[1] if adam is not None else torch.zeros(Q.shape[0], device=P.device)

@@ -22,6 +22,9 @@ from .. import _native as N
 from .AbstractRecommender import GeneralRecommender, _tqdm
 
 
+NEUMF_PRECISIONS = {"fp32": 0, "bf16_inputs": 1, "bf16": 2}     # daisy_neumf_ctx_set_precision levels
+
+
 class NeuMF(GeneralRecommender):
     def __init__(self, config):
         """Config keys as in NeuMFRecommender.py:40-78."""
@@ -38,7 +41,10 @@ class NeuMF(GeneralRecommender):
         self.num_layers = int(config["num_layers"])
         # knob of the native path (absent from the reference config): 'fp32' = parity mode (default),
         # 'bf16' = bf16-input MFMA in the MLP tower (throughput mode, BASELINE configs[3])
+        # 'fp32' (parity mode) / 'bf16_inputs' (fp32 in HBM, bf16 MFMA operands) / 'bf16' (bf16-stored activations)
         self.precision = str(config.get("precision", "fp32")).lower()
+        if self.precision not in NEUMF_PRECISIONS:
+            raise ValueError(f"config['precision'] must be one of {sorted(NEUMF_PRECISIONS)}, got {self.precision!r}")
         if self.model not in ("NeuMF-pre",) and self.model not in ops.NEUMF_MODELS:
             # the reference treats every other name as the full model (NeuMFRecommender.py:67-70,118-132)
             self._native_model = "NeuMF"
@@ -134,7 +140,7 @@ class NeuMF(GeneralRecommender):
     def _ctx(self, rows):
         ctx = ops.NeumfContext(rows, self.factors, self.num_layers, self.embed_user_GMF.num_embeddings,
                                self.embed_item_GMF.num_embeddings, model=self._native_model, device=self.device)
-        ctx.set_precision({"fp32": 0, "bf16_inputs": 1, "bf16": 2}.get(self.precision, 0))
+        ctx.set_precision(NEUMF_PRECISIONS[self.precision])
         return ctx
 
     # -- reference surface ---------------------------------------------------------------------------

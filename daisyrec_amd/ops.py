@@ -192,6 +192,8 @@ def feistel_positions(n, seed, epoch=0, device="cuda"):
 def feistel_positions_at(ids, n, seed, epoch=0):
     """pos[k] = position of triple ids[k] in the device shuffle of all n triples (a rank's rows of a multi-GPU fit)."""
     out = torch.empty(ids.shape[0], dtype=torch.int64, device=ids.device)
+    if ids.numel() == 0:            # a rank without rows (the native entry rejects n_ids == 0)
+        return out
     check(lib.daisy_feistel_positions_at(_ptr(ids, torch.int64, "ids"), ids.shape[0], int(n), int(seed), int(epoch),
                                          _ptr(out, torch.int64, "out"), _stream()))
     return out

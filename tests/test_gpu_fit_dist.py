@@ -100,6 +100,15 @@ def test_fit_over_ranks_with_small_lopsided_batches(tmp_path):
     _compare(tmp_path, world, "loader", True, SMALL)
 
 
+def test_fit_over_ranks_lopsided_with_the_device_shuffle(tmp_path):
+    """the same lopsided split with shuffle_mode='device': a rank without rows has no positions to compute (the native
+    entry rejects an empty id list) and must still join every exchange - it used to raise alone and leave the other
+    ranks blocked in their all-reduce"""
+    world = 4
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "device", True, "gloo", SMALL), nprocs=world, join=True)
+    _compare(tmp_path, world, "device", True, SMALL)
+
+
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
 def test_fit_over_rccl_ranks_equals_the_single_process_fit(tmp_path):
     world = min(torch.cuda.device_count(), 8)
@@ -116,6 +125,7 @@ def test_rank_share_plans_tile_the_epoch_plan():
     pos = ops.feistel_positions(n, 7, 2, device=dev)
     some = torch.tensor([0, 5, n - 1, 17, 5], device=dev)
     assert torch.equal(ops.feistel_positions_at(some, n, 7, 2), pos[some])
+    assert ops.feistel_positions_at(some[:0], n, 7, 2).numel() == 0
     whole = ops.EpochPlan(n, U, I, device=dev).build_indexed(ops.TrainIndex(tr, U, I), B, order="feistel", seed=7, epoch=2)
     nb = whole.num_batches
     got = [[] for _ in range(nb)]

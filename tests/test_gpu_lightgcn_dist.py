@@ -53,6 +53,41 @@ def test_row_range_products_tile_the_full_product(reproducible, d):
     g.close()
 
 
+@pytest.mark.parametrize("d", [64, 20])
+def test_row_range_products_with_isolated_nodes_at_the_boundaries(d):
+    """user_num / item_num come from the full dataset, the graph from the train split: nodes without an edge are
+    common.  An odd entry range next to such a node must not spill into a row that is not adjacent (the
+    borrowed entry's partial sum used to land outside the caller's block); the guard rows around every block stay
+    untouched beyond the two spare rows."""
+    from daisyrec_amd import ops
+    rng = np.random.default_rng(11)
+    Uq, Iq, n = 96, 64, 1500
+    N = Uq + Iq
+    for world in (2, 3, 5, 8):
+        rows = (N + world - 1) // world
+        gu, gi = rng.integers(0, Uq, n), rng.integers(0, Iq, n)
+        # empty the nodes on either side of every shard boundary (and one whole shard's first rows)
+        dead = set()
+        for r in range(1, world):
+            dead.update({r * rows - 1, r * rows, r * rows + 1})
+        keep = np.array([(u not in dead) and ((Uq + i) not in dead) for u, i in zip(gu, gi)])
+        gu, gi = gu[keep], gi[keep]
+        if len(gu) % 2 == 0:                                      # make odd ranges likely on both sides
+            gu, gi = gu[:-1], gi[:-1]
+        g = ops.LgcnGraph(torch.from_numpy(gu).to(DEV), torch.from_numpy(gi).to(DEV), Uq, Iq)
+        X = torch.randn(N, d, device=DEV)
+        want = LG.spmm(LG.norm_adj_csr(gu, gi, Uq, Iq), X.cpu().numpy().astype(np.float64))
+        for r in range(world):
+            lo, hi = min(r * rows, N), min((r + 1) * rows, N)
+            guard = 4
+            big = torch.full((rows + 2 + 2 * guard, d), 7.0, device=DEV)
+            blk = big[guard:guard + rows + 2]
+            own = g.spmm_rows(X, blk, lo, hi).cpu().numpy()
+            assert np.abs(own - want[lo:hi]).max() < 2e-6, (world, r)
+            assert bool((big[:guard] == 7.0).all()) and bool((big[guard + rows + 2:] == 7.0).all()), (world, r)
+        g.close()
+
+
 def _train(shard):
     from daisyrec_amd.model.LightGCNRecommender import LightGCN
     from daisyrec_amd.utils.dataset import BasicDataset, get_dataloader

@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--native-sampler", action="store_true", help="also rebind daisy.utils.sampler.BasicNegtiveSampler")
     ap.add_argument("--native-front-end", action="store_true",
                     help="also rebind daisy.utils.utils.get_ur / get_ir / build_candidates_set (no Python row loops)")
+    ap.add_argument("--extra-path", action="append", default=[],
+                    help="directories put in front of sys.path (e.g. a stand-in for a package the image lacks)")
     ap.add_argument("rest", nargs=argparse.REMAINDER)
     a = ap.parse_args()
     rest = a.rest[1:] if a.rest[:1] == ["--"] else a.rest
@@ -49,6 +51,8 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tests", "golden", "_shims"))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.abspath(a.daisy))
+    for extra in a.extra_path:
+        sys.path.insert(0, os.path.abspath(extra))
 
     import daisyrec_amd.dropin as dropin
     dropin.install(sampler=a.native_sampler, front_end=a.native_front_end)
