@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=None,
                     help="interactions per GPU per step (default 2M at N=1, 16M per rank at N>1: DESIGN.md section 5)")
     ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c3", "tiny"])
+    ap.add_argument("--nnz", type=int, default=None,
+                    help="override the workload's interaction count (the table shapes U, I and the batch stay: a shorter "
+                         "epoch of the same per-step regime)")
     ap.add_argument("--item-mode", default="fused", choices=["fused", "chunked", "atomic", "sorted"])
     ap.add_argument("--plan", default="auto", choices=["auto", "indexed", "sorted"],
                     help="epoch plan layout: indexed = partitioned (staged step only), sorted = radix-sorted")
@@ -133,6 +136,9 @@ def run_workload(a, rank, world, dev, wl, want_cpu_batches=0):
     else:
         U_loc, I, nnz_loc, scaling = 20_000, 5_000, 1_000_000, "weak"
         name = "tiny smoke workload (NOT a BASELINE config)"
+    if a.nnz is not None:
+        nnz_loc = a.nnz // world
+        name += f" [interactions cut to {a.nnz}: same tables and batch, shorter epoch]"
     B = a.batch if a.batch is not None else ((1 << 21) if world == 1 else (1 << 24))
     B = min(B, nnz_loc)
     lr, reg = 0.01, a.reg

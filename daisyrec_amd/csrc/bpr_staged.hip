@@ -44,6 +44,27 @@
 
 namespace daisy {
 
+// stage rows: written once by the user pass, read by the item pass of the same step and never again - the stores
+// are nontemporal so that they do not evict the factor tables from L2 / the Infinity Cache (-2.5 % per step at both
+// BASELINE shapes; nontemporal LOADS of the stage measured neutral to slightly worse and stay off)
+#ifndef DAISY_STAGE_NT
+#define DAISY_STAGE_NT 1
+#endif
+#if DAISY_STAGE_NT & 1
+#define DAISY_STAGE_STORE(r, p, l, d) (r).store_nt(p, l, d)
+#else
+#define DAISY_STAGE_STORE(r, p, l, d) (r).store(p, l, d)
+#endif
+#if DAISY_STAGE_NT & 2
+#define DAISY_STAGE_LOAD(r, p, l, d) (r).load_nt(p, l, d)
+#else
+#define DAISY_STAGE_LOAD(r, p, l, d) (r).load(p, l, d)
+#endif
+#ifndef DAISY_ITEM_WINDOW
+#define DAISY_ITEM_WINDOW 1
+#endif
+constexpr int kItemWinFloats = 6144;      // 24 KB of Q rows per workgroup of the item pass (96 rows at d = 64)
+
 constexpr int kStagedUserBlock = 128, kStagedItemBlock = 256;    // threads per workgroup of the two passes (measured:
                                                                  // user pass 387 -> 360 us at 128, item pass indifferent)
 
@@ -856,9 +877,9 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 
                         Row<C> m;
 #pragma unroll
                         for (int k = 0; k < C::NE; ++k) m.v[k] = cp * pr[x].v[k];
-                        m.store(stage + (int64_t)sl * d, lane, d);
+                        DAISY_STAGE_STORE(m, stage + (int64_t)sl * d, lane, d);
                     } else {
-                        pr[x].store(stage + (int64_t)sl * d, lane, d);
+                        DAISY_STAGE_STORE(pr[x], stage + (int64_t)sl * d, lane, d);
                     }
 #pragma unroll
                     for (int k = 0; k < C::NE; ++k)
@@ -985,13 +1006,31 @@ struct ItemEdges2 {
 // what the owner of a finished segment does with  g = sum_e w_e * stage[slot(e)]  and the entry counts:
 //   APPLY:  Q[item] -= lr * (g + reg_1*(np+nn)*sign(q) + reg_2*(np/|Q[i]|_F + nn/|Q[j]|_F)*q)   (MFRecommender.py:88-89)
 //   else:   gQ[item] = g (data term), cnt[item] = (np, nn): what a multi-GPU step reduce-scatters
+// pre-step rows of Q staged in LDS for the commits of one chunk (k_staged_item): rows [first, first + rows)
+struct QWindow { const float *lds; int32_t first, rows; };
+
 template <class C, bool APPLY>
 __device__ __forceinline__ void item_commit(float *__restrict__ Qo, float *__restrict__ cnt_out, int64_t item,
                                             const Row<C> &g, float np, float nn, int lane, int d, float lr,
-                                            float reg_1, float rI, float rJ) {
+                                            float reg_1, float rI, float rJ, const QWindow win = QWindow{nullptr, 0, 0}) {
     if constexpr (APPLY) {
         Row<C> q;
-        q.load(Qo + item * d, lane, d);
+        bool in_lds = false;
+        if constexpr (C::VEC == 4) {
+            const uint32_t off = (uint32_t)((int32_t)item - win.first);
+            if (off < (uint32_t)win.rows) {            // the row waits in LDS: no dependent trip to memory
+                in_lds = true;
+                const float *src = win.lds + (size_t)off * d;
+#pragma unroll
+                for (int c = 0; c < C::NV; ++c) {
+                    const int e = (c * C::LPR + lane) * 4;
+                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (C::EXACT || e < d) t = *reinterpret_cast<const float4 *>(src + e);
+                    q.v[c * 4 + 0] = t.x; q.v[c * 4 + 1] = t.y; q.v[c * 4 + 2] = t.z; q.v[c * 4 + 3] = t.w;
+                }
+            }
+        }
+        if (!in_lds) q.load(Qo + item * d, lane, d);
         const float w1 = reg_1 * (np + nn), w2 = np * rI + nn * rJ;
 #pragma unroll
         for (int k = 0; k < C::NE; ++k) {
@@ -1031,6 +1070,12 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     __shared__ float part_acc[2 * G * ROWF];               // [group][head|tail] parked partial sums
     __shared__ float part_np[2 * G], part_nn[2 * G];
     __shared__ int part_slot[2 * G];                       //      the slot each belongs to (-1: unused)
+    // Q rows of the chunk's item range [first item, last item], copied by LDS-DMA while the stage rows are in flight:
+    // a commit inside the reduction then costs no dependent trip to memory (at a few entries per item - 10 M x 1 M
+    // shapes - 355 -> 320 us per pass).  Only for d % 4 == 0 (16-byte units); rows past the window (sparse batches: few
+    // entries spread over many items) are loaded directly.
+    constexpr bool WIN = APPLY && C::VEC == 4 && DAISY_ITEM_WINDOW;
+    __shared__ __attribute__((aligned(16))) float qwin[WIN ? kItemWinFloats : 4];
 
     const int tid = threadIdx.x;
     const int lane = tid % C::LPR;
@@ -1062,6 +1107,24 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         const int32_t item_prev = (cnt > 0 && t0 > 0) ? (int32_t)(k_prev >> 1) : -1;
         const int32_t item_next = (cnt > 0 && t1 < n) ? (int32_t)(k_next >> 1) : -1;
         const int32_t chunk_prev_item = (c0 > 0) ? (int32_t)(k_cprev >> 1) : -1;
+        QWindow win{qwin, 0, 0};
+        if constexpr (WIN) {
+            const int64_t c1 = (c0 + E < n) ? (c0 + E) : n;
+            win.first = (int32_t)((v.e_key[c0] & v.imask) >> 1);
+            const int32_t item_hi = (int32_t)((v.e_key[c1 - 1] & v.imask) >> 1);
+            const int32_t cap = kItemWinFloats / d;
+            win.rows = (item_hi - win.first + 1 < cap) ? (item_hi - win.first + 1) : cap;
+            const int units = win.rows * (d >> 2);                      // 16-byte units, contiguous in Q
+            const float *src = Qo + (int64_t)win.first * d;
+            const int wave_base = __builtin_amdgcn_readfirstlane((tid / kWave) * kWave);
+            for (int u0 = 0; u0 < units; u0 += BLK) {                   // (workgroup-uniform trip count)
+                const int u = u0 + tid;
+                if (u < units)
+                    __builtin_amdgcn_global_load_lds(src + 4 * (int64_t)u,
+                                                     (__attribute__((address_space(3))) void *)(qwin + 4 * (u0 + wave_base)),
+                                                     16, 0, 0);
+            }
+        }
         if (tid < 2 * G) part_slot[tid] = -1;
         if (tid <= G) { slot_item[tid] = -1; slot_shared[tid] = 0; }
         const int32_t item_first = group_bcast<C>(my_item, 0);
@@ -1082,15 +1145,16 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         Row<C> p[RUN];
         if (__all(cnt == RUN)) {        // wave-uniform: every run of this wave is full
 #pragma unroll
-            for (int x = 0; x < RUN; ++x) p[x].load(stage + (int64_t)group_bcast<C>(slot_me, x) * d, lane, d);
+            for (int x = 0; x < RUN; ++x) DAISY_STAGE_LOAD(p[x], stage + (int64_t)group_bcast<C>(slot_me, x) * d, lane, d);
         } else {
 #pragma unroll
             for (int x = 0; x < RUN; ++x) {
                 const uint32_t sx = group_bcast<C>(slot_me, x);
-                if (x < cnt) p[x].load(stage + (int64_t)sx * d, lane, d);
+                if (x < cnt) DAISY_STAGE_LOAD(p[x], stage + (int64_t)sx * d, lane, d);
                 else p[x].zero();
             }
         }
+        if constexpr (WIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the window has landed before anyone reads it
         __syncthreads();
 
         if (cnt > 0) {
@@ -1112,7 +1176,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             float np = 0.f, nn = 0.f;
             auto finish = [&](bool ends_here, bool to_next_chunk) {
                 if (cur_slot < 0 && ends_here) {    // interior: this group owns the item's row
-                    item_commit<C, APPLY>(Qo, cnt_out, cur_item, acc, np, nn, lane, d, lr, reg_1, rI, rJ);
+                    item_commit<C, APPLY>(Qo, cnt_out, cur_item, acc, np, nn, lane, d, lr, reg_1, rI, rJ, win);
                 } else {                            // crosses a run boundary: park it for the slot's finisher
                     const int s = (cur_slot >= 0) ? cur_slot : group + 1;
                     const int q = group * 2 + ((cur_slot >= 0) ? 0 : 1);
@@ -1180,7 +1244,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                     if (from_prev && to_next) ed.whole[chunk] = 1;
                 }
             } else {
-                item_commit<C, APPLY>(Qo, cnt_out, r, g, sp, sn, lane, d, lr, reg_1, rI, rJ);
+                item_commit<C, APPLY>(Qo, cnt_out, r, g, sp, sn, lane, d, lr, reg_1, rI, rJ, win);
             }
         }
         __syncthreads();   // the slots are reused by the next chunk

@@ -145,6 +145,37 @@ struct Row {
             }
         }
     }
+    // streaming flavours (nontemporal: the line is not kept in L2 / the Infinity Cache): rows that are written once
+    // and read once by a LATER kernel - the stage of the staged step - should not evict the factor tables
+    __device__ __forceinline__ void load_nt(const float *__restrict__ row, int lane, int d) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int c = 0; c < C::NV; ++c) {
+            const int e = (c * C::LPR + lane) * C::VEC;
+            if constexpr (C::VEC == 4) {
+                v4f t = {0.f, 0.f, 0.f, 0.f};
+                if (C::EXACT || e < d) t = __builtin_nontemporal_load(reinterpret_cast<const v4f *>(row + e));
+                v[c * 4 + 0] = t.x; v[c * 4 + 1] = t.y; v[c * 4 + 2] = t.z; v[c * 4 + 3] = t.w;
+            } else {
+                v[c] = (C::EXACT || e < d) ? __builtin_nontemporal_load(row + e) : 0.f;
+            }
+        }
+    }
+    __device__ __forceinline__ void store_nt(float *__restrict__ row, int lane, int d) const {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+#pragma unroll
+        for (int c = 0; c < C::NV; ++c) {
+            const int e = (c * C::LPR + lane) * C::VEC;
+            if (C::EXACT || e < d) {
+                if constexpr (C::VEC == 4) {
+                    const v4f t = {v[c * 4 + 0], v[c * 4 + 1], v[c * 4 + 2], v[c * 4 + 3]};
+                    __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(row + e));
+                } else {
+                    __builtin_nontemporal_store(v[c], row + e);
+                }
+            }
+        }
+    }
     __device__ __forceinline__ void store(float *__restrict__ row, int lane, int d) const {
 #pragma unroll
         for (int c = 0; c < C::NV; ++c) {
@@ -269,6 +300,10 @@ inline int dispatch_d(int d, F &&f) {
         set_error("unsupported factor count d=%d (1..%d)", d, kMaxD);
         return DAISY_ERR_ARG;
     }
+#ifdef DAISY_ONLY_D64       // development builds (make dev): one row shape, a tenth of the compile time
+    if (d != 64) { set_error("this development build of the library only has d=64 (got %d)", d); return DAISY_ERR_ARG; }
+    return f(RowCfg<16, 4, 1, true>{});
+#else
     if (d == 32) return f(RowCfg<8, 4, 1, true>{});
     if (d == 64) return f(RowCfg<16, 4, 1, true>{});
     if (d == 128) return f(RowCfg<16, 4, 2, true>{});
@@ -283,6 +318,7 @@ inline int dispatch_d(int d, F &&f) {
     if (d <= 64) return f(RowCfg<16, 1, 4>{});
     if (d <= 256) return f(RowCfg<16, 1, 16>{});
     return f(RowCfg<32, 1, 16>{});
+#endif
 }
 
 // ----------------------------------------------------------------------------
