@@ -371,7 +371,8 @@ def expand_triples(users, pos_items, js):
 # --------------------------------------------------------------------------
 # Device shuffle (DAISY_ORDER_FEISTEL): a keyed bijection of [0, n) that stands in
 # for RandomSampler's torch.randperm (dataset.py:5-7, shuffle=True) on the
-# throughput path.  4-round balanced Feistel network on 2h bits, a two-step
+# throughput path.  4-round Feistel network on ceil(log2 n) bits (halves of a and b = a or a+1
+# bits that swap places every round: balanced for an even bit count), a two-step
 # multiply-xorshift round function on 24-bit multiplies (full-rate on CDNA),
 # Philox round keys, cycle walking.
 # --------------------------------------------------------------------------
@@ -407,19 +408,19 @@ def feistel_positions(n, seed, epoch=0):
     assert n <= (1 << 30)
     bits = 2
     while bits < 30 and (1 << bits) < n:
-        bits += 2
-    h = np.uint64(bits // 2)
-    mask = np.uint64((1 << (bits // 2)) - 1)
+        bits += 1                                   # the smallest power-of-two domain >= n
+    a, b = bits // 2, bits - bits // 2              # halves of a and b bits (b = a or a + 1), swapping places every round
+    mask_a, mask_b = np.uint64((1 << a) - 1), np.uint64((1 << b) - 1)
     keys = [np.uint64(_draw_u64(seed, epoch | (1 << 61), r) & _M32) for r in range(FEISTEL_ROUNDS)]
     x = np.arange(n, dtype=np.uint64)
     todo = np.ones(n, dtype=bool)
     while todo.any():
         v = x[todo]
-        L, R = v >> h, v & mask
-        for r in range(FEISTEL_ROUNDS):
-            f = _feistel_round(R, keys[r]) & mask
-            L, R = R, L ^ f
-        v = (L << h) | R
+        L, R = v >> np.uint64(b), v & mask_b
+        for r in range(0, FEISTEL_ROUNDS, 2):
+            L, R = R, L ^ (_feistel_round(R, keys[r]) & mask_a)
+            L, R = R, L ^ (_feistel_round(R, keys[r + 1]) & mask_b)
+        v = (L << np.uint64(b)) | R
         x[todo] = v
         todo[todo] = v >= np.uint64(n)
     return x.astype(np.int64)

@@ -70,6 +70,43 @@ def main():
     for _ in range(3):
         step()
     ms = ev_time(step, steps)
+    ov = os.environ.get("PROBE_OVERLAP", "")
+    if ov:
+        # epochs with the NEXT epoch's plan built on a side stream while this epoch's steps run
+        lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
+        main = torch.cuda.Stream(device=dev, priority=-1) if ov == "prio" else torch.cuda.current_stream()
+        side = torch.cuda.Stream(device=dev, priority=0)
+        plans = [plan, ops.EpochPlan(n, U, I, device=dev)]
+        plans[1].build_indexed(index, B, order="feistel", seed=1, epoch=99)
+        torch.cuda.synchronize()
+
+        def epochs(E):
+            cur = 0
+            ready = None
+            with torch.cuda.stream(main):
+                for e in range(E):
+                    if ready is not None:
+                        main.wait_event(ready)
+                    side.wait_stream(main)                   # the other plan's last epoch has been consumed
+                    with torch.cuda.stream(side):
+                        plans[cur ^ 1].build_indexed(index, B, order="feistel", seed=1, epoch=100 + e)
+                        ready = side.record_event()
+                    for kk in range(nb):
+                        ctx.set_batch_from_plan(plans[cur], kk)
+                        ctx.sgd_step(P, Q, 0.01, 1e-3, 1e-3, item_mode=ops.ITEM_MODES["fused"])
+                    cur ^= 1
+
+        epochs(1)
+        torch.cuda.synchronize()
+        E = 3
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(main)
+        epochs(E)
+        b.record(main)
+        torch.cuda.synchronize()
+        tot_ov = a.elapsed_time(b) / (E * nb)
+        print(f"[{wl} {tag}] overlap={ov}: {tot_ov * 1e3:.1f} us/step incl. plan  frac(total) {1548 * B / (tot_ov * 1e-3) / 8e12:.3f}  "
+              f"(sequential: {(ms + plan_ms / nb) * 1e3:.1f})", flush=True)
     loss, bad = (float(x) for x in ctx.epoch_acc.cpu())
     per_step_plan = plan_ms / nb
     tot = ms + per_step_plan
