@@ -32,7 +32,13 @@ struct BatchView {
     // written by the gradient-output user pass (Adam); the SGD user pass updates bu and b0 in place.
     float *bu, *bi, *b0;
     float *g_bu, *g_bi, *g_b0;
+    // set for the duration of daisy_bpr_sgd_step / daisy_bpr_fit_epoch_sgd: the epoch's count of non-finite step
+    // losses (epoch_acc[1]).  Once it is > 0 every kernel that changes a table returns at once: the epoch stops at its
+    // first non-finite loss like the reference's loop (AbstractRecommender.py:122-123), with one host sync per epoch
+    const double *halt;
 };
+
+__device__ __forceinline__ bool halted(const double *halt) { return halt != nullptr && *halt > 0.0; }
 
 }  // namespace daisy
 
@@ -53,6 +59,7 @@ struct StreamView {
     int32_t e_stride;
     uint32_t pos_base;
     int64_t B, E;
+    const double *halt;      // see BatchView::halt
 };
 }  // namespace daisy
 

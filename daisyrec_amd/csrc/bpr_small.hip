@@ -206,6 +206,11 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
         }
         __syncthreads();
         const float rU = s_inv[0], rI = s_inv[1], rJ = s_inv[2];
+        // AbstractRecommender.py:122-123: a non-finite loss ends the training BEFORE that step's backward.  The loss is
+        // finite iff its seven sums are; every thread reads the same seven words, so the exit is uniform.
+        bool finite = true;
+#pragma unroll
+        for (int q = 0; q <= DAISY_ST_SQ_J; ++q) { const double x = s_stats[q]; finite = finite && (x == x) && !isinf(x); }
         if (tid == 0) {       // MFRecommender.py:88-89,94-95 (slots 7..10 are written here and read by nobody until the end)
             const double nU = s_stats[DAISY_ST_NORM_U], nI = s_stats[DAISY_ST_NORM_I], nJ = s_stats[DAISY_ST_NORM_J];
             const double loss = s_stats[DAISY_ST_LOSS_DATA] +
@@ -216,6 +221,7 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
             if (!(loss == loss) || isinf(loss)) nan_epoch += 1.0;
             if (step_losses) step_losses[k] = loss;
         }
+        if (!finite) break;    // the tables stay as step k-1 left them; the host raises when it reads epoch_acc[1]
 
         // ---- B, item side: entries sorted by item; the head of a run owns Q[item]
         const int nE = 2 * Bk;

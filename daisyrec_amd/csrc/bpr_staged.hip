@@ -295,6 +295,9 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(PartSrc src, PosF
         for (int x = tid; x < cnt; x += kPartThreads) {
             const uint32_t dg = sdig[x];
             const int64_t o = (int64_t)goff[dg] + (x - tstart[dg]);
+#ifdef DAISY_PART_NOSTORE
+            if (o != 0x7fffffffffff) continue;
+#endif
             if constexpr (SAMPLES) {
                 const uint4 q = rec4[x];
                 dst.user[o] = q.x;
@@ -403,6 +406,7 @@ StreamView plan_stream_view(const daisy_epoch_plan *p, int64_t k) {
     v.e_stride = 1;
     v.umask = v.imask = 0xFFFFFFFFu;
     v.pos_base = pos_base;
+    v.halt = nullptr;
     return v;
 }
 
@@ -718,6 +722,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 
     float lr, float reg_1, float reg_2, int loss_type, float gamma, float *__restrict__ stage,
     float2 *__restrict__ coef, float *__restrict__ p_sqnorm, double *__restrict__ partials, UserEdges ed,
     PreNorm pre) {
+    if (halted(v.halt)) return;            // an earlier step of this epoch had a non-finite loss: the epoch has stopped
     constexpr int G = StagedUserCfg<C, BLK>::G, RUN = StagedUserCfg<C, BLK>::RUN, E = StagedUserCfg<C, BLK>::E;
     constexpr int ROWF = C::NE * C::LPR;
     __shared__ float part_acc[2 * G * ROWF];
@@ -959,7 +964,8 @@ __global__ __launch_bounds__(kBlock) void k_staged_user_edges(float *__restrict_
                                                               const double *__restrict__ stats, float lr,
                                                               float reg_1, float reg_2, UserEdges ed,
                                                               float *__restrict__ p_sqnorm, PreNorm pre,
-                                                              ReduceJob red) {
+                                                              ReduceJob red, const double *__restrict__ halt) {
+    if (halted(halt)) return;              // (the riding reduction too: the epoch's sums stay at the offending step)
     const double sq_pre = prenorm_sum(stats, pre);
     unsigned nb = gridDim.x, bid = blockIdx.x;
     if (red.nblocks > 0) {            // workgroup 0 (dispatched first: its chain of dependent loads is the longest)
@@ -1054,6 +1060,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                                                         const double *__restrict__ stats, float lr,
                                                         float reg_1, float reg_2, ItemEdges2 ed,
                                                         const int64_t *__restrict__ erange) {
+    if (halted(v.halt)) return;            // this step's loss (reduced behind the user pass) or an earlier one was not finite
     constexpr int G = StagedItemCfg<C, BLK>::G, RUN = StagedItemCfg<C, BLK>::RUN, E = StagedItemCfg<C, BLK>::E;
     // erange: only the entries [erange[0], erange[1]) - an item range of the batch (the entries are sorted by item, so
     // no segment crosses the cut and the piece is reduced exactly like a whole batch).  Multi-GPU steps cut the item
@@ -1258,7 +1265,9 @@ __global__ __launch_bounds__(kBlock) void k_staged_item_edges(ItemEdges2 ed, int
                                                               float *__restrict__ Qo, float *__restrict__ cnt_out,
                                                               const double *__restrict__ stats, float lr,
                                                               float reg_1, float reg_2,
-                                                              const int64_t *__restrict__ erange, int chunk_entries) {
+                                                              const int64_t *__restrict__ erange, int chunk_entries,
+                                                              const double *__restrict__ halt) {
+    if (halted(halt)) return;
     if (erange) nchunks = (erange[1] - erange[0] + chunk_entries - 1) / chunk_entries;      // chunks of the slice
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
@@ -1417,7 +1426,7 @@ static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_ty
         if (overflow) return DAISY_OK;
         const ReduceJob red{ctx->partials, ride_reduce ? *grid_out : 0, stats, epoch_acc, step_loss};
         hipLaunchKernelGGL((k_staged_user_edges<C>), dim3(grid_for(nchunks_out, C::GROUPS_PER_BLOCK) + (ride_reduce ? 1 : 0)),
-                           dim3(kBlock), 0, s, P, nchunks_out, d, stats, lr, reg_1, reg_2, ed, ctx->p_sqnorm, pre, red);
+                           dim3(kBlock), 0, s, P, nchunks_out, d, stats, lr, reg_1, reg_2, ed, ctx->p_sqnorm, pre, red, v.halt);
         return DAISY_OK;
     });
     if (rc) return rc;
@@ -1449,7 +1458,7 @@ static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_
                 hipLaunchKernelGGL((k_staged_item<C, BLK, PM, AP>), g, b, 0, s, ctx->p_stage, ctx->coef, v, d, Qo, cnt_out, \
                                    stats, lr, reg_1, reg_2, ed, erange);                                             \
                 hipLaunchKernelGGL((k_staged_item_edges<C, AP>), ge, dim3(kBlock), 0, s, ed, nchunks, d, Qo, cnt_out, stats, lr, \
-                                   reg_1, reg_2, erange, StagedItemCfg<C, BLK>::E);                                  \
+                                   reg_1, reg_2, erange, StagedItemCfg<C, BLK>::E, v.halt);                          \
             } while (0)
             if (premul && apply) DAISY_LAUNCH_SI(true, true);
             else if (premul) DAISY_LAUNCH_SI(true, false);
@@ -1457,9 +1466,7 @@ static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_
             else DAISY_LAUNCH_SI(false, false);
 #undef DAISY_LAUNCH_SI
         };
-        static const int tune_iblk = getenv("DAISY_STAGED_IBLK") ? atoi(getenv("DAISY_STAGED_IBLK")) : 0;
-        if (tune_iblk == 128 && C::NE == 4 && C::LPR == 16) go(std::integral_constant<int, 128>{});      // (A/B knob, d = 64 only)
-        else go(std::integral_constant<int, kStagedItemBlock>{});
+        go(std::integral_constant<int, kStagedItemBlock>{});        // (128-thread workgroups measured the same, r02 / r03)
         return DAISY_OK;
     });
     if (rc) return rc;

@@ -277,6 +277,7 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_atomic(
     const float *__restrict__ P, const float *__restrict__ Q, BatchView v,
     const float2 *__restrict__ coef, int d, const double *__restrict__ stats, float reg_1,
     float reg_2, float *__restrict__ gQ) {
+    if (halted(v.halt)) return;
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
@@ -323,6 +324,7 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_sorted(
     const float *__restrict__ P, const float *__restrict__ Q, const float2 *__restrict__ coef,
     BatchView v, int d, const double *__restrict__ stats, float reg_1, float reg_2,
     float *__restrict__ gQ) {
+    if (halted(v.halt)) return;
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
@@ -393,6 +395,7 @@ struct ItemEdges {
     int32_t *item;       // [2*nchunks]     their item (-1: none)
     float *b;            // [2*nchunks]     FM: partial coefficient sums
     int32_t *whole;      // [nchunks]       the head edge's segment also runs on into the next chunk
+    const double *halt = nullptr;   // BatchView::halt of the step the records belong to
 };
 
 template <class C, int RUN_OVERRIDE = 0, bool DET = false, bool XH = false>      // XH: the gathered rows are bf16
@@ -400,6 +403,7 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
                                                               const float2 *__restrict__ coef,
                                                               BatchView v, int d,
                                                               float *__restrict__ gQ, ItemEdges edges = ItemEdges{}) {
+    if (halted(v.halt)) return;
     constexpr int G = RunCfg<C, RUN_OVERRIDE>::G, RUN = RunCfg<C, RUN_OVERRIDE>::RUN,
                   E = RunCfg<C, RUN_OVERRIDE>::E;
     constexpr int ROWF = C::NE * C::LPR;
@@ -599,6 +603,7 @@ __global__ __launch_bounds__(kBlock) void k_item_grad_chunked(const float *__res
 template <class C>
 __global__ __launch_bounds__(kBlock) void k_item_edges(ItemEdges edges, int64_t nchunks, int d,
                                                        float *__restrict__ gQ, float *__restrict__ g_bi) {
+    if (halted(edges.halt)) return;
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
@@ -640,6 +645,7 @@ template <class C>
 __global__ __launch_bounds__(kBlock) void k_item_reg(const float *__restrict__ Q, BatchView v, int d,
                                                      const double *__restrict__ stats, float reg_1,
                                                      float reg_2, float *__restrict__ gQ) {
+    if (halted(v.halt)) return;
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
@@ -670,6 +676,7 @@ __global__ __launch_bounds__(kBlock) void k_user(float *__restrict__ P, const fl
                                                  BatchView v, const float2 *__restrict__ coef, int d,
                                                  const double *__restrict__ stats, float lr,
                                                  float reg_1, float reg_2, float *__restrict__ gP) {
+    if (halted(v.halt)) return;
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
@@ -725,6 +732,7 @@ __global__ __launch_bounds__(kBlock) void k_item_apply(float *__restrict__ Q, fl
                                                        BatchView v, int64_t n_dense, int d, float lr,
                                                        int dense, const double *__restrict__ stats,
                                                        float reg_1, float reg_2) {
+    if (halted(v.halt)) return;
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
@@ -796,6 +804,7 @@ __global__ __launch_bounds__(kBlock) void k_user_chunked(
     int d, const double *__restrict__ stats, float lr, float reg_1, float reg_2,
     float *__restrict__ edge_vec, int32_t *__restrict__ edge_user, float *__restrict__ edge_n,
     int32_t *__restrict__ edge_whole) {
+    if (halted(v.halt)) return;
     constexpr int G = UserRunCfg<C>::G, RUN = UserRunCfg<C>::RUN, E = UserRunCfg<C>::E;
     constexpr int ROWF = C::NE * C::LPR;
     // run-crossing partial sums are parked per group (<= 2: the run it continues, the run it hands on)
@@ -989,7 +998,8 @@ __global__ __launch_bounds__(kBlock) void k_user_edges(float *__restrict__ P, in
                                                        const int32_t *__restrict__ edge_user,
                                                        const float *__restrict__ edge_n,
                                                        const int32_t *__restrict__ edge_whole,
-                                                       float *__restrict__ u_bias) {
+                                                       float *__restrict__ u_bias, const double *__restrict__ halt) {
+    if (halted(halt)) return;
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
@@ -1337,6 +1347,7 @@ static BatchView plan_view(const daisy_epoch_plan *p, int64_t k) {
     v.imask = p->imask;
     v.pointwise = p->pointwise;
     v.bu = v.bi = v.b0 = v.g_bu = v.g_bi = v.g_b0 = nullptr;
+    v.halt = nullptr;
     return v;
 }
 
@@ -1359,6 +1370,7 @@ static StreamView stream_view_of(const BatchView &v) {
     sv.e_key = v.ekey; sv.e_pos = reinterpret_cast<const uint32_t *>(v.esu); sv.e_stride = 2;
     sv.umask = v.umask; sv.imask = v.imask; sv.pos_base = 0;
     sv.B = v.B; sv.E = 2 * v.B;
+    sv.halt = nullptr;
     return sv;
 }
 
@@ -1795,7 +1807,7 @@ static int item_grad_impl(daisy_bpr_ctx *ctx, const float *P, const float *Q, co
                                    dim3(kBlock), 0, s, P, ctx->coef, v, d, gQ);
             else if (tune_det) {
                 const int64_t nchunks = (2 * v.B + RunCfg<C>::E - 1) / RunCfg<C>::E;
-                ItemEdges ed{ctx->edge_vec, ctx->edge_user, ctx->edge_n, ctx->edge_whole};
+                ItemEdges ed{ctx->edge_vec, ctx->edge_user, ctx->edge_n, ctx->edge_whole, v.halt};
                 hipLaunchKernelGGL((k_item_grad_chunked<C, 0, true>), dim3(grid_for(2 * v.B, RunCfg<C>::E, tune_cap)),
                                    dim3(kBlock), 0, s, P, ctx->coef, v, d, gQ, ed);
                 hipLaunchKernelGGL((k_item_edges<C>), dim3(grid_for(nchunks, C::GROUPS_PER_BLOCK)), dim3(kBlock), 0, s,
@@ -1878,7 +1890,7 @@ static int user_pass(daisy_bpr_ctx *ctx, float *P, const float *Q, const double 
                                ctx->edge_user, ctx->edge_n, ctx->edge_whole);
             hipLaunchKernelGGL((k_user_edges<C>), dim3(grid_for(nchunks, C::GROUPS_PER_BLOCK)),
                                dim3(kBlock), 0, s, P, nchunks, d, stats, lr, reg_1, reg_2, ctx->edge_vec,
-                               ctx->edge_user, ctx->edge_n, ctx->edge_whole, v.bu);
+                               ctx->edge_user, ctx->edge_n, ctx->edge_whole, v.bu, v.halt);
         } else if (sgd)
             hipLaunchKernelGGL((k_user<C, true>), dim3(grid), dim3(kBlock), 0, s, P, Q, v, ctx->coef, d,
                                stats, lr, reg_1, reg_2, gP);
@@ -2045,6 +2057,14 @@ int daisy_bpr_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t loss_type
                        daisy_stream_t stream) {
     DAISY_CHECK_ARG(ctx && P && Q && stats, "sgd_step: NULL argument");
     if (!ctx->batch_set) { set_error("sgd_step: no batch set"); return DAISY_ERR_STATE; }
+    // with an epoch accumulator the step belongs to an epoch loop: it does nothing once a step of the epoch has had a
+    // non-finite loss (AbstractRecommender.py:122-123 raises before that step's backward; here the phase kernels stop
+    // exactly there, the staged step has already moved the user rows of the offending step when its loss is known)
+    struct HaltScope {
+        daisy_bpr_ctx *c;
+        HaltScope(daisy_bpr_ctx *c_, const double *h) : c(c_) { c->v.halt = h; c->sv.halt = h; }
+        ~HaltScope() { c->v.halt = nullptr; c->sv.halt = nullptr; }
+    } halt_scope(ctx, epoch_acc ? epoch_acc + 1 : nullptr);
     if (item_mode == DAISY_ITEM_FUSED) {
         // the staged step (bpr_staged.hip): pairwise losses without FM biases; anything else runs the phase kernels
         if (staged_supported(ctx, loss_type))

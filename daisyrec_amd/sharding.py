@@ -94,6 +94,7 @@ class UserShardedBprTrainer:
         self._native_rs = self.collective and dist.get_backend(group) == "nccl"
         self.slices = min(16, max(1, int(slices))) if self.staged and hasattr(ctx, "staged_item_slice") else 1
         self.side = None
+        self.timeline = None         # enable_timing(): per-step (start, compute queued, end) events
         if self.staged:
             I, d = Q.shape
             S = self.slices
@@ -109,6 +110,37 @@ class UserShardedBprTrainer:
             self.Q_gather = Q if Ipad == I else torch.zeros(Ipad, d, dtype=torch.float32, device=Q.device)
             self.own_lo = self.rank * self.rows                     # (of slice 0; slice s: + s*world*rows)
             self.own_hi = min(self.own_lo + self.rows, I)
+
+    # -- instrumentation -------------------------------------------------------------------------
+    def enable_timing(self, on=True):
+        """Record three events per step on the step's stream: start / the step's own kernels all queued, the item
+        exchange about to be waited for / end.  `step_split()` then reports, per step, the time up to the second
+        event ("compute": kernels plus the two small all-reduces they wait for) and the time after it ("exposed
+        exchange": reduce-scatter, owner update, all-gather as far as they did not hide under the item pass)."""
+        self.timeline = [] if (on and self.Q.is_cuda) else None
+
+    def _mark(self, which):
+        if self.timeline is None:
+            return
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream(self.Q.device))
+        if which == 0:
+            self.timeline.append([ev, None, None])
+        else:
+            self.timeline[-1][which] = ev
+
+    def step_split(self, last=None):
+        """(compute_ms, exposed_exchange_ms) averaged over the last `last` timed steps (synchronises)"""
+        if not self.timeline:
+            return None
+        torch.cuda.synchronize(self.Q.device)
+        rows = [t for t in self.timeline if t[1] is not None and t[2] is not None]
+        rows = rows[-last:] if last else rows
+        if not rows:
+            return None
+        comp = sum(t[0].elapsed_time(t[1]) for t in rows) / len(rows)
+        exch = sum(t[1].elapsed_time(t[2]) for t in rows) / len(rows)
+        return comp, exch
 
     # -- collectives -----------------------------------------------------------------------------
     def _all_reduce(self, t, async_op=False):
@@ -165,6 +197,7 @@ class UserShardedBprTrainer:
 
     def _step_staged(self):
         c, I = self.ctx, self.Q.shape[0]
+        self._mark(0)
         c.staged_prenorm(self.P)
         self._all_reduce(c.stats[N.ST_SQ_U_PRE:N.ST_SQ_U_PRE + 1])
         c.staged_user(self.P, self.Q, self.lr, self.reg_1, self.reg_2, self.loss_type, self.gamma)
@@ -175,7 +208,10 @@ class UserShardedBprTrainer:
             if w0 is not None:
                 w0.wait()
             c.finalize(self.reg_1, self.reg_2)           # every rank: the GLOBAL loss and norms
-            return self._exchange_items()
+            self._mark(1)
+            out = self._exchange_items()
+            self._mark(2)
+            return out
         # item pass range by range; the exchange of range s runs on the side stream under the pass over range s+1
         c.staged_item_slices(self.bounds)
         fin = None
@@ -186,7 +222,9 @@ class UserShardedBprTrainer:
                     w0.wait()
                 c.finalize(self.reg_1, self.reg_2)
             self._exchange_slice(s_)
+        self._mark(1)
         self._join_side()
+        self._mark(2)
         return c.stats
 
     def _on_side(self):
@@ -239,11 +277,15 @@ class UserShardedBprTrainer:
         if not self.staged:
             raise NotImplementedError("an empty local batch is only supported by the staged protocol")
         c = self.ctx
+        self._mark(0)
         c.stats.zero_()
         self._all_reduce(c.stats[N.ST_SQ_U_PRE:N.ST_SQ_U_PRE + 1])
         self._all_reduce(c.stats[:7])
         c.finalize(self.reg_1, self.reg_2)
-        return self._exchange_items()
+        self._mark(1)
+        out = self._exchange_items()
+        self._mark(2)
+        return out
 
     def _step_phases(self):
         c = self.ctx
