@@ -27,8 +27,9 @@ PLAN_POINTWISE = 2
 STATS_LEN = 16
 ST_LOSS_DATA, ST_L1_U, ST_L1_I, ST_L1_J, ST_SQ_U, ST_SQ_I, ST_SQ_J = range(7)
 ST_LOSS, ST_NORM_U, ST_NORM_I, ST_NORM_J = 7, 8, 9, 10
+ST_SUM_COEF = 12
 ST_SQ_U_PRE = 13
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _p = C.c_void_p
 _i32, _i64, _u64, _f32, _sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
@@ -81,6 +82,8 @@ SIGNATURES = {
     "daisy_item_apply_counts": (C.c_int, [_p, _p, _p, _i64, _i32, _f32, _f32, _f32, _p, _p]),
     "daisy_bpr_staged_item_slices": (C.c_int, [_p, _p, _i32, _p]),
     "daisy_bpr_staged_item_slice": (C.c_int, [_p, _i32, _p, _p, _i32, _f32, _f32, _f32, _p, _p]),
+    "daisy_bpr_staged_adam_step": (C.c_int, [_p, _p, _p, _i32, _f32, _f32, _f32, _f32, _p, _p, _p, _p, _p, _p, _p,
+                                             _f32, _f32, _f32, _i64, _p, _p, _p, _p]),
     "daisy_bpr_forward": (C.c_int, [_p, _p, _p, _i32, _f32, _p, _p]),
     "daisy_bpr_finalize": (C.c_int, [_p, _p, _f32, _f32, _p, _p, _p]),
     "daisy_bpr_item_grad": (C.c_int, [_p, _p, _p, _p, _f32, _f32, _p, _i32, _p]),

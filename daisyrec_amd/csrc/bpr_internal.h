@@ -60,6 +60,8 @@ struct StreamView {
     uint32_t pos_base;
     int64_t B, E;
     const double *halt;      // see BatchView::halt
+    int32_t pointwise;       // rows are (user, item, label): E = B entries in the partitioned layout; the sorted
+                             // layout keeps an inert negative slot per sample (E = 2B)
 };
 }  // namespace daisy
 
@@ -76,6 +78,8 @@ struct daisy_train_index {
     uint32_t *ent_t;          // [2n] triple index | slot << 31, sorted by ent_key (stable: t ascending)
     uint32_t *ent_key;        // [2n] item << 1 | slot
     size_t bytes;
+    int32_t pointwise;        // rows are (user, item, label): ONE entry per row (n_ent = n), else two (n_ent = 2n)
+    int64_t n_ent;
 };
 
 // Epoch plan: the whole epoch laid out batch by batch (see the header comment of bpr_train.hip).
@@ -238,6 +242,55 @@ __device__ __forceinline__ void reduce_partials_block(const double *__restrict__
     }
 }
 
+
+// torch.optim.Adam single-tensor math on one row fragment: the expressions of k_adam_dense (bpr_train.hip), shared by the
+// lazy row updates there and by the row owners of the staged step
+template <class C>
+__device__ __forceinline__ void adam_row(Row<C> &w, Row<C> &m, Row<C> &v, const Row<C> &g, float step_size, float bc2_sqrt,
+                                         float beta1, float beta2, float eps) {
+    const float w1 = 1.f - beta1, w2 = 1.f - beta2;
+#pragma unroll
+    for (int k = 0; k < C::NE; ++k) {
+        const float gg = g.v[k];
+        const float mm = fmaf(w1, gg - m.v[k], m.v[k]);
+        const float vv = fmaf(w2 * gg, gg, beta2 * v.v[k]);
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        w.v[k] = w.v[k] - step_size * (mm / denom);
+        m.v[k] = mm;
+        v.v[k] = vv;
+    }
+}
+
+// Optimiser of a table's row owners in the staged step (bpr_staged.hip).  SGD: w -= lr * g.  Adam (template flag): the
+// lazy form of torch.optim.Adam - the rows a step references have been brought to step t-1 before the pass
+// (daisy_bpr_staged_adam_catchup), the owner applies step t with the row's gradient and stamps last[row] = t.
+struct RowOpt {
+    float lr;
+    float *m, *v;              // [rows][d] first / second moments
+    int32_t *last;             // [rows] the step each row is current for
+    float step_size, bc2_sqrt, beta1, beta2, eps;     // step t's lr / (1 - beta1^t) and sqrt(1 - beta2^t): the host's bits
+    int32_t t;
+};
+
+// FM (FMRecommender.py:61-68): score += u_bias[u] + i_bias[item] + bias_.  bu == nullptr: plain MF.  grad_out: the
+// bias gradients go to g_bu / g_bi (and stats[DAISY_ST_SUM_COEF] for bias_) for a dense optimiser; else SGD in place.
+struct StagedBias { float *bu, *bi, *b0; float *g_bu, *g_bi; int32_t grad_out; };
+
+template <class C, bool ADAM>
+__device__ __forceinline__ void row_apply(Row<C> &w, const Row<C> &g, const RowOpt &o, int64_t row, int lane, int d) {
+    if constexpr (ADAM) {
+        Row<C> m, v;
+        m.load(o.m + row * d, lane, d);
+        v.load(o.v + row * d, lane, d);
+        adam_row<C>(w, m, v, g, o.step_size, o.bc2_sqrt, o.beta1, o.beta2, o.eps);
+        m.store(o.m + row * d, lane, d);
+        v.store(o.v + row * d, lane, d);
+        if (lane == 0) o.last[row] = o.t;
+    } else {
+#pragma unroll
+        for (int k = 0; k < C::NE; ++k) w.v[k] = fmaf(-o.lr, g.v[k], w.v[k]);
+    }
+}
 
 __device__ __forceinline__ float inv_or_zero(double n, float reg_2) {
     return (n > 0.0) ? (float)((double)reg_2 / n) : 0.f;  // d|X|_F/dX = 0 at X = 0 (torch)

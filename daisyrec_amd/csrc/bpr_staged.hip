@@ -35,6 +35,7 @@
 // explicit permutation, or the keyed Feistel bijection of (seed, epoch) computed in registers; the stage
 // slot of a sample is pos(t) - k*B, which both its sample record and its two entry records can compute
 // without ever meeting.  32 B of plan per interaction.
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -348,15 +349,20 @@ __global__ void k_batch_offsets(const uint32_t *__restrict__ pos, int64_t n, Bat
 
 // ---- static index ---------------------------------------------------------------------------------------
 // bad[0] |= 1 when a (user - user_base, item, item) lies outside [0,U) x [0,I) x [0,I)
+// pointwise: rows are (user, item, label) - one entry per row, the third column is not an id
 __global__ void k_index_entries(const int32_t *__restrict__ triples, int64_t n, int32_t user_base, int64_t U,
                                 int64_t I, uint32_t *__restrict__ key, uint32_t *__restrict__ val,
-                                uint32_t *__restrict__ ukey, uint32_t *__restrict__ uval, int *__restrict__ bad) {
+                                uint32_t *__restrict__ ukey, uint32_t *__restrict__ uval, int *__restrict__ bad,
+                                int pointwise) {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x) {
         const int32_t *row = triples + 3 * t;
         const int64_t u = (int64_t)row[0] - user_base, i = row[1], j = row[2];
-        const bool ok = u >= 0 && u < U && i >= 0 && i < I && j >= 0 && j < I;
+        const bool ok = u >= 0 && u < U && i >= 0 && i < I && (pointwise || (j >= 0 && j < I));
         if (!ok) atomicOr(bad, 1);
-        if (key) {
+        if (key && pointwise) {
+            key[t] = ok ? ((uint32_t)i << 1) : 0u;
+            val[t] = (uint32_t)t;
+        } else if (key) {
             key[2 * t] = ok ? ((uint32_t)i << 1) : 0u;
             val[2 * t] = (uint32_t)t;
             key[2 * t + 1] = ok ? (((uint32_t)j << 1) | 1u) : 1u;
@@ -397,16 +403,18 @@ StreamView plan_stream_view(const daisy_epoch_plan *p, int64_t k) {
     v.B = (p->n - lo < p->batch_size) ? (p->n - lo) : p->batch_size;
     const uint32_t pos_base = (uint32_t)lo;           // stage slot = epoch position - k*B in both layouts
     if (p->h_off) { lo = p->h_off[k]; v.B = p->h_off[k + 1] - lo; }      // a rank's share of the epoch
-    v.E = 2 * v.B;
+    const int64_t epl = p->pointwise ? 1 : 2;          // entries per sample (point-wise rows have no negative item)
+    v.E = epl * v.B;
     v.s_user = p->p_user[c] + lo;
     v.s_ij = p->p_ij[c] + lo;
     v.s_pos = p->p_pos[c] + lo;
-    v.e_key = p->p_ekey[c] + 2 * lo;
-    v.e_pos = p->p_epos[c] + 2 * lo;
+    v.e_key = p->p_ekey[c] + epl * lo;
+    v.e_pos = p->p_epos[c] + epl * lo;
     v.e_stride = 1;
     v.umask = v.imask = 0xFFFFFFFFu;
     v.pos_base = pos_base;
     v.halt = nullptr;
+    v.pointwise = p->pointwise;
     return v;
 }
 
@@ -518,7 +526,7 @@ static int plan_build_partitioned(daisy_epoch_plan *p, const daisy_train_index *
     // the destination set; then the samples
     for (int what = 0; what < 2; ++what) {
         const bool entries = (what == 0);
-        const int64_t m = entries ? 2 * n : n;
+        const int64_t m = entries ? ix->n_ent : n;
         int64_t tile_elems, ntiles;
         part_tiling(m, tile_elems, ntiles);
         for (int pass = 0; pass < passes; ++pass) {
@@ -575,7 +583,7 @@ static int plan_build_partitioned(daisy_epoch_plan *p, const daisy_train_index *
     }
     p->p_cur = 0;
     p->n = n; p->batch_size = batch_size; p->num_batches = nb;
-    p->pointwise = 0;
+    p->pointwise = ix->pointwise;
     p->kind = 1;
     if (subset) {          // where every batch starts: one small copy and one host sync per epoch
         hipLaunchKernelGGL(k_batch_offsets, dim3(grid_for(nb + 1, kBlock)), dim3(kBlock), 0, s, p->p_pos[0], n, bd, nb,
@@ -691,42 +699,65 @@ __device__ __forceinline__ double prenorm_sum(const double *__restrict__ stats, 
     return wave_sum_f64(t);
 }
 
-template <class C>
-__device__ __forceinline__ void user_finish_row(Row<C> &p, const Row<C> &acc, float n, float lr,
-                                                float reg_1, float rU) {
+// what the owner of a finished user run does with g = sum_s dL/dx_s (q_i - q_j) over the run's n samples:
+// regulariser (MFRecommender.py:94-95), the optimiser's step on P[u] in place, the row-norm cache
+template <class C, bool ADAM>
+__device__ __forceinline__ void user_commit(float *__restrict__ P, float *__restrict__ p_sqnorm, int64_t user, Row<C> &p,
+                                            const Row<C> &acc, float n, float reg_1, float rU, const RowOpt &opt, int lane,
+                                            int d) {
     const float w1 = reg_1 * n, w2 = rU * n;
+    Row<C> g;
 #pragma unroll
-    for (int k = 0; k < C::NE; ++k) {
-        const float g = acc.v[k] + fmaf(w2, p.v[k], w1 * sgn(p.v[k]));
-        p.v[k] = fmaf(-lr, g, p.v[k]);
+    for (int k = 0; k < C::NE; ++k) g.v[k] = acc.v[k] + fmaf(w2, p.v[k], w1 * sgn(p.v[k]));
+    row_apply<C, ADAM>(p, g, opt, user, lane, d);
+    p.store(P + user * d, lane, d);
+    const float sq = row_dot<C>(p, p);
+    if (lane == 0) p_sqnorm[user] = sq;
+}
+
+// FM: the user bias follows its user's run (u_bias[u] -= lr * sum of the run's dL/dpos + dL/dneg, or the sum itself
+// for a dense optimiser)
+__device__ __forceinline__ void user_bias_commit(const StagedBias &fm, int64_t user, float sb, float lr, int lane) {
+    if (fm.bu && lane == 0) {
+        if (fm.grad_out) fm.g_bu[user] = sb;
+        else fm.bu[user] = fmaf(-lr, sb, fm.bu[user]);
     }
 }
 
 struct UserEdges {
     float *vec;        // [2*nchunks][d] partial user gradients of runs that cross a chunk boundary
     int32_t *user;     // [2*nchunks]    their user (-1: none); [2c] head edge, [2c+1] tail edge
-    float *n;          // [2*nchunks]    their sample counts
+    float *n;          // [2*nchunks][2] their sample counts and (FM) coefficient sums
     int32_t *whole;    // [nchunks]      the head edge's run also fills the whole chunk
 };
 
+// how a sample reaches the item pass:
+//   kModePremul  pairwise loss with dL/dneg = -dL/dpos (BPR, HL): stage[slot] = dL/dpos * p_u serves both entries
+//   kModePlain   any pairwise loss: stage[slot] = p_u, coef[slot] = (dL/dpos, dL/dneg) (TOP1; FM's pairwise runs,
+//                whose item biases need the bare coefficients)
+//   kModePoint   point-wise loss (CL / SL, MFRecommender.py:75-81): rows are (user, item, label), ONE entry per
+//                sample, stage[slot] = dL/dpred * p_u (+ coef[slot].x = dL/dpred when there are FM biases)
+enum { kModePremul = 0, kModePlain = 1, kModePoint = 2 };
+
 // Forward + user update in one pass over the user-grouped samples (see the header comment).
-//   in-run user:          its group owns P[u]: P[u] -= lr*(sum_s c_s(q_i - q_j) + n*reg(p)), in place
+//   in-run user:          its group owns P[u]: regulariser + optimiser step in place
 //   run crossing groups:  partial sums parked in LDS, added by the slot's finisher in group order
 //   run crossing chunks:  edge records, chained by k_staged_user_edges in chunk order
-// (no atomics, fixed summation order: bitwise reproducible).  PREMUL: stage[slot] = dL/dpos * p_u, valid for
-// the losses with dL/dneg = -dL/dpos (BPR, HL); otherwise stage[slot] = p_u and coef[slot] = (dL/dpos, dL/dneg).
+// (no atomics, fixed summation order: bitwise reproducible).
 // HAS_POS: the stage slot of a sample comes from the plan (partitioned layout) instead of its position.
-template <class C, int BLK, bool PREMUL, bool HAS_POS>
+template <class C, int BLK, int MODE, bool HAS_POS, bool ADAM>
 __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 ? 4 : 2, 8))) void k_staged_user(
     float *__restrict__ P, const float *__restrict__ Q, StreamView v, int d, const double *__restrict__ stats,
-    float lr, float reg_1, float reg_2, int loss_type, float gamma, float *__restrict__ stage,
+    RowOpt opt, float reg_1, float reg_2, int loss_type, float gamma, float *__restrict__ stage,
     float2 *__restrict__ coef, float *__restrict__ p_sqnorm, double *__restrict__ partials, UserEdges ed,
-    PreNorm pre) {
+    PreNorm pre, StagedBias fm) {
     if (halted(v.halt)) return;            // an earlier step of this epoch had a non-finite loss: the epoch has stopped
     constexpr int G = StagedUserCfg<C, BLK>::G, RUN = StagedUserCfg<C, BLK>::RUN, E = StagedUserCfg<C, BLK>::E;
     constexpr int ROWF = C::NE * C::LPR;
+    constexpr bool PAIR = MODE != kModePoint;
+    constexpr bool BIAS = MODE != kModePremul;          // FM biases ride on the plain / point flavours only
     __shared__ float part_acc[2 * G * ROWF];
-    __shared__ float part_n[2 * G];
+    __shared__ float part_n[2 * G], part_b[2 * G];
     __shared__ int part_slot[2 * G];
     __shared__ int slot_user[G + 1], slot_next[G + 1];
     __shared__ int run_first[G], run_last[G];
@@ -737,7 +768,9 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 
     const int64_t n = v.B;
     const int64_t nchunks = (n + E - 1) / E;
     const float rU = inv_or_zero(sqrt(prenorm_sum(stats, pre)), reg_2);
-    float acc7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool has_bias = BIAS && fm.bu != nullptr;
+    const float b0 = has_bias ? fm.b0[0] : 0.f;
+    float acc7[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
         const int64_t c0 = chunk * E;
@@ -769,14 +802,23 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 
             run_first[group] = cnt > 0 ? user_first : -2;
             run_last[group] = cnt > 0 ? user_last : -2;
         }
+        // FM: the biases of lane x's own sample (scalar gathers: the tables are small next to the factor rows)
+        float my_bsp = 0.f, my_bsn = 0.f;
+        if constexpr (BIAS) {
+            if (has_bias && lane < cnt) {
+                const float bu = fm.bu[k_me];
+                my_bsp = (bu + fm.bi[ij_me.x]) + b0;                 // FMRecommender.py:66
+                if constexpr (PAIR) my_bsn = (bu + fm.bi[ij_me.y]) + b0;
+            }
+        }
 
-        // ---- hop 2: the three rows of every sample of the run
-        Row<C> qi[RUN], qj[RUN], pr[RUN];
-        if (__all(cnt == RUN)) {        // wave-uniform: no branch between the 3*RUN gathers
+        // ---- hop 2: the rows of every sample of the run
+        Row<C> qi[RUN], qj[PAIR ? RUN : 1], pr[RUN];
+        if (__all(cnt == RUN)) {        // wave-uniform: no branch between the gathers
 #pragma unroll
             for (int x = 0; x < RUN; ++x) {
                 qi[x].load(Q + (int64_t)group_bcast<C>(my_ij.x, x) * d, lane, d);
-                qj[x].load(Q + (int64_t)group_bcast<C>(my_ij.y, x) * d, lane, d);
+                if constexpr (PAIR) qj[x].load(Q + (int64_t)group_bcast<C>(my_ij.y, x) * d, lane, d);
                 pr[x].load(P + (int64_t)group_bcast<C>(my_user, x) * d, lane, d);
             }
         } else {
@@ -787,10 +829,11 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 
                 const int jx = group_bcast<C>(my_ij.y, x);
                 if (x < cnt) {
                     qi[x].load(Q + (int64_t)ix * d, lane, d);
-                    qj[x].load(Q + (int64_t)jx * d, lane, d);
+                    if constexpr (PAIR) qj[x].load(Q + (int64_t)jx * d, lane, d);
                     pr[x].load(P + (int64_t)ux * d, lane, d);
                 } else {
-                    qi[x].zero(); qj[x].zero(); pr[x].zero();
+                    qi[x].zero(); pr[x].zero();
+                    if constexpr (PAIR) qj[x].zero();
                 }
             }
         }
@@ -815,25 +858,31 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 
             for (int x = 0; x < RUN; ++x) {
                 if (x < cnt) {
                     const float sp = row_dot<C>(pr[x], qi[x]);
-                    const float sn = row_dot<C>(pr[x], qj[x]);
+                    float sn = 0.f;
+                    if constexpr (PAIR) sn = row_dot<C>(pr[x], qj[x]);
                     if (lane == x) { my_sp = sp; my_sn = sn; }
 #pragma unroll
                     for (int k = 0; k < C::NE; ++k) {
                         acc7[1] += fabsf(pr[x].v[k]);
                         acc7[2] += fabsf(qi[x].v[k]);
-                        acc7[3] += fabsf(qj[x].v[k]);
                         acc7[4] = fmaf(pr[x].v[k], pr[x].v[k], acc7[4]);
                         acc7[5] = fmaf(qi[x].v[k], qi[x].v[k], acc7[5]);
-                        acc7[6] = fmaf(qj[x].v[k], qj[x].v[k], acc7[6]);
+                        if constexpr (PAIR) {
+                            acc7[3] += fabsf(qj[x].v[k]);
+                            acc7[6] = fmaf(qj[x].v[k], qj[x].v[k], acc7[6]);
+                        }
                     }
                 }
             }
             float2 my_c = make_float2(0.f, 0.f);
             if (lane < cnt) {
                 float term;
+                if constexpr (BIAS) { my_sp += my_bsp; my_sn += my_bsn; }
+                if constexpr (!PAIR) my_sn = (float)my_ij.y;               // the label (sampler.py:93-98)
                 pair_coef(loss_type, my_sp, my_sn, gamma, term, my_c.x, my_c.y);
                 acc7[0] += term;
-                if constexpr (!PREMUL) coef[slot_me] = my_c;
+                if constexpr (BIAS) acc7[7] += my_c.x + my_c.y;            // dL/d bias_ (FM)
+                if (MODE == kModePlain || (MODE == kModePoint && has_bias)) coef[slot_me] = my_c;
             }
 
             // ---- user gradient over the runs of equal users; the staged rows leave on the way
@@ -841,14 +890,12 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 
             Row<C> pcur = pr[0];                     // pre-step P row of the current run's user
             Row<C> acc;
             acc.zero();
-            float cn_ = 0.f;
+            float cn_ = 0.f, sb_ = 0.f;
             auto finish = [&](bool ends_here, bool to_next_chunk, const Row<C> &prow) {
                 if (cur_slot < 0 && ends_here) {     // this group owns P[cur_user]
                     Row<C> pn = prow;
-                    user_finish_row<C>(pn, acc, cn_, lr, reg_1, rU);
-                    pn.store(P + (int64_t)cur_user * d, lane, d);
-                    const float sq = row_dot<C>(pn, pn);
-                    if (lane == 0) p_sqnorm[cur_user] = sq;
+                    user_commit<C, ADAM>(P, p_sqnorm, cur_user, pn, acc, cn_, reg_1, rU, opt, lane, d);
+                    if constexpr (BIAS) user_bias_commit(fm, cur_user, sb_, opt.lr, lane);
                 } else {
                     const int s = (cur_slot >= 0) ? cur_slot : group + 1;
                     const int q = group * 2 + ((cur_slot >= 0) ? 0 : 1);
@@ -858,6 +905,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 
                     if (lane == 0) {
                         part_slot[q] = s;
                         part_n[q] = cn_;
+                        part_b[q] = sb_;
                         slot_user[s] = cur_user;
                         if (to_next_chunk) slot_next[s] = 1;
                     }
@@ -876,9 +924,9 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 
                         cur_slot = -1;
                         pcur = pr[x];
                         acc.zero();
-                        cn_ = 0.f;
+                        cn_ = 0.f; sb_ = 0.f;
                     }
-                    if constexpr (PREMUL) {
+                    if constexpr (MODE != kModePlain) {
                         Row<C> m;
 #pragma unroll
                         for (int k = 0; k < C::NE; ++k) m.v[k] = cp * pr[x].v[k];
@@ -887,9 +935,12 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 
                         DAISY_STAGE_STORE(pr[x], stage + (int64_t)sl * d, lane, d);
                     }
 #pragma unroll
-                    for (int k = 0; k < C::NE; ++k)
-                        acc.v[k] = fmaf(cp, qi[x].v[k], fmaf(cn, qj[x].v[k], acc.v[k]));
+                    for (int k = 0; k < C::NE; ++k) {
+                        if constexpr (PAIR) acc.v[k] = fmaf(cp, qi[x].v[k], fmaf(cn, qj[x].v[k], acc.v[k]));
+                        else acc.v[k] = fmaf(cp, qi[x].v[k], acc.v[k]);
+                    }
                     cn_ += 1.f;
+                    if constexpr (BIAS) sb_ += cp + cn;
                 }
             }
             const bool continues = (t1 < n) && (user_next == cur_user);
@@ -905,28 +956,28 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 
             if (uu < 0) continue;
             Row<C> g;
             g.zero();
-            float ns = 0.f;
+            float ns = 0.f, sb = 0.f;
             for (int q = 0; q < 2 * G; ++q) {
                 if (part_slot[q] != s) continue;
                 const float *src = part_acc + q * ROWF;
 #pragma unroll
                 for (int k = 0; k < C::NE; ++k) g.v[k] += src[k * C::LPR + lane];
                 ns += part_n[q];
+                sb += part_b[q];
             }
             const bool from_prev = (s == 0), to_next = slot_next[s] != 0;
             if (!from_prev && !to_next) {
                 Row<C> p;
                 p.load(P + (int64_t)uu * d, lane, d);
-                user_finish_row<C>(p, g, ns, lr, reg_1, rU);
-                p.store(P + (int64_t)uu * d, lane, d);
-                const float sq = row_dot<C>(p, p);
-                if (lane == 0) p_sqnorm[uu] = sq;
+                user_commit<C, ADAM>(P, p_sqnorm, uu, p, g, ns, reg_1, rU, opt, lane, d);
+                if constexpr (BIAS) user_bias_commit(fm, uu, sb, opt.lr, lane);
             } else {
                 const int64_t e = 2 * chunk + (from_prev ? 0 : 1);
                 g.store(ed.vec + e * d, lane, d);
                 if (lane == 0) {
                     ed.user[e] = uu;
-                    ed.n[e] = ns;
+                    ed.n[2 * e] = ns;
+                    ed.n[2 * e + 1] = sb;
                     if (from_prev && to_next) ed.whole[chunk] = 1;
                 }
             }
@@ -936,18 +987,17 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 
     __shared__ double sm7[BLK / kWave][8];
     const int wave = tid / kWave;
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
+    for (int k = 0; k < 8; ++k) {
         const double w = (double)wave_sum_f32_dpp(acc7[k]);     // fp32 inside the wave, fp64 across waves and workgroups
         if ((tid % kWave) == 0) sm7[wave][k] = w;
     }
     __syncthreads();
-    if (tid < 7) {
+    if (tid < 8) {
         double t = 0.0;
 #pragma unroll
         for (int w = 0; w < BLK / kWave; ++w) t += sm7[w][tid];
-        partials[(int64_t)blockIdx.x * 8 + tid] = t;
+        partials[(int64_t)blockIdx.x * 8 + tid] = t;           // [7]: sum of dL/dpos + dL/dneg (FM's bias_; 0 without biases)
     }
-    if (tid == 7) partials[(int64_t)blockIdx.x * 8 + 7] = 0.0;   // (no FM biases on the staged path)
 }
 
 // chains of edge records: the chunk whose TAIL edge starts a run owns it.  A user whose run crosses a
@@ -959,12 +1009,13 @@ struct ReduceJob {
     int nblocks;                 // 0: no reduction rides on this launch
     double *stats, *epoch_acc, *step_loss;
 };
-template <class C>
+template <class C, bool ADAM>
 __global__ __launch_bounds__(kBlock) void k_staged_user_edges(float *__restrict__ P, int64_t nchunks, int d,
-                                                              const double *__restrict__ stats, float lr,
+                                                              const double *__restrict__ stats, RowOpt opt,
                                                               float reg_1, float reg_2, UserEdges ed,
                                                               float *__restrict__ p_sqnorm, PreNorm pre,
-                                                              ReduceJob red, const double *__restrict__ halt) {
+                                                              ReduceJob red, const double *__restrict__ halt,
+                                                              StagedBias fm) {
     if (halted(halt)) return;              // (the riding reduction too: the epoch's sums stay at the offending step)
     const double sq_pre = prenorm_sum(stats, pre);
     unsigned nb = gridDim.x, bid = blockIdx.x;
@@ -972,6 +1023,9 @@ __global__ __launch_bounds__(kBlock) void k_staged_user_edges(float *__restrict_
         if (bid == 0) {
             reduce_partials_block(red.partials, red.nblocks, red.stats, true, reg_1, reg_2, red.epoch_acc, red.step_loss);
             if (threadIdx.x == 0 && pre.n) red.stats[DAISY_ST_SQ_U_PRE] = sq_pre;
+            // FM, SGD: bias_ -= lr * sum_b (dL/dpos + dL/dneg)  (a dense optimiser reads the sum from stats instead)
+            if (threadIdx.x == 0 && fm.bu && !fm.grad_out)
+                fm.b0[0] = fmaf(-opt.lr, (float)red.stats[DAISY_ST_SUM_COEF], fm.b0[0]);
             return;
         }
         nb -= 1; bid -= 1;
@@ -985,40 +1039,41 @@ __global__ __launch_bounds__(kBlock) void k_staged_user_edges(float *__restrict_
         if (uu < 0) continue;
         Row<C> acc, t;
         acc.load(ed.vec + (2 * c + 1) * d, lane, d);
-        float ns = ed.n[2 * c + 1];
+        float ns = ed.n[2 * (2 * c + 1)], sb = ed.n[2 * (2 * c + 1) + 1];
         for (int64_t k = c + 1; k < nchunks && ed.user[2 * k] == uu; ++k) {
             t.load(ed.vec + (2 * k) * d, lane, d);
 #pragma unroll
             for (int q = 0; q < C::NE; ++q) acc.v[q] += t.v[q];
-            ns += ed.n[2 * k];
+            ns += ed.n[2 * (2 * k)];
+            sb += ed.n[2 * (2 * k) + 1];
             if (!ed.whole[k]) break;
         }
         Row<C> p;
         p.load(P + (int64_t)uu * d, lane, d);
-        user_finish_row<C>(p, acc, ns, lr, reg_1, rU);
-        p.store(P + (int64_t)uu * d, lane, d);
-        const float sq = row_dot<C>(p, p);
-        if (lane == 0) p_sqnorm[uu] = sq;
+        user_commit<C, ADAM>(P, p_sqnorm, uu, p, acc, ns, reg_1, rU, opt, lane, d);
+        user_bias_commit(fm, uu, sb, opt.lr, lane);
     }
 }
 
 struct ItemEdges2 {
     float *vec;          // [2*nchunks][d]  partial gradient rows; [2c] head edge (inherited), [2c+1] tail edge
     int32_t *item;       // [2*nchunks]     their item (-1: none)
-    float *cnt;          // [2*nchunks][2]  their (n_pos, n_neg)
+    float *cnt;          // [2*nchunks][4]  their (n_pos, n_neg, sum of the coefficients (FM), -)
     int32_t *whole;      // [nchunks]       the head edge's segment also runs on into the next chunk
 };
 
-// what the owner of a finished segment does with  g = sum_e w_e * stage[slot(e)]  and the entry counts:
-//   APPLY:  Q[item] -= lr * (g + reg_1*(np+nn)*sign(q) + reg_2*(np/|Q[i]|_F + nn/|Q[j]|_F)*q)   (MFRecommender.py:88-89)
-//   else:   gQ[item] = g (data term), cnt[item] = (np, nn): what a multi-GPU step reduce-scatters
 // pre-step rows of Q staged in LDS for the commits of one chunk (k_staged_item): rows [first, first + rows)
 struct QWindow { const float *lds; int32_t first, rows; };
 
-template <class C, bool APPLY>
+// what the owner of a finished segment does with  g = sum_e w_e * stage[slot(e)]  and the entry counts:
+//   APPLY:  regulariser reg_1*(np+nn)*sign(q) + reg_2*(np/|Q[i]|_F + nn/|Q[j]|_F)*q  (MFRecommender.py:88-89), then the
+//           optimiser's step on Q[item] in place; FM: i_bias[item] follows with the sum of the coefficients
+//   else:   gQ[item] = g (data term), cnt[item] = (np, nn): what a multi-GPU step reduce-scatters
+template <class C, bool APPLY, bool ADAM>
 __device__ __forceinline__ void item_commit(float *__restrict__ Qo, float *__restrict__ cnt_out, int64_t item,
-                                            const Row<C> &g, float np, float nn, int lane, int d, float lr,
-                                            float reg_1, float rI, float rJ, const QWindow win = QWindow{nullptr, 0, 0}) {
+                                            const Row<C> &g, float np, float nn, float sb, int lane, int d,
+                                            const RowOpt &opt, float reg_1, float rI, float rJ, const StagedBias &fm,
+                                            const QWindow win = QWindow{nullptr, 0, 0}) {
     if constexpr (APPLY) {
         Row<C> q;
         bool in_lds = false;
@@ -1038,12 +1093,15 @@ __device__ __forceinline__ void item_commit(float *__restrict__ Qo, float *__res
         }
         if (!in_lds) q.load(Qo + item * d, lane, d);
         const float w1 = reg_1 * (np + nn), w2 = np * rI + nn * rJ;
+        Row<C> gg;
 #pragma unroll
-        for (int k = 0; k < C::NE; ++k) {
-            const float gg = g.v[k] + fmaf(w2, q.v[k], w1 * sgn(q.v[k]));
-            q.v[k] = fmaf(-lr, gg, q.v[k]);
-        }
+        for (int k = 0; k < C::NE; ++k) gg.v[k] = g.v[k] + fmaf(w2, q.v[k], w1 * sgn(q.v[k]));
+        row_apply<C, ADAM>(q, gg, opt, item, lane, d);
         q.store(Qo + item * d, lane, d);
+        if (fm.bi && lane == 0) {
+            if (fm.grad_out) fm.g_bi[item] = sb;
+            else fm.bi[item] = fmaf(-opt.lr, sb, fm.bi[item]);
+        }
     } else {
         g.store(Qo + item * d, lane, d);
         if (lane == 0) { cnt_out[2 * item] = np; cnt_out[2 * item + 1] = nn; }
@@ -1053,13 +1111,16 @@ __device__ __forceinline__ void item_commit(float *__restrict__ Qo, float *__res
 // Item pass over the staged rows (see the header comment): the run/slot/edge segmented reduction of
 // k_item_grad_chunked<DET> (bpr_train.hip) with the coefficient inside the gathered row and the commit in
 // the owner.  A workgroup takes a chunk of G*RUN consecutive entries, every lane group a run of RUN.
-template <class C, int BLK, bool PREMUL, bool APPLY>
+// MODE (see k_staged_user): premul - entry weight +/-1; plain - the sample's (dL/dpos, dL/dneg) gathered from coef;
+// point - weight 1 (a negative slot, which only the sorted layout's point-wise batches have, is inert: weight 0, not
+// counted).
+template <class C, int BLK, int MODE, bool APPLY, bool ADAM>
 __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_staged_item(const float *__restrict__ stage,
                                                         const float2 *__restrict__ coef, StreamView v, int d,
                                                         float *__restrict__ Qo, float *__restrict__ cnt_out,
-                                                        const double *__restrict__ stats, float lr,
+                                                        const double *__restrict__ stats, RowOpt opt,
                                                         float reg_1, float reg_2, ItemEdges2 ed,
-                                                        const int64_t *__restrict__ erange) {
+                                                        const int64_t *__restrict__ erange, StagedBias fm) {
     if (halted(v.halt)) return;            // this step's loss (reduced behind the user pass) or an earlier one was not finite
     constexpr int G = StagedItemCfg<C, BLK>::G, RUN = StagedItemCfg<C, BLK>::RUN, E = StagedItemCfg<C, BLK>::E;
     // erange: only the entries [erange[0], erange[1]) - an item range of the batch (the entries are sorted by item, so
@@ -1072,10 +1133,11 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         v.E = erange[1] - lo;
     }
     constexpr int ROWF = C::NE * C::LPR;
+    constexpr bool BIAS = MODE != kModePremul;
     __shared__ int slot_item[G + 1], slot_shared[G + 1];
     __shared__ int run_first[G], run_last[G];
     __shared__ float part_acc[2 * G * ROWF];               // [group][head|tail] parked partial sums
-    __shared__ float part_np[2 * G], part_nn[2 * G];
+    __shared__ float part_np[2 * G], part_nn[2 * G], part_b[2 * G];
     __shared__ int part_slot[2 * G];                       //      the slot each belongs to (-1: unused)
     // Q rows of the chunk's item range [first item, last item], copied by LDS-DMA while the stage rows are in flight:
     // a commit inside the reduction then costs no dependent trip to memory (at a few entries per item - 10 M x 1 M
@@ -1089,6 +1151,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     const int group = tid / C::LPR;
     const int64_t n = v.E;
     const int64_t nchunks = (n + E - 1) / E;
+    const bool has_bias = BIAS && fm.bi != nullptr;
     float rI = 0.f, rJ = 0.f;
     if constexpr (APPLY) {
         rI = inv_or_zero(stats[DAISY_ST_NORM_I], reg_2);
@@ -1141,13 +1204,17 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             run_last[group] = cnt > 0 ? item_last : -2;
         }
 
-        // ---- hop 2: all staged rows of the run (and, for the losses whose two coefficients differ, theirs)
-        float my_w;
-        if constexpr (PREMUL) {
+        // ---- hop 2: all staged rows of the run (and, for the flavours whose coefficients are not in the row, theirs)
+        float my_w, my_c = 0.f;             // weight of the entry's staged row; its bare coefficient (FM's item bias)
+        if constexpr (MODE == kModePremul) {
             my_w = (lane < cnt) ? (my_neg ? -1.f : 1.f) : 0.f;
-        } else {
+        } else if constexpr (MODE == kModePlain) {
             const float2 c2 = coef[slot_me];
             my_w = (lane < cnt) ? (my_neg ? c2.y : c2.x) : 0.f;
+            my_c = my_w;
+        } else {
+            my_w = (lane < cnt && !my_neg) ? 1.f : 0.f;
+            if (has_bias) my_c = (lane < cnt && !my_neg) ? coef[slot_me].x : 0.f;
         }
         Row<C> p[RUN];
         if (__all(cnt == RUN)) {        // wave-uniform: every run of this wave is full
@@ -1180,10 +1247,10 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             int32_t cur_item = item_first;
             Row<C> acc;
             acc.zero();
-            float np = 0.f, nn = 0.f;
+            float np = 0.f, nn = 0.f, sb = 0.f;
             auto finish = [&](bool ends_here, bool to_next_chunk) {
                 if (cur_slot < 0 && ends_here) {    // interior: this group owns the item's row
-                    item_commit<C, APPLY>(Qo, cnt_out, cur_item, acc, np, nn, lane, d, lr, reg_1, rI, rJ, win);
+                    item_commit<C, APPLY, ADAM>(Qo, cnt_out, cur_item, acc, np, nn, sb, lane, d, opt, reg_1, rI, rJ, fm, win);
                 } else {                            // crosses a run boundary: park it for the slot's finisher
                     const int s = (cur_slot >= 0) ? cur_slot : group + 1;
                     const int q = group * 2 + ((cur_slot >= 0) ? 0 : 1);
@@ -1194,6 +1261,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                         part_slot[q] = s;
                         part_np[q] = np;
                         part_nn[q] = nn;
+                        part_b[q] = sb;
                         slot_item[s] = cur_item;
                         if (to_next_chunk) slot_shared[s] = 1;
                     }
@@ -1210,12 +1278,17 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                         cur_item = it;
                         cur_slot = -1;
                         acc.zero();
-                        np = 0.f; nn = 0.f;
+                        np = 0.f; nn = 0.f; sb = 0.f;
                     }
 #pragma unroll
                     for (int k = 0; k < C::NE; ++k) acc.v[k] = fmaf(wx, p[x].v[k], acc.v[k]);
-                    np += 1.f - ng;
-                    nn += ng;
+                    if constexpr (MODE == kModePoint) {
+                        np += 1.f - ng;             // (an inert negative slot is not counted)
+                    } else {
+                        np += 1.f - ng;
+                        nn += ng;
+                    }
+                    if constexpr (BIAS) sb += group_bcast<C>(my_c, x);
                 }
             }
             const bool continues = (t1 < n) && (item_next == cur_item);
@@ -1231,7 +1304,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             if (r < 0) continue;
             Row<C> g;
             g.zero();
-            float sp = 0.f, sn = 0.f;
+            float sp = 0.f, sn = 0.f, sc = 0.f;
             for (int q = 0; q < 2 * G; ++q) {
                 if (part_slot[q] != s) continue;
                 const float *src = part_acc + q * ROWF;
@@ -1239,6 +1312,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 for (int k = 0; k < C::NE; ++k) g.v[k] += src[k * C::LPR + lane];
                 sp += part_np[q];
                 sn += part_nn[q];
+                sc += part_b[q];
             }
             const bool from_prev = (s == 0), to_next = slot_shared[s] != 0;
             if (from_prev || to_next) {
@@ -1246,12 +1320,13 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                 g.store(ed.vec + e * d, lane, d);
                 if (lane == 0) {
                     ed.item[e] = r;
-                    ed.cnt[2 * e] = sp;
-                    ed.cnt[2 * e + 1] = sn;
+                    ed.cnt[4 * e] = sp;
+                    ed.cnt[4 * e + 1] = sn;
+                    ed.cnt[4 * e + 2] = sc;
                     if (from_prev && to_next) ed.whole[chunk] = 1;
                 }
             } else {
-                item_commit<C, APPLY>(Qo, cnt_out, r, g, sp, sn, lane, d, lr, reg_1, rI, rJ, win);
+                item_commit<C, APPLY, ADAM>(Qo, cnt_out, r, g, sp, sn, sc, lane, d, opt, reg_1, rI, rJ, fm, win);
             }
         }
         __syncthreads();   // the slots are reused by the next chunk
@@ -1260,13 +1335,13 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
 
 // chains of edge records - the chunk whose TAIL edge starts a segment owns it and adds the head edges of
 // the chunks it runs through, in chunk order (single writer per row, fixed order)
-template <class C, bool APPLY>
+template <class C, bool APPLY, bool ADAM>
 __global__ __launch_bounds__(kBlock) void k_staged_item_edges(ItemEdges2 ed, int64_t nchunks, int d,
                                                               float *__restrict__ Qo, float *__restrict__ cnt_out,
-                                                              const double *__restrict__ stats, float lr,
+                                                              const double *__restrict__ stats, RowOpt opt,
                                                               float reg_1, float reg_2,
                                                               const int64_t *__restrict__ erange, int chunk_entries,
-                                                              const double *__restrict__ halt) {
+                                                              const double *__restrict__ halt, StagedBias fm) {
     if (halted(halt)) return;
     if (erange) nchunks = (erange[1] - erange[0] + chunk_entries - 1) / chunk_entries;      // chunks of the slice
     const int lane = threadIdx.x % C::LPR;
@@ -1282,16 +1357,17 @@ __global__ __launch_bounds__(kBlock) void k_staged_item_edges(ItemEdges2 ed, int
         if (it < 0) continue;
         Row<C> acc, t;
         acc.load(ed.vec + (2 * c + 1) * d, lane, d);
-        float sp = ed.cnt[2 * (2 * c + 1)], sn = ed.cnt[2 * (2 * c + 1) + 1];
+        float sp = ed.cnt[4 * (2 * c + 1)], sn = ed.cnt[4 * (2 * c + 1) + 1], sc = ed.cnt[4 * (2 * c + 1) + 2];
         for (int64_t k = c + 1; k < nchunks && ed.item[2 * k] == it; ++k) {
             t.load(ed.vec + (2 * k) * d, lane, d);
 #pragma unroll
             for (int q = 0; q < C::NE; ++q) acc.v[q] += t.v[q];
-            sp += ed.cnt[2 * (2 * k)];
-            sn += ed.cnt[2 * (2 * k) + 1];
+            sp += ed.cnt[4 * (2 * k)];
+            sn += ed.cnt[4 * (2 * k) + 1];
+            sc += ed.cnt[4 * (2 * k) + 2];
             if (!ed.whole[k]) break;
         }
-        item_commit<C, APPLY>(Qo, cnt_out, it, acc, sp, sn, lane, d, lr, reg_1, rI, rJ);
+        item_commit<C, APPLY, ADAM>(Qo, cnt_out, it, acc, sp, sn, sc, lane, d, opt, reg_1, rI, rJ, fm);
     }
 }
 
@@ -1312,7 +1388,9 @@ __global__ __launch_bounds__(kBlock) void k_item_apply_counts(float *__restrict_
         if (np + nn == 0.f) continue;              // untouched by every rank: the row does not move
         Row<C> gr, z;
         gr.load(g + r * d, lane, d);
-        item_commit<C, true>(Q, nullptr, r, gr, np, nn, lane, d, lr, reg_1, rI, rJ);
+        RowOpt opt{};
+        opt.lr = lr;
+        item_commit<C, true, false>(Q, nullptr, r, gr, np, nn, 0.f, lane, d, opt, reg_1, rI, rJ, StagedBias{});
         z.zero();
         z.store(g + r * d, lane, d);
         if (lane == 0) { cnt[2 * r] = 0.f; cnt[2 * r + 1] = 0.f; }
@@ -1336,9 +1414,11 @@ __global__ void k_slice_ranges(StreamView v, SliceBounds bounds, int S, int64_t 
 // ---------------------------------------------------------------------------------------------------------
 // host side of the staged step
 // ---------------------------------------------------------------------------------------------------------
+// the staged step covers every loss of the reference (loss.py:5-33, MFRecommender.py:70-97): the point-wise ones
+// need a point-wise batch (rows (user, item, label)) and vice versa; FM biases ride on the plain / point flavours
 bool staged_supported(const daisy_bpr_ctx *ctx, int loss_type) {
-    return loss_type >= DAISY_LOSS_BPR && loss_type <= DAISY_LOSS_TL && !ctx->bu &&
-           !(ctx->batch_kind == 0 && ctx->v.pointwise);
+    if (loss_type < DAISY_LOSS_BPR || loss_type > DAISY_LOSS_SL) return false;
+    return (loss_type >= DAISY_LOSS_CL) == (ctx->sv.pointwise != 0);
 }
 
 static int staged_check(daisy_bpr_ctx *ctx, int loss_type, const char *who) {
@@ -1348,7 +1428,7 @@ static int staged_check(daisy_bpr_ctx *ctx, int loss_type, const char *who) {
         return DAISY_ERR_ARG;
     }
     if (!staged_supported(ctx, loss_type)) {
-        set_error("%s: the staged step covers the pairwise losses (BPR, HL, TL) without FM biases", who);
+        set_error("%s: loss type %d does not match the batch layout (point-wise=%d)", who, loss_type, ctx->sv.pointwise);
         return DAISY_ERR_ARG;
     }
     return DAISY_OK;
@@ -1383,50 +1463,99 @@ static int staged_prenorm(daisy_bpr_ctx *ctx, const float *P, double *stats, boo
 
 static inline bool premul_loss(int loss_type) { return loss_type == DAISY_LOSS_BPR || loss_type == DAISY_LOSS_HL; }
 
+// flavour of the two passes (k_staged_user): FM's pairwise runs take the plain one (its item biases need the bare
+// coefficients)
+static int staged_mode(const daisy_bpr_ctx *ctx, int loss_type) {
+    if (loss_type >= DAISY_LOSS_CL) return kModePoint;
+    return (premul_loss(loss_type) && !ctx->bu) ? kModePremul : kModePlain;
+}
+
+static StagedBias staged_bias(const daisy_bpr_ctx *ctx, bool grad_out) {
+    StagedBias fm{ctx->bu, ctx->bi, ctx->b0, ctx->g_bu, ctx->g_bi, grad_out ? 1 : 0};
+    return fm;
+}
+
+// optimiser of one table's row owners; adam == nullptr: SGD
+struct StagedAdam {           // the lazy Adam state of both tables for step t (daisy_bpr_staged_adam_step)
+    float *mP, *vP; int32_t *lastP;
+    float *mQ, *vQ; int32_t *lastQ;
+    float step_size, bc2_sqrt, beta1, beta2, eps;
+    int32_t t;
+};
+static RowOpt row_opt(float lr, const StagedAdam *a, bool user_side) {
+    RowOpt o{};
+    o.lr = lr;
+    if (a) {
+        o.m = user_side ? a->mP : a->mQ;
+        o.v = user_side ? a->vP : a->vQ;
+        o.last = user_side ? a->lastP : a->lastQ;
+        o.step_size = a->step_size; o.bc2_sqrt = a->bc2_sqrt;
+        o.beta1 = a->beta1; o.beta2 = a->beta2; o.eps = a->eps;
+        o.t = a->t;
+    }
+    return o;
+}
+
+// workgroup size of the user pass: 128 threads; ONE wave (its barriers are free) for rows of two float4 per
+// lane (64 < d <= 128: 1.40 -> 1.27 ms per 2M-sample step at d=128; slower at d <= 64 (0.60 -> 0.71), and
+// rows of four float4 per lane would need more edge records than the context holds)
+template <class C>
+struct StagedUserBlk {
+    static constexpr int value = (C::NE == 8 && C::LPR == 16) ? 64 : ((C::LPR <= 32) ? kStagedUserBlock : kBlock);
+};
+
 // n_pre > 0: the pre-norm comes from k_unorm's partial sums, else from stats[SQ_U_PRE].  ride_reduce (single-GPU
 // step): the reduction of this pass's own sums (stats, loss; into epoch_acc / step_loss) rides on the edge
 // launch; else the caller reduces
 static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_type, float gamma, float lr,
                        float reg_1, float reg_2, double *stats, int *grid_out, int n_pre, bool ride_reduce,
-                       double *epoch_acc, double *step_loss, hipStream_t s) {
+                       double *epoch_acc, double *step_loss, hipStream_t s, const StagedAdam *adam = nullptr,
+                       bool bias_grad_out = false) {
     const StreamView &v = ctx->sv;
     const int d = ctx->d;
-    const bool premul = premul_loss(loss_type), has_pos = v.s_pos != nullptr;
+    const int mode = staged_mode(ctx, loss_type);
+    const bool has_pos = v.s_pos != nullptr;
     UserEdges ed{ctx->edge_vec, ctx->edge_user, ctx->edge_n, ctx->edge_whole};
     const PreNorm pre{ctx->partials + (size_t)kMaxGrid * 8, n_pre};
+    const RowOpt opt = row_opt(lr, adam, true);
+    const StagedBias fm = staged_bias(ctx, bias_grad_out);
     static const int tune_ug = getenv("DAISY_STAGED_UGRID") ? atoi(getenv("DAISY_STAGED_UGRID")) : kMaxGrid;
-    static const int tune_blk = getenv("DAISY_STAGED_UBLK") ? atoi(getenv("DAISY_STAGED_UBLK")) : 0;     // 0: by row shape
     int64_t nchunks_out = 0;
     bool overflow = false;
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
-        auto go = [&](auto blk_tag) {
-            constexpr int BLK = decltype(blk_tag)::value;
-            const int64_t nchunks = (v.B + StagedUserCfg<C, BLK>::E - 1) / StagedUserCfg<C, BLK>::E;
-            if (nchunks > ctx->edge_chunks) { overflow = true; return; }
-            const int gu = grid_for(nchunks, 1, tune_ug < kMaxGrid ? tune_ug : kMaxGrid);
-            *grid_out = gu;
-            nchunks_out = nchunks;
-#define DAISY_LAUNCH_SU(PM, HP)                                                                                         \
-            hipLaunchKernelGGL((k_staged_user<C, BLK, PM, HP>), dim3(gu), dim3(BLK), 0, s, P, Q, v, d, stats, lr, reg_1, \
-                               reg_2, loss_type, gamma, ctx->p_stage, ctx->coef, ctx->p_sqnorm, ctx->partials, ed, pre)
-            if (premul && has_pos) DAISY_LAUNCH_SU(true, true);
-            else if (premul) DAISY_LAUNCH_SU(true, false);
-            else if (has_pos) DAISY_LAUNCH_SU(false, true);
-            else DAISY_LAUNCH_SU(false, false);
-#undef DAISY_LAUNCH_SU
+        constexpr int BLK = StagedUserBlk<C>::value;
+        const int64_t nchunks = (v.B + StagedUserCfg<C, BLK>::E - 1) / StagedUserCfg<C, BLK>::E;
+        if (nchunks > ctx->edge_chunks) { overflow = true; return DAISY_OK; }
+        const int gu = grid_for(nchunks, 1, tune_ug < kMaxGrid ? tune_ug : kMaxGrid);
+        *grid_out = gu;
+        nchunks_out = nchunks;
+        auto launch = [&](auto mode_tag, auto hp_tag, auto adam_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            constexpr bool HP = decltype(hp_tag)::value, AD = decltype(adam_tag)::value;
+            hipLaunchKernelGGL((k_staged_user<C, BLK, MODE, HP, AD>), dim3(gu), dim3(BLK), 0, s, P, Q, v, d, stats, opt,
+                               reg_1, reg_2, loss_type, gamma, ctx->p_stage, ctx->coef, ctx->p_sqnorm, ctx->partials, ed,
+                               pre, fm);
         };
-        // workgroup size of the user pass: 128 threads; ONE wave (its barriers are free) for rows of two float4 per
-        // lane (64 < d <= 128: 1.40 -> 1.27 ms per 2M-sample step at d=128; slower at d <= 64 (0.60 -> 0.71), and
-        // rows of four float4 per lane would need more edge records than the context holds)
-        const int blk = tune_blk ? tune_blk : ((C::NE == 8 && C::LPR == 16) ? 64 : kStagedUserBlock);
-        if (blk == 64 && C::NE == 8 && C::LPR == 16) go(std::integral_constant<int, 64>{});
-        else if (blk <= 128 && C::LPR <= 32) go(std::integral_constant<int, 128>{});
-        else go(std::integral_constant<int, kBlock>{});
-        if (overflow) return DAISY_OK;
+        auto by_adam = [&](auto mode_tag, auto hp_tag) {
+            if (adam) launch(mode_tag, hp_tag, std::true_type{});
+            else launch(mode_tag, hp_tag, std::false_type{});
+        };
+        auto by_pos = [&](auto mode_tag) {
+            if (has_pos) by_adam(mode_tag, std::true_type{});
+            else by_adam(mode_tag, std::false_type{});
+        };
+        if (mode == kModePremul) by_pos(std::integral_constant<int, kModePremul>{});
+        else if (mode == kModePlain) by_pos(std::integral_constant<int, kModePlain>{});
+        else by_pos(std::integral_constant<int, kModePoint>{});
         const ReduceJob red{ctx->partials, ride_reduce ? *grid_out : 0, stats, epoch_acc, step_loss};
-        hipLaunchKernelGGL((k_staged_user_edges<C>), dim3(grid_for(nchunks_out, C::GROUPS_PER_BLOCK) + (ride_reduce ? 1 : 0)),
-                           dim3(kBlock), 0, s, P, nchunks_out, d, stats, lr, reg_1, reg_2, ed, ctx->p_sqnorm, pre, red, v.halt);
+        const dim3 ge(grid_for(nchunks_out, C::GROUPS_PER_BLOCK) + (ride_reduce ? 1 : 0));
+        if (adam)
+            hipLaunchKernelGGL((k_staged_user_edges<C, true>), ge, dim3(kBlock), 0, s, P, nchunks_out, d, stats, opt, reg_1,
+                               reg_2, ed, ctx->p_sqnorm, pre, red, v.halt, fm);
+        else
+            hipLaunchKernelGGL((k_staged_user_edges<C, false>), ge, dim3(kBlock), 0, s, P, nchunks_out, d, stats, opt, reg_1,
+                               reg_2, ed, ctx->p_sqnorm, pre, red, v.halt, fm);
         return DAISY_OK;
     });
     if (rc) return rc;
@@ -1438,35 +1567,40 @@ static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_ty
 // apply != 0: Qo = Q, updated in place; else Qo = gQ (data term), cnt_out f32[I][2]
 // slice >= 0: only the entries of item slice `slice` (daisy_bpr_staged_item_slices has run for this batch)
 static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_out, bool apply, float lr,
-                       float reg_1, float reg_2, const double *stats, hipStream_t s, int slice = -1) {
+                       float reg_1, float reg_2, const double *stats, hipStream_t s, int slice = -1,
+                       const StagedAdam *adam = nullptr, bool bias_grad_out = false) {
     const int64_t *erange = (slice >= 0) ? ctx->slice_rng + slice : nullptr;
     const StreamView &v = ctx->sv;
     const int d = ctx->d;
-    const bool premul = premul_loss(loss_type);
+    const int mode = staged_mode(ctx, loss_type);
     ItemEdges2 ed{ctx->edge_vec, ctx->edge_user, ctx->edge_cnt, ctx->edge_whole};
+    const RowOpt opt = row_opt(lr, adam, false);
+    const StagedBias fm = staged_bias(ctx, bias_grad_out);
+    if (adam && !apply) { set_error("staged item pass: the Adam owner update needs the in-place form"); return DAISY_ERR_ARG; }
     static const int tune_ig = getenv("DAISY_STAGED_IGRID") ? atoi(getenv("DAISY_STAGED_IGRID")) : 16384;
     bool overflow = false;
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
-        auto go = [&](auto blk_tag) {
-            constexpr int BLK = decltype(blk_tag)::value;
-            const int64_t nchunks = (v.E + StagedItemCfg<C, BLK>::E - 1) / StagedItemCfg<C, BLK>::E;
-            if (nchunks > ctx->edge_chunks) { overflow = true; return; }
-            const dim3 g(grid_for(v.E, StagedItemCfg<C, BLK>::E, tune_ig)), b(BLK), ge(grid_for(nchunks, C::GROUPS_PER_BLOCK));
-#define DAISY_LAUNCH_SI(PM, AP)                                                                                   \
-            do {                                                                                                     \
-                hipLaunchKernelGGL((k_staged_item<C, BLK, PM, AP>), g, b, 0, s, ctx->p_stage, ctx->coef, v, d, Qo, cnt_out, \
-                                   stats, lr, reg_1, reg_2, ed, erange);                                             \
-                hipLaunchKernelGGL((k_staged_item_edges<C, AP>), ge, dim3(kBlock), 0, s, ed, nchunks, d, Qo, cnt_out, stats, lr, \
-                                   reg_1, reg_2, erange, StagedItemCfg<C, BLK>::E, v.halt);                          \
-            } while (0)
-            if (premul && apply) DAISY_LAUNCH_SI(true, true);
-            else if (premul) DAISY_LAUNCH_SI(true, false);
-            else if (apply) DAISY_LAUNCH_SI(false, true);
-            else DAISY_LAUNCH_SI(false, false);
-#undef DAISY_LAUNCH_SI
+        constexpr int BLK = kStagedItemBlock;        // (128-thread workgroups measured the same, r02 / r03)
+        const int64_t nchunks = (v.E + StagedItemCfg<C, BLK>::E - 1) / StagedItemCfg<C, BLK>::E;
+        if (nchunks > ctx->edge_chunks) { overflow = true; return DAISY_OK; }
+        const dim3 g(grid_for(v.E, StagedItemCfg<C, BLK>::E, tune_ig)), b(BLK), ge(grid_for(nchunks, C::GROUPS_PER_BLOCK));
+        auto launch = [&](auto mode_tag, auto ap_tag, auto adam_tag) {
+            constexpr int MODE = decltype(mode_tag)::value;
+            constexpr bool AP = decltype(ap_tag)::value, AD = decltype(adam_tag)::value;
+            hipLaunchKernelGGL((k_staged_item<C, BLK, MODE, AP, AD>), g, b, 0, s, ctx->p_stage, ctx->coef, v, d, Qo, cnt_out,
+                               stats, opt, reg_1, reg_2, ed, erange, fm);
+            hipLaunchKernelGGL((k_staged_item_edges<C, AP, AD>), ge, dim3(kBlock), 0, s, ed, nchunks, d, Qo, cnt_out, stats,
+                               opt, reg_1, reg_2, erange, StagedItemCfg<C, BLK>::E, v.halt, fm);
         };
-        go(std::integral_constant<int, kStagedItemBlock>{});        // (128-thread workgroups measured the same, r02 / r03)
+        auto by_apply = [&](auto mode_tag) {
+            if (apply && adam) launch(mode_tag, std::true_type{}, std::true_type{});
+            else if (apply) launch(mode_tag, std::true_type{}, std::false_type{});
+            else launch(mode_tag, std::false_type{}, std::false_type{});
+        };
+        if (mode == kModePremul) by_apply(std::integral_constant<int, kModePremul>{});
+        else if (mode == kModePlain) by_apply(std::integral_constant<int, kModePlain>{});
+        else by_apply(std::integral_constant<int, kModePoint>{});
         return DAISY_OK;
     });
     if (rc) return rc;
@@ -1485,6 +1619,80 @@ int staged_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int loss_type, float
     if ((rc = staged_prenorm(ctx, P, stats, false, &n_pre, s))) return rc;
     if ((rc = staged_user(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, stats, &gu, n_pre, true, epoch_acc, step_loss, s))) return rc;
     if ((rc = staged_item(ctx, loss_type, Q, nullptr, true, lr, reg_1, reg_2, stats, s))) return rc;
+    ctx->fwd_done = false;
+    return DAISY_OK;
+}
+
+// ---- lazy Adam on the staged step ------------------------------------------------------------------------
+// Rows a batch references are brought to step t-1 before its forward pass (the zero-gradient replay of
+// adam_claim_row, bpr_train.hip).  Samples are grouped by user and entries sorted by item, so the first record of a
+// run of equal ids is the row's single owner: no atomics.  The user side also refreshes the row-norm cache.
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_staged_adam_catchup(StreamView v, int d, float *__restrict__ P,
+                                                                float *__restrict__ Q, StagedAdam a,
+                                                                const float2 *__restrict__ table,
+                                                                float *__restrict__ p_sqnorm) {
+    if (halted(v.halt)) return;
+    const int lane = threadIdx.x % C::LPR, group = threadIdx.x / C::LPR;
+    const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
+    const int64_t total = v.B + v.E;
+    for (int64_t x = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; x < total; x += gstride) {
+        const bool user_side = x < v.B;
+        int64_t row;
+        if (user_side) {
+            row = (int64_t)(v.s_user[x] & v.umask);
+            if (x > 0 && (int64_t)(v.s_user[x - 1] & v.umask) == row) continue;
+        } else {
+            const int64_t e = x - v.B;
+            row = (int64_t)((v.e_key[e] & v.imask) >> 1);
+            if (e > 0 && (int64_t)((v.e_key[e - 1] & v.imask) >> 1) == row) continue;
+        }
+        float *W = user_side ? P : Q, *M = user_side ? a.mP : a.mQ, *V = user_side ? a.vP : a.vQ;
+        int32_t *last = user_side ? a.lastP : a.lastQ;
+        const int32_t old = last[row];
+        if (old >= a.t - 1) continue;
+        Row<C> w, m, vv, g;
+        w.load(W + row * d, lane, d); m.load(M + row * d, lane, d); vv.load(V + row * d, lane, d);
+        g.zero();
+        for (int32_t st = old + 1; st < a.t; ++st) {                  // zero-gradient steps old+1 .. t-1
+            const float2 c = table[st];
+            adam_row<C>(w, m, vv, g, c.x, c.y, a.beta1, a.beta2, a.eps);
+        }
+        w.store(W + row * d, lane, d); m.store(M + row * d, lane, d); vv.store(V + row * d, lane, d);
+        if (lane == 0) last[row] = a.t - 1;
+        if (user_side) {
+            const float sq = row_dot<C>(w, w);
+            if (lane == 0) p_sqnorm[row] = sq;
+        }
+    }
+}
+
+int staged_adam_step(daisy_bpr_ctx *ctx, float *P, float *Q, int loss_type, float gamma, float reg_1, float reg_2,
+                     const StagedAdam &a, const float *table, bool bias_grad_out, double *stats, double *epoch_acc,
+                     double *step_loss, hipStream_t s) {
+    int rc = staged_check(ctx, loss_type, "staged_adam_step");
+    if (rc) return rc;
+    const StreamView &v = ctx->sv;
+    const int d = ctx->d;
+    // the row-norm cache has to exist before the catch-up refreshes the rows it changes
+    rc = dispatch_d(d, [&](auto cfg) {
+        using C = decltype(cfg);
+        if (ctx->p_sqnorm_of != P) {
+            hipLaunchKernelGGL((k_row_sqnorm<C>), dim3(grid_for(ctx->U, C::GROUPS_PER_BLOCK * 4)), dim3(kBlock), 0, s,
+                               P, ctx->U, d, ctx->p_sqnorm);
+            ctx->p_sqnorm_of = P;
+        }
+        hipLaunchKernelGGL((k_staged_adam_catchup<C>), dim3(grid_for(v.B + v.E, C::GROUPS_PER_BLOCK, kMaxGridSparse)),
+                           dim3(kBlock), 0, s, v, d, P, Q, a, reinterpret_cast<const float2 *>(table), ctx->p_sqnorm);
+        return DAISY_OK;
+    });
+    if (rc) return rc;
+    DAISY_LAUNCH_CHECK();
+    int gu = 0, n_pre = 0;
+    if ((rc = staged_prenorm(ctx, P, stats, false, &n_pre, s))) return rc;
+    if ((rc = staged_user(ctx, P, Q, loss_type, gamma, 0.f, reg_1, reg_2, stats, &gu, n_pre, true, epoch_acc, step_loss, s,
+                          &a, bias_grad_out))) return rc;
+    if ((rc = staged_item(ctx, loss_type, Q, nullptr, true, 0.f, reg_1, reg_2, stats, s, -1, &a, bias_grad_out))) return rc;
     ctx->fwd_done = false;
     return DAISY_OK;
 }
@@ -1508,9 +1716,12 @@ int daisy_train_index_create(daisy_train_index **out, const int32_t *triples, in
     hipStream_t s = S(stream);
     const int64_t n = n_triples;
     const bool sorted = (flags & DAISY_PLAN_TRIPLES_USER_SORTED) != 0;
+    const int pointwise = (flags & DAISY_PLAN_POINTWISE) ? 1 : 0;
     daisy_train_index *ix = new daisy_train_index();
     memset(ix, 0, sizeof(*ix));
     ix->n = n; ix->U = user_num; ix->I = item_num; ix->user_base = user_base;
+    ix->pointwise = pointwise;
+    ix->n_ent = pointwise ? n : 2 * n;
     // scratch: unsorted entry pairs [2n] x2, (unsorted user pairs [n] x2 + sorted pairs [n] x2), bad flag, sort temp
     const size_t t_sort = sort_pairs_i32_temp_bytes(2 * n);
     size_t off = 0;
@@ -1550,7 +1761,7 @@ int daisy_train_index_create(daisy_train_index **out, const int32_t *triples, in
     const int32_t *src = triples;
     if (!sorted) {   // CSR order first: stable sort of the row indices by user, then one gather
         hipLaunchKernelGGL(k_index_entries, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, triples, n, user_base,
-                           user_num, item_num, (uint32_t *)nullptr, (uint32_t *)nullptr, uk, uv, bad);
+                           user_num, item_num, (uint32_t *)nullptr, (uint32_t *)nullptr, uk, uv, bad, pointwise);
         rc = sort_pairs_i32(scratch + o_tmp, t_sort, (const int32_t *)uk, (int32_t *)uk2, (const int32_t *)uv,
                             (int32_t *)orig, n, bits_for(user_num), s);
         if (rc) return fail(rc);
@@ -1560,9 +1771,9 @@ int daisy_train_index_create(daisy_train_index **out, const int32_t *triples, in
     }
     ix->triples = src;
     hipLaunchKernelGGL(k_index_entries, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, src, n, user_base, user_num,
-                       item_num, k, v, (uint32_t *)nullptr, (uint32_t *)nullptr, bad);
+                       item_num, k, v, (uint32_t *)nullptr, (uint32_t *)nullptr, bad, pointwise);
     rc = sort_pairs_i32(scratch + o_tmp, t_sort, (const int32_t *)k, (int32_t *)ix->ent_key, (const int32_t *)v,
-                        (int32_t *)ix->ent_t, 2 * n, bits_for(item_num) + 1, s);
+                        (int32_t *)ix->ent_t, ix->n_ent, bits_for(item_num) + 1, s);
     if (rc) return fail(rc);
     int bad_host = 0;
     if (hipMemcpyAsync(&bad_host, bad, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
@@ -1691,6 +1902,31 @@ int daisy_bpr_staged_item_slice(daisy_bpr_ctx *ctx, int32_t loss_type, float *gQ
     DAISY_CHECK_ARG(slice >= 0 && slice < ctx->n_slices, "staged_item_slice: slice %d of %d (daisy_bpr_staged_item_slices first)",
                     slice, ctx->n_slices);
     return staged_item(ctx, loss_type, gQ, cnt, false, lr, reg_1, reg_2, stats, S(stream), slice);
+}
+
+int daisy_bpr_staged_adam_step(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t loss_type, float gamma, float lr,
+                               float reg_1, float reg_2, float *mP, float *vP, int32_t *lastP, float *mQ, float *vQ,
+                               int32_t *lastQ, const float *table, float beta1, float beta2, float eps, int64_t step,
+                               double *stats, double *epoch_acc, double *step_loss, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(ctx && P && Q && mP && vP && lastP && mQ && vQ && lastQ && table && stats && step >= 1,
+                    "staged_adam_step: bad argument");
+    StagedAdam a{mP, vP, lastP, mQ, vQ, lastQ, 0.f, 0.f, beta1, beta2, eps, (int32_t)step};
+    // step `step`'s constants: the host arithmetic of daisy_adam_dense / daisy_adam_lazy_table (same bits as table[step])
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    a.step_size = (float)((double)lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    struct HaltScope {
+        daisy_bpr_ctx *c;
+        HaltScope(daisy_bpr_ctx *c_, const double *h) : c(c_) { c->v.halt = h; c->sv.halt = h; }
+        ~HaltScope() { c->v.halt = nullptr; c->sv.halt = nullptr; }
+    } halt_scope(ctx, epoch_acc ? epoch_acc + 1 : nullptr);
+    const bool bias_grad_out = ctx->bu != nullptr;         // FM: the caller's dense optimiser steps the biases
+    if (bias_grad_out && !(ctx->g_bu && ctx->g_bi)) {
+        set_error("staged_adam_step: the context has biases but no g_u_bias / g_i_bias outputs");
+        return DAISY_ERR_ARG;
+    }
+    return staged_adam_step(ctx, P, Q, loss_type, gamma, reg_1, reg_2, a, table, bias_grad_out, stats, epoch_acc,
+                            step_loss, S(stream));
 }
 
 int daisy_item_apply_counts(float *Q, float *g, float *cnt, int64_t rows, int32_t d, float lr, float reg_1,

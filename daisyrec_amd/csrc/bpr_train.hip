@@ -1055,22 +1055,6 @@ __global__ __launch_bounds__(kBlock) void k_adam_dense(float *__restrict__ W, fl
 // entry point computes them on the host, so the replay uses the same bits.  Result: identical to daisy_adam_dense
 // in every step (tested bit for bit), HBM traffic proportional to the rows a step touches.
 // ---------------------------------------------------------------------------------------------------------
-template <class C>
-__device__ __forceinline__ void adam_row(Row<C> &w, Row<C> &m, Row<C> &v, const Row<C> &g, float step_size, float bc2_sqrt,
-                                         float beta1, float beta2, float eps) {
-    const float w1 = 1.f - beta1, w2 = 1.f - beta2;
-#pragma unroll
-    for (int k = 0; k < C::NE; ++k) {
-        const float gg = g.v[k];
-        const float mm = fmaf(w1, gg - m.v[k], m.v[k]);
-        const float vv = fmaf(w2 * gg, gg, beta2 * v.v[k]);
-        const float denom = sqrtf(vv) / bc2_sqrt + eps;
-        w.v[k] = w.v[k] - step_size * (mm / denom);
-        m.v[k] = mm;
-        v.v[k] = vv;
-    }
-}
-
 struct AdamTable { float *W, *g, *m, *v; int32_t *last; };
 struct AdamHyper { const float2 *table; float beta1, beta2, eps; int32_t t; };
 
@@ -1371,6 +1355,7 @@ static StreamView stream_view_of(const BatchView &v) {
     sv.umask = v.umask; sv.imask = v.imask; sv.pos_base = 0;
     sv.B = v.B; sv.E = 2 * v.B;
     sv.halt = nullptr;
+    sv.pointwise = v.pointwise;
     return sv;
 }
 
@@ -1575,7 +1560,7 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
     c->edge_chunks = (int64_t)max_chunks;
     const size_t o_ev = take(n_edge * (size_t)d * 4), o_eu = take(n_edge * 4), o_en = take(n_edge * 8);
     const size_t o_ew = take(n_edge * 4);
-    const size_t o_ec = take(n_edge * 8);
+    const size_t o_ec = take(n_edge * 16);        // staged item pass: (n_pos, n_neg, coefficient sum, -) per edge record
     const size_t o_sr = take((kMaxItemSlices + 1) * 8);
     const size_t o_ps = take((size_t)max_batch * (size_t)d * 4);
     const size_t o_pn = take((size_t)user_num * 4);

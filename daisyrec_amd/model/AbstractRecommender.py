@@ -254,7 +254,7 @@ class GeneralRecommender(AbstractRecommender):
         last_loss = 0.0
         try:
             if n_loc:
-                index = ops.TrainIndex(mine, hi - lo, I, user_base=lo)
+                index = ops.TrainIndex(mine, hi - lo, I, user_base=lo, pointwise=loss_id in ops.POINTWISE_LOSSES)
                 plan = ops.EpochPlan(n_loc, hi - lo, I, device=P.device)
             for epoch in range(1, self.epochs + 1):
                 self.train()
@@ -324,6 +324,12 @@ class GeneralRecommender(AbstractRecommender):
         ctx = ops.BprContext(B, P.shape[1], P.shape[0], Q.shape[0], device=P.device)
         plan = ops.EpochPlan(n, P.shape[0], Q.shape[0], device=P.device)
         biases = self._biases() if hasattr(self, "_biases") else None     # FM: (u_bias, i_bias, bias_)
+        pointwise = loss_id in ops.POINTWISE_LOSSES      # rows are (user, item, label), sampler.py:93-98
+        # The staged step over the partitioned plan (forward fused into the user update, item rows committed by their
+        # segment owner): SGD and Adam, every loss of loss.py, FM's biases.  Adagrad / RMSprop run the phase kernels with
+        # the dense optimisers.  Batches of a few hundred samples go through the sorted plan instead: fit_epoch_sgd then
+        # runs the whole epoch inside one persistent workgroup (SGD, pairwise, no biases; csrc/bpr_small.hip).
+        staged = item_mode == ops.ITEM_MODES["fused"] and opt in ("sgd", "adam") and B > ops.SMALL_BATCH_MAX
         adam = (_AdamState(P, Q, self.lr, biases, kind=opt, max_steps=self.epochs * ((n + B - 1) // B),
                            lazy=((3 * B < P.shape[0] + Q.shape[0]
                                   and (P.numel() + Q.numel()) * 4 >= LAZY_ADAM_MIN_TABLE_BYTES)
@@ -334,18 +340,12 @@ class GeneralRecommender(AbstractRecommender):
             ctx.set_bias(*biases, g_u_bias=adam.g[0] if adam is not None else None, g_i_bias=g_i_bias,
                          g_bias=adam.g[2] if adam is not None else None)
         user_sorted = ops.triples_user_sorted(triples[:n])
-        pointwise = loss_id in ops.POINTWISE_LOSSES      # rows are (user, item, label), sampler.py:93-98
-        # the staged step over the partitioned plan: SGD, pairwise loss, no FM biases
-        # (batches of a few hundred samples go through the sorted plan instead: fit_epoch_sgd then runs the
-        # whole epoch inside one persistent workgroup, csrc/bpr_small.hip)
-        staged = (item_mode == ops.ITEM_MODES["fused"] and adam is None and not pointwise and biases is None
-                  and B > ops.SMALL_BATCH_MAX)
         if self._sharded_world() > 1:
-            if item_mode == ops.ITEM_MODES["fused"] and adam is None and not pointwise and biases is None:
+            if item_mode == ops.ITEM_MODES["fused"] and adam is None and biases is None:
                 ctx.close()
                 plan.close()
                 return self._fit_sharded(train_loader, triples, n, B, loss_id)
-            self.logger.info("torch.distributed is initialised, but only SGD + pairwise loss + item_mode 'fused' "
+            self.logger.info("torch.distributed is initialised, but only SGD without FM biases + item_mode 'fused' "
                              "shards the users over the ranks: every rank trains the whole model")
         if item_mode == ops.ITEM_MODES["fused"] and not staged and B > ops.SMALL_BATCH_MAX:
             item_mode = ops.ITEM_MODES["chunked"]
@@ -353,7 +353,7 @@ class GeneralRecommender(AbstractRecommender):
         last_loss = 0.0
         try:
             if staged:      # indexed once per fit (also validates the id ranges)
-                index = ops.TrainIndex(triples[:n], P.shape[0], Q.shape[0], user_sorted=user_sorted)
+                index = ops.TrainIndex(triples[:n], P.shape[0], Q.shape[0], user_sorted=user_sorted, pointwise=pointwise)
             epochs = range(1, self.epochs + 1)
             bar = _tqdm(epochs) if (_tqdm is not None and self.show_progress) else None
             for epoch in (bar if bar is not None else epochs):
@@ -418,17 +418,42 @@ class _AdamState:
     and, for FM, the three bias tensors (AbstractRecommender.py:54-61)."""
 
     def __init__(self, P, Q, lr, biases=None, kind="adam", max_steps=0, lazy=False):
+        self.kind = kind
         self.opt = ops.DenseOptimizer(kind, lr)
-        self.gP = torch.zeros_like(P)
+        self._gP = None
+        self._P = P
         # FM: gradient buffers of (u_bias, i_bias, bias_)
         self.w = [] if biases is None else [b.view(-1) for b in biases]
         self.g = [torch.zeros_like(b) for b in self.w]
-        # lazy=True, Adam on the two tables alone (MF): the exact lazy form - rows without a gradient are replayed when
-        # they are next needed instead of being rewritten in every step (ops.LazyAdam: same bits as the dense
-        # optimiser); between flush() calls only the rows of the batches seen so far are current
+        # lazy=True, Adam: the exact lazy form - rows without a gradient are replayed when they are next needed instead
+        # of being rewritten in every step (ops.LazyAdam: same bits as the dense optimiser); between flush() calls only
+        # the rows of the batches seen so far are current.  The staged step (item_mode 'fused') always runs it.
+        self._lazy_args = (P, Q, lr, max_steps)
         self.lazy = ops.LazyAdam(P, Q, lr, max_steps) if (lazy and kind == "adam" and biases is None) else None
+        self.lazy_staged = None
+
+    @property
+    def gP(self):
+        if self._gP is None:             # (the staged step forms no dense user gradient)
+            self._gP = torch.zeros_like(self._P)
+        return self._gP
 
     def step(self, ctx, P, Q, reg_1, reg_2, loss_id, item_mode):
+        if self.kind == "adam" and item_mode == ops.ITEM_MODES["fused"]:
+            # the staged step: forward fused into the user update, item rows committed by their segment owner, every
+            # owner applies torch's Adam to its row (moments read and written once per touched row)
+            if self.lazy_staged is None:
+                self.lazy_staged = self.lazy if self.lazy is not None else ops.LazyAdam(*self._lazy_args)
+                self.lazy = None
+            self.opt.next_step()
+            self.lazy_staged.staged_step(ctx, reg_1, reg_2, loss_id)
+            if self.w:                   # FM: the biases through the dense optimiser (three small vectors)
+                self.g[2].copy_(ctx.stats[ops.N.ST_SUM_COEF:ops.N.ST_SUM_COEF + 1])
+                for w, g in zip(self.w, self.g):
+                    self.opt.step(w, g)
+            return
+        if item_mode == ops.ITEM_MODES["fused"]:
+            item_mode = ops.ITEM_MODES["chunked"]
         if self.lazy is not None:
             self.lazy.catchup(ctx)            # the rows this batch reads are brought to the previous step first
             ctx.forward(P, Q, loss_id)
@@ -449,5 +474,6 @@ class _AdamState:
 
     def flush(self):
         """every row up to the current step (end of an epoch: before the tables are read by anything but a step)"""
-        if self.lazy is not None:
-            self.lazy.flush()
+        for lz in (self.lazy, self.lazy_staged):
+            if lz is not None:
+                lz.flush()

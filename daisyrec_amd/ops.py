@@ -58,7 +58,8 @@ class TrainIndex:
     sorted by item, built once per fit (BasicDataset's triple array is immutable, dataset.py:21).
     Raises ValueError when an id lies outside the tables (the reference: IndexError in nn.Embedding)."""
 
-    def __init__(self, triples, user_num: int, item_num: int, user_base: int = 0, user_sorted=None):
+    def __init__(self, triples, user_num: int, item_num: int, user_base: int = 0, user_sorted=None, pointwise=False):
+        """pointwise: rows are (user, item, label) (CL / SL, sampler.py:93-98): one item entry per row"""
         if user_sorted is None:
             user_sorted = triples_user_sorted(triples)
         self.triples = triples            # kept alive: a user-sorted array is indexed in place
@@ -68,7 +69,8 @@ class TrainIndex:
         with torch.cuda.device(triples.device):
             check(lib.daisy_train_index_create(C.byref(self._h), _ptr(triples, torch.int32, "triples"), self.n,
                                                self.user_num, self.item_num, int(user_base),
-                                               N.PLAN_TRIPLES_USER_SORTED if user_sorted else 0, _stream()))
+                                               (N.PLAN_TRIPLES_USER_SORTED if user_sorted else 0)
+                                               | (N.PLAN_POINTWISE if pointwise else 0), _stream()))
 
     @property
     def nbytes(self):
@@ -487,6 +489,26 @@ class LazyAdam:
             _ptr(self.v[1], f, "vQ"), _ptr(self.last[1], torch.int32, "lastQ"), _ptr(self._table, f, "table"),
             self.BETA1, self.BETA2, self.EPS, self.t, _stream()))
 
+    def staged_step(self, ctx, reg_1, reg_2, loss_type=N.LOSS_BPR, gamma=1e-10, step_loss=None, accumulate=True):
+        """One Adam step on the current batch through the staged kernels (forward fused into the user update, item rows
+        committed by their segment owner): catch-up of the rows the batch references, then step t on the rows that
+        have a gradient.  FM contexts: the bias gradients land in the context's g_u_bias / g_i_bias and
+        stats[ST_SUM_COEF] (bias_) for the caller's dense optimiser."""
+        self.t += 1
+        if self.t > self._table_steps:
+            self._grow(2 * self.t)
+        ctx._sync_norm_cache(self.P)
+        self._ctx = ctx
+        f = torch.float32
+        check(lib.daisy_bpr_staged_adam_step(
+            ctx._h, _ptr(self.P, f, "P"), _ptr(self.Q, f, "Q"), int(loss_type), float(gamma), self.lr, float(reg_1),
+            float(reg_2), _ptr(self.m[0], f, "mP"), _ptr(self.v[0], f, "vP"), _ptr(self.last[0], torch.int32, "lastP"),
+            _ptr(self.m[1], f, "mQ"), _ptr(self.v[1], f, "vQ"), _ptr(self.last[1], torch.int32, "lastQ"),
+            _ptr(self._table, f, "table"), self.BETA1, self.BETA2, self.EPS, self.t,
+            _ptr(ctx.stats, torch.float64, "stats"),
+            _ptr(ctx.epoch_acc, torch.float64, "epoch_acc") if accumulate else None,
+            _ptr(step_loss, torch.float64, "step_loss"), _stream()))
+
     def flush(self):
         f = torch.float32
         for W, m, v, last in ((self.P, self.m[0], self.v[0], self.last[0]), (self.Q, self.m[1], self.v[1], self.last[1])):
@@ -494,6 +516,8 @@ class LazyAdam:
                                             _ptr(last, torch.int32, "last"), W.shape[0], W.shape[1],
                                             _ptr(self._table, f, "table"), self.BETA1, self.BETA2, self.EPS, self.t,
                                             _stream()))
+        if getattr(self, "_ctx", None) is not None:      # the flush rewrote rows of P behind the staged step's row-norm cache
+            self._ctx.invalidate_cache()
 
 
 def _bias_ptrs(biases):

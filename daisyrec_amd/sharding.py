@@ -85,8 +85,7 @@ class UserShardedBprTrainer:
             # FM's bias gradients (stats[SUM_COEF], g_i_bias) are not part of either exchange: the replicas
             # would drift apart silently
             raise NotImplementedError("UserShardedBprTrainer: contexts with FM biases are not supported")
-        self.staged = (self.item_mode == N.ITEM_FUSED and hasattr(ctx, "staged_user")
-                       and self.loss_type in (N.LOSS_BPR, N.LOSS_HL, N.LOSS_TL))
+        self.staged = self.item_mode == N.ITEM_FUSED and hasattr(ctx, "staged_user")
         if self.item_mode == N.ITEM_FUSED and not self.staged:
             self.item_mode = N.ITEM_CHUNKED
         # collectives the backend lacks are emulated with the ones it has (gloo: no reduce_scatter);

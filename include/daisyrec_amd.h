@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DAISY_ABI_VERSION 3
+#define DAISY_ABI_VERSION 4
 
 typedef void *daisy_stream_t; /* hipStream_t */
 
@@ -196,6 +196,17 @@ int daisy_bpr_staged_item_slices(daisy_bpr_ctx *ctx, const int32_t *item_bounds,
                                  daisy_stream_t stream);
 int daisy_bpr_staged_item_slice(daisy_bpr_ctx *ctx, int32_t loss_type, float *gQ, float *cnt, int32_t slice,
                                 float lr, float reg_1, float reg_2, const double *stats, daisy_stream_t stream);
+/* The staged step with torch.optim.Adam on both tables (AbstractRecommender.py:54; ABI 4), lazy form: the rows the
+ * current batch references are first brought to step `step`-1 (zero-gradient replays, see daisy_adam_lazy_catchup),
+ * then the user pass and the item pass apply step `step` to the rows they own (moments m*, v*, stamps last*: the
+ * state of daisy_adam_lazy_* / ops.LazyAdam; `table` = daisy_adam_lazy_table(lr, ...) copied to the device).  Rows no batch has
+ * referenced stay behind until daisy_adam_lazy_flush.  Same arithmetic as daisy_adam_dense on every element.
+ * FM biases (daisy_bpr_ctx_set_bias): their gradients go to g_u_bias / g_i_bias / stats[DAISY_ST_SUM_COEF] for the
+ * caller's dense optimiser.  Every loss of loss.py:5-33; point-wise ones on point-wise batches. */
+int daisy_bpr_staged_adam_step(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t loss_type, float gamma, float lr,
+                               float reg_1, float reg_2, float *mP, float *vP, int32_t *lastP, float *mQ, float *vQ, int32_t *lastQ,
+                               const float *table, float beta1, float beta2, float eps, int64_t step, double *stats,
+                               double *epoch_acc, double *step_loss, daisy_stream_t stream);
 /* rows of batch k held by this plan (host value; -1: no such batch) */
 int64_t daisy_epoch_plan_batch_rows(const daisy_epoch_plan *plan, int64_t k);
 

@@ -55,8 +55,11 @@ def test_fm_kat_steps_sgd(kat_fm, item_mode):
         ctx.close()
 
 
-def test_fm_kat_adam(kat_fm):
-    """Dense Adam over the five FM parameters, phase entry points + daisy_adam_dense."""
+@pytest.mark.parametrize("item_mode", ["sorted", "fused"])
+def test_fm_kat_adam(kat_fm, item_mode):
+    """Adam over the five FM parameters: phase entry points + daisy_adam_dense ('sorted'), and the staged step
+    ('fused': the row owners apply torch's Adam to the rows with a gradient, rows without one are replayed by
+    flush(); the three bias vectors through the dense optimiser)."""
     from daisyrec_amd import ops
     from daisyrec_amd.model.AbstractRecommender import _AdamState
     g = kat_fm
@@ -71,7 +74,8 @@ def test_fm_kat_adam(kat_fm):
         ctx.set_bias(w[2], w[3], w[4], g_u_bias=adam.g[0], g_i_bias=adam.g[1], g_bias=adam.g[2])
         for s in range(ns):
             ctx.set_batch(_t(g[f"{name}/u"][s]), _t(g[f"{name}/i"][s]), _t(g[f"{name}/j"][s]))
-            adam.step(ctx, w[0], w[1], r1, r2, lt, ops.ITEM_MODES["sorted"])
+            adam.step(ctx, w[0], w[1], r1, r2, lt, ops.ITEM_MODES[item_mode])
+            adam.flush()
             ref = float(g[f"{name}/loss"][s])
             assert abs(float(ctx.stats[7].cpu()) - ref) <= 1e-5 * abs(ref), (name, s)
             for k, key in enumerate(KEYS):

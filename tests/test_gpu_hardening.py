@@ -258,3 +258,54 @@ def test_lazy_adam_equals_dense_adam_bit_for_bit():
             assert torch.equal(Pa, Pb) and torch.equal(Qa, Qb), (d, U, I, B)
         for a, b in zip(res[0][1], res[1][1]):
             assert torch.equal(a, b), (d, U, I, B)
+
+
+@pytest.mark.parametrize("path", ["small", "chunked", "staged"])
+def test_epoch_stops_at_the_first_non_finite_loss(ops, path):
+    """AbstractRecommender.py:122-123: the reference raises when a batch's loss is NaN/inf, BEFORE that batch's
+    backward.  The native epoch loop has one host sync per epoch; a device-side flag makes every later kernel of the
+    epoch a no-op instead.  Batch k_bad is the first that references an item whose row is NaN: the small-batch and the
+    phase loops leave both tables exactly as k_bad steps left them; the staged step (forward fused into the user
+    update) has moved the user rows of the offending batch, nothing else."""
+    rng = np.random.default_rng(3)
+    U, I, d = 400, 120, 64
+    B = {"small": 128, "chunked": 512, "staged": 512}[path]
+    nb, k_bad = 6, 3
+    n = nb * B
+    u = np.sort(rng.integers(0, U, n)).astype(np.int32)          # identity order: batch k = rows [k*B, (k+1)*B)
+    i = rng.integers(0, 100, n).astype(np.int32)
+    j = rng.integers(0, 100, n).astype(np.int32)
+    i[k_bad * B + 5] = 110                                        # the poisoned item enters in batch k_bad
+    P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    Q0[110] = np.nan
+    tri = np.stack([u, i, j], 1)
+    mode = ops.ITEM_MODES["fused" if path != "chunked" else "chunked"]
+
+    def run(rows):
+        P, Q = _t(P0), _t(Q0)
+        t = _t(tri[:rows])
+        ctx = ops.BprContext(B, d, U, I)
+        plan = ops.EpochPlan(rows, U, I)
+        if path == "staged":
+            idx = ops.TrainIndex(t, U, I, user_sorted=True)
+            plan.build_indexed(idx, B, order="identity")
+        else:
+            plan.build(t, B, order="identity", user_sorted=True)
+        ctx.fit_epoch_sgd(plan, P, Q, 0.05, 1e-3, 1e-3, item_mode=mode)
+        acc = ctx.epoch_acc.cpu().numpy().copy()
+        out = P.cpu().numpy(), Q.cpu().numpy(), acc
+        ctx.close(); plan.close()
+        return out
+
+    P_ok, Q_ok, acc_ok = run(k_bad * B)                            # the first k_bad batches alone: all finite
+    assert acc_ok[1] == 0
+    P_bad, Q_bad, acc_bad = run(n)                                 # the whole epoch
+    assert acc_bad[1] == 1, acc_bad                                # exactly ONE non-finite step was counted: the epoch stopped there
+    assert np.array_equal(Q_bad[:110], Q_ok[:110]) and np.array_equal(Q_bad[111:], Q_ok[111:])
+    if path == "staged":
+        touched = np.unique(u[k_bad * B:(k_bad + 1) * B])
+        keep = np.setdiff1d(np.arange(U), touched)
+        assert np.array_equal(P_bad[keep], P_ok[keep])
+    else:
+        assert np.array_equal(P_bad, P_ok)

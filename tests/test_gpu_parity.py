@@ -60,7 +60,10 @@ def test_kat_steps_sgd(ops, kat_steps, item_mode):
         ctx.close()
 
 
-def test_kat_adam(ops, kat_steps):
+@pytest.mark.parametrize("item_mode", ["sorted", "fused"])
+def test_kat_adam(ops, kat_steps, item_mode):
+    """torch.optim.Adam against the reference's vectors: the phase kernels + the dense optimiser ('sorted'), and the
+    staged step, whose row owners apply Adam themselves ('fused'; flush() replays the rows without a gradient)"""
     from daisyrec_amd.model.AbstractRecommender import _AdamState
     g, name = kat_steps, "bpr_adam"
     U, I, d, B, ns = (int(x) for x in g[f"{name}/meta"])
@@ -70,7 +73,8 @@ def test_kat_adam(ops, kat_steps):
     adam = _AdamState(P, Q, lr)
     for s in range(ns):
         ctx.set_batch(_t(g[f"{name}/u"][s]), _t(g[f"{name}/i"][s]), _t(g[f"{name}/j"][s]))
-        adam.step(ctx, P, Q, r1, r2, ops.LOSS_IDS["BPR"], ops.ITEM_MODES["sorted"])
+        adam.step(ctx, P, Q, r1, r2, ops.LOSS_IDS["BPR"], ops.ITEM_MODES[item_mode])
+        adam.flush()
         ref = float(g[f"{name}/loss"][s])
         assert abs(float(ctx.stats[7].cpu()) - ref) <= 1e-5 * abs(ref)
         np.testing.assert_allclose(P.cpu().numpy(), g[f"{name}/P"][s], rtol=0, atol=2e-6)

@@ -1,5 +1,2 @@
-L=$GRAFT_REPO_ROOT/daisyrec_amd/lib
 cd $GRAFT_REPO_ROOT
-for wl in c2; do
-bash tools/r03_run.sh x1_$wl $wl DAISY_LIB_OVERRIDE=$L/dev_x1/libdaisyrec_hip.so
-done
+timeout 280 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fm.py -x -q -m gpu -k "kat or pointwise or fm_step or adam" 2>&1 | tail -25
