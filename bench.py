@@ -401,11 +401,12 @@ def main():
     data = build_data(a, rank, world, dev, wl)
     r = measure(a, data, rank, world, dev, B_main, a.slices, a.steps, a.warmup, want_cpu)
     sweep = []
-    if world > 1 and wl == "c3" and not a.no_sweep and a.item_mode == "fused" and a.batch is None:
+    if world > 1 and wl in ("c3", "tiny") and not a.no_sweep and a.item_mode == "fused" and (a.batch is None or wl == "tiny"):
         # the regimes of DESIGN.md section 5 in one launch: the exchange is a fixed 2 x 231 MB per step and rank, so
         # the batch decides how much compute it is spread over; slices > 1 hides it under the item pass
-        for Bl in (1 << 21, 1 << 23, 1 << 24):
-            for sl in (1, 8):
+        # (the tiny workload runs a miniature of the same sweep: it exists to exercise this code on a one-GPU box)
+        for Bl in ((1 << 21, 1 << 23, 1 << 24) if wl == "c3" else (1 << 14, 1 << 16)):
+            for sl in ((1, 8) if wl == "c3" else (1, 4)):
                 if (min(Bl, data["n"]), sl) == (r["B"], r["slices"]):
                     sweep.append(r)
                     continue
@@ -428,12 +429,12 @@ def main():
                                   "algorithmic_bytes_per_interaction": ALGO_BYTES_PER_INTERACTION_SGD(64)}}
 
     ref = None
-    if world > 1 and wl == "c3" and not a.no_ref:
+    if world > 1 and wl in ("c3", "tiny") and not a.no_ref:
         # the same workload on ONE GPU (rank 0; the others wait), so that the N-GPU / 1-GPU ratio on
         # BASELINE configs[2] is on this line
         if rank == 0:
             d1 = build_data(a, 0, 1, dev, wl)
-            r1 = measure(a, d1, 0, 1, dev, 1 << 21, 1, None, a.warmup)
+            r1 = measure(a, d1, 0, 1, dev, (1 << 21) if wl == "c3" else (1 << 16), 1, None, a.warmup)
             free_data(d1)
             ref = {"value": r1["steps"] * r1["B"] / r1["dt"], "unit": "interactions/s", "n_gpus": 1,
                    "steps": r1["steps"], "ms_per_step": r1["dt"] / r1["steps"] * 1e3, "batch": r1["B"],

@@ -153,3 +153,16 @@ def test_bench_self_spawns_its_ranks():
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 2 * 65536 and out["value"] > 0
+    # the self-diagnosing part of a multi-rank run: who took part, are the replicas identical and
+    # equal to the single-GPU fit, where does a step's time go, the B_local x slices sweep with its speed-ups
+    dd = out["distributed"]
+    assert dd["world_size"] == 2 and len(dd["ranks"]) == 2 and dd["backend"] == "gloo" and dd["rccl_version"]
+    rc = out["replica_check"]
+    assert rc["q_checksum_identical_on_all_ranks"] is True and rc["loss_equal_to_1e-6"] is True, rc
+    assert rc["q_max_abs_diff_vs_1gpu"] < 1e-5 and rc["p_max_abs_diff_vs_1gpu"] < 1e-5, rc
+    sp = out["step_split_ms"]
+    assert sp["compute"] > 0 and sp["exposed_exchange"] >= 0
+    assert out["single_gpu_same_workload"]["value"] > 0 and out["speedup_vs_single_gpu_same_workload"] > 0
+    pts = out["sweep"]
+    assert {(p["batch_per_gpu"], p["slices"]) for p in pts} == {(16384, 1), (16384, 4), (65536, 1), (65536, 4)}
+    assert all(p["value"] > 0 and p["compute_ms"] > 0 and "meets_6x" in p for p in pts)
