@@ -84,6 +84,11 @@ SIGNATURES = {
     "daisy_bpr_staged_item_slice": (C.c_int, [_p, _i32, _p, _p, _i32, _f32, _f32, _f32, _p, _p]),
     "daisy_bpr_staged_adam_step": (C.c_int, [_p, _p, _p, _i32, _f32, _f32, _f32, _f32, _p, _p, _p, _p, _p, _p, _p,
                                              _f32, _f32, _f32, _i64, _p, _p, _p, _p]),
+    "daisy_bpr_staged_adam_catchup_users": (C.c_int, [_p, _p, _p, _p, _p, _p, _f32, _f32, _f32, _i64, _p]),
+    "daisy_bpr_staged_user_adam": (C.c_int, [_p, _p, _p, _i32, _f32, _f32, _f32, _f32, _p, _p, _p, _f32, _f32, _f32, _i64,
+                                             _p, _p]),
+    "daisy_item_apply_counts_adam": (C.c_int, [_p, _p, _p, _p, _p, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _i64,
+                                               _p, _p]),
     "daisy_bpr_forward": (C.c_int, [_p, _p, _p, _i32, _f32, _p, _p]),
     "daisy_bpr_finalize": (C.c_int, [_p, _p, _f32, _f32, _p, _p, _p]),
     "daisy_bpr_item_grad": (C.c_int, [_p, _p, _p, _p, _f32, _f32, _p, _i32, _p]),

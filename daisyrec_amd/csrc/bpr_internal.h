@@ -62,6 +62,7 @@ struct StreamView {
     const double *halt;      // see BatchView::halt
     int32_t pointwise;       // rows are (user, item, label): E = B entries in the partitioned layout; the sorted
                              // layout keeps an inert negative slot per sample (E = 2B)
+    int32_t p_stream;        // the user pass reads P with nontemporal loads (set by the host for tables >> the caches)
 };
 }  // namespace daisy
 

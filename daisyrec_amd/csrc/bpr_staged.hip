@@ -64,7 +64,10 @@ namespace daisy {
 #ifndef DAISY_ITEM_WINDOW
 #define DAISY_ITEM_WINDOW 1
 #endif
-constexpr int kItemWinFloats = 6144;      // 24 KB of Q rows per workgroup of the item pass (96 rows at d = 64)
+constexpr size_t kStreamTableBytes = (size_t)512 << 20;   // user tables beyond this are read past the caches (k_staged_user)
+constexpr int kItemWinFloats = 6144;      // 24 KB of Q rows per workgroup of the item pass (96 rows at d = 64); rows of two
+                                          // float4 per lane get 16 KB, wider ones none (their partial-sum slots already
+                                          // take the LDS that four workgroups per CU leave)
 
 constexpr int kStagedUserBlock = 128, kStagedItemBlock = 256;    // threads per workgroup of the two passes (measured:
                                                                  // user pass 387 -> 360 us at 128, item pass indifferent)
@@ -415,6 +418,7 @@ StreamView plan_stream_view(const daisy_epoch_plan *p, int64_t k) {
     v.pos_base = pos_base;
     v.halt = nullptr;
     v.pointwise = p->pointwise;
+    v.p_stream = 0;
     return v;
 }
 
@@ -710,7 +714,7 @@ __device__ __forceinline__ void user_commit(float *__restrict__ P, float *__rest
 #pragma unroll
     for (int k = 0; k < C::NE; ++k) g.v[k] = acc.v[k] + fmaf(w2, p.v[k], w1 * sgn(p.v[k]));
     row_apply<C, ADAM>(p, g, opt, user, lane, d);
-    p.store(P + user * d, lane, d);
+    p.store(P + user * d, lane, d);        // (nontemporal stores of the user rows measured no different)
     const float sq = row_dot<C>(p, p);
     if (lane == 0) p_sqnorm[user] = sq;
 }
@@ -814,7 +818,17 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 
 
         // ---- hop 2: the rows of every sample of the run
         Row<C> qi[RUN], qj[PAIR ? RUN : 1], pr[RUN];
-        if (__all(cnt == RUN)) {        // wave-uniform: no branch between the gathers
+        if (__all(cnt == RUN) && v.p_stream) {     // (wave-uniform: no branch between the gathers)
+            // a user table far beyond the Infinity Cache: its rows come back once every few steps, so they are read
+            // past the caches and leave them to Q (10 M x 1 M shapes: 449 -> 420 us per pass; at 1 M users, where
+            // most rows return in the next step, the same loads measured 3 % slower: the host decides)
+#pragma unroll
+            for (int x = 0; x < RUN; ++x) {
+                qi[x].load(Q + (int64_t)group_bcast<C>(my_ij.x, x) * d, lane, d);
+                if constexpr (PAIR) qj[x].load(Q + (int64_t)group_bcast<C>(my_ij.y, x) * d, lane, d);
+                pr[x].load_nt(P + (int64_t)group_bcast<C>(my_user, x) * d, lane, d);
+            }
+        } else if (__all(cnt == RUN)) {
 #pragma unroll
             for (int x = 0; x < RUN; ++x) {
                 qi[x].load(Q + (int64_t)group_bcast<C>(my_ij.x, x) * d, lane, d);
@@ -1143,8 +1157,9 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
     // a commit inside the reduction then costs no dependent trip to memory (at a few entries per item - 10 M x 1 M
     // shapes - 355 -> 320 us per pass).  Only for d % 4 == 0 (16-byte units); rows past the window (sparse batches: few
     // entries spread over many items) are loaded directly.
-    constexpr bool WIN = APPLY && C::VEC == 4 && DAISY_ITEM_WINDOW;
-    __shared__ __attribute__((aligned(16))) float qwin[WIN ? kItemWinFloats : 4];
+    constexpr bool WIN = APPLY && C::VEC == 4 && C::NE <= 8 && DAISY_ITEM_WINDOW;
+    constexpr int WINF = (C::NE <= 4) ? kItemWinFloats : (kItemWinFloats * 2 / 3);
+    __shared__ __attribute__((aligned(16))) float qwin[WIN ? WINF : 4];
 
     const int tid = threadIdx.x;
     const int lane = tid % C::LPR;
@@ -1182,7 +1197,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
             const int64_t c1 = (c0 + E < n) ? (c0 + E) : n;
             win.first = (int32_t)((v.e_key[c0] & v.imask) >> 1);
             const int32_t item_hi = (int32_t)((v.e_key[c1 - 1] & v.imask) >> 1);
-            const int32_t cap = kItemWinFloats / d;
+            const int32_t cap = WINF / d;
             win.rows = (item_hi - win.first + 1 < cap) ? (item_hi - win.first + 1) : cap;
             const int units = win.rows * (d >> 2);                      // 16-byte units, contiguous in Q
             const float *src = Qo + (int64_t)win.first * d;
@@ -1397,6 +1412,45 @@ __global__ __launch_bounds__(kBlock) void k_item_apply_counts(float *__restrict_
     }
 }
 
+// The same owner step with torch.optim.Adam (multi-GPU staged step): DENSE over the owner's block - every row steps in
+// every step like torch's optimiser (rows without an entry: zero gradient, the moments decay), at I/N rows per rank.
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_item_apply_counts_adam(float *__restrict__ Q, float *__restrict__ g,
+                                                                   float *__restrict__ cnt, float *__restrict__ m,
+                                                                   float *__restrict__ vv, int64_t rows, int d,
+                                                                   float reg_1, float reg_2, RowOpt opt,
+                                                                   const double *__restrict__ stats) {
+    const int lane = threadIdx.x % C::LPR;
+    const int group = threadIdx.x / C::LPR;
+    const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
+    const float rI = inv_or_zero(stats[DAISY_ST_NORM_I], reg_2);
+    const float rJ = inv_or_zero(stats[DAISY_ST_NORM_J], reg_2);
+    for (int64_t r = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; r < rows; r += gstride) {
+        const float np = cnt[2 * r], nn = cnt[2 * r + 1];
+        Row<C> q, gr, mr, vr;
+        q.load(Q + r * d, lane, d);
+        mr.load(m + r * d, lane, d);
+        vr.load(vv + r * d, lane, d);
+        gr.zero();
+        if (np + nn != 0.f) {
+            gr.load(g + r * d, lane, d);
+            const float w1 = reg_1 * (np + nn), w2 = np * rI + nn * rJ;
+#pragma unroll
+            for (int k = 0; k < C::NE; ++k) gr.v[k] += fmaf(w2, q.v[k], w1 * sgn(q.v[k]));
+        }
+        adam_row<C>(q, mr, vr, gr, opt.step_size, opt.bc2_sqrt, opt.beta1, opt.beta2, opt.eps);
+        q.store(Q + r * d, lane, d);
+        mr.store(m + r * d, lane, d);
+        vr.store(vv + r * d, lane, d);
+        if (np + nn != 0.f) {
+            Row<C> z;
+            z.zero();
+            z.store(g + r * d, lane, d);
+            if (lane == 0) { cnt[2 * r] = 0.f; cnt[2 * r + 1] = 0.f; }
+        }
+    }
+}
+
 // rng[s] = first entry of the batch whose item is >= bounds.b[s]  (s = 0..S; the entries are sorted by item)
 struct SliceBounds { int32_t b[kMaxItemSlices + 1]; };
 __global__ void k_slice_ranges(StreamView v, SliceBounds bounds, int S, int64_t *__restrict__ rng) {
@@ -1496,6 +1550,16 @@ static RowOpt row_opt(float lr, const StagedAdam *a, bool user_side) {
     return o;
 }
 
+static StagedAdam adam_consts(float lr, float beta1, float beta2, float eps, int64_t step) {
+    StagedAdam a{};
+    // step `step`'s constants: the host arithmetic of daisy_adam_dense / daisy_adam_lazy_table (same bits as table[step])
+    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+    a.step_size = (float)((double)lr / bc1);
+    a.bc2_sqrt = (float)sqrt(bc2);
+    a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.t = (int32_t)step;
+    return a;
+}
+
 // workgroup size of the user pass: 128 threads; ONE wave (its barriers are free) for rows of two float4 per
 // lane (64 < d <= 128: 1.40 -> 1.27 ms per 2M-sample step at d=128; slower at d <= 64 (0.60 -> 0.71), and
 // rows of four float4 per lane would need more edge records than the context holds)
@@ -1511,10 +1575,12 @@ static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_ty
                        float reg_1, float reg_2, double *stats, int *grid_out, int n_pre, bool ride_reduce,
                        double *epoch_acc, double *step_loss, hipStream_t s, const StagedAdam *adam = nullptr,
                        bool bias_grad_out = false) {
-    const StreamView &v = ctx->sv;
+    StreamView v = ctx->sv;
     const int d = ctx->d;
     const int mode = staged_mode(ctx, loss_type);
     const bool has_pos = v.s_pos != nullptr;
+    static const int tune_ps = getenv("DAISY_STAGED_PSTREAM") ? atoi(getenv("DAISY_STAGED_PSTREAM")) : -1;
+    v.p_stream = (tune_ps >= 0) ? tune_ps : ((size_t)ctx->U * (size_t)d * 4 > kStreamTableBytes ? 1 : 0);
     UserEdges ed{ctx->edge_vec, ctx->edge_user, ctx->edge_n, ctx->edge_whole};
     const PreNorm pre{ctx->partials + (size_t)kMaxGrid * 8, n_pre};
     const RowOpt opt = row_opt(lr, adam, true);
@@ -1631,11 +1697,11 @@ template <class C>
 __global__ __launch_bounds__(kBlock) void k_staged_adam_catchup(StreamView v, int d, float *__restrict__ P,
                                                                 float *__restrict__ Q, StagedAdam a,
                                                                 const float2 *__restrict__ table,
-                                                                float *__restrict__ p_sqnorm) {
+                                                                float *__restrict__ p_sqnorm, int users_only) {
     if (halted(v.halt)) return;
     const int lane = threadIdx.x % C::LPR, group = threadIdx.x / C::LPR;
     const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
-    const int64_t total = v.B + v.E;
+    const int64_t total = users_only ? v.B : v.B + v.E;
     for (int64_t x = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; x < total; x += gstride) {
         const bool user_side = x < v.B;
         int64_t row;
@@ -1683,7 +1749,7 @@ int staged_adam_step(daisy_bpr_ctx *ctx, float *P, float *Q, int loss_type, floa
             ctx->p_sqnorm_of = P;
         }
         hipLaunchKernelGGL((k_staged_adam_catchup<C>), dim3(grid_for(v.B + v.E, C::GROUPS_PER_BLOCK, kMaxGridSparse)),
-                           dim3(kBlock), 0, s, v, d, P, Q, a, reinterpret_cast<const float2 *>(table), ctx->p_sqnorm);
+                           dim3(kBlock), 0, s, v, d, P, Q, a, reinterpret_cast<const float2 *>(table), ctx->p_sqnorm, 0);
         return DAISY_OK;
     });
     if (rc) return rc;
@@ -1910,11 +1976,8 @@ int daisy_bpr_staged_adam_step(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t l
                                double *stats, double *epoch_acc, double *step_loss, daisy_stream_t stream) {
     DAISY_CHECK_ARG(ctx && P && Q && mP && vP && lastP && mQ && vQ && lastQ && table && stats && step >= 1,
                     "staged_adam_step: bad argument");
-    StagedAdam a{mP, vP, lastP, mQ, vQ, lastQ, 0.f, 0.f, beta1, beta2, eps, (int32_t)step};
-    // step `step`'s constants: the host arithmetic of daisy_adam_dense / daisy_adam_lazy_table (same bits as table[step])
-    const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
-    a.step_size = (float)((double)lr / bc1);
-    a.bc2_sqrt = (float)sqrt(bc2);
+    StagedAdam a = adam_consts(lr, beta1, beta2, eps, step);
+    a.mP = mP; a.vP = vP; a.lastP = lastP; a.mQ = mQ; a.vQ = vQ; a.lastQ = lastQ;
     struct HaltScope {
         daisy_bpr_ctx *c;
         HaltScope(daisy_bpr_ctx *c_, const double *h) : c(c_) { c->v.halt = h; c->sv.halt = h; }
@@ -1927,6 +1990,67 @@ int daisy_bpr_staged_adam_step(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t l
     }
     return staged_adam_step(ctx, P, Q, loss_type, gamma, reg_1, reg_2, a, table, bias_grad_out, stats, epoch_acc,
                             step_loss, S(stream));
+}
+
+int daisy_bpr_staged_adam_catchup_users(daisy_bpr_ctx *ctx, float *P, float *mP, float *vP, int32_t *lastP,
+                                        const float *table, float beta1, float beta2, float eps, int64_t step,
+                                        daisy_stream_t stream) {
+    DAISY_CHECK_ARG(ctx && P && mP && vP && lastP && table && step >= 1, "staged_adam_catchup_users: bad argument");
+    if (!ctx->batch_set) { set_error("staged_adam_catchup_users: no batch set"); return DAISY_ERR_STATE; }
+    StagedAdam a = adam_consts(0.f, beta1, beta2, eps, step);
+    a.mP = mP; a.vP = vP; a.lastP = lastP;
+    hipStream_t s = S(stream);
+    const StreamView &v = ctx->sv;
+    const int d = ctx->d;
+    int rc = dispatch_d(d, [&](auto cfg) {
+        using C = decltype(cfg);
+        if (ctx->p_sqnorm_of != P) {
+            hipLaunchKernelGGL((k_row_sqnorm<C>), dim3(grid_for(ctx->U, C::GROUPS_PER_BLOCK * 4)), dim3(kBlock), 0, s,
+                               P, ctx->U, d, ctx->p_sqnorm);
+            ctx->p_sqnorm_of = P;
+        }
+        hipLaunchKernelGGL((k_staged_adam_catchup<C>), dim3(grid_for(v.B, C::GROUPS_PER_BLOCK, kMaxGridSparse)), dim3(kBlock),
+                           0, s, v, d, P, (float *)nullptr, a, reinterpret_cast<const float2 *>(table), ctx->p_sqnorm, 1);
+        return DAISY_OK;
+    });
+    if (rc) return rc;
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
+int daisy_bpr_staged_user_adam(daisy_bpr_ctx *ctx, float *P, const float *Q, int32_t loss_type, float gamma, float lr,
+                               float reg_1, float reg_2, float *mP, float *vP, int32_t *lastP, float beta1, float beta2,
+                               float eps, int64_t step, double *stats, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(ctx && P && Q && stats && mP && vP && lastP && step >= 1, "staged_user_adam: NULL argument");
+    int rc = staged_check(ctx, loss_type, "staged_user_adam");
+    if (rc) return rc;
+    if (ctx->p_sqnorm_of != P) {
+        set_error("staged_user_adam: daisy_bpr_staged_prenorm has not run on this table");
+        return DAISY_ERR_STATE;
+    }
+    if (ctx->bu) { set_error("staged_user_adam: contexts with FM biases are not supported by the phase form"); return DAISY_ERR_ARG; }
+    StagedAdam a = adam_consts(lr, beta1, beta2, eps, step);
+    a.mP = mP; a.vP = vP; a.lastP = lastP;
+    int gu = 0;
+    if ((rc = staged_user(ctx, P, Q, loss_type, gamma, 0.f, reg_1, reg_2, stats, &gu, 0, false, nullptr, nullptr, S(stream), &a))) return rc;
+    return launch_reduce_partials(ctx->partials, gu, stats, false, 0.f, 0.f, nullptr, nullptr, S(stream));
+}
+
+int daisy_item_apply_counts_adam(float *Q, float *g, float *cnt, float *m, float *v, int64_t rows, int32_t d, float lr,
+                                 float reg_1, float reg_2, float beta1, float beta2, float eps, int64_t step,
+                                 const double *stats, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(Q && g && cnt && m && v && stats && rows > 0 && step >= 1, "item_apply_counts_adam: bad argument");
+    const StagedAdam a = adam_consts(lr, beta1, beta2, eps, step);
+    const RowOpt opt = row_opt(lr, &a, false);
+    int rc = dispatch_d(d, [&](auto cfg) {
+        using C = decltype(cfg);
+        hipLaunchKernelGGL((k_item_apply_counts_adam<C>), dim3(grid_for(rows, C::GROUPS_PER_BLOCK * 2)), dim3(kBlock), 0,
+                           S(stream), Q, g, cnt, m, v, rows, (int)d, reg_1, reg_2, opt, stats);
+        return DAISY_OK;
+    });
+    if (rc) return rc;
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
 }
 
 int daisy_item_apply_counts(float *Q, float *g, float *cnt, int64_t rows, int32_t d, float lr, float reg_1,

@@ -1356,6 +1356,7 @@ static StreamView stream_view_of(const BatchView &v) {
     sv.B = v.B; sv.E = 2 * v.B;
     sv.halt = nullptr;
     sv.pointwise = v.pointwise;
+    sv.p_stream = 0;
     return sv;
 }
 

@@ -219,7 +219,7 @@ class GeneralRecommender(AbstractRecommender):
         inv[perm] = torch.arange(n, dtype=torch.int64, device=row_ids.device)
         return inv[row_ids].contiguous()
 
-    def _fit_sharded(self, train_loader, triples, n, B, loss_id):
+    def _fit_sharded(self, train_loader, triples, n, B, loss_id, opt="sgd"):
         """`fit` over the ranks of a torch.distributed job (one process per GPU).  Every rank calls it
         with the same loader and the same seeds.  Users - with their interactions and their rows of P - are split
         into contiguous ranges; Q is replicated.  Batch k of rank r = its rows among positions [k*B, (k+1)*B) of
@@ -248,7 +248,8 @@ class GeneralRecommender(AbstractRecommender):
         ctx = ops.BprContext(B, d, hi - lo, I, device=P.device)        # stage slots are positions inside a GLOBAL batch
         index = plan = None
         trainer = UserShardedBprTrainer(ctx, P_loc, Q, lo, self.lr, self.reg_1, self.reg_2, loss_type=loss_id,
-                                        item_mode=ops.ITEM_MODES["fused"], slices=self.exchange_slices)
+                                        item_mode=ops.ITEM_MODES["fused"], slices=self.exchange_slices,
+                                        adam_steps=(self.epochs * ((n + B - 1) // B)) if opt == "adam" else 0)
         acc = torch.zeros(2, dtype=torch.float64, device=P.device)
         nb = (n + B - 1) // B
         last_loss = 0.0
@@ -281,6 +282,8 @@ class GeneralRecommender(AbstractRecommender):
                     self.logger.info("Satisfy early stop mechanism")
                     break
                 last_loss = current_loss
+            if trainer.adam is not None:                               # the rows no batch referenced lately -> the last step
+                trainer.adam.flush(ctx)
             for r in range(world):                                     # every rank ends with the whole user table
                 a, b = user_range(U, world, r)
                 if b > a:
@@ -341,11 +344,11 @@ class GeneralRecommender(AbstractRecommender):
                          g_bias=adam.g[2] if adam is not None else None)
         user_sorted = ops.triples_user_sorted(triples[:n])
         if self._sharded_world() > 1:
-            if item_mode == ops.ITEM_MODES["fused"] and adam is None and biases is None:
+            if item_mode == ops.ITEM_MODES["fused"] and opt in ("sgd", "adam") and biases is None:
                 ctx.close()
                 plan.close()
-                return self._fit_sharded(train_loader, triples, n, B, loss_id)
-            self.logger.info("torch.distributed is initialised, but only SGD without FM biases + item_mode 'fused' "
+                return self._fit_sharded(train_loader, triples, n, B, loss_id, opt)
+            self.logger.info("torch.distributed is initialised, but only SGD / Adam without FM biases + item_mode 'fused' "
                              "shards the users over the ranks: every rank trains the whole model")
         if item_mode == ops.ITEM_MODES["fused"] and not staged and B > ops.SMALL_BATCH_MAX:
             item_mode = ops.ITEM_MODES["chunked"]

@@ -251,6 +251,29 @@ class BprContext:
                                         float(lr), float(reg_1), float(reg_2),
                                         _ptr(self.stats, torch.float64, "stats"), _stream()))
 
+    def staged_adam_catchup_users(self, P, adam):
+        """multi-GPU Adam: the rows of P the current batch references -> step adam.t - 1 (zero-gradient replays)"""
+        self._sync_norm_cache(P)
+        f = torch.float32
+        check(lib.daisy_bpr_staged_adam_catchup_users(
+            self._h, _ptr(P, f, "P"), _ptr(adam.mP, f, "mP"), _ptr(adam.vP, f, "vP"), _ptr(adam.lastP, torch.int32, "lastP"),
+            _ptr(adam.table, f, "table"), adam.BETA1, adam.BETA2, adam.EPS, adam.t, _stream()))
+
+    def staged_user_adam(self, P, Q, adam, reg_1, reg_2, loss_type=N.LOSS_BPR, gamma=1e-10):
+        f = torch.float32
+        check(lib.daisy_bpr_staged_user_adam(
+            self._h, _ptr(P, f, "P"), _ptr(Q, f, "Q"), int(loss_type), float(gamma), adam.lr, float(reg_1), float(reg_2),
+            _ptr(adam.mP, f, "mP"), _ptr(adam.vP, f, "vP"), _ptr(adam.lastP, torch.int32, "lastP"), adam.BETA1, adam.BETA2,
+            adam.EPS, adam.t, _ptr(self.stats, torch.float64, "stats"), _stream()))
+
+    def item_apply_counts_adam(self, Q_rows, g_rows, cnt_rows, m_rows, v_rows, adam, reg_1, reg_2):
+        """The row owner's DENSE Adam step over its block of Q after the reduce-scatter of (g, cnt); clears g and cnt."""
+        f = torch.float32
+        check(lib.daisy_item_apply_counts_adam(
+            _ptr(Q_rows, f, "Q"), _ptr(g_rows, f, "g"), _ptr(cnt_rows, f, "cnt"), _ptr(m_rows, f, "m"), _ptr(v_rows, f, "v"),
+            Q_rows.shape[0], Q_rows.shape[1], adam.lr, float(reg_1), float(reg_2), adam.BETA1, adam.BETA2, adam.EPS, adam.t,
+            _ptr(self.stats, torch.float64, "stats"), _stream()))
+
     def staged_item_slices(self, item_bounds):
         """Cut the item pass of the current batch at the given items (host ints, bounds[0] = 0, bounds[-1] >= item_num,
         at most 16 slices): `staged_item_slice(s, ...)` then reduces the entries of items [bounds[s], bounds[s+1])."""
@@ -518,6 +541,47 @@ class LazyAdam:
                                             _stream()))
         if getattr(self, "_ctx", None) is not None:      # the flush rewrote rows of P behind the staged step's row-norm cache
             self._ctx.invalidate_cache()
+
+
+class ShardedAdam:
+    """torch.optim.Adam for the user-sharded step (sharding.UserShardedBprTrainer): the rank's rows of P in the lazy form
+    (moments + stamps per local user; catch-up of a batch's rows before its forward, flush at the end), the rank's OWN
+    block(s) of Q densely (every owned row steps in every step, like torch).  Same expressions as daisy_adam_dense."""
+
+    BETA1, BETA2, EPS = 0.9, 0.999, 1e-8
+
+    def __init__(self, P_local, owned_q_rows, d, lr, max_steps):
+        dev = P_local.device
+        self.P, self.lr, self.t = P_local, float(lr), 0
+        self.mP, self.vP = torch.zeros_like(P_local), torch.zeros_like(P_local)
+        self.lastP = torch.zeros(P_local.shape[0], dtype=torch.int32, device=dev)
+        self.mQ = torch.zeros(owned_q_rows, d, dtype=torch.float32, device=dev)
+        self.vQ = torch.zeros(owned_q_rows, d, dtype=torch.float32, device=dev)
+        self._steps = 0
+        self.table = None
+        self._grow(max(int(max_steps), 1))
+
+    def _grow(self, n_steps):
+        host = (C.c_float * (2 * (n_steps + 1)))()
+        check(lib.daisy_adam_lazy_table(self.lr, self.BETA1, self.BETA2, n_steps, host))
+        self.table = torch.frombuffer(host, dtype=torch.float32).clone().to(self.P.device)
+        self._steps = n_steps
+
+    def next_step(self):
+        self.t += 1
+        if self.t > self._steps:
+            self._grow(2 * self.t)
+
+    def flush(self, ctx=None):
+        """every local row of P up to the current step"""
+        if self.t == 0 or self.P.shape[0] == 0:
+            return
+        f = torch.float32
+        check(lib.daisy_adam_lazy_flush(_ptr(self.P, f, "W"), _ptr(self.mP, f, "m"), _ptr(self.vP, f, "v"),
+                                        _ptr(self.lastP, torch.int32, "last"), self.P.shape[0], self.P.shape[1],
+                                        _ptr(self.table, f, "table"), self.BETA1, self.BETA2, self.EPS, self.t, _stream()))
+        if ctx is not None:
+            ctx.invalidate_cache()
 
 
 def _bias_ptrs(biases):

@@ -69,7 +69,10 @@ class UserShardedBprTrainer:
     table; both are updated in place."""
 
     def __init__(self, ctx, P_local, Q, user_lo, lr, reg_1, reg_2, loss_type=N.LOSS_BPR,
-                 gamma=1e-10, item_mode=N.ITEM_FUSED, group=None, overlap=True, always_collective=False, slices=1):
+                 gamma=1e-10, item_mode=N.ITEM_FUSED, group=None, overlap=True, always_collective=False, slices=1,
+                 adam_steps=0):
+        """adam_steps > 0: torch.optim.Adam instead of SGD (staged protocol only; the value sizes the table of per-step
+        constants, it grows on demand): lazy on the rank's rows of P, dense on its own block(s) of Q (ops.ShardedAdam)"""
         self.ctx, self.P, self.Q = ctx, P_local, Q
         self.user_lo = int(user_lo)
         self.lr, self.reg_1, self.reg_2 = float(lr), float(reg_1), float(reg_2)
@@ -109,6 +112,12 @@ class UserShardedBprTrainer:
             self.Q_gather = Q if Ipad == I else torch.zeros(Ipad, d, dtype=torch.float32, device=Q.device)
             self.own_lo = self.rank * self.rows                     # (of slice 0; slice s: + s*world*rows)
             self.own_hi = min(self.own_lo + self.rows, I)
+        self.adam = None
+        if adam_steps:
+            if not self.staged:
+                raise NotImplementedError("UserShardedBprTrainer: Adam needs the staged protocol (item_mode 'fused')")
+            from .ops import ShardedAdam
+            self.adam = ShardedAdam(P_local, self.rows * self.slices, Q.shape[1], lr, adam_steps)
 
     # -- instrumentation -------------------------------------------------------------------------
     def enable_timing(self, on=True):
@@ -197,9 +206,15 @@ class UserShardedBprTrainer:
     def _step_staged(self):
         c, I = self.ctx, self.Q.shape[0]
         self._mark(0)
+        if self.adam is not None:
+            self.adam.next_step()
+            c.staged_adam_catchup_users(self.P, self.adam)       # the batch's rows of P -> step t-1, before anything reads them
         c.staged_prenorm(self.P)
         self._all_reduce(c.stats[N.ST_SQ_U_PRE:N.ST_SQ_U_PRE + 1])
-        c.staged_user(self.P, self.Q, self.lr, self.reg_1, self.reg_2, self.loss_type, self.gamma)
+        if self.adam is not None:
+            c.staged_user_adam(self.P, self.Q, self.adam, self.reg_1, self.reg_2, self.loss_type, self.gamma)
+        else:
+            c.staged_user(self.P, self.Q, self.lr, self.reg_1, self.reg_2, self.loss_type, self.gamma)
         w0 = self._all_reduce(c.stats[:7], async_op=self.overlap)
         if self.slices == 1:
             c.staged_item(self.lr, self.reg_1, self.reg_2, gQ=self.gQ[:I], cnt=self.cnt[:I],
@@ -251,7 +266,11 @@ class UserShardedBprTrainer:
             lo = a + self.rank * self.rows
             hi = min(lo + self.rows, I)
             n_own = max(hi - lo, 0)
-            if n_own > 0:
+            if n_own > 0 and self.adam is not None:     # dense Adam over the owned block (moments of slice s_'s block)
+                mo = s_ * self.rows
+                c.item_apply_counts_adam(self.Q[lo:hi], self.g_own[:n_own], self.c_own[:n_own], self.adam.mQ[mo:mo + n_own],
+                                         self.adam.vQ[mo:mo + n_own], self.adam, self.reg_1, self.reg_2)
+            elif n_own > 0:
                 c.item_apply_counts(self.Q[lo:hi], self.g_own[:n_own], self.c_own[:n_own], self.lr, self.reg_1, self.reg_2)
             if self.collective:
                 if self.Q_gather is self.Q:
@@ -277,6 +296,8 @@ class UserShardedBprTrainer:
             raise NotImplementedError("an empty local batch is only supported by the staged protocol")
         c = self.ctx
         self._mark(0)
+        if self.adam is not None:
+            self.adam.next_step()
         c.stats.zero_()
         self._all_reduce(c.stats[N.ST_SQ_U_PRE:N.ST_SQ_U_PRE + 1])
         self._all_reduce(c.stats[:7])

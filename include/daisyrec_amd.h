@@ -207,6 +207,20 @@ int daisy_bpr_staged_adam_step(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t l
                                float reg_1, float reg_2, float *mP, float *vP, int32_t *lastP, float *mQ, float *vQ, int32_t *lastQ,
                                const float *table, float beta1, float beta2, float eps, int64_t step, double *stats,
                                double *epoch_acc, double *step_loss, daisy_stream_t stream);
+/* The same in phases, for a multi-GPU step (user-sharded): the users' rows of P are rank-local
+ * and keep the lazy form - catchup_users brings the rows the local batch references to step-1, staged_user_adam is
+ * daisy_bpr_staged_user with the Adam owner update; the item side goes through the gradient form of
+ * daisy_bpr_staged_item and, after the reduce-scatter, daisy_item_apply_counts_adam: torch's DENSE Adam over the owner's
+ * block of Q (every row steps in every step; moments m, v [rows][d] of the block). */
+int daisy_bpr_staged_adam_catchup_users(daisy_bpr_ctx *ctx, float *P, float *mP, float *vP, int32_t *lastP,
+                                        const float *table, float beta1, float beta2, float eps, int64_t step,
+                                        daisy_stream_t stream);
+int daisy_bpr_staged_user_adam(daisy_bpr_ctx *ctx, float *P, const float *Q, int32_t loss_type, float gamma, float lr,
+                               float reg_1, float reg_2, float *mP, float *vP, int32_t *lastP, float beta1, float beta2,
+                               float eps, int64_t step, double *stats, daisy_stream_t stream);
+int daisy_item_apply_counts_adam(float *Q, float *g, float *cnt, float *m, float *v, int64_t rows, int32_t d, float lr,
+                                 float reg_1, float reg_2, float beta1, float beta2, float eps, int64_t step,
+                                 const double *stats, daisy_stream_t stream);
 /* rows of batch k held by this plan (host value; -1: no such batch) */
 int64_t daisy_epoch_plan_batch_rows(const daisy_epoch_plan *plan, int64_t k);
 
