@@ -708,13 +708,14 @@ __device__ __forceinline__ double prenorm_sum(const double *__restrict__ stats, 
 template <class C, bool ADAM>
 __device__ __forceinline__ void user_commit(float *__restrict__ P, float *__restrict__ p_sqnorm, int64_t user, Row<C> &p,
                                             const Row<C> &acc, float n, float reg_1, float rU, const RowOpt &opt, int lane,
-                                            int d) {
+                                            int d, bool stream_row = false) {
     const float w1 = reg_1 * n, w2 = rU * n;
     Row<C> g;
 #pragma unroll
     for (int k = 0; k < C::NE; ++k) g.v[k] = acc.v[k] + fmaf(w2, p.v[k], w1 * sgn(p.v[k]));
     row_apply<C, ADAM>(p, g, opt, user, lane, d);
-    p.store(P + user * d, lane, d);        // (nontemporal stores of the user rows measured no different)
+    if (stream_row) p.store_nt(P + user * d, lane, d);      // (a table far beyond the caches: see StreamView::p_stream)
+    else p.store(P + user * d, lane, d);
     const float sq = row_dot<C>(p, p);
     if (lane == 0) p_sqnorm[user] = sq;
 }
@@ -819,9 +820,10 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 
         // ---- hop 2: the rows of every sample of the run
         Row<C> qi[RUN], qj[PAIR ? RUN : 1], pr[RUN];
         if (__all(cnt == RUN) && v.p_stream) {     // (wave-uniform: no branch between the gathers)
-            // a user table far beyond the Infinity Cache: its rows come back once every few steps, so they are read
-            // past the caches and leave them to Q (10 M x 1 M shapes: 449 -> 420 us per pass; at 1 M users, where
-            // most rows return in the next step, the same loads measured 3 % slower: the host decides)
+            // a user table far beyond the Infinity Cache: its rows come back once every few steps, so they are read and
+            // written past the caches and leave them to Q (10 M x 1 M shapes: 449 -> 420 us per pass with BOTH the loads
+            // and the owner's store nontemporal - either alone measured no gain; at 1 M users, where most rows return in
+            // the next step, 3 % slower: the host decides)
 #pragma unroll
             for (int x = 0; x < RUN; ++x) {
                 qi[x].load(Q + (int64_t)group_bcast<C>(my_ij.x, x) * d, lane, d);
@@ -908,7 +910,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 
             auto finish = [&](bool ends_here, bool to_next_chunk, const Row<C> &prow) {
                 if (cur_slot < 0 && ends_here) {     // this group owns P[cur_user]
                     Row<C> pn = prow;
-                    user_commit<C, ADAM>(P, p_sqnorm, cur_user, pn, acc, cn_, reg_1, rU, opt, lane, d);
+                    user_commit<C, ADAM>(P, p_sqnorm, cur_user, pn, acc, cn_, reg_1, rU, opt, lane, d, v.p_stream != 0);
                     if constexpr (BIAS) user_bias_commit(fm, cur_user, sb_, opt.lr, lane);
                 } else {
                     const int s = (cur_slot >= 0) ? cur_slot : group + 1;
