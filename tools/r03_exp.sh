@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 560 python -m pytest tests -q -m gpu --durations=6 2>&1 | tail -22
+O=gpurun_out/r03
+timeout 150 python tools/sweep_batch.py 2>/dev/null | tee $O/batch_sweep.txt
+timeout 200 python tools/sweep_factors.py 2>/dev/null | tee $O/factor_sweep.txt
