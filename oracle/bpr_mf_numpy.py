@@ -426,13 +426,14 @@ def feistel_positions(n, seed, epoch=0):
     return x.astype(np.int64)
 
 
-def partitioned_plan(triples, pos, batch_size, user_base=0):
+def partitioned_plan(triples, pos, batch_size, user_base=0, pointwise=False):
     """The partitioned epoch plan (daisy_epoch_plan_build_indexed): what one pass over
     DataLoader(BasicDataset(triples), batch_size, shuffle) serves (dataset.py:5-27), laid out batch by
     batch.  `pos[t]` = position of triple t in the epoch order (identity, inverse of the sampler's
     permutation, or feistel_positions).  Static index: triples in CSR order (stable sort by user), their
     2n entries (item << 1 | slot) stably sorted; the plan is the stable partition of both by batch id.
-    Returns (samples int64 [n,3] with user - user_base, sample_pos [n], entry_key [2n], entry_pos [2n])."""
+    pointwise: rows are (user, item, label) (CL / SL, sampler.py:93-98) - ONE entry per row, `item << 1`.
+    Returns (samples int64 [n,3] with user - user_base, sample_pos [n], entry_key [2n or n], entry_pos [2n or n])."""
     triples = np.asarray(triples, dtype=np.int64)
     pos = np.asarray(pos, dtype=np.int64)
     order = np.argsort(triples[:, 0], kind="stable")          # CSR order
@@ -442,10 +443,14 @@ def partitioned_plan(triples, pos, batch_size, user_base=0):
     so = np.argsort(batch, kind="stable")
     samples = tri[so].copy()
     samples[:, 0] -= user_base
-    key = np.empty(2 * n, dtype=np.int64)
-    key[0::2] = tri[:, 1] << 1
-    key[1::2] = (tri[:, 2] << 1) | 1
-    t = np.repeat(np.arange(n), 2)
+    if pointwise:
+        key = tri[:, 1] << 1
+        t = np.arange(n)
+    else:
+        key = np.empty(2 * n, dtype=np.int64)
+        key[0::2] = tri[:, 1] << 1
+        key[1::2] = (tri[:, 2] << 1) | 1
+        t = np.repeat(np.arange(n), 2)
     eo = np.argsort(key, kind="stable")                       # static item index
     ekey, et = key[eo], t[eo]
     bo = np.argsort(batch[et], kind="stable")

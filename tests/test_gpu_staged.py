@@ -61,6 +61,31 @@ def test_partitioned_plan_bit_exact(n, B, U, I, sort):
     plan.close()
 
 
+@pytest.mark.parametrize("n,B,U,I", [(1000, 64, 300, 200), (4097, 256, 300, 200), (70000, 100, 900, 1200)])
+def test_partitioned_plan_pointwise_bit_exact(n, B, U, I):
+    """point-wise rows (user, item, label): ONE item entry per row in the static index and in every batch of the plan;
+    the label travels in the sample's third column and is not an id (it may exceed nothing: no range check)"""
+    from daisyrec_amd import ops
+    tri = _triples(n, U, I, n + 1)
+    tri[:, 2] = np.random.default_rng(n).integers(0, 2, n)              # labels
+    tri[::7, 2] = I + 5                                                 # (not an item id: must not be validated as one)
+    t_dev = torch.from_numpy(tri).to(DEV)
+    index = ops.TrainIndex(t_dev, U, I, pointwise=True)
+    plan = ops.EpochPlan(n, U, I)
+    nb = (n + B - 1) // B
+    pos = O.feistel_positions(n, 4, 2)
+    plan.build_indexed(index, B, order="feistel", seed=4, epoch=2)
+    samples, spos, ekey, epos = O.partitioned_plan(tri, pos, B, pointwise=True)
+    for k in range(nb):
+        lo, hi = k * B, min((k + 1) * B, n)
+        u, i, j, ei, es, _ = (t.cpu().numpy() for t in plan.read_batch(k, B))
+        assert np.array_equal(np.stack([u, i, j], 1), samples[lo:hi]), k
+        assert np.array_equal(ei[:hi - lo], ekey[lo:hi] >> 1), k
+        assert np.array_equal(es[:hi - lo].astype(np.uint32), (epos[lo:hi] - lo).astype(np.uint32)), k
+    index.close()
+    plan.close()
+
+
 def test_index_rejects_out_of_range_ids():
     from daisyrec_amd import ops
     tri = _triples(500, 40, 30, 1)
@@ -85,16 +110,20 @@ def _tables(U, I, d, seed, scale=0.1):
 
 
 @pytest.mark.parametrize("d", [64, 32, 8, 20, 128, 100, 7, 256])
-@pytest.mark.parametrize("loss", ["BPR", "HL", "TL"])
+@pytest.mark.parametrize("loss", ["BPR", "HL", "TL", "CL", "SL"])
 def test_staged_epoch_matches_oracle(d, loss):
     """A whole epoch through the partitioned plan + fit_epoch_sgd(fused), replayed by the oracle on the
-    batches the plan serves: hot users/items, runs that cross lane groups and chunks, a partial batch."""
+    batches the plan serves: hot users/items, runs that cross lane groups and chunks, a partial batch.
+    CL / SL: point-wise rows (user, item, label), one entry per row."""
     from daisyrec_amd import ops
     U, I, n, B = 37, 23, 1500, 400         # heavy collisions: every row is shared inside a batch
     tri = _triples(n, U, I, d)
+    point = loss in ("CL", "SL")
+    if point:
+        tri[:, 2] = np.random.default_rng(d).integers(0, 2, n)
     P0, Q0 = _tables(U, I, d, d + 1)
     t_dev = torch.from_numpy(tri).to(DEV)
-    index, plan = ops.TrainIndex(t_dev, U, I), ops.EpochPlan(n, U, I)
+    index, plan = ops.TrainIndex(t_dev, U, I, pointwise=point), ops.EpochPlan(n, U, I)
     plan.build_indexed(index, B, order="feistel", seed=5, epoch=1)
     nb = plan.num_batches
     P, Q = torch.from_numpy(P0).to(DEV), torch.from_numpy(Q0).to(DEV)
@@ -108,6 +137,91 @@ def test_staged_epoch_matches_oracle(d, loss):
         want, Pn, Qn = O.mf_sgd_step(Pn, Qn, rows[:, 0], rows[:, 1], rows[:, 2], 0.05, 1e-3, 2e-3, loss_type=lid)
         assert abs(float(sl[k].cpu()) - want) <= 1e-5 * abs(want), (k, float(sl[k].cpu()), want)
     assert np.abs(P.cpu().numpy() - Pn).max() < 5e-6 and np.abs(Q.cpu().numpy() - Qn).max() < 5e-6
+    ctx.close(); plan.close(); index.close()
+
+
+@pytest.mark.parametrize("d,loss", [(64, "BPR"), (32, "TL"), (100, "BPR"), (64, "CL"), (20, "SL"), (128, "HL")])
+def test_staged_adam_epochs_match_the_dense_oracle(d, loss):
+    """torch.optim.Adam applied by the row owners of the staged step (lazy: catch-up of the referenced rows, step t on the
+    rows with a gradient, flush at the epoch's end) against oracle.DenseAdam - every row of both tables in every step -
+    over two epochs of colliding batches: runs across lane groups and chunks (the slot finishers and the edge kernels
+    apply Adam too), rows that skip steps (the second epoch's plan differs), a partial batch."""
+    from daisyrec_amd import ops
+    from daisyrec_amd.model.AbstractRecommender import _AdamState
+    U, I, n, B = 61, 43, 1300, 400
+    tri = _triples(n, U, I, d + 3)
+    tri[:300, 0] = 5                       # a run that crosses chunks
+    tri[300:330, 1] = 7
+    point = loss in ("CL", "SL")
+    if point:
+        tri[:, 2] = np.random.default_rng(d).integers(0, 2, n)
+    P0, Q0 = _tables(U, I, d, d + 2)
+    t_dev = torch.from_numpy(tri).to(DEV)
+    index, plan = ops.TrainIndex(t_dev, U, I, pointwise=point), ops.EpochPlan(n, U, I)
+    P, Q = torch.from_numpy(P0).to(DEV), torch.from_numpy(Q0).to(DEV)
+    ctx = ops.BprContext(B, d, U, I)
+    lid, lr = ops.LOSS_IDS[loss], 0.01
+    adam = _AdamState(P, Q, lr, None, kind="adam", max_steps=4)        # (the table of step constants grows on demand)
+    ref = O.DenseAdam([P0.shape, Q0.shape], lr)
+    Pn, Qn = P0.copy(), Q0.copy()
+    for epoch in (1, 2):
+        plan.build_indexed(index, B, order="feistel", seed=9, epoch=epoch)
+        for k, (rows, _, _) in enumerate(_plan_batches(plan, plan.num_batches, B)):
+            ctx.set_batch_from_plan(plan, k)
+            adam.step(ctx, P, Q, 1e-3, 2e-3, lid, ops.ITEM_MODES["fused"])
+            if point:
+                want, gP, gQ = O.mf_point_grad(Pn, Qn, rows[:, 0], rows[:, 1], rows[:, 2], 1e-3, 2e-3, lid)
+            else:
+                want, gP, gQ = O.mf_pair_grad(Pn, Qn, rows[:, 0], rows[:, 1], rows[:, 2], 1e-3, 2e-3, lid)
+            Pn, Qn = ref.step([Pn, Qn], [gP, gQ])
+            got = float(ctx.stats[7].cpu())
+            assert abs(got - want) <= 2e-5 * abs(want), (epoch, k, got, want)
+        adam.flush()
+        torch.cuda.synchronize()
+        # Adam divides by sqrt(v): where a gradient element is itself round-off sized (the data term cancelling the
+        # regulariser) its fp32 noise decides a step of up to lr in BOTH implementations - a handful of the ~10^4
+        # elements; everything else agrees to fp32 round-off
+        for got, want_t in ((P.cpu().numpy(), Pn), (Q.cpu().numpy(), Qn)):
+            diff = np.abs(got - want_t)
+            assert (diff > 2e-5).mean() < 2e-3 and diff.max() < 0.5 * lr * 2 * epoch * plan.num_batches, (epoch, diff.max())
+            assert np.median(diff) < 1e-7
+    ctx.close(); plan.close(); index.close()
+
+
+@pytest.mark.parametrize("d,loss", [(64, "BPR"), (32, "TL"), (100, "CL"), (64, "SL")])
+def test_staged_fm_epoch_matches_oracle(d, loss):
+    """FM's biases on the staged step (plain / point flavours): a whole epoch through the partitioned plan against
+    oracle.fm_numpy.fm_sgd_step - the user bias along its run, the item bias along its segment, bias_ from the batch sum"""
+    from daisyrec_amd import ops
+    from oracle import fm_numpy as F
+    U, I, n, B = 37, 23, 1500, 400
+    tri = _triples(n, U, I, d + 5)
+    tri[:200, 0] = 3
+    point = loss in ("CL", "SL")
+    if point:
+        tri[:, 2] = np.random.default_rng(d).integers(0, 2, n)
+    P0, Q0 = _tables(U, I, d, d + 4)
+    rng = np.random.default_rng(d)
+    bu0, bi0 = (rng.standard_normal(U) * 0.1).astype(np.float32), (rng.standard_normal(I) * 0.1).astype(np.float32)
+    b00 = np.array([0.05], np.float32)
+    t_dev = torch.from_numpy(tri).to(DEV)
+    index, plan = ops.TrainIndex(t_dev, U, I, pointwise=point), ops.EpochPlan(n, U, I)
+    plan.build_indexed(index, B, order="feistel", seed=5, epoch=1)
+    nb = plan.num_batches
+    w = [torch.from_numpy(x.copy()).to(DEV) for x in (P0, Q0, bu0, bi0, b00)]
+    ctx = ops.BprContext(B, d, U, I)
+    ctx.set_bias(w[2], w[3], w[4], g_i_bias=torch.zeros(I, device=DEV))
+    sl = torch.zeros(nb, dtype=torch.float64, device=DEV)
+    lid = ops.LOSS_IDS[loss]
+    lr = 0.002 if loss == "SL" else 0.05         # (the squared loss diverges at 0.05 on these collision-heavy batches)
+    ctx.fit_epoch_sgd(plan, w[0], w[1], lr, 1e-3, 2e-3, loss_type=lid, item_mode=ops.ITEM_MODES["fused"], step_losses=sl)
+    torch.cuda.synchronize()
+    cur = [P0, Q0, bu0, bi0, b00]
+    for k, (rows, _, _) in enumerate(_plan_batches(plan, nb, B)):
+        want, *cur = F.fm_sgd_step(*cur, rows[:, 0], rows[:, 1], rows[:, 2], lr, 1e-3, 2e-3, loss_type=lid)
+        assert abs(float(sl[k].cpu()) - want) <= 1e-5 * abs(want), (k, float(sl[k].cpu()), want)
+    for got, want in zip(w, cur):
+        assert np.abs(got.cpu().numpy().reshape(-1) - np.asarray(want).reshape(-1)).max() < 6e-6
     ctx.close(); plan.close(); index.close()
 
 

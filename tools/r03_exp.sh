@@ -1,4 +1,2 @@
 cd $GRAFT_REPO_ROOT
-O=gpurun_out/r03
-timeout 150 python tools/sweep_batch.py 2>/dev/null | tee $O/batch_sweep.txt
-timeout 200 python tools/sweep_factors.py 2>/dev/null | tee $O/factor_sweep.txt
+timeout 280 python -m pytest tests/test_gpu_staged.py -q -m gpu -k "fm_epoch" 2>&1 | grep -v "^$" | tail -6
