@@ -54,6 +54,9 @@ class LightGCN(GeneralRecommender):
         # initialised torch.distributed job (every rank runs the same fit with the same seeds: the batches are
         # replicated, the sparse products - the bulk of a step - are split); False keeps everything local
         self.shard_rows = config.get("shard_rows", "auto")
+        # multi-GPU propagation: sub-blocks per layer whose all-gather overlaps the next sub-block's reduction
+        # (None: 4 on RCCL, 1 elsewhere)
+        self.propagation_pieces = config.get("propagation_pieces")
         self._sharded = None
         self.restore_user_e = None
         self.restore_item_e = None
@@ -96,7 +99,8 @@ class LightGCN(GeneralRecommender):
             return g
         if self._sharded is None:
             from ..sharding import RowShardedPropagation
-            self._sharded = RowShardedPropagation(g, self.user_num + self.item_num, self.factors, self.device)
+            self._sharded = RowShardedPropagation(g, self.user_num + self.item_num, self.factors, self.device,
+                                                  pieces=self.propagation_pieces)
         return self._sharded
 
     def forward(self):

@@ -341,34 +341,67 @@ class RowShardedPropagation:
     `graph` is a daisyrec_amd.ops.LgcnGraph holding the WHOLE adjacency (4.7 M entries x 20 B for Amazon-Book: the
     matrix is small, the work is not), or a stand-in with the same `spmm_rows`."""
 
-    def __init__(self, graph, N, d, device, group=None):
+    def __init__(self, graph, N, d, device, group=None, pieces=None):
+        """pieces: each layer's row block is produced in that many sub-blocks, and sub-block k is all-gathered on a side
+        stream while sub-block k+1 is reduced (default: 4 on RCCL, 1 elsewhere) - at Amazon-Book size a layer's
+        exchange (37 MB) outweighs its compute on 8 GPUs, so the two must at least not be serialised as well."""
         self.g, self.N, self.d, self.group = graph, int(N), int(d), group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.rows = (self.N + self.world - 1) // self.world
+        self._native = self.world > 1 and dist.get_backend(group) == "nccl"
+        if pieces is None:
+            pieces = 4 if self._native else 1
+        self.pieces = max(1, int(pieces)) if self.world > 1 else 1
+        rows = (self.N + self.world - 1) // self.world
+        self.prow = (rows + self.pieces - 1) // self.pieces           # rows per sub-block
+        self.rows = self.prow * self.pieces                            # rows per rank (padded to a multiple of the pieces)
         self.lo = min(self.rank * self.rows, self.N)
         self.hi = min(self.lo + self.rows, self.N)
-        self._native = self.world > 1 and dist.get_backend(group) == "nccl"
-        self.block = torch.zeros(self.rows + 2, d, dtype=torch.float32, device=device)     # own rows + 2 spare rows
-        self.full = torch.zeros(self.rows * self.world, d, dtype=torch.float32, device=device)
+        is_cuda = torch.device(device).type == "cuda"
+        self.side = torch.cuda.Stream(device=device) if (self.pieces > 1 and is_cuda) else None
+        # one buffer per sub-block: its rows + a spare row on either side (the segmented reduction may spill a partial
+        # neighbour row there); pieces in flight must not share storage
+        self.blocks = [torch.zeros(self.prow + 2, d, dtype=torch.float32, device=device) for _ in range(self.pieces)]
+        self.block = self.blocks[0]
+        # gathered sub-blocks: full[p][r] = rank r's sub-block p, i.e. node rows [r*rows + p*prow, +prow)
+        self.full = torch.zeros(self.pieces, self.world, self.prow, d, dtype=torch.float32, device=device)
         self.work = [torch.empty(self.N, d, dtype=torch.float32, device=device) for _ in range(2)]
 
     def spmm(self, X, Y):
         """Y = A_hat X on every rank"""
-        own = self.g.spmm_rows(X, self.block, self.lo, self.hi)
         if self.world == 1:
+            own = self.g.spmm_rows(X, self.blocks[0], self.lo, self.hi)
             Y.copy_(own)
             return Y
-        mine = self.block[1:1 + self.rows]                # padded to R rows (tail rows of the last rank: don't care)
+        cur = torch.cuda.current_stream(X.device) if self.side is not None else None
+        for p in range(self.pieces):
+            a = min(self.lo + p * self.prow, self.N)
+            b = min(a + self.prow, self.hi)
+            blk = self.blocks[p]
+            if b > a:
+                self.g.spmm_rows(X, blk, a, b)
+            mine = blk[1:1 + self.prow]                   # (rows past the rank's / the table's end: don't care)
+            if self.side is not None:                     # the exchange of this piece runs under the next piece's reduction
+                self.side.wait_stream(cur)
+                with torch.cuda.stream(self.side):
+                    self._gather(self.full[p], mine)
+            else:
+                self._gather(self.full[p], mine)
+        if self.side is not None:
+            cur.wait_stream(self.side)
+        # node order: rank r, piece p, row i  <-  full[p][r][i]
+        Y.copy_(self.full.permute(1, 0, 2, 3).reshape(self.world * self.rows, self.d)[:self.N])
+        return Y
+
+    def _gather(self, out, mine):
+        """out[r] = rank r's `mine`"""
         if self._native:
-            dist.all_gather_into_tensor(self.full, mine, group=self.group)
+            dist.all_gather_into_tensor(out.view(self.world * self.prow, self.d), mine, group=self.group)
         else:
             parts = [torch.empty_like(mine) for _ in range(self.world)]
             dist.all_gather(parts, mine.clone(), group=self.group)
-            for r, p in enumerate(parts):
-                self.full[r * self.rows:(r + 1) * self.rows].copy_(p)
-        Y.copy_(self.full[:self.N])
-        return Y
+            for r, part in enumerate(parts):
+                out[r].copy_(part)
 
     def propagate(self, E0, num_layers, out):
         """out = mean_k A_hat^k E0  (LightGCNRecommender.py:117-129)"""

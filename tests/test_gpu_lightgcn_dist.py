@@ -95,6 +95,7 @@ def _train(shard):
     torch.manual_seed(0)
     cfg = mf_config(user_num=U, item_num=I, factors=D, num_layers=L, algo_name="lightgcn", reg_1=1e-3, reg_2=1e-3,
                     lr=0.01, epochs=2, batch_size=512, shard_rows=shard, item_mode="sorted",
+                    propagation_pieces=int(os.environ["DAISY_TEST_PIECES"]) if "DAISY_TEST_PIECES" in os.environ else None,
                     inter_matrix=sp.coo_matrix((np.ones(NNZ, np.float32), (gu, gi)), shape=(U, I)))
     model = LightGCN(cfg)
     model.fit(get_dataloader(BasicDataset(samples), batch_size=512, shuffle=True, num_workers=0))
@@ -139,7 +140,11 @@ def _check(tmp_path, world):
     assert losses[1] < losses[0]
 
 
-def test_row_sharded_training_on_three_ranks(tmp_path):
+@pytest.mark.parametrize("pieces", [1, 3])
+def test_row_sharded_training_on_three_ranks(tmp_path, pieces, monkeypatch):
+    """pieces > 1: every layer's row block in sub-blocks, sub-block k all-gathered on a side stream while sub-block k+1
+    is reduced; the node count (1150) is divisible neither by 3 ranks nor by 3 x 3 sub-blocks (padded tails)"""
+    monkeypatch.setenv("DAISY_TEST_PIECES", str(pieces))
     world = 3
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "gloo"), nprocs=world, join=True)
     _check(tmp_path, world)
