@@ -54,6 +54,8 @@ struct GemmOp {
     float drop_scale;
     uint64_t drop_seed;
     int64_t k_chunk;                      // reduction range per blockIdx.z
+    int64_t slice_stride;                 // EPI_ATOMIC: != 0 - slice z STORES its partial product at C + z * slice_stride
+                                          // (summed in slice order by k_reduce_slices: reproducible); 0 - fp32 atomics into C
     int vec_a, vec_b;                     // set by launch_gemm: operand qualifies for the float4 path
     int bf16;                             // throughput mode: bf16-input MFMA where the tile shape allows it
     // bf16 STORAGE (precision level 2: activations and a copy of the weights live as bf16 in HBM): when A16 is set the
@@ -71,6 +73,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmOp &op, floatx16 (&acc)[
     // 32-bit offsets from the tile origin (a tile spans < 2^31 elements of C: 128 rows x ldc)
     const int scn = op.scn ? (int)op.scn : 1;
     float *__restrict__ Ct = op.C + m0 * op.ldc + (int64_t)n0 * scn;
+    if constexpr (EPI == EPI_ATOMIC) Ct += (int64_t)blockIdx.z * op.slice_stride;
     const float *__restrict__ Gt = (EPI == EPI_GATE && op.gate) ? op.gate + m0 * op.ldg + n0 : nullptr;
     const int ldc = (int)op.ldc, ldg = (int)op.ldg;
 #pragma unroll
@@ -93,8 +96,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmOp &op, floatx16 (&acc)[
                         v = drop_keep(op.drop_seed, op.drop_stream,
                                       (uint64_t)(m0 + ml) * (uint64_t)op.N + (uint64_t)(n0 + nl), op.drop_thresh)
                                 ? v * op.drop_scale : 0.f;
-                if constexpr (EPI == EPI_ATOMIC) unsafeAtomicAdd(Ct + ml * ldc + nl * scn, v);
-                else Ct[ml * ldc + nl * scn] = v;
+                if constexpr (EPI == EPI_ATOMIC) {
+                    if (op.slice_stride) Ct[ml * ldc + nl * scn] = v;
+                    else unsafeAtomicAdd(Ct + ml * ldc + nl * scn, v);
+                } else Ct[ml * ldc + nl * scn] = v;
             }
         }
 }
@@ -830,7 +835,7 @@ __global__ __launch_bounds__(kBlock) void k_nmf_loss(const float *__restrict__ p
                                                      int loss_type, float gamma, int pointwise,
                                                      float *__restrict__ dpred,
                                                      double *__restrict__ stats,
-                                                     float *__restrict__ gbp) {
+                                                     float *__restrict__ gbp_ws) {
     // gbp = sum_b (cp_b + cn_b), paired per sample: under BPR / HL every pair is exactly 0, as it is in
     // the reference's autograd (a rounding residue here would be blown up to +-lr by Adam)
     double acc = 0.0;
@@ -845,9 +850,16 @@ __global__ __launch_bounds__(kBlock) void k_nmf_loss(const float *__restrict__ p
     }
     acc = wave_sum_f64(acc);
     const double sb = wave_sum_f64((double)accb);
+    __shared__ double smb[kBlock / kWave];
     if (threadIdx.x % kWave == 0) {
         atomicAdd(stats + DAISY_NST_LOSS_DATA, acc);
-        if (sb != 0.0) unsafeAtomicAdd(gbp, (float)sb);
+        smb[threadIdx.x / kWave] = sb;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {                            // waves in order; the workgroups' sums are added by k_reduce_slices
+        double t = 0.0;
+        for (int w = 0; w < kBlock / kWave; ++w) t += smb[w];
+        gbp_ws[blockIdx.x] = (float)t;
     }
 }
 
@@ -865,16 +877,35 @@ __global__ void k_nmf_finalize(double *__restrict__ stats, float reg_1, float re
     stats[DAISY_NST_LOSS] = stats[DAISY_NST_LOSS_DATA] + (double)reg_1 * l1 + (double)reg_2 * fro;
 }
 
+// out[c] += sum_s ws[s][c], s = 0 .. nslices-1 in that order: the second half of every reduction over the batch rows
+// whose first half is spread over workgroups (split-K slices of the weight-gradient GEMMs, row tiles of the column
+// sums, workgroups of the predict layer's backward pass).  Fixed order instead of fp32 atomics: two runs of a step
+// give the same bits.
+__global__ __launch_bounds__(kBlock) void k_reduce_slices(const float *__restrict__ ws, int nslices, int64_t len,
+                                                          float *__restrict__ out) {
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < len; c += (int64_t)gridDim.x * blockDim.x) {
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+        int sidx = 0;
+        for (; sidx + 3 < nslices; sidx += 4) {                          // four loads in flight, fixed association
+            t0 += ws[(int64_t)sidx * len + c];
+            t1 += ws[(int64_t)(sidx + 1) * len + c];
+            t2 += ws[(int64_t)(sidx + 2) * len + c];
+            t3 += ws[(int64_t)(sidx + 3) * len + c];
+        }
+        for (; sidx < nslices; ++sidx) t0 += ws[(int64_t)sidx * len + c];
+        out[c] += (t0 + t1) + (t2 + t3);
+    }
+}
+
 // dZ_L[r] = dpred[r] * Wp[dg:] gated by x_L[r] > 0;  gWp += sum_r dpred[r]*[g[r] | x_L[r]];  gbp += sum dpred
+// (the column sums leave as one row of `ws` per workgroup: ws[blockIdx.x][dg + nl], summed by k_reduce_slices)
 template <bool H = false>
 __global__ __launch_bounds__(kBlock) void k_nmf_pred_bwd(const float *__restrict__ dpred,
                                                          const float *__restrict__ G, int dg,
                                                          const float *__restrict__ XL, int nl,
                                                          const float *__restrict__ Wp, int64_t R,
-                                                         float *__restrict__ DZ, float *__restrict__ gWp) {
-    __shared__ float col[512];                       // dg + nl <= 2 * kMaxD
-    for (int c = threadIdx.x; c < dg + nl; c += kBlock) col[c] = 0.f;
-    __syncthreads();
+                                                         float *__restrict__ DZ, float *__restrict__ ws) {
+    __shared__ float colg[kBlock / 16][128];         // one sweep of 128 columns: every lane group's partial sums
     const int lane = threadIdx.x % 16, group = threadIdx.x / 16;
     const int64_t gstride = (int64_t)gridDim.x * (kBlock / 16);
     for (int c0 = 0; c0 < dg + nl; c0 += 16 * 8) {   // 8 column registers per lane per sweep
@@ -897,13 +928,16 @@ __global__ __launch_bounds__(kBlock) void k_nmf_pred_bwd(const float *__restrict
             }
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int c = c0 + q * 16 + lane;
-            if (c < dg + nl) atomicAdd(&col[c], part[q]);
+        for (int q = 0; q < 8; ++q) colg[group][q * 16 + lane] = part[q];
+        __syncthreads();
+        if ((int)threadIdx.x < 128 && c0 + (int)threadIdx.x < dg + nl) {           // groups in order
+            float t = 0.f;
+#pragma unroll
+            for (int gq = 0; gq < kBlock / 16; ++gq) t += colg[gq][threadIdx.x];
+            ws[(int64_t)blockIdx.x * (dg + nl) + c0 + threadIdx.x] = t;
         }
+        __syncthreads();
     }
-    __syncthreads();
-    for (int c = threadIdx.x; c < dg + nl; c += kBlock) unsafeAtomicAdd(gWp + c, col[c]);
 }
 
 // the same for dg == nl == d <= 64, d % 4 == 0 (every NeuMF tower: the last layer is `factors` wide like the GMF
@@ -913,10 +947,8 @@ __global__ __launch_bounds__(kBlock) void k_nmf_pred_bwd_v(const float *__restri
                                                            const float *__restrict__ G, int d,
                                                            const float *__restrict__ XL,
                                                            const float *__restrict__ Wp, int64_t R,
-                                                           float *__restrict__ DZ, float *__restrict__ gWp) {
-    __shared__ float col[128];
-    if (threadIdx.x < 128) col[threadIdx.x] = 0.f;
-    __syncthreads();
+                                                           float *__restrict__ DZ, float *__restrict__ ws) {
+    __shared__ float colg[kBlock / 16][128];          // [lane group][g columns 0..63 | x columns 64..127]
     const int lane = threadIdx.x % 16, group = threadIdx.x / 16;
     const bool on = 4 * lane < d;
     const int c4 = on ? 4 * lane : 0;
@@ -952,17 +984,21 @@ __global__ __launch_bounds__(kBlock) void k_nmf_pred_bwd_v(const float *__restri
                 *reinterpret_cast<float4 *>(DZ + r * d + c4) = make_float4(dz[0], dz[1], dz[2], dz[3]);
         }
     }
-    if (on) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { atomicAdd(&col[c4 + k], pg[k]); atomicAdd(&col[64 + c4 + k], px[k]); }
-    }
+    for (int k = 0; k < 4; ++k) { colg[group][4 * lane + k] = on ? pg[k] : 0.f; colg[group][64 + 4 * lane + k] = on ? px[k] : 0.f; }
     __syncthreads();
     const int t = (int)threadIdx.x;
-    if (t < d) unsafeAtomicAdd(gWp + t, col[t]);
-    else if (t >= 64 && t < 64 + d) unsafeAtomicAdd(gWp + d + (t - 64), col[t]);
+    if (t < 128) {                                    // lane groups in order; ws row = [g columns (d) | x columns (d)]
+        float acc = 0.f;
+#pragma unroll
+        for (int gq = 0; gq < kBlock / 16; ++gq) acc += colg[gq][t];
+        if (t < d) ws[(int64_t)blockIdx.x * (2 * d) + t] = acc;
+        else if (t >= 64 && t < 64 + d) ws[(int64_t)blockIdx.x * (2 * d) + d + (t - 64)] = acc;
+    }
 }
 
-// out[n] += sum_r X[r*ld + n]: a block takes 64 columns x kColsumRows rows (grid = column tiles x row tiles)
+// ws[row tile][n] = sum over the tile's rows of X[r*ld + n]: a block takes 64 columns x kColsumRows rows (grid = column
+// tiles x row tiles); k_reduce_slices adds the row tiles in order
 constexpr int kColsumRows = 512;
 template <bool H = false>
 __global__ __launch_bounds__(kBlock) void k_colsum(const float *__restrict__ X, int64_t R, int N, int64_t ld,
@@ -984,7 +1020,7 @@ __global__ __launch_bounds__(kBlock) void k_colsum(const float *__restrict__ X, 
     }
     sm[rr][c] = s0 + s1;
     __syncthreads();
-    if (rr == 0 && n < N) unsafeAtomicAdd(out + n, (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]));
+    if (rr == 0 && n < N) out[(int64_t)blockIdx.y * N + n] = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
 }
 
 // the same for a bf16 matrix whose rows are whole 16-byte vectors (N % 8 == 0, N <= 2048, ld == N): a thread owns
@@ -1022,7 +1058,7 @@ __global__ __launch_bounds__(kBlock) void k_colsum_h(const uint16_t *__restrict_
     for (int c = threadIdx.x; c < N; c += kBlock) {   // column c: vector c/8, element c%8, summed over the row groups
         float t = 0.f;
         for (int g = 0; g < rpp; ++g) t += sm[g * vpr + c / 8][c % 8];
-        unsafeAtomicAdd(out + c, t);
+        out[(int64_t)blockIdx.x * N + c] = t;          // (row tile blockIdx.x of the workspace: see k_colsum)
     }
 }
 
@@ -1200,7 +1236,42 @@ struct daisy_neumf_ctx {
     int32_t *sc_edge_item, *sc_edge_whole;
     void *sc_tmp; size_t sc_tmp_bytes;
     int bf16;                                // daisy_neumf_ctx_set_precision: 0 fp32, 1 bf16 MFMA inputs, 2 bf16 storage
+    // per-workgroup partial sums of the reductions over the batch rows (split-K slices of the weight-gradient GEMMs,
+    // row tiles of the column sums ...), added in a fixed order by k_reduce_slices; allocated at the first training step
+    float *det_ws;
+    size_t det_ws_floats;
 };
+
+constexpr int kWgradChunkDefault = 2048;
+static int wgrad_chunk() {
+    static const int v = getenv("DAISY_WGRAD_CHUNK") ? atoi(getenv("DAISY_WGRAD_CHUNK")) : kWgradChunkDefault;
+    return v > 0 ? v : kWgradChunkDefault;
+}
+
+static int neumf_need_det_ws(daisy_neumf_ctx *ctx) {
+    if (ctx->det_ws) return DAISY_OK;
+    const size_t splits = ((size_t)ctx->max_rows + wgrad_chunk() - 1) / wgrad_chunk();
+    size_t layer = 1024;                               // (predict layer: <= 1024 workgroups x 512 columns, covered below)
+    for (int l = 1; l <= ctx->L; ++l) {
+        const size_t e = (size_t)ctx->width[l] * ctx->width[l - 1];
+        if (e > layer) layer = e;
+    }
+    size_t n = splits * layer;
+    const size_t pred = (size_t)1024 * 512;
+    if (pred > n) n = pred;
+    hipError_t e = hipMalloc((void **)&ctx->det_ws, n * sizeof(float));
+    if (e != hipSuccess) {
+        ctx->det_ws = nullptr;
+        set_error("neumf: hipMalloc(%zu) for the reduction workspace failed: %s", n * sizeof(float), hipGetErrorString(e));
+        return DAISY_ERR_HIP;
+    }
+    ctx->det_ws_floats = n;
+    return DAISY_OK;
+}
+
+static void reduce_slices(const float *ws, int nslices, int64_t len, float *out, hipStream_t s) {
+    hipLaunchKernelGGL(k_reduce_slices, dim3(grid_for(len, kBlock, 2048)), dim3(kBlock), 0, s, ws, nslices, len, out);
+}
 
 static inline hipStream_t NS(daisy_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
@@ -1384,6 +1455,7 @@ int daisy_neumf_ctx_create(daisy_neumf_ctx **out, int64_t max_rows, int32_t fact
     c->d = factors; c->L = num_layers; c->model = model;
     c->bf16 = 0;
     c->sc_arena = nullptr;
+    c->det_ws = nullptr; c->det_ws_floats = 0;
     c->dm = factors << (num_layers - 1);
     c->width[0] = 2 * c->dm;
     for (int l = 1; l <= num_layers; ++l) c->width[l] = c->width[l - 1] / 2;
@@ -1418,6 +1490,7 @@ int daisy_neumf_ctx_destroy(daisy_neumf_ctx *ctx) {
     if (!ctx) return DAISY_OK;
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->sc_arena) (void)hipFree(ctx->sc_arena);
+    if (ctx->det_ws) (void)hipFree(ctx->det_ws);
     delete ctx;
     return DAISY_OK;
 }
@@ -1469,8 +1542,12 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
     src.u = u; src.i = i; src.j = pointwise ? i : j; src.B = B;
     int rc = neumf_forward_rows(ctx, params, src, R, true, pointwise, thresh, scale, seed, stats, s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_nmf_loss, dim3(grid_for(B, kBlock * 2)), dim3(kBlock), 0, s, ctx->pred, j, B,
-                       (int)loss_type, gamma, pointwise, ctx->dpred, stats, g.bp);
+    if ((rc = neumf_need_det_ws(ctx))) return rc;
+    float *ws = ctx->det_ws;
+    const int loss_grid = grid_for(B, kBlock * 2);
+    hipLaunchKernelGGL(k_nmf_loss, dim3(loss_grid), dim3(kBlock), 0, s, ctx->pred, j, B,
+                       (int)loss_type, gamma, pointwise, ctx->dpred, stats, ws);
+    reduce_slices(ws, loss_grid, 1, g.bp, s);
     hipLaunchKernelGGL(k_nmf_finalize, dim3(1), dim3(64), 0, s, stats, reg_1, reg_2, pointwise);
     DAISY_LAUNCH_CHECK();
     // ---- backward
@@ -1482,15 +1559,16 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
     static const int tune_scatter = getenv("DAISY_NMF_SCATTER_OWNER") ? atoi(getenv("DAISY_NMF_SCATTER_OWNER")) : 1;
     const bool owner_scatter = tune_scatter != 0;
     const bool vec_pred = dg == nl && dg > 0 && dg <= 64 && dg % 4 == 0;          // NeuMF proper (not the GMF / MLP ablations)
-    const int pb_grid = grid_for(R, kBlock / 16 * 8, 512);         // few workgroups: each ends with 2d global atomics
+    const int pb_grid = vec_pred ? grid_for(R, kBlock / 16 * 8, 512) : grid_for(R, kBlock / 16 * 16, 1024);
     if (vec_pred && H) hipLaunchKernelGGL((k_nmf_pred_bwd_v<true>), dim3(pb_grid), dim3(kBlock), 0, s, ctx->dpred, ctx->G, dg,
-                                          ctx->X[L], p.Wp, R, dz, g.Wp);
+                                          ctx->X[L], p.Wp, R, dz, ws);
     else if (vec_pred) hipLaunchKernelGGL((k_nmf_pred_bwd_v<false>), dim3(pb_grid), dim3(kBlock), 0, s, ctx->dpred, ctx->G, dg,
-                                          ctx->X[L], p.Wp, R, dz, g.Wp);
-    else if (H) hipLaunchKernelGGL((k_nmf_pred_bwd<true>), dim3(grid_for(R, kBlock / 16 * 16, 1024)), dim3(kBlock), 0, s, ctx->dpred,
-                              ctx->G, dg, ctx->X[L], nl, p.Wp, R, dz, g.Wp);
-    else hipLaunchKernelGGL((k_nmf_pred_bwd<false>), dim3(grid_for(R, kBlock / 16 * 16, 1024)), dim3(kBlock), 0, s, ctx->dpred,
-                            ctx->G, dg, ctx->X[L], nl, p.Wp, R, dz, g.Wp);
+                                          ctx->X[L], p.Wp, R, dz, ws);
+    else if (H) hipLaunchKernelGGL((k_nmf_pred_bwd<true>), dim3(pb_grid), dim3(kBlock), 0, s, ctx->dpred,
+                              ctx->G, dg, ctx->X[L], nl, p.Wp, R, dz, ws);
+    else hipLaunchKernelGGL((k_nmf_pred_bwd<false>), dim3(pb_grid), dim3(kBlock), 0, s, ctx->dpred,
+                            ctx->G, dg, ctx->X[L], nl, p.Wp, R, dz, ws);
+    reduce_slices(ws, pb_grid, dg + nl, g.Wp, s);       // gWp += the workgroups' column sums, in workgroup order
     DAISY_LAUNCH_CHECK();
     if (model != DAISY_NEUMF_GMF) {
         for (int l = L; l >= 1; --l) {
@@ -1508,23 +1586,35 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
                 w.M = n_in; w.N = n_out;
             }
             w.K = R;
-            static const int wchunk = getenv("DAISY_WGRAD_CHUNK") ? atoi(getenv("DAISY_WGRAD_CHUNK")) : 2048;
-            w.k_chunk = wchunk;
+            w.k_chunk = wgrad_chunk();
             w.bf16 = ctx->bf16 ? 1 : 0;
+            // split-K slices land side by side in the workspace and are added in slice order (no fp32 atomics)
+            const int64_t wlen = (int64_t)n_out * n_in;
+            const int wsplits = (int)((w.k_chunk < R) ? (R + w.k_chunk - 1) / w.k_chunk : 1);
+            float *wdst = w.C;
+            w.C = ws;
+            w.slice_stride = wlen;
             const dim3 cs_grid((unsigned)((n_out + 63) / 64), (unsigned)((R + kColsumRows - 1) / kColsumRows));
             if (H) {
                 w.A16 = reinterpret_cast<const uint16_t *>(w.A);
                 w.B16 = reinterpret_cast<const uint16_t *>(w.B);
                 if (!gemm_h_ok(w)) { set_error("neumf: weight gradient of layer %d does not tile for the bf16-storage GEMM", l); return DAISY_ERR_STATE; }
                 launch_gemm_h<EPI_ATOMIC>(w, s);
-                if (n_out % 8 == 0 && kBlock % (n_out / 8) == 0)
-                    hipLaunchKernelGGL(k_colsum_h, dim3((unsigned)((R + kColsumRowsH - 1) / kColsumRowsH)), dim3(kBlock), 0, s,
-                                       reinterpret_cast<const uint16_t *>(dz), R, n_out, g.b[l - 1]);
-                else
-                    hipLaunchKernelGGL((k_colsum<true>), cs_grid, dim3(kBlock), 0, s, dz, R, n_out, (int64_t)n_out, g.b[l - 1]);
+                reduce_slices(ws, wsplits, wlen, wdst, s);
+                if (n_out % 8 == 0 && kBlock % (n_out / 8) == 0) {
+                    const int tiles = (int)((R + kColsumRowsH - 1) / kColsumRowsH);
+                    hipLaunchKernelGGL(k_colsum_h, dim3((unsigned)tiles), dim3(kBlock), 0, s,
+                                       reinterpret_cast<const uint16_t *>(dz), R, n_out, ws);
+                    reduce_slices(ws, tiles, n_out, g.b[l - 1], s);
+                } else {
+                    hipLaunchKernelGGL((k_colsum<true>), cs_grid, dim3(kBlock), 0, s, dz, R, n_out, (int64_t)n_out, ws);
+                    reduce_slices(ws, (int)cs_grid.y, n_out, g.b[l - 1], s);
+                }
             } else {
                 launch_gemm<EPI_ATOMIC>(w, s);
-                hipLaunchKernelGGL((k_colsum<false>), cs_grid, dim3(kBlock), 0, s, dz, R, n_out, (int64_t)n_out, g.b[l - 1]);
+                reduce_slices(ws, wsplits, wlen, wdst, s);
+                hipLaunchKernelGGL((k_colsum<false>), cs_grid, dim3(kBlock), 0, s, dz, R, n_out, (int64_t)n_out, ws);
+                reduce_slices(ws, (int)cs_grid.y, n_out, g.b[l - 1], s);
             }
             GemmOp x{};                                   // dZ_{l-1}[R, n_in] = (dZ W_l) gated
             x.A = dz; x.sam = n_out; x.sak = 1;

@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 280 python -m pytest tests/test_gpu_lightgcn_dist.py tests/test_gpu_lightgcn.py -q -m gpu 2>&1 | grep -v "^$" | tail -12
+for lv in 2 0; do timeout 100 python tools/neumf_steps.py $lv 262144 2>&1 | tail -1; done
+timeout 100 python tools/neumf_steps.py 0 256 2>&1 | tail -1
+timeout 100 python tools/neumf_steps.py 2 65536 2>&1 | tail -1
