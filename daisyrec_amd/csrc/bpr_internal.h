@@ -122,6 +122,7 @@ struct daisy_epoch_plan {
     void *ptemp;                        // rocPRIM scan scratch
     void *parena2;                      // second record set (plans with more than 256 batches: LSD passes ping-pong)
     int32_t p_cur;                      // record set holding the finished plan
+    uint64_t build_gen;                 // counts the builds of this plan (what a batch index refers to)
     // daisy_epoch_plan_build_positions: this plan holds a SUBSET of the epoch's rows (one rank's share), batch k =
     // the held rows whose epoch position lies in [k*B, (k+1)*B): record ranges differ per batch
     int64_t *h_off;                     // host, [num_batches+1] first record of every batch (NULL: k*batch_size)
@@ -160,6 +161,12 @@ struct daisy_bpr_ctx {
     int last_item_mode;  // mode of the last daisy_bpr_item_grad: the user pass of the same step follows it
     float *bu, *bi, *b0, *g_bu, *g_bi, *g_b0;   // FM bias parameters (daisy_bpr_ctx_set_bias); bu == nullptr: MF
     bool batch_set, fwd_done;
+    // the plan batch the context is set to (partitioned layout), and - staged step, single GPU - the batch whose
+    // pre-norm sum(|P[u]|^2) the previous step's item pass has already produced on the side (see staged_sgd_step)
+    const daisy_epoch_plan *cur_plan; int64_t cur_k; uint64_t cur_gen;
+    const daisy_epoch_plan *pre_plan; int64_t pre_k; uint64_t pre_gen;
+    const float *pre_P; const double *pre_stats; int pre_n;     // pre_n > 0: partial sums in `partials`; 0: stats[SQ_U_PRE]
+    bool pre_ready;
 };
 
 

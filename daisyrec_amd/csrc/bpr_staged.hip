@@ -612,6 +612,7 @@ static int plan_build_partitioned(daisy_epoch_plan *p, const daisy_train_index *
         p->d_off = nullptr; p->h_off_cap = 0;
     }
     p->built = true;
+    ++p->build_gen;
     return DAISY_OK;
 }
 
@@ -689,6 +690,32 @@ __global__ __launch_bounds__(kBlock) void k_unorm_reduce(const double *__restric
         __syncthreads();
     }
     if (threadIdx.x == 0) stats[DAISY_ST_SQ_U_PRE] = sm[0];
+}
+
+// The NEXT batch's pre-norm riding on this step's item pass (single-GPU epoch loops): once the user pass and its edge
+// kernel are done, P and the row-norm cache are final for this step, so the extra workgroups [first_block, gridDim.x)
+// of the item-pass launch do k_unorm's work for batch k+1 and an extra workgroup of the item-edge launch adds the
+// partial sums (RideReduce) - two launches less per step (k_unorm, k_unorm_reduce: ~12 us of kernels and two
+// kernel boundaries of a 0.57 ms step, one of five launches below ~130 k samples).
+struct RideUnorm {
+    const float *p_sqnorm; const uint32_t *s_user; uint32_t umask; int64_t B;
+    double *partials; int first_block, nblocks;      // nblocks == 0: nothing rides
+};
+struct RideReduce { const double *partials; int n; double *stats; };    // n == 0: nothing rides
+
+__device__ __forceinline__ void unorm_block(const RideUnorm &r, int b) {
+    double acc = 0.0;
+    for (int64_t s = (int64_t)b * blockDim.x + threadIdx.x; s < r.B; s += (int64_t)r.nblocks * blockDim.x)
+        acc += (double)r.p_sqnorm[r.s_user[s] & r.umask];
+    __shared__ double sm_ride[kBlock / kWave];
+    const double w = wave_sum_f64(acc);
+    if ((threadIdx.x % kWave) == 0) sm_ride[threadIdx.x / kWave] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < (int)blockDim.x / kWave; ++k) t += sm_ride[k];
+        r.partials[b] = t;
+    }
 }
 
 // Sum |P[u_s]|^2 over the batch as the user pass needs it before its first update.  n_pre == 0: stats holds it (the
@@ -1136,8 +1163,14 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
                                                         float *__restrict__ Qo, float *__restrict__ cnt_out,
                                                         const double *__restrict__ stats, RowOpt opt,
                                                         float reg_1, float reg_2, ItemEdges2 ed,
-                                                        const int64_t *__restrict__ erange, StagedBias fm) {
+                                                        const int64_t *__restrict__ erange, StagedBias fm,
+                                                        RideUnorm ride) {
     if (halted(v.halt)) return;            // this step's loss (reduced behind the user pass) or an earlier one was not finite
+    if (ride.nblocks && (int)blockIdx.x >= ride.first_block) {      // the next batch's pre-norm rides on this launch
+        unorm_block(ride, (int)blockIdx.x - ride.first_block);
+        return;
+    }
+    const int item_grid = ride.nblocks ? ride.first_block : (int)gridDim.x;
     constexpr int G = StagedItemCfg<C, BLK>::G, RUN = StagedItemCfg<C, BLK>::RUN, E = StagedItemCfg<C, BLK>::E;
     // erange: only the entries [erange[0], erange[1]) - an item range of the batch (the entries are sorted by item, so
     // no segment crosses the cut and the piece is reduced exactly like a whole batch).  Multi-GPU steps cut the item
@@ -1175,7 +1208,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) voi
         rJ = inv_or_zero(stats[DAISY_ST_NORM_J], reg_2);
     }
 
-    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += gridDim.x) {
+    for (int64_t chunk = blockIdx.x; chunk < nchunks; chunk += item_grid) {
         const int64_t c0 = chunk * E;
         const int64_t t0 = c0 + (int64_t)group * RUN;
         const int64_t t1 = (t0 + RUN < n) ? (t0 + RUN) : n;
@@ -1358,12 +1391,30 @@ __global__ __launch_bounds__(kBlock) void k_staged_item_edges(ItemEdges2 ed, int
                                                               const double *__restrict__ stats, RowOpt opt,
                                                               float reg_1, float reg_2,
                                                               const int64_t *__restrict__ erange, int chunk_entries,
-                                                              const double *__restrict__ halt, StagedBias fm) {
+                                                              const double *__restrict__ halt, StagedBias fm,
+                                                              RideReduce rr) {
     if (halted(halt)) return;
+    unsigned nb = gridDim.x;
+    if (rr.n) {                            // the last workgroup adds the next batch's pre-norm partial sums (k_unorm_reduce)
+        nb -= 1;
+        if (blockIdx.x == nb) {
+            __shared__ double sm[kBlock];
+            double t = 0.0;
+            for (int b = threadIdx.x; b < rr.n; b += kBlock) t += rr.partials[b];
+            sm[threadIdx.x] = t;
+            __syncthreads();
+            for (int off = kBlock / 2; off > 0; off >>= 1) {
+                if ((int)threadIdx.x < off) sm[threadIdx.x] += sm[threadIdx.x + off];
+                __syncthreads();
+            }
+            if (threadIdx.x == 0) rr.stats[DAISY_ST_SQ_U_PRE] = sm[0];
+            return;
+        }
+    }
     if (erange) nchunks = (erange[1] - erange[0] + chunk_entries - 1) / chunk_entries;      // chunks of the slice
     const int lane = threadIdx.x % C::LPR;
     const int group = threadIdx.x / C::LPR;
-    const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
+    const int64_t gstride = (int64_t)nb * C::GROUPS_PER_BLOCK;
     float rI = 0.f, rJ = 0.f;
     if constexpr (APPLY) {
         rI = inv_or_zero(stats[DAISY_ST_NORM_I], reg_2);
@@ -1577,6 +1628,7 @@ static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_ty
                        float reg_1, float reg_2, double *stats, int *grid_out, int n_pre, bool ride_reduce,
                        double *epoch_acc, double *step_loss, hipStream_t s, const StagedAdam *adam = nullptr,
                        bool bias_grad_out = false) {
+    ctx->pre_ready = false;                // (P is about to change: a pre-norm computed ahead of this pass is stale)
     StreamView v = ctx->sv;
     const int d = ctx->d;
     const int mode = staged_mode(ctx, loss_type);
@@ -1636,7 +1688,9 @@ static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_ty
 // slice >= 0: only the entries of item slice `slice` (daisy_bpr_staged_item_slices has run for this batch)
 static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_out, bool apply, float lr,
                        float reg_1, float reg_2, const double *stats, hipStream_t s, int slice = -1,
-                       const StagedAdam *adam = nullptr, bool bias_grad_out = false) {
+                       const StagedAdam *adam = nullptr, bool bias_grad_out = false,
+                       RideUnorm ride = RideUnorm{nullptr, nullptr, 0u, 0, nullptr, 0, 0},
+                       RideReduce rr = RideReduce{nullptr, 0, nullptr}) {
     const int64_t *erange = (slice >= 0) ? ctx->slice_rng + slice : nullptr;
     const StreamView &v = ctx->sv;
     const int d = ctx->d;
@@ -1652,14 +1706,17 @@ static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_
         constexpr int BLK = kStagedItemBlock;        // (128-thread workgroups measured the same, r02 / r03)
         const int64_t nchunks = (v.E + StagedItemCfg<C, BLK>::E - 1) / StagedItemCfg<C, BLK>::E;
         if (nchunks > ctx->edge_chunks) { overflow = true; return DAISY_OK; }
-        const dim3 g(grid_for(v.E, StagedItemCfg<C, BLK>::E, tune_ig)), b(BLK), ge(grid_for(nchunks, C::GROUPS_PER_BLOCK));
+        const int gi = grid_for(v.E, StagedItemCfg<C, BLK>::E, tune_ig);
+        RideUnorm ru = ride;
+        ru.first_block = gi;                 // the riding workgroups follow the item pass's own
+        const dim3 g(gi + ru.nblocks), b(BLK), ge(grid_for(nchunks, C::GROUPS_PER_BLOCK) + (rr.n ? 1 : 0));
         auto launch = [&](auto mode_tag, auto ap_tag, auto adam_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
             constexpr bool AP = decltype(ap_tag)::value, AD = decltype(adam_tag)::value;
             hipLaunchKernelGGL((k_staged_item<C, BLK, MODE, AP, AD>), g, b, 0, s, ctx->p_stage, ctx->coef, v, d, Qo, cnt_out,
-                               stats, opt, reg_1, reg_2, ed, erange, fm);
+                               stats, opt, reg_1, reg_2, ed, erange, fm, ru);
             hipLaunchKernelGGL((k_staged_item_edges<C, AP, AD>), ge, dim3(kBlock), 0, s, ed, nchunks, d, Qo, cnt_out, stats,
-                               opt, reg_1, reg_2, erange, StagedItemCfg<C, BLK>::E, v.halt, fm);
+                               opt, reg_1, reg_2, erange, StagedItemCfg<C, BLK>::E, v.halt, fm, rr);
         };
         auto by_apply = [&](auto mode_tag) {
             if (apply && adam) launch(mode_tag, std::true_type{}, std::true_type{});
@@ -1681,12 +1738,36 @@ int staged_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int loss_type, float
                     float reg_2, double *stats, double *epoch_acc, double *step_loss, hipStream_t s) {
     int rc = staged_check(ctx, loss_type, "sgd_step");
     if (rc) return rc;
-    // five launches (six for large batches, see staged_prenorm): pre-norm partial sums, user pass, its edges (+ the
-    // reduction of its sums), item pass, its edges
+    // four launches inside an epoch: user pass, its edges (+ the reduction of its sums), item pass (+ the NEXT batch's
+    // pre-norm partial sums), its edges (+ their reduction); the first step of an epoch computes its own pre-norm
+    // first (k_unorm, and k_unorm_reduce for large batches)
+    static const int tune_ride = getenv("DAISY_STAGED_RIDE") ? atoi(getenv("DAISY_STAGED_RIDE")) : 1;
     int gu = 0, n_pre = 0;
-    if ((rc = staged_prenorm(ctx, P, stats, false, &n_pre, s))) return rc;
+    const bool have_pre = ctx->pre_ready && ctx->cur_plan && ctx->pre_plan == ctx->cur_plan && ctx->pre_k == ctx->cur_k &&
+                          ctx->pre_gen == ctx->cur_gen && ctx->cur_gen == ctx->cur_plan->build_gen && ctx->pre_P == P &&
+                          ctx->p_sqnorm_of == P && (ctx->pre_n > 0 || ctx->pre_stats == stats);
+    ctx->pre_ready = false;                  // consumed, or stale
+    if (have_pre) n_pre = ctx->pre_n;        // > 0: partial sums wait behind the user pass's own; 0: stats[SQ_U_PRE] holds the sum
+    else if ((rc = staged_prenorm(ctx, P, stats, false, &n_pre, s))) return rc;
     if ((rc = staged_user(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, stats, &gu, n_pre, true, epoch_acc, step_loss, s))) return rc;
-    if ((rc = staged_item(ctx, loss_type, Q, nullptr, true, lr, reg_1, reg_2, stats, s))) return rc;
+    // the next batch of the same plan: its pre-norm rides on this step's item pass
+    RideUnorm ride{nullptr, nullptr, 0u, 0, nullptr, 0, 0};
+    RideReduce rr{nullptr, 0, nullptr};
+    const daisy_epoch_plan *pl = ctx->cur_plan;
+    if (tune_ride && pl && pl->kind == 1 && ctx->cur_gen == pl->build_gen && ctx->cur_k + 1 < pl->num_batches &&
+        daisy_epoch_plan_batch_rows(pl, ctx->cur_k + 1) > 0) {
+        const StreamView nv = plan_stream_view(pl, ctx->cur_k + 1);
+        const int gn = grid_for(nv.B, kBlock * 4);
+        const bool fold = gn <= kPreBlocks / 2;              // (the same rule as staged_prenorm)
+        ride.p_sqnorm = ctx->p_sqnorm; ride.s_user = nv.s_user; ride.umask = nv.umask; ride.B = nv.B;
+        ride.partials = fold ? ctx->partials + (size_t)kMaxGrid * 8 : ctx->partials;
+        ride.nblocks = gn;
+        if (!fold) { rr.partials = ride.partials; rr.n = gn; rr.stats = stats; }
+        ctx->pre_plan = pl; ctx->pre_k = ctx->cur_k + 1; ctx->pre_gen = ctx->cur_gen;
+        ctx->pre_P = P; ctx->pre_stats = stats; ctx->pre_n = fold ? gn : 0;
+    }
+    if ((rc = staged_item(ctx, loss_type, Q, nullptr, true, lr, reg_1, reg_2, stats, s, -1, nullptr, false, ride, rr))) return rc;
+    ctx->pre_ready = ride.nblocks > 0;
     ctx->fwd_done = false;
     return DAISY_OK;
 }

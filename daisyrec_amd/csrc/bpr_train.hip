@@ -1311,6 +1311,7 @@ static int plan_build(daisy_epoch_plan *p, const int32_t *triples, int64_t n, in
     free(p->h_off); p->h_off = nullptr; p->h_off_cap = 0;          // (a plan that held a rank's share before)
     if (p->d_off) { (void)hipFree(p->d_off); p->d_off = nullptr; }
     p->n = n; p->batch_size = batch_size; p->num_batches = nb; p->built = true;
+    ++p->build_gen;
     p->pointwise = pointwise;
     p->kind = 0;
     return DAISY_OK;
@@ -1540,6 +1541,8 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
     c->last_item_mode = DAISY_ITEM_SORTED;
     c->pointwise = 0;
     c->bu = c->bi = c->b0 = c->g_bu = c->g_bi = c->g_b0 = nullptr;
+    c->cur_plan = c->pre_plan = nullptr; c->cur_k = c->pre_k = -1; c->cur_gen = c->pre_gen = 0;
+    c->pre_P = nullptr; c->pre_stats = nullptr; c->pre_n = 0; c->pre_ready = false;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     const size_t o_coef = take((size_t)max_batch * 8);
@@ -1655,11 +1658,13 @@ int daisy_bpr_set_batch_from_plan(daisy_bpr_ctx *ctx, const daisy_epoch_plan *pl
         memset(&ctx->v, 0, sizeof(ctx->v));
         ctx->v.B = ctx->sv.B;
         ctx->batch_kind = 1;
+        ctx->cur_plan = plan; ctx->cur_k = k; ctx->cur_gen = plan->build_gen;
     } else {
         ctx->v = plan_view(plan, k);
         ctx->sv = stream_view_of(ctx->v);
         ctx->batch_kind = 0;
         view_bias(ctx);
+        ctx->cur_plan = nullptr;
     }
     ctx->batch_set = true; ctx->fwd_done = false; ctx->n_slices = 0;
     return DAISY_OK;
@@ -1684,6 +1689,7 @@ int daisy_bpr_set_batch_from_triples(daisy_bpr_ctx *ctx, const int32_t *triples,
     ctx->sv = stream_view_of(ctx->v);
     ctx->batch_kind = 0;
     view_bias(ctx);
+    ctx->cur_plan = nullptr;
     ctx->batch_set = true; ctx->fwd_done = false; ctx->n_slices = 0;
     return DAISY_OK;
 }

@@ -1,4 +1,2 @@
 cd $GRAFT_REPO_ROOT
-for lv in 2 0; do timeout 100 python tools/neumf_steps.py $lv 262144 2>&1 | tail -1; done
-timeout 100 python tools/neumf_steps.py 0 256 2>&1 | tail -1
-timeout 100 python tools/neumf_steps.py 2 65536 2>&1 | tail -1
+timeout 400 python -m pytest tests/test_gpu_staged.py tests/test_gpu_property.py tests/test_gpu_hardening.py tests/test_gpu_parity.py tests/test_gpu_fm.py tests/test_gpu_plan.py tests/test_gpu_torch_ops.py -q -m gpu 2>&1 | grep -v "^$" | tail -8
