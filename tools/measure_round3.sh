@@ -17,7 +17,7 @@ timeout 200 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/
 python $R/tools/pmc_traffic.py $O/pmc_rd $O/pmc_wr $O/pmc_traffic.json 2097152 "profiles/r03_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --steps 12 (round 3 kernels: staged step with nontemporal stage stores + Q window, partitioned plan)" > /dev/null
 rm -rf $O/pmc_rd $O/pmc_wr
 cd $R
-for ps in 0 1 0 1; do TAG=pstream$ps DAISY_STAGED_PSTREAM=$ps timeout 100 python tools/r03_probe.py c3s 40 2>&1 | grep "^\[" ; done | tee $O/pstream_ab.txt
+if [ -n "$PSTREAM_AB" ]; then for ps in 0 1 0 1; do TAG=pstream$ps DAISY_STAGED_PSTREAM=$ps timeout 100 python tools/r03_probe.py c3s 40 2>&1 | grep "^\[" ; done | tee $O/pstream_ab.txt; fi
 head -14 $O/mf_kernel_summary.txt | cut -c1-64,100-170
 python - <<PY
 import json
