@@ -122,7 +122,9 @@ struct daisy_epoch_plan {
     void *ptemp;                        // rocPRIM scan scratch
     void *parena2;                      // second record set (plans with more than 256 batches: LSD passes ping-pong)
     int32_t p_cur;                      // record set holding the finished plan
-    uint64_t build_gen;                 // counts the builds of this plan (what a batch index refers to)
+    uint64_t build_gen;                 // id of the build the plan currently holds, unique in the process (what a
+                                        // batch index refers to: a context that computed something ahead for "batch k+1"
+                                        // must not mistake a rebuilt - or another plan at the same address - for it)
     // daisy_epoch_plan_build_positions: this plan holds a SUBSET of the epoch's rows (one rank's share), batch k =
     // the held rows whose epoch position lies in [k*B, (k+1)*B): record ranges differ per batch
     int64_t *h_off;                     // host, [num_batches+1] first record of every batch (NULL: k*batch_size)
@@ -171,6 +173,7 @@ struct daisy_bpr_ctx {
 
 
 namespace daisy {
+uint64_t next_plan_build_id();          // capi.hip
 // bpr_staged.hip
 bool staged_supported(const daisy_bpr_ctx *ctx, int loss_type);
 int staged_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int loss_type, float gamma, float lr, float reg_1,

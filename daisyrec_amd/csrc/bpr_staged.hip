@@ -612,7 +612,7 @@ static int plan_build_partitioned(daisy_epoch_plan *p, const daisy_train_index *
         p->d_off = nullptr; p->h_off_cap = 0;
     }
     p->built = true;
-    ++p->build_gen;
+    p->build_gen = next_plan_build_id();
     return DAISY_OK;
 }
 

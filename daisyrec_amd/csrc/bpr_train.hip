@@ -1311,7 +1311,7 @@ static int plan_build(daisy_epoch_plan *p, const int32_t *triples, int64_t n, in
     free(p->h_off); p->h_off = nullptr; p->h_off_cap = 0;          // (a plan that held a rank's share before)
     if (p->d_off) { (void)hipFree(p->d_off); p->d_off = nullptr; }
     p->n = n; p->batch_size = batch_size; p->num_batches = nb; p->built = true;
-    ++p->build_gen;
+    p->build_gen = next_plan_build_id();
     p->pointwise = pointwise;
     p->kind = 0;
     return DAISY_OK;

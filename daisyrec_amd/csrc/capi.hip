@@ -1,11 +1,19 @@
 // Error reporting, ABI version and the memory-system micro-benchmarks.
 #include <stdarg.h>
 
+#include <atomic>
+
 #include "common.h"
 
 namespace daisy {
 
 static thread_local char g_err[512] = "";
+
+// ids of epoch-plan builds, unique in the process (daisy_epoch_plan::build_gen)
+uint64_t next_plan_build_id() {
+    static std::atomic<uint64_t> counter{0};
+    return ++counter;
+}
 
 void set_error(const char *fmt, ...) {
     va_list ap;
