@@ -134,3 +134,51 @@ class OracleContext:
         Q_rows.copy_(torch.from_numpy((q - lr * g).astype(np.float32)))
         g_rows.zero_()
         cnt_rows.zero_()
+
+    # ---- torch.optim.Adam through the sharded protocol (sharding.UserShardedBprTrainer(adam_steps=...)): the HIP path
+    # keeps the rank's rows of P in the lazy form and steps the owner's block of Q densely; restated here with the dense
+    # oracle optimiser - every row of P_local in every step (zero gradient for rows without a sample; steps this rank
+    # sat out are caught up first), every row of an owned block per owner call
+    def staged_adam_catchup_users(self, P, adam):
+        if not hasattr(self, "_p_adam"):
+            self._p_adam = O.DenseAdam([tuple(P.shape)], adam.lr)
+        self._catch_up_p(P, adam.t - 1)
+
+    def _catch_up_p(self, P, upto):
+        while self._p_adam.t < upto:                                   # zero-gradient steps
+            (Pn,) = self._p_adam.step([P.numpy()], [np.zeros(tuple(P.shape))])
+            P.copy_(torch.from_numpy(Pn))
+
+    def oracle_flush_p(self, P, adam):
+        if not hasattr(self, "_p_adam"):
+            self._p_adam = O.DenseAdam([tuple(P.shape)], adam.lr)
+        self._catch_up_p(P, adam.t)
+
+    def staged_user_adam(self, P, Q, adam, reg_1, reg_2, loss_type=0, gamma=1e-10):
+        self.forward(P, Q, loss_type, gamma)
+        P64, Q64 = P.numpy().astype(np.float64), Q.numpy().astype(np.float64)
+        self.pu_pre = P64[self.u].copy()
+        qi, qj = Q64[self.i], Q64[self.j]
+        nU = float(self.stats[13]) ** 0.5
+        g = np.zeros_like(P64)
+        np.add.at(g, self.u, self.cp[:, None] * qi + self.cn[:, None] * qj + reg_1 * np.sign(self.pu_pre)
+                  + reg_2 * self._fro(self.pu_pre, nU))
+        assert self._p_adam.t == adam.t - 1
+        (Pn,) = self._p_adam.step([P.numpy()], [g])
+        P.copy_(torch.from_numpy(Pn))
+
+    def item_apply_counts_adam(self, Q_rows, g_rows, cnt_rows, m_rows, v_rows, adam, reg_1, reg_2):
+        key = m_rows.data_ptr()                                        # one dense optimiser per owned block
+        if not hasattr(self, "_q_adam"):
+            self._q_adam = {}
+        opt = self._q_adam.setdefault(key, O.DenseAdam([tuple(Q_rows.shape)], adam.lr))
+        assert opt.t == adam.t - 1, "every owned block steps exactly once per global step"
+        nI, nJ = float(self.stats[9]), float(self.stats[10])
+        q = Q_rows.numpy().astype(np.float64)
+        npos, nneg = cnt_rows[:, 0:1].numpy().astype(np.float64), cnt_rows[:, 1:2].numpy().astype(np.float64)
+        g = g_rows.numpy().astype(np.float64) + reg_1 * (npos + nneg) * np.sign(q) \
+            + reg_2 * (npos * self._fro(q, nI) + nneg * self._fro(q, nJ))
+        (Qn,) = opt.step([Q_rows.numpy()], [g])
+        Q_rows.copy_(torch.from_numpy(Qn))
+        g_rows.zero_()
+        cnt_rows.zero_()

@@ -26,7 +26,7 @@ def _data(lopsided=False):
     return P0, Q0, batches
 
 
-def _worker(rank, world, port, out_dir, mode, lopsided=False, slices=1):
+def _worker(rank, world, port, out_dir, mode, lopsided=False, slices=1, adam=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from daisyrec_amd.sharding import UserShardedBprTrainer, shard_triples, user_range
@@ -38,7 +38,8 @@ def _worker(rank, world, port, out_dir, mode, lopsided=False, slices=1):
     from daisyrec_amd import _native as N
     ctx = OracleContext(B, D, hi - lo, I)
     tr = UserShardedBprTrainer(ctx, P, Q, lo, LR, R1, R2, overlap=(rank % 2 == 0),
-                               item_mode={"fused": N.ITEM_FUSED, "chunked": N.ITEM_CHUNKED}[mode], slices=slices)
+                               item_mode={"fused": N.ITEM_FUSED, "chunked": N.ITEM_CHUNKED}[mode], slices=slices,
+                               adam_steps=2 if adam else 0)       # (the table of step constants grows on demand)
     assert tr.staged == (mode == "fused") and tr.slices == (slices if mode == "fused" else 1)
     losses = []
     for b in batches:
@@ -48,6 +49,8 @@ def _worker(rank, world, port, out_dir, mode, lopsided=False, slices=1):
         else:
             stats = tr.step_from_triples(torch.from_numpy(mine))
         losses.append(float(stats[7]))
+    if adam:
+        ctx.oracle_flush_p(P, tr.adam)         # (the HIP path: ShardedAdam.flush - the rows the last steps did not reference)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), P=P.numpy(), Q=Q.numpy(), lo=lo, hi=hi,
              losses=np.array(losses), acc=float(ctx.epoch_acc[0]))
     dist.destroy_process_group()
@@ -122,6 +125,32 @@ def test_sliced_exchange_equals_single_process(tmp_path, world, slices):
         np.testing.assert_allclose(o["losses"], ref_losses, rtol=1e-9)
         np.testing.assert_allclose(o["Q"], Q, atol=2e-6)
         np.testing.assert_allclose(o["P"], P[int(o["lo"]):int(o["hi"])], atol=2e-6)
+    for o in outs[1:]:
+        np.testing.assert_array_equal(outs[0]["Q"], o["Q"])
+
+
+@pytest.mark.parametrize("world,slices", [(2, 1), (4, 3)])
+def test_sharded_adam_equals_single_process_dense_adam(tmp_path, world, slices):
+    """torch.optim.Adam through the sharded protocol (trainer orchestration only; the kernels are tested on the GPU):
+    per step the catch-up / user pass with Adam on every rank's rows of P, the gradient form of the item pass, the
+    reduce-scatter, the owner's DENSE Adam on its block of Q - with slices > 1 a rank owns one block per slice, each with
+    its own moments - and the all-gather; a step in which some ranks own no sample; against oracle.DenseAdam on the
+    union batches."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "fused", True, slices, True), nprocs=world, join=True)
+    P, Q, batches = _data(True)
+    opt = O.DenseAdam([P.shape, Q.shape], LR)
+    ref_losses = []
+    for b in batches:
+        loss, gP, gQ = O.mf_pair_grad(P, Q, b[:, 0], b[:, 1], b[:, 2], R1, R2)
+        P, Q = opt.step([P, Q], [gP, gQ])
+        ref_losses.append(loss)
+    outs = [np.load(os.path.join(str(tmp_path), f"r{r}.npz")) for r in range(world)]
+    for o in outs:
+        np.testing.assert_allclose(o["losses"], ref_losses, rtol=1e-7)
+        np.testing.assert_allclose(o["Q"], Q, atol=1e-5)
+        np.testing.assert_allclose(o["P"], P[int(o["lo"]):int(o["hi"])], atol=1e-5)
     for o in outs[1:]:
         np.testing.assert_array_equal(outs[0]["Q"], o["Q"])
 

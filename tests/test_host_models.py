@@ -94,3 +94,38 @@ def test_optimizer_and_loss_names_follow_the_reference():
         FM(mf_config(user_num=5, item_num=5, factors=8, optimizer="sparse_adam"))._resolve_optimizer()
     with pytest.raises(NotImplementedError):
         m._build_criterion("XX")
+
+
+def test_native_knobs_are_parsed_strictly():
+    """config['lazy_adam'] from yaml / CLI strings (bool('false') is True), unknown NeuMF precisions"""
+    from daisyrec_amd.model.AbstractRecommender import _parse_lazy_adam
+    from daisyrec_amd.model.MFRecommender import MF
+    from daisyrec_amd.model.NeuMFRecommender import NeuMF
+    for v, want in ((True, True), (False, False), ("true", True), ("False", False), ("0", False), ("1", True),
+                    (0, False), (1, True), ("auto", "auto"), ("AUTO", "auto"), ("off", False), ("yes", True)):
+        assert _parse_lazy_adam(v) == want, v
+    for bad in ("maybe", "", None, 2, "lazy"):
+        with pytest.raises(ValueError):
+            _parse_lazy_adam(bad)
+    assert MF(mf_config(user_num=30, item_num=20, lazy_adam="false")).lazy_adam is False
+    with pytest.raises(ValueError):
+        MF(mf_config(user_num=30, item_num=20, lazy_adam="sometimes"))
+    base = dict(user_num=30, item_num=20, factors=8, num_layers=2, dropout=0.0, model_name="NeuMF", GMF_model=None,
+                MLP_model=None, algo_name="neumf")
+    assert NeuMF(mf_config(**base, precision="bf16")).precision == "bf16"
+    with pytest.raises(ValueError, match="precision"):
+        NeuMF(mf_config(**base, precision="fp16"))
+
+
+def test_sharded_adam_table_matches_the_dense_optimisers_constants():
+    """ops.ShardedAdam / ops.LazyAdam take their per-step constants from daisy_adam_lazy_table: lr / (1 - beta1^t) and
+    sqrt(1 - beta2^t), the host arithmetic of daisy_adam_dense (torch.optim.Adam's bias corrections)"""
+    import ctypes as C
+    from daisyrec_amd import _native as N
+    n = 12
+    host = (C.c_float * (2 * (n + 1)))()
+    N.check(N.lib.daisy_adam_lazy_table(0.01, 0.9, 0.999, n, host))
+    t = np.frombuffer(host, dtype=np.float32).reshape(n + 1, 2)
+    lr, b1, b2 = (float(np.float32(x)) for x in (0.01, 0.9, 0.999))        # the C entry takes floats
+    for s in range(1, n + 1):
+        assert t[s, 0] == np.float32(lr / (1.0 - b1 ** s)) and t[s, 1] == np.float32(np.sqrt(1.0 - b2 ** s)), s
