@@ -55,8 +55,10 @@ enum daisy_item_mode {
     DAISY_ITEM_CHUNKED = 2, /* segmented reduction through LDS accumulators (throughput mode) */
     DAISY_ITEM_FUSED = 3    /* daisy_bpr_sgd_step / daisy_bpr_fit_epoch_sgd only: the STAGED step (forward fused
                                into the user pass, coefficient-scaled user rows staged for the item pass,
-                               item rows committed by the owner of their segment); pairwise losses without
-                               FM biases, otherwise = CHUNKED.  Bitwise reproducible. */
+                               item rows committed by the owner of their segment); every loss of loss.py:5-33
+                               (point-wise ones on point-wise batches), with or without FM biases (ABI 4).
+                               Bitwise reproducible.  After a step inside an epoch loop stats[DAISY_ST_SQ_U_PRE]
+                               already holds the NEXT batch's value (it rides on this step's item pass). */
 };
 
 /* order of an epoch (what DataLoader(shuffle=...) decides, dataset.py:5-7) */
@@ -162,7 +164,9 @@ int daisy_feistel_positions_at(const int64_t *ids, int64_t n_ids, int64_t n, uin
  * daisy_train_index_create validates 0 <= user - user_base < user_num, 0 <= item < item_num for every
  * triple (one host sync) and returns DAISY_ERR_ARG where the reference raises IndexError in
  * nn.Embedding (MFRecommender.py:64-65).  flags: DAISY_PLAN_TRIPLES_USER_SORTED - the array is already
- * in CSR order and is used in place (the caller keeps it alive); otherwise the index owns a sorted copy.
+ * in CSR order and is used in place (the caller keeps it alive); otherwise the index owns a sorted copy;
+ * DAISY_PLAN_POINTWISE (ABI 4) - rows are (user, item, label) (CL / SL, sampler.py:93-98): ONE item entry per
+ * row, the third column is carried as the label and not validated as an id.
  * ---------------------------------------------------------------------- */
 typedef struct daisy_train_index daisy_train_index;
 int daisy_train_index_create(daisy_train_index **out, const int32_t *triples, int64_t n_triples,
@@ -261,7 +265,9 @@ int daisy_bpr_ctx_set_pointwise(daisy_bpr_ctx *ctx, int32_t pointwise);
  *   daisy_bpr_user_grad      writes g_u_bias[u] (f32[U]) and g_bias[0] instead (needed only for this
  *                            call; may be NULL otherwise) - dense Adam then runs daisy_adam_dense on them.
  * The regularisers of FM.calc_loss (FMRecommender.py:77-93) are those of MF: embeddings only.
- * DAISY_ITEM_FUSED falls back to DAISY_ITEM_CHUNKED while biases are attached. */
+ * DAISY_ITEM_FUSED (ABI 4): the staged step carries the biases itself - the user pass adds them to the scores and
+ * updates u_bias[u] along each user run, the item pass i_bias[item] along each segment, bias from
+ * stats[DAISY_ST_SUM_COEF] (SGD in place; daisy_bpr_staged_adam_step writes g_u_bias / g_i_bias instead). */
 int daisy_bpr_ctx_set_bias(daisy_bpr_ctx *ctx, float *u_bias, float *i_bias, float *bias,
                            float *g_u_bias, float *g_i_bias, float *g_bias);
 /* make batch k of a built plan current (no copy) */
