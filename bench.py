@@ -400,9 +400,18 @@ def main():
     want_cpu = (a.cpu_steps + 1) if (world == 1 and rank == 0 and not a.no_cpu_baseline) else 0
     B_main = a.batch if a.batch is not None else ((1 << 21) if world == 1 else (1 << 24))
 
+    def guarded(what, fn, *args):
+        """a diagnostic leg must not cost the run its headline number: an exception in it (raised alike on every rank - the
+        legs are collective) is put on the line instead"""
+        try:
+            return fn(*args)
+        except Exception as e:                          # noqa: BLE001
+            import traceback
+            return {"error": f"{what}: {type(e).__name__}: {e}", "traceback": traceback.format_exc()[-1500:]}
+
     check = None
     if world > 1 and not a.no_replica_check and a.item_mode == "fused":
-        check = replica_check(a, rank, world, dev)
+        check = guarded("replica_check", replica_check, a, rank, world, dev)
 
     data = build_data(a, rank, world, dev, wl)
     r = measure(a, data, rank, world, dev, B_main, a.slices, a.steps, a.warmup, want_cpu)
@@ -417,7 +426,8 @@ def main():
                     sweep.append(r)
                     continue
                 fb = max(1, data["n"] // min(Bl, data["n"]))
-                sweep.append(measure(a, data, rank, world, dev, Bl, sl, min(fb, 16), 2))
+                sweep.append(guarded(f"sweep point B_local={Bl} slices={sl}", measure, a, data, rank, world, dev, Bl, sl,
+                                     min(fb, 16), 2))
     free_data(data)
 
     secondary = None
@@ -439,13 +449,15 @@ def main():
         # the same workload on ONE GPU (rank 0; the others wait), so that the N-GPU / 1-GPU ratio on
         # BASELINE configs[2] is on this line
         if rank == 0:
-            d1 = build_data(a, 0, 1, dev, wl)
-            r1 = measure(a, d1, 0, 1, dev, (1 << 21) if wl == "c3" else (1 << 16), 1, None, a.warmup)
-            free_data(d1)
-            ref = {"value": r1["steps"] * r1["B"] / r1["dt"], "unit": "interactions/s", "n_gpus": 1,
-                   "steps": r1["steps"], "ms_per_step": r1["dt"] / r1["steps"] * 1e3, "batch": r1["B"],
-                   "workload": r1["name"],
-                   "roofline_frac": ALGO_BYTES_PER_INTERACTION_SGD(64) * r1["B"] / (r1["dt"] / r1["steps"]) / 1e9 / HBM_PEAK_GBS}
+            def one_gpu():
+                d1 = build_data(a, 0, 1, dev, wl)
+                r1 = measure(a, d1, 0, 1, dev, (1 << 21) if wl == "c3" else (1 << 16), 1, None, a.warmup)
+                free_data(d1)
+                return {"value": r1["steps"] * r1["B"] / r1["dt"], "unit": "interactions/s", "n_gpus": 1,
+                        "steps": r1["steps"], "ms_per_step": r1["dt"] / r1["steps"] * 1e3, "batch": r1["B"],
+                        "workload": r1["name"],
+                        "roofline_frac": ALGO_BYTES_PER_INTERACTION_SGD(64) * r1["B"] / (r1["dt"] / r1["steps"]) / 1e9 / HBM_PEAK_GBS}
+            ref = guarded("single-GPU reference", one_gpu)      # (the other ranks wait at the barrier either way)
         dist.barrier()
 
     if rank == 0:
@@ -503,10 +515,16 @@ def main():
                                    "per rank and step (about 3x at 2M); the sweep measures it")
         if ref is not None:
             out["single_gpu_same_workload"] = ref
-            out["speedup_vs_single_gpu_same_workload"] = value / ref["value"]
+            if "error" in ref:
+                ref = None
+            else:
+                out["speedup_vs_single_gpu_same_workload"] = value / ref["value"]
         if sweep:
             pts = []
             for s_ in sweep:
+                if "error" in s_:
+                    pts.append(s_)
+                    continue
                 v = s_["steps"] * s_["B"] * world / s_["dt"]
                 pt = {"batch_per_gpu": s_["B"], "slices": s_["slices"], "steps": s_["steps"], "value": v,
                       "ms_per_step": s_["dt"] / s_["steps"] * 1e3,
