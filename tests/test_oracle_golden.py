@@ -248,3 +248,56 @@ def test_lazy_adam_replay_is_the_dense_sequence():
         G[touched[s - 1]] = grads[s - 1]
         (W,) = opt.step([W], [G])
     np.testing.assert_allclose(W, Wd, rtol=0, atol=2e-6)
+
+
+def test_partitioned_plan_restatement_from_first_principles():
+    """The partitioned epoch plan is this repo's construction (the reference has a DataLoader): its oracle restatement
+    is checked against what dataset.py:5-27 defines - batch k serves exactly the rows at epoch positions [kB, (k+1)B) -
+    and against the layout the kernels rely on: samples of a batch grouped by user in a stable order, its entries sorted
+    by (item, slot) in a stable order, every entry pointing at a sample of its own batch.  Pairwise and point-wise rows."""
+    import numpy as np
+    from oracle import bpr_mf_numpy as O
+    rng = np.random.default_rng(17)
+    for n, B, U, I, pointwise in ((1, 1, 1, 1, False), (57, 8, 9, 7, False), (300, 64, 20, 31, True), (1000, 333, 50, 40, False)):
+        tri = np.stack([rng.integers(0, U, n), rng.integers(0, I, n),
+                        rng.integers(0, 2, n) if pointwise else rng.integers(0, I, n)], 1)
+        pos = rng.permutation(n)
+        samples, spos, ekey, epos = O.partitioned_plan(tri, pos, B, pointwise=pointwise)
+        epl = 1 if pointwise else 2
+        assert len(samples) == n and len(ekey) == epl * n
+        nb = (n + B - 1) // B
+        for k in range(nb):
+            lo, hi = k * B, min((k + 1) * B, n)
+            rows, rp = samples[lo:hi], spos[lo:hi]
+            assert np.array_equal(np.sort(rp), np.arange(lo, hi))                 # exactly the loader's batch k
+            by_pos = {int(p): tuple(int(x) for x in tri[t]) for t, p in enumerate(pos)}
+            assert all(tuple(int(x) for x in r) == by_pos[int(p)] for r, p in zip(rows, rp))
+            assert np.all(np.diff(rows[:, 0]) >= 0)                               # grouped by user ...
+            csr = np.argsort(tri[:, 0], kind="stable")                            # ... ties in CSR (array) order
+            rank_in_csr = np.empty(n, np.int64)
+            rank_in_csr[csr] = np.arange(n)
+            t_of = {int(p): t for t, p in enumerate(pos)}
+            r_csr = np.array([rank_in_csr[t_of[int(p)]] for p in rp])
+            assert np.all(np.diff(r_csr) > 0)
+            ek, ep = ekey[epl * lo:epl * hi], epos[epl * lo:epl * hi]
+            assert np.all(np.diff(ek) >= 0)                                       # sorted by item << 1 | slot
+            assert np.all((ep >= lo) & (ep < hi))                                 # entries point into their own batch
+            want = []                                                             # the multiset of (key, position)
+            for r, p in zip(rows, rp):
+                want.append((int(r[1]) << 1, int(p)))
+                if not pointwise:
+                    want.append(((int(r[2]) << 1) | 1, int(p)))
+            assert sorted(want) == sorted(zip(ek.tolist(), ep.tolist()))
+
+
+def test_feistel_positions_is_a_keyed_bijection_for_every_size_class():
+    """the device shuffle's restatement: a permutation of 0..n-1 for even and odd bit counts of the network's domain,
+    different per (seed, epoch), the same for the same key"""
+    import numpy as np
+    from oracle import bpr_mf_numpy as O
+    for n in (1, 2, 3, 4, 5, 8, 9, 31, 33, 511, 513, 4096, 4097, 100003):
+        p = O.feistel_positions(n, 5, 1)
+        assert np.array_equal(np.sort(p), np.arange(n)), n
+        assert np.array_equal(p, O.feistel_positions(n, 5, 1))
+        if n > 8:
+            assert not np.array_equal(p, O.feistel_positions(n, 5, 2)) and not np.array_equal(p, O.feistel_positions(n, 6, 1))
