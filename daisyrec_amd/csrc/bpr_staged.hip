@@ -778,7 +778,7 @@ enum { kModePremul = 0, kModePlain = 1, kModePoint = 2 };
 // (no atomics, fixed summation order: bitwise reproducible).
 // HAS_POS: the stage slot of a sample comes from the plan (partitioned layout) instead of its position.
 template <class C, int BLK, int MODE, bool HAS_POS, bool ADAM>
-__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(C::NE <= 4 ? 4 : 2, 8))) void k_staged_user(
+__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((C::NE <= 4 && !ADAM) ? 4 : 2, 8))) void k_staged_user(
     float *__restrict__ P, const float *__restrict__ Q, StreamView v, int d, const double *__restrict__ stats,
     RowOpt opt, float reg_1, float reg_2, int loss_type, float gamma, float *__restrict__ stage,
     float2 *__restrict__ coef, float *__restrict__ p_sqnorm, double *__restrict__ partials, UserEdges ed,
@@ -1158,7 +1158,7 @@ __device__ __forceinline__ void item_commit(float *__restrict__ Qo, float *__res
 // point - weight 1 (a negative slot, which only the sorted layout's point-wise batches have, is inert: weight 0, not
 // counted).
 template <class C, int BLK, int MODE, bool APPLY, bool ADAM>
-__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_staged_item(const float *__restrict__ stage,
+__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(ADAM ? 2 : 4, 8))) void k_staged_item(const float *__restrict__ stage,
                                                         const float2 *__restrict__ coef, StreamView v, int d,
                                                         float *__restrict__ Qo, float *__restrict__ cnt_out,
                                                         const double *__restrict__ stats, RowOpt opt,
