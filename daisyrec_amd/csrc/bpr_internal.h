@@ -121,6 +121,8 @@ struct daisy_epoch_plan {
     uint32_t *p_inv;                    // [n]   inverse of an explicit permutation (DAISY_ORDER_PERM)
     void *ptemp;                        // rocPRIM scan scratch
     void *parena2;                      // second record set (plans with more than 256 batches: LSD passes ping-pong)
+    void *p_onepass;                    // look-back words + tickets of the one-pass partition (DAISY_PLAN_ONEPASS=1)
+    size_t p_onepass_bytes;
     int32_t p_cur;                      // record set holding the finished plan
     uint64_t build_gen;                 // id of the build the plan currently holds, unique in the process (what a
                                         // batch index refers to: a context that computed something ahead for "batch k+1"

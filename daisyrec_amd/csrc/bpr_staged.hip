@@ -318,6 +318,227 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(PartSrc src, PosF
     }
 }
 
+// ---- one-pass partition (opt-in: DAISY_PLAN_ONEPASS=1) ----------------------------------------------------------
+// The counting pass, the scan and the scatter of one digit in ONE launch: a workgroup draws a tile of 8192 records
+// by ticket, computes the tile's epoch positions into LDS (the Feistel walk: ALU only, it overlaps the memory phase of
+// the other workgroup on the CU), publishes the tile's digit counts, finds its offsets by a decoupled look-back over
+// the tiles before it (Merrill & Garland; one 8-byte {flag, count} word per tile and digit, relaxed agent-scope
+// atomics on both sides: MI355X_MICROARCH "8-B agent atomics both sides"), and scatters sub-tile by sub-tile exactly
+// like k_part_scatter.  Against the three-launch form it saves the parked positions (4 B written + 4 B read per
+// record) and the serial ALU-bound counting launches.  Tickets make the look-back deadlock-free: every tile a
+// workgroup waits for was drawn earlier, is therefore resident, and publishes its counts before it waits itself.
+// Only for one LSD pass (<= 256 batches) over a whole epoch (bucket k starts at k * records-per-batch).
+// State (profiles/r03_onepass_check.txt): record-for-record identical to the three-launch build in every order
+// (tests/test_gpu_staged.py runs both), but SLOWER today - 0.99 against 0.66 ms at 20 M samples - and therefore off:
+// 58 / 74 KB of LDS leave two workgroups per CU (the scatter kernel runs three), too few loads in flight for pass B.
+constexpr int kOneSubs = 4;
+constexpr int kOneTile = kOneSubs * kPartSub;           // 8192 records per workgroup
+constexpr int kOnePer = kOneTile / kPartThreads;        // 32 records per thread
+constexpr uint64_t kOneAgg = (uint64_t)1 << 62, kOnePrefix = (uint64_t)2 << 62, kOneVal = ((uint64_t)1 << 62) - 1;
+
+struct OnePass {
+    uint64_t *state;        // [ndig][tile_stride]  flag << 62 | count   (0 = not published; zeroed before the launch)
+    uint32_t *ticket;       // [1] zeroed before the launch
+    int64_t tile_stride;
+    int64_t bucket_elems;   // records of a full bucket (entries per sample x batch size): bucket k starts at k * this
+};
+
+__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t x) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+        const uint32_t lo = __shfl_xor((uint32_t)x, off, kWave), hi = __shfl_xor((uint32_t)(x >> 32), off, kWave);
+        x += ((uint64_t)hi << 32) | lo;
+    }
+    return x;
+}
+
+template <bool SAMPLES>
+__global__ __launch_bounds__(kPartThreads) void k_part_onepass(PartSrc src, PosFn pf, BatchDiv bd, int64_t n, int nbits,
+                                                               int ndig, OnePass op, PartDst dst) {
+    __shared__ uint32_t lpos[kOneTile];                  // entries: triple index, then (both) the epoch position
+    __shared__ uint4 rec4[SAMPLES ? kPartSub : 1];
+    __shared__ uint2 rec2[SAMPLES ? 1 : kPartSub];
+    __shared__ uint8_t sdig[kPartSub];
+    __shared__ uint32_t wcnt[kPartWaves][256];
+    __shared__ uint32_t tstart[256], goff[256], tot[256], hist[256];
+    __shared__ uint32_t wsum[kPartWaves];
+    __shared__ uint32_t s_tile;
+
+    const int tid = threadIdx.x, wave = tid / kWave, wl = tid % kWave;
+    const uint64_t lt_mask = ((uint64_t)1 << wl) - 1;
+    if (tid == 0) s_tile = atomicAdd(op.ticket, 1u);
+    hist[tid] = 0;
+    goff[tid] = 0;
+    __syncthreads();
+    const int64_t tile = (int64_t)s_tile;
+    const int64_t lo = tile * kOneTile;
+    const int64_t hi = (lo + kOneTile < n) ? lo + kOneTile : n;
+    const int cnt_tile = (int)(hi - lo);                 // >= 1: the grid has ceil(n / kOneTile) workgroups
+
+    // ---- pass A: positions and digit counts.  Thread (wave, wl) owns the slots sub*2048 + wave*512 + r*64 + wl - the
+    // records pass B will hold in round r of sub-tile sub; its k-th slot (k = sub*8 + r) grows with k
+    auto slot = [&](int k) -> int { return ((k >> 3) << 11) + (wave << 9) + ((k & 7) << 6) + wl; };
+    if constexpr (!SAMPLES) {
+#pragma unroll 8
+        for (int k = 0; k < kOnePer; ++k) {
+            const int x = slot(k);
+            if (x < cnt_tile) lpos[x] = src.ent_t[lo + x] & ~kNegBit;      // read back by this thread only
+        }
+    }
+    if (pf.mode == DAISY_ORDER_FEISTEL) {                // every lane walks its own strip (see k_part_count)
+        const uint32_t nn = (uint32_t)pf.n;
+        int k = 0, x = slot(0);
+        bool active = x < cnt_tile;
+        auto first = [&]() -> uint32_t {
+            uint32_t t;
+            if constexpr (SAMPLES) t = (uint32_t)(lo + x);
+            else t = lpos[x];
+            return pf.orig ? pf.orig[t] : t;
+        };
+        uint32_t v = active ? first() : 0u;
+        while (active) {
+            v = feistel_once(v, pf.fk);
+            if (v < nn) {
+                lpos[x] = v;
+                atomicAdd(&hist[batch_of(v, bd) & 255u], 1u);
+                ++k;
+                active = false;
+                if (k < kOnePer) {
+                    x = slot(k);
+                    active = x < cnt_tile;
+                    if (active) v = first();
+                }
+            }
+        }
+    } else {
+        for (int k = 0; k < kOnePer; ++k) {
+            const int x = slot(k);
+            if (x < cnt_tile) {
+                uint32_t t;
+                if constexpr (SAMPLES) t = (uint32_t)(lo + x);
+                else t = lpos[x];
+                const uint32_t v = pos_of(pf, t);
+                lpos[x] = v;
+                atomicAdd(&hist[batch_of(v, bd) & 255u], 1u);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- publish the tile's counts, then look back for the records of every digit in the tiles before this one
+    if (tid < ndig) {
+        uint64_t *w = op.state + (int64_t)tid * op.tile_stride + tile;
+        __hip_atomic_store(w, (tile == 0 ? kOnePrefix : kOneAgg) | (uint64_t)hist[tid], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int dg = wave; dg < ndig; dg += kPartWaves) {   // wave-uniform loop: one digit per wave and trip
+        uint64_t *row = op.state + (int64_t)dg * op.tile_stride;
+        uint64_t excl = 0;
+        int64_t base = tile - 1;                         // lane l looks at tile base - l
+        while (base >= 0) {
+            const int64_t idx = base - wl;
+            uint64_t st = kOnePrefix;                    // before tile 0: a prefix of nothing
+            if (idx >= 0) st = __hip_atomic_load(row + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t flag = (uint32_t)(st >> 62);
+            const uint64_t m_pref = __ballot(flag == 2u), m_empty = __ballot(flag == 0u);
+            const int fp = m_pref ? (int)__builtin_ctzll(m_pref) : 64;     // nearest tile that already knows its prefix
+            const uint64_t need = (fp >= 63) ? ~(uint64_t)0 : (((uint64_t)1 << (fp + 1)) - 1);
+            if (m_empty & need) {                        // somebody up to there has not published yet: poll again
+                __builtin_amdgcn_s_sleep(4);
+                continue;
+            }
+            excl += wave_sum_u64((wl <= fp) ? (st & kOneVal) : 0);
+            if (fp < 64) break;
+            base -= kWave;
+        }
+        if (wl == 0) {
+            goff[dg] = (uint32_t)((uint64_t)dg * (uint64_t)op.bucket_elems + excl);
+            if (tile > 0)
+                __hip_atomic_store(row + tile, kOnePrefix | (excl + (uint64_t)hist[dg]), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+
+    // ---- pass B: the stable scatter of k_part_scatter, sub-tile by sub-tile, positions from LDS
+    for (int sb = 0; sb * kPartSub < cnt_tile; ++sb) {
+        const int64_t sub = lo + (int64_t)sb * kPartSub;
+#pragma unroll
+        for (int w = 0; w < kPartWaves; ++w) wcnt[w][tid] = 0;
+        __syncthreads();
+        uint32_t r_a[kPartK], r_b[kPartK], r_c[kPartK], r_p[kPartK], r_rank[kPartK], r_dig[kPartK];
+        const int xbase = sb * kPartSub + wave * (kWave * kPartK);
+#pragma unroll
+        for (int r = 0; r < kPartK; ++r) {
+            const int x = xbase + r * kWave + wl;
+            const bool valid = x < cnt_tile;
+            const int xc = valid ? x : cnt_tile - 1;
+            const int64_t ec = lo + xc;
+            if constexpr (SAMPLES) {
+                const int32_t *row = src.triples + 3 * ec;
+                r_a[r] = (uint32_t)(row[0] - src.user_base);
+                r_b[r] = (uint32_t)row[1];
+                r_c[r] = (uint32_t)row[2];
+            } else {
+                r_a[r] = src.key[ec];
+            }
+            r_p[r] = lpos[xc];
+            const uint32_t dgt = batch_of(r_p[r], bd) & 255u;
+            const uint64_t peers = match_digit(dgt, valid, nbits);
+            const uint32_t base = wcnt[wave][dgt];
+            const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+            if (valid && rank == 0) wcnt[wave][dgt] = base + (uint32_t)__popcll(peers);
+            r_rank[r] = base + rank;
+            r_dig[r] = valid ? dgt : 0xFFFFFFFFu;
+        }
+        __syncthreads();
+        uint32_t t = 0;
+#pragma unroll
+        for (int w = 0; w < kPartWaves; ++w) { const uint32_t c = wcnt[w][tid]; wcnt[w][tid] = t; t += c; }
+        tot[tid] = t;
+        uint32_t inc = t;
+#pragma unroll
+        for (int off = 1; off < kWave; off <<= 1) {
+            const uint32_t up = __shfl_up(inc, off, kWave);
+            if (wl >= off) inc += up;
+        }
+        if (wl == kWave - 1) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t wprefix = 0;
+#pragma unroll
+        for (int w = 0; w < kPartWaves; ++w) if (w < wave) wprefix += wsum[w];
+        tstart[tid] = wprefix + inc - t;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < kPartK; ++r) {
+            if (r_dig[r] != 0xFFFFFFFFu) {
+                const uint32_t x = tstart[r_dig[r]] + wcnt[wave][r_dig[r]] + r_rank[r];
+                if constexpr (SAMPLES) rec4[x] = make_uint4(r_a[r], r_b[r], r_c[r], r_p[r]);
+                else rec2[x] = make_uint2(r_a[r], r_p[r]);
+                sdig[x] = (uint8_t)r_dig[r];
+            }
+        }
+        __syncthreads();
+        const int cnt = (int)((hi - sub < kPartSub) ? (hi - sub) : kPartSub);
+        for (int x = tid; x < cnt; x += kPartThreads) {
+            const uint32_t dg = sdig[x];
+            const int64_t o = (int64_t)goff[dg] + (x - tstart[dg]);
+            if constexpr (SAMPLES) {
+                const uint4 q = rec4[x];
+                dst.user[o] = q.x;
+                dst.ij[o] = make_int2((int)q.y, (int)q.z);
+                dst.pos[o] = q.w;
+            } else {
+                const uint2 q = rec2[x];
+                dst.key[o] = q.x;
+                dst.pos[o] = q.y;
+            }
+        }
+        __syncthreads();
+        goff[tid] += tot[tid];
+    }
+}
+
 // inv[perm[p]] = p  (DAISY_ORDER_PERM: perm[p] = triple served at position p)
 __global__ void k_invert_perm(const int64_t *__restrict__ perm, int64_t n, uint32_t *__restrict__ inv) {
     for (int64_t p = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; p < n; p += (int64_t)gridDim.x * blockDim.x) {
@@ -526,6 +747,51 @@ static int plan_build_partitioned(daisy_epoch_plan *p, const daisy_train_index *
     }
     const BatchDiv bd = make_batch_div(batch_size);
 
+    const int tune_onepass = getenv("DAISY_PLAN_ONEPASS") ? atoi(getenv("DAISY_PLAN_ONEPASS")) : 0;
+    if (tune_onepass && passes == 1 && !subset) {
+        // ---- one launch per record kind (k_part_onepass); its look-back words and tickets are zeroed by one memset
+        const int64_t nt_e = (ix->n_ent + kOneTile - 1) / kOneTile, nt_s = (n + kOneTile - 1) / kOneTile;
+        const int ndig = (int)nb;
+        const size_t words = (size_t)ndig * (size_t)(nt_e + nt_s);
+        const size_t bytes = words * 8 + 64;
+        if (p->p_onepass_bytes < bytes) {
+            if (p->p_onepass) (void)hipFree(p->p_onepass);
+            p->p_onepass = nullptr; p->p_onepass_bytes = 0;
+            // room for every batch size of this plan: 256 digits, the tiles of max_triples
+            const size_t cap_tiles = (size_t)((2 * p->max_triples + kOneTile - 1) / kOneTile + (p->max_triples + kOneTile - 1) / kOneTile);
+            size_t cap = (size_t)256 * cap_tiles * 8 + 64;
+            if (cap < bytes) cap = bytes;
+            hipError_t e = hipMalloc(&p->p_onepass, cap);
+            if (e != hipSuccess) {
+                set_error("epoch_plan_build_indexed: hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
+                p->p_onepass = nullptr;
+                return DAISY_ERR_HIP;
+            }
+            p->p_onepass_bytes = cap;
+        }
+        DAISY_HIP(hipMemsetAsync(p->p_onepass, 0, bytes, s));
+        uint64_t *st = (uint64_t *)p->p_onepass;
+        uint32_t *tickets = (uint32_t *)(st + words);
+        PartSrc src;
+        memset(&src, 0, sizeof(src));
+        src.triples = ix->triples; src.user_base = ix->user_base;
+        src.ent_t = ix->ent_t; src.key = ix->ent_key;
+        PartDst dst;
+        dst.user = p->p_user[0]; dst.ij = p->p_ij[0]; dst.key = p->p_ekey[0];
+        OnePass op;
+        op.state = st; op.ticket = tickets; op.tile_stride = nt_e;
+        op.bucket_elems = (ix->pointwise ? 1 : 2) * batch_size;
+        dst.pos = p->p_epos[0];
+        hipLaunchKernelGGL((k_part_onepass<false>), dim3((unsigned)nt_e), dim3(kPartThreads), 0, s, src, pf, bd, ix->n_ent,
+                           bbits, ndig, op, dst);
+        DAISY_LAUNCH_CHECK();
+        op.state = st + (size_t)ndig * (size_t)nt_e; op.ticket = tickets + 1; op.tile_stride = nt_s;
+        op.bucket_elems = batch_size;
+        dst.pos = p->p_pos[0];
+        hipLaunchKernelGGL((k_part_onepass<true>), dim3((unsigned)nt_s), dim3(kPartThreads), 0, s, src, pf, bd, n, bbits,
+                           ndig, op, dst);
+        DAISY_LAUNCH_CHECK();
+    } else
     // ---- entries first: their counting pass parks the positions in the (still unused) sample arrays of
     // the destination set; then the samples
     for (int what = 0; what < 2; ++what) {

@@ -1208,6 +1208,7 @@ static int plan_free(daisy_epoch_plan *p) {
         if (p->k64[k]) (void)hipFree(p->k64[k]);
     if (p->parena) (void)hipFree(p->parena);
     if (p->parena2) (void)hipFree(p->parena2);
+    if (p->p_onepass) (void)hipFree(p->p_onepass);
     if (p->d_off) (void)hipFree(p->d_off);
     free(p->h_off);
     delete p;

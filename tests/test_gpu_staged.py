@@ -31,8 +31,12 @@ def _plan_batches(plan, nb, B):
                                           (513, 1000, 50, 70, False), (7, 1, 5, 5, False),
                                           (70000, 100, 900, 1200, False),        # 700 batches: two LSD passes
                                           (300000, 4096, 20000, 3000, True)])
-def test_partitioned_plan_bit_exact(n, B, U, I, sort):
+@pytest.mark.parametrize("onepass", [0, 1])
+def test_partitioned_plan_bit_exact(n, B, U, I, sort, onepass, monkeypatch):
+    """onepass = 1: the opt-in single-launch partition with a decoupled look-back (k_part_onepass; plans of at most 256
+    batches, others take the three-launch build) must produce the very same records"""
     from daisyrec_amd import ops
+    monkeypatch.setenv("DAISY_PLAN_ONEPASS", str(onepass))
     tri = _triples(n, U, I, n, sort)
     t_dev = torch.from_numpy(tri).to(DEV)
     index = ops.TrainIndex(t_dev, U, I)
@@ -62,10 +66,12 @@ def test_partitioned_plan_bit_exact(n, B, U, I, sort):
 
 
 @pytest.mark.parametrize("n,B,U,I", [(1000, 64, 300, 200), (4097, 256, 300, 200), (70000, 100, 900, 1200)])
-def test_partitioned_plan_pointwise_bit_exact(n, B, U, I):
+@pytest.mark.parametrize("onepass", [0, 1])
+def test_partitioned_plan_pointwise_bit_exact(n, B, U, I, onepass, monkeypatch):
     """point-wise rows (user, item, label): ONE item entry per row in the static index and in every batch of the plan;
     the label travels in the sample's third column and is not an id (it may exceed nothing: no range check)"""
     from daisyrec_amd import ops
+    monkeypatch.setenv("DAISY_PLAN_ONEPASS", str(onepass))
     tri = _triples(n, U, I, n + 1)
     tri[:, 2] = np.random.default_rng(n).integers(0, 2, n)              # labels
     tri[::7, 2] = I + 5                                                 # (not an item id: must not be validated as one)
