@@ -352,7 +352,10 @@ __device__ __forceinline__ uint64_t wave_sum_u64(uint64_t x) {
     return x;
 }
 
-template <bool SAMPLES>
+// FRONT (DAISY_PLAN_ONEPASS=2, written after the round's GPU budget - compiled, never run): every record of the tile is
+// loaded into registers before the Feistel walk (32 or 96 loads per lane in flight, two workgroups per CU leave 256
+// VGPRs per lane), so pass B has no global loads left: reads overlap the ALU phase instead of depending on occupancy.
+template <bool SAMPLES, bool FRONT>
 __global__ __launch_bounds__(kPartThreads) void k_part_onepass(PartSrc src, PosFn pf, BatchDiv bd, int64_t n, int nbits,
                                                                int ndig, OnePass op, PartDst dst) {
     __shared__ uint32_t lpos[kOneTile];                  // entries: triple index, then (both) the epoch position
@@ -383,6 +386,22 @@ __global__ __launch_bounds__(kPartThreads) void k_part_onepass(PartSrc src, PosF
         for (int k = 0; k < kOnePer; ++k) {
             const int x = slot(k);
             if (x < cnt_tile) lpos[x] = src.ent_t[lo + x] & ~kNegBit;      // read back by this thread only
+        }
+    }
+    uint32_t q_a[FRONT ? kOnePer : 1], q_b[(FRONT && SAMPLES) ? kOnePer : 1], q_c[(FRONT && SAMPLES) ? kOnePer : 1];
+    if constexpr (FRONT) {
+#pragma unroll
+        for (int k = 0; k < kOnePer; ++k) {
+            const int x = slot(k);
+            const int64_t ec = lo + ((x < cnt_tile) ? x : cnt_tile - 1);
+            if constexpr (SAMPLES) {
+                const int32_t *row = src.triples + 3 * ec;
+                q_a[k] = (uint32_t)(row[0] - src.user_base);
+                q_b[k] = (uint32_t)row[1];
+                q_c[k] = (uint32_t)row[2];
+            } else {
+                q_a[k] = src.key[ec];
+            }
         }
     }
     if (pf.mode == DAISY_ORDER_FEISTEL) {                // every lane walks its own strip (see k_part_count)
@@ -461,7 +480,9 @@ __global__ __launch_bounds__(kPartThreads) void k_part_onepass(PartSrc src, PosF
     __syncthreads();
 
     // ---- pass B: the stable scatter of k_part_scatter, sub-tile by sub-tile, positions from LDS
-    for (int sb = 0; sb * kPartSub < cnt_tile; ++sb) {
+#pragma unroll
+    for (int sb = 0; sb < kOneSubs; ++sb) {              // (unrolled: FRONT indexes its record registers by sb*8 + r)
+        if (sb * kPartSub >= cnt_tile) break;
         const int64_t sub = lo + (int64_t)sb * kPartSub;
 #pragma unroll
         for (int w = 0; w < kPartWaves; ++w) wcnt[w][tid] = 0;
@@ -474,7 +495,10 @@ __global__ __launch_bounds__(kPartThreads) void k_part_onepass(PartSrc src, PosF
             const bool valid = x < cnt_tile;
             const int xc = valid ? x : cnt_tile - 1;
             const int64_t ec = lo + xc;
-            if constexpr (SAMPLES) {
+            if constexpr (FRONT) {
+                r_a[r] = q_a[sb * kPartK + r];
+                if constexpr (SAMPLES) { r_b[r] = q_b[sb * kPartK + r]; r_c[r] = q_c[sb * kPartK + r]; }
+            } else if constexpr (SAMPLES) {
                 const int32_t *row = src.triples + 3 * ec;
                 r_a[r] = (uint32_t)(row[0] - src.user_base);
                 r_b[r] = (uint32_t)row[1];
@@ -782,14 +806,22 @@ static int plan_build_partitioned(daisy_epoch_plan *p, const daisy_train_index *
         op.state = st; op.ticket = tickets; op.tile_stride = nt_e;
         op.bucket_elems = (ix->pointwise ? 1 : 2) * batch_size;
         dst.pos = p->p_epos[0];
-        hipLaunchKernelGGL((k_part_onepass<false>), dim3((unsigned)nt_e), dim3(kPartThreads), 0, s, src, pf, bd, ix->n_ent,
-                           bbits, ndig, op, dst);
+        if (tune_onepass == 2)
+            hipLaunchKernelGGL((k_part_onepass<false, true>), dim3((unsigned)nt_e), dim3(kPartThreads), 0, s, src, pf, bd,
+                               ix->n_ent, bbits, ndig, op, dst);
+        else
+            hipLaunchKernelGGL((k_part_onepass<false, false>), dim3((unsigned)nt_e), dim3(kPartThreads), 0, s, src, pf, bd,
+                               ix->n_ent, bbits, ndig, op, dst);
         DAISY_LAUNCH_CHECK();
         op.state = st + (size_t)ndig * (size_t)nt_e; op.ticket = tickets + 1; op.tile_stride = nt_s;
         op.bucket_elems = batch_size;
         dst.pos = p->p_pos[0];
-        hipLaunchKernelGGL((k_part_onepass<true>), dim3((unsigned)nt_s), dim3(kPartThreads), 0, s, src, pf, bd, n, bbits,
-                           ndig, op, dst);
+        if (tune_onepass == 2)
+            hipLaunchKernelGGL((k_part_onepass<true, true>), dim3((unsigned)nt_s), dim3(kPartThreads), 0, s, src, pf, bd, n,
+                               bbits, ndig, op, dst);
+        else
+            hipLaunchKernelGGL((k_part_onepass<true, false>), dim3((unsigned)nt_s), dim3(kPartThreads), 0, s, src, pf, bd, n,
+                               bbits, ndig, op, dst);
         DAISY_LAUNCH_CHECK();
     } else
     // ---- entries first: their counting pass parks the positions in the (still unused) sample arrays of

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""The one-pass partition (csrc/bpr_staged.hip::k_part_onepass, DAISY_PLAN_ONEPASS=1) against the three-launch plan
-build (count / scan / scatter), which the GPU tests pin to the oracle: every batch of both builds must be identical,
-record for record.  Also times both.   timeout 60 python tools/r03_onepass_check.py [quick]"""
+"""The one-pass partition (csrc/bpr_staged.hip::k_part_onepass; DAISY_PLAN_ONEPASS=1: positions parked in LDS, records
+loaded per sub-tile; =2: records front-loaded into registers) against the three-launch plan build (count / scan /
+scatter), which the GPU tests pin to the oracle: every batch of every build must be identical, record for record.
+Also times them.   timeout 60 python tools/r03_onepass_check.py [quick] [flags, e.g. 0,1,2]"""
 import os
 import sys
 import time
@@ -12,7 +13,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from daisyrec_amd import ops  # noqa: E402
 
 dev = torch.device("cuda")
-quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
+quick = "quick" in sys.argv[1:]
+FLAGS = next((a.split(",") for a in sys.argv[1:] if a[0].isdigit()), ["0", "1", "2"])
+assert FLAGS[0] == "0", "the three-launch build is the reference of the comparison"
 # (n, U, I, B, order, pointwise): a partial last tile, a last batch that is not full, > 64 tiles (several look-back
 # windows), one batch only, the identity order (every tile feeds few buckets)
 CASES = [(300_001, 5000, 3000, 16384, "feistel", False),
@@ -43,7 +46,7 @@ for n, U, I, B, order, pointwise in CASES:
     triples = torch.stack([u, i, j], 1).contiguous()
     index = ops.TrainIndex(triples, U, I, user_sorted=True, pointwise=pointwise)
     res, ms = {}, {}
-    for flag in ("0", "1"):
+    for flag in FLAGS:
         os.environ["DAISY_PLAN_ONEPASS"] = flag
         plan = ops.EpochPlan(n, U, I, device=dev)
         plan.build_indexed(index, B, order=order, seed=3, epoch=1)
@@ -56,10 +59,10 @@ for n, U, I, B, order, pointwise in CASES:
         plan.build_indexed(index, B, order=order, seed=3, epoch=1)
         res[flag] = batches(plan, plan.num_batches, B, pointwise)
         plan.close()
-    same = all(torch.equal(a, b) for ka, kb in zip(res["0"], res["1"]) for a, b in zip(ka, kb))
-    ok &= same
-    print(f"n={n} B={B} {order}{' pointwise' if pointwise else ''}: identical={same}  three-launch {ms['0']:.3f} ms  "
-          f"one-pass {ms['1']:.3f} ms", flush=True)
+    same = {f: all(torch.equal(a, b) for ka, kb in zip(res["0"], res[f]) for a, b in zip(ka, kb)) for f in FLAGS[1:]}
+    ok &= all(same.values())
+    print(f"n={n} B={B} {order}{' pointwise' if pointwise else ''}: three-launch {ms['0']:.3f} ms  "
+          + "  ".join(f"one-pass[{f}] {ms[f]:.3f} ms identical={same[f]}" for f in FLAGS[1:]), flush=True)
     index.close()
 os.environ["DAISY_PLAN_ONEPASS"] = "0"
 print("ONEPASS_OK" if ok else "ONEPASS_MISMATCH")
