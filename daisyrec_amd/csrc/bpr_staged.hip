@@ -210,14 +210,19 @@ __global__ __launch_bounds__(kPartThreads) void k_part_count(PartSrc src, PosFn 
 // order, so ranks are stable), the sub-tile is sorted by digit in LDS and leaves as one contiguous piece per
 // bucket.  SAMPLES: records (user, i, j, pos); else (key, pos).  STATIC: samples come from the triple array
 // and their position is src.pos (parked by the counting pass) or recomputed (entries always carry theirs in src.pos).
-template <bool SAMPLES, bool STATIC>
+// WALK (DAISY_PLAN_ONEPASS=3, compiled but not yet run): nothing was parked by the counting pass - the sub-tile's
+// positions are computed here, every lane walking its own eight records (k_part_count's strip walk) into LDS, so the
+// Feistel ALU work hides under the scatter's memory time and 8 B per record of parked-position traffic disappear.
+template <bool SAMPLES, bool STATIC, bool WALK = false>
 __global__ __launch_bounds__(kPartThreads) void k_part_scatter(PartSrc src, PosFn pf, BatchDiv bd, int64_t n,
                                                                int shift, int nbits, int ndig,
                                                                int64_t tile_elems, int64_t ntiles,
                                                                const uint32_t *__restrict__ offsets,
                                                                PartDst dst) {
+    static_assert(!WALK || STATIC, "only the static source lacks positions");
     __shared__ uint4 rec4[SAMPLES ? kPartSub : 1];
     __shared__ uint2 rec2[SAMPLES ? 1 : kPartSub];
+    __shared__ uint32_t lp[WALK ? kPartSub : 1];
     __shared__ uint8_t sdig[kPartSub];
     __shared__ uint32_t wcnt[kPartWaves][256];
     __shared__ uint32_t tstart[256], goff[256], tot[256];
@@ -235,12 +240,62 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(PartSrc src, PosF
         __syncthreads();
         uint32_t r_a[kPartK], r_b[kPartK], r_c[kPartK], r_p[kPartK], r_rank[kPartK], r_dig[kPartK];
         const int64_t wbase = sub + (int64_t)wave * (kWave * kPartK);
+        if constexpr (WALK) {
+            // slot of the record this thread holds in round r: wave*512 + r*64 + wl (read back by this thread only)
+            const int xw = wave * (kWave * kPartK) + wl;
+            if constexpr (!SAMPLES) {
+#pragma unroll
+                for (int r = 0; r < kPartK; ++r) {
+                    const int64_t e = wbase + r * kWave + wl;
+                    if (e < hi) lp[xw + r * kWave] = src.ent_t[e] & ~kNegBit;
+                }
+            }
+            auto first = [&](int r, int64_t e) -> uint32_t {
+                uint32_t t;
+                if constexpr (SAMPLES) t = (uint32_t)e;
+                else t = lp[xw + r * kWave];
+                return t;
+            };
+            if (pf.mode == DAISY_ORDER_FEISTEL) {
+                const uint32_t nn = (uint32_t)pf.n;
+                int r = 0;
+                int64_t e = wbase + wl;
+                bool active = e < hi;
+                uint32_t v = 0;
+                if (active) { v = first(0, e); if (pf.orig) v = pf.orig[v]; }
+                while (active) {
+                    v = feistel_once(v, pf.fk);
+                    if (v < nn) {
+                        lp[xw + r * kWave] = v;
+                        ++r;
+                        e += kWave;
+                        active = (r < kPartK) && (e < hi);
+                        if (active) { v = first(r, e); if (pf.orig) v = pf.orig[v]; }
+                    }
+                }
+            } else {
+                for (int r = 0; r < kPartK; ++r) {
+                    const int64_t e = wbase + r * kWave + wl;
+                    if (e < hi) lp[xw + r * kWave] = pos_of(pf, first(r, e));
+                }
+            }
+        }
 #pragma unroll
         for (int r = 0; r < kPartK; ++r) {
             const int64_t e = wbase + r * kWave + wl;
             const bool valid = e < hi;
             const int64_t ec = valid ? e : hi - 1;
-            if constexpr (SAMPLES) {
+            if constexpr (WALK) {
+                if constexpr (SAMPLES) {
+                    const int32_t *row = src.triples + 3 * ec;
+                    r_a[r] = (uint32_t)(row[0] - src.user_base);
+                    r_b[r] = (uint32_t)row[1];
+                    r_c[r] = (uint32_t)row[2];
+                } else {
+                    r_a[r] = src.key[ec];
+                }
+                r_p[r] = valid ? lp[wave * (kWave * kPartK) + r * kWave + wl] : 0u;
+            } else if constexpr (SAMPLES) {
                 if constexpr (STATIC) {
                     const int32_t *row = src.triples + 3 * ec;
                     r_a[r] = (uint32_t)(row[0] - src.user_base);
@@ -771,8 +826,11 @@ static int plan_build_partitioned(daisy_epoch_plan *p, const daisy_train_index *
     }
     const BatchDiv bd = make_batch_div(batch_size);
 
+    // 0 (default): count (positions parked) / scan / scatter.  1, 2: k_part_onepass (2: front-loaded).  3: count / scan /
+    // scatter with nothing parked - the scatter walks the positions itself (k_part_scatter<.., WALK>)
     const int tune_onepass = getenv("DAISY_PLAN_ONEPASS") ? atoi(getenv("DAISY_PLAN_ONEPASS")) : 0;
-    if (tune_onepass && passes == 1 && !subset) {
+    const bool walk = tune_onepass == 3;
+    if ((tune_onepass == 1 || tune_onepass == 2) && passes == 1 && !subset) {
         // ---- one launch per record kind (k_part_onepass); its look-back words and tickets are zeroed by one memset
         const int64_t nt_e = (ix->n_ent + kOneTile - 1) / kOneTile, nt_s = (n + kOneTile - 1) / kOneTile;
         const int ndig = (int)nb;
@@ -850,13 +908,14 @@ static int plan_build_partitioned(daisy_epoch_plan *p, const daisy_train_index *
                 src.triples = ix->triples; src.user_base = ix->user_base;
                 src.ent_t = ix->ent_t; src.key = ix->ent_key;
                 if (entries) {
-                    src.pos = scratch_pos;
+                    uint32_t *park = walk ? nullptr : scratch_pos;
+                    src.pos = park;
                     hipLaunchKernelGGL((k_part_count<1>), dim3((unsigned)ntiles), dim3(kPartThreads), 0, s, src, pf,
-                                       bd, m, shift, bits_here, ndig, tile_elems, ntiles, scratch_pos, p->p_counts);
+                                       bd, m, shift, bits_here, ndig, tile_elems, ntiles, park, p->p_counts);
                 } else {
                     // the Feistel positions of the samples are parked in the (otherwise unused) inverse-permutation
                     // buffer; identity / explicit orders are a load or nothing, so they are simply re-evaluated
-                    uint32_t *park = (order_mode == DAISY_ORDER_FEISTEL) ? p->p_inv : nullptr;
+                    uint32_t *park = (order_mode == DAISY_ORDER_FEISTEL && !walk) ? p->p_inv : nullptr;
                     src.pos = park;
                     hipLaunchKernelGGL((k_part_count<0>), dim3((unsigned)ntiles), dim3(kPartThreads), 0, s, src, pf,
                                        bd, m, shift, bits_here, ndig, tile_elems, ntiles, park, p->p_counts);
@@ -871,7 +930,13 @@ static int plan_build_partitioned(daisy_epoch_plan *p, const daisy_train_index *
             rc = exclusive_scan_u32(p->ptemp, p->ptemp_bytes, p->p_counts, p->p_offsets, (int64_t)ndig * ntiles, s);
             if (rc) return rc;
             const dim3 g((unsigned)ntiles), b(kPartThreads);
-            if (entries)
+            if (pass == 0 && walk && entries)
+                hipLaunchKernelGGL((k_part_scatter<false, true, true>), g, b, 0, s, src, pf, bd, m, shift, bits_here, ndig,
+                                   tile_elems, ntiles, p->p_offsets, dst);
+            else if (pass == 0 && walk)
+                hipLaunchKernelGGL((k_part_scatter<true, true, true>), g, b, 0, s, src, pf, bd, m, shift, bits_here, ndig,
+                                   tile_elems, ntiles, p->p_offsets, dst);
+            else if (entries)
                 hipLaunchKernelGGL((k_part_scatter<false, false>), g, b, 0, s, src, pf, bd, m, shift, bits_here, ndig,
                                    tile_elems, ntiles, p->p_offsets, dst);
             else if (pass == 0)

@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """The one-pass partition (csrc/bpr_staged.hip::k_part_onepass; DAISY_PLAN_ONEPASS=1: positions parked in LDS, records
-loaded per sub-tile; =2: records front-loaded into registers) against the three-launch plan build (count / scan /
-scatter), which the GPU tests pin to the oracle: every batch of every build must be identical, record for record.
-Also times them.   timeout 60 python tools/r03_onepass_check.py [quick] [flags, e.g. 0,1,2]"""
+loaded per sub-tile; =2: records front-loaded into registers; =3: three launches with nothing parked, the scatter walks
+the positions itself) against the default three-launch plan build (count with parked positions / scan / scatter), which
+the GPU tests pin to the oracle: every batch of every build must be identical, record for record.
+Also times them.   timeout 60 python tools/r03_onepass_check.py [quick] [flags, e.g. 0,1,3]"""
 import os
 import sys
 import time
@@ -14,7 +15,7 @@ from daisyrec_amd import ops  # noqa: E402
 
 dev = torch.device("cuda")
 quick = "quick" in sys.argv[1:]
-FLAGS = next((a.split(",") for a in sys.argv[1:] if a[0].isdigit()), ["0", "1", "2"])
+FLAGS = next((a.split(",") for a in sys.argv[1:] if a[0].isdigit()), ["0", "1", "2", "3"])
 assert FLAGS[0] == "0", "the three-launch build is the reference of the comparison"
 # (n, U, I, B, order, pointwise): a partial last tile, a last batch that is not full, > 64 tiles (several look-back
 # windows), one batch only, the identity order (every tile feeds few buckets)
@@ -62,7 +63,7 @@ for n, U, I, B, order, pointwise in CASES:
     same = {f: all(torch.equal(a, b) for ka, kb in zip(res["0"], res[f]) for a, b in zip(ka, kb)) for f in FLAGS[1:]}
     ok &= all(same.values())
     print(f"n={n} B={B} {order}{' pointwise' if pointwise else ''}: three-launch {ms['0']:.3f} ms  "
-          + "  ".join(f"one-pass[{f}] {ms[f]:.3f} ms identical={same[f]}" for f in FLAGS[1:]), flush=True)
+          + "  ".join(f"variant[{f}] {ms[f]:.3f} ms identical={same[f]}" for f in FLAGS[1:]), flush=True)
     index.close()
 os.environ["DAISY_PLAN_ONEPASS"] = "0"
 print("ONEPASS_OK" if ok else "ONEPASS_MISMATCH")
