@@ -101,3 +101,25 @@ def test_get_ur_get_ir_build_the_reference_dicts(ml100k):
             assert get_ur(big) == U.get_ur(big) and get_ir(big) == U.get_ir(big)
         finally:
             sys.path.remove(ref)
+
+
+def test_bench_byte_model_and_roofline_arithmetic():
+    """bench.py's roofline object (task brief 4): SURVEY 8(d)'s 24 d + 12 B per interaction, priced against 8 TB/s; at
+    N = 1 the achieved rate is never better than the wall clock says (a GPU-event mean below it is ignored)"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    assert bench.ALGO_BYTES_PER_INTERACTION_SGD(64) == 1548 and bench.ALGO_BYTES_PER_INTERACTION_SGD(32) == 780
+    assert bench.HBM_PEAK_GBS == 8000.0
+    B, steps = 1 << 21, 10
+    r = {"step_ms": [0.60] * steps, "dt": 0.0066, "steps": steps, "d": 64, "B": B}          # wall: 0.66 ms per step
+    ach, gpu_ms = bench.roofline_of(r, 1)
+    assert abs(gpu_ms - 0.60) < 1e-12
+    assert abs(ach - 1548 * B / 0.66e-3 / 1e9) < 1e-6 * ach                                # the slower of the two clocks
+    r["dt"] = 0.0050                                                                        # wall below the event mean
+    ach, _ = bench.roofline_of(r, 1)
+    assert abs(ach - 1548 * B / 0.60e-3 / 1e9) < 1e-6 * ach
+    ach8, _ = bench.roofline_of(dict(r, dt=0.0090), 8)                                      # N > 1: per-GPU event time
+    assert abs(ach8 - 1548 * B / 0.60e-3 / 1e9) < 1e-6 * ach8
+    assert 0.0 < ach / bench.HBM_PEAK_GBS < 1.0
