@@ -182,3 +182,19 @@ class OracleContext:
         Q_rows.copy_(torch.from_numpy(Qn))
         g_rows.zero_()
         cnt_rows.zero_()
+
+
+class OracleGraph:
+    """CPU stand-in for `daisyrec_amd.ops.LgcnGraph` (only what sharding.RowShardedPropagation.spmm calls): row ranges
+    of A_hat X from the numpy oracle's CSR."""
+
+    def __init__(self, users, items, user_num, item_num):
+        from oracle import lightgcn_numpy as LG
+        self.LG = LG
+        self.csr = LG.norm_adj_csr(users, items, user_num, item_num)
+
+    def spmm_rows(self, X, Yrows, row_lo, row_hi):
+        assert Yrows.shape[0] >= row_hi - row_lo + 2 and Yrows.is_contiguous()
+        full = self.LG.spmm(self.csr, X.numpy().astype(np.float64))
+        Yrows[1:1 + row_hi - row_lo] = torch.from_numpy(full[row_lo:row_hi].astype(np.float32))
+        return Yrows[1:1 + row_hi - row_lo]

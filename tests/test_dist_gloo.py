@@ -164,3 +164,48 @@ def test_user_range_partition():
         assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
     t = np.array([[0, 1, 2], [9, 1, 2], [4, 0, 0]], dtype=np.int32)
     assert sum(len(shard_triples(t, 10, 3, k)) for k in range(3)) == 3
+
+
+# ---- LightGCN: the row-sharded product (sharding.RowShardedPropagation.spmm) on CPU ---------------------------
+LU, LI, LD, LNNZ = 37, 26, 8, 400          # 63 nodes: divisible neither by 2 nor by 3 ranks x 3 pieces
+
+
+def _lg_data():
+    rng = np.random.default_rng(21)
+    gu, gi = rng.integers(0, LU, LNNZ), rng.integers(0, LI, LNNZ)
+    gu[gu == 5] = 6                         # isolated nodes: user 5 and item 0 have no edge
+    gi[gi == 0] = 1
+    X = rng.standard_normal((LU + LI, LD)).astype(np.float32)
+    return gu, gi, X
+
+
+def _lg_worker(rank, world, port, out_dir, pieces):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from daisyrec_amd.sharding import RowShardedPropagation
+    from oracle_backend import OracleGraph
+    gu, gi, X = _lg_data()
+    N = LU + LI
+    prop = RowShardedPropagation(OracleGraph(gu, gi, LU, LI), N, LD, "cpu", pieces=pieces)
+    assert prop.pieces == pieces and prop.rows * world >= N and prop.side is None
+    x = torch.from_numpy(X)
+    y1 = prop.spmm(x, torch.empty(N, LD)).clone()
+    y2 = prop.spmm(y1, torch.empty(N, LD)).clone()          # a second layer through the same buffers
+    np.savez(os.path.join(out_dir, f"lg{rank}.npz"), y1=y1.numpy(), y2=y2.numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,pieces", [(2, 1), (2, 3), (3, 1), (3, 3)])
+def test_row_sharded_lightgcn_product_on_cpu(tmp_path, world, pieces):
+    """every rank reduces its node range (in `pieces` sub-blocks) and all-gathers the blocks: all ranks end with the
+    whole product in node order, padded tails and isolated nodes included (LightGCNRecommender.py:117-129)"""
+    from oracle import lightgcn_numpy as LG
+    mp.spawn(_lg_worker, args=(world, _free_port(), str(tmp_path), pieces), nprocs=world, join=True)
+    gu, gi, X = _lg_data()
+    csr = LG.norm_adj_csr(gu, gi, LU, LI)
+    want1 = LG.spmm(csr, X.astype(np.float64))
+    want2 = LG.spmm(csr, want1)
+    for r in range(world):
+        o = np.load(os.path.join(str(tmp_path), f"lg{r}.npz"))
+        np.testing.assert_allclose(o["y1"], want1, atol=1e-6)
+        np.testing.assert_allclose(o["y2"], want2, atol=1e-5)
