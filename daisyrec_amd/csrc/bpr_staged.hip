@@ -776,7 +776,13 @@ static int plan_need_partitioned(daisy_epoch_plan *p, int set) {
 }
 
 static void part_tiling(int64_t n, int64_t &tile_elems, int64_t &ntiles) {
-    int64_t subs = (n + (int64_t)kPartSub * 16384 - 1) / ((int64_t)kPartSub * 16384);
+    // at most this many tiles (workgroups): fewer, longer tiles write consecutive pieces of a bucket from the same
+    // workgroup a few microseconds apart (the partial lines at the piece boundaries merge in L2) - a sweep that is
+    // still to be run (the counters say the scatter writes 2.1x its records); 16384 is the count every measurement
+    // so far was taken with
+    const int64_t cap_env = getenv("DAISY_PART_TILES") ? atoll(getenv("DAISY_PART_TILES")) : 16384;   // (per build)
+    const int64_t cap = cap_env < 256 ? 256 : (cap_env > 16384 ? 16384 : cap_env);      // (the count buffers hold 16384 + 1)
+    int64_t subs = (n + (int64_t)kPartSub * cap - 1) / ((int64_t)kPartSub * cap);
     if (subs < 1) subs = 1;
     tile_elems = subs * kPartSub;
     ntiles = (n + tile_elems - 1) / tile_elems;

@@ -9,6 +9,6 @@ mkdir -p $O
 {
   timeout 120 python tools/r03_onepass_check.py 2>&1 | grep -E "^n=|ONEPASS"
   for wl in c2 c3s; do
-    TAG=plans PROBE_PLAN_VARIANTS=${VARIANTS:-0,2,3,1} timeout 120 python tools/r03_probe.py $wl 40 2>&1 | grep "^\["
+    TAG=plans PROBE_PLAN_VARIANTS=${VARIANTS:-0,0:4096,0:2048,2,3,3:4096,1} timeout 120 python tools/r03_probe.py $wl 40 2>&1 | grep "^\["
   done
 } | tee $O/plan_variants.txt

@@ -110,13 +110,19 @@ def main():
               f"(sequential: {(ms + plan_ms / nb) * 1e3:.1f})", flush=True)
     variants = os.environ.get("PROBE_PLAN_VARIANTS", "")   # e.g. "0,2,3,1": DAISY_PLAN_ONEPASS values (read per build), twice each
     if variants:
-        for v in variants.split(",") * 2:
-            os.environ["DAISY_PLAN_ONEPASS"] = v
+        for v in variants.split(",") * 2:                   # "flag" or "flag:tiles" (DAISY_PART_TILES, three-launch forms)
+            flag, _, tiles = v.partition(":")
+            os.environ["DAISY_PLAN_ONEPASS"] = flag
+            if tiles:
+                os.environ["DAISY_PART_TILES"] = tiles
+            else:
+                os.environ.pop("DAISY_PART_TILES", None)
             build()
             t = ev_time(build, 3)
             print(f"[{wl} {tag}] plan variant {v}: {t:.3f} ms/epoch = {t / nb * 1e3:.1f} us/step  "
                   f"-> frac(total) {1548 * B / ((ms + t / nb) * 1e-3) / 8e12:.3f}", flush=True)
         os.environ.pop("DAISY_PLAN_ONEPASS", None)
+        os.environ.pop("DAISY_PART_TILES", None)
     loss, bad = (float(x) for x in ctx.epoch_acc.cpu())
     per_step_plan = plan_ms / nb
     tot = ms + per_step_plan
