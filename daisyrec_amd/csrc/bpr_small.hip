@@ -373,6 +373,7 @@ int small_fit_epoch(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, float *P, 
     if (rc) return rc;
     DAISY_LAUNCH_CHECK();
     ctx->p_sqnorm_of = nullptr;          // P rows changed behind the staged step's row-norm cache
+    ctx->pre_ready = false;              // (and behind a pre-norm computed ahead of its step)
     ctx->batch_set = false;
     ctx->fwd_done = false;
     return DAISY_OK;

@@ -2362,6 +2362,7 @@ int64_t daisy_epoch_plan_batch_rows(const daisy_epoch_plan *plan, int64_t k) {
 int daisy_bpr_ctx_invalidate_cache(daisy_bpr_ctx *ctx) {
     DAISY_CHECK_ARG(ctx != nullptr, "ctx_invalidate_cache: NULL context");
     ctx->p_sqnorm_of = nullptr;
+    ctx->pre_ready = false;       // the next batch's pre-norm that rode on the last item pass was summed from the old cache
     return DAISY_OK;
 }
 

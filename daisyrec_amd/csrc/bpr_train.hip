@@ -1868,6 +1868,7 @@ static int user_pass(daisy_bpr_ctx *ctx, float *P, const float *Q, const double 
                      float reg_1, float reg_2, float *gP, bool sgd, daisy_stream_t stream,
                      bool chunked = false) {
     ctx->p_sqnorm_of = nullptr;   // P rows change behind the row-norm cache of the staged step
+    ctx->pre_ready = false;       // (and behind a pre-norm the staged step computed ahead)
     if (!ctx->fwd_done) { set_error("user update: forward has not run for this batch"); return DAISY_ERR_STATE; }
     hipStream_t s = S(stream);
     const BatchView &v = ctx->v;
