@@ -22,8 +22,15 @@ def _has_gpu():
         return False
 
 
+GPU_TEST_TIMEOUT_S = 900      # a hung kernel must fail its test, not hang the GPU box until the driver's own limit
+
+
 def pytest_collection_modifyitems(config, items):
     if _has_gpu():
+        if config.pluginmanager.hasplugin("timeout"):          # pytest-timeout: dump the stacks and leave the process
+            for item in items:
+                if "gpu" in item.keywords and item.get_closest_marker("timeout") is None:
+                    item.add_marker(pytest.mark.timeout(GPU_TEST_TIMEOUT_S, method="thread"))
         return
     skip = pytest.mark.skip(reason="no HIP device in this container")
     for item in items:
