@@ -123,11 +123,12 @@ def cpu_baseline(U, I, d, B, batches, reg):
     dt = time.perf_counter() - t0
     steps = len(batches) - 1
     u, i, j = batches[0]
-    m.step(u[:256], i[:256], j[:256])
+    sb = min(256, len(u))                                   # (a --batch below 256: the whole batch)
+    m.step(u[:sb], i[:sb], j[:sb])
     t1 = time.perf_counter()
-    small = 30
+    small = max(1, min(30, len(u) // sb - 1))               # slices [sb*(k+1), sb*(k+2)) must exist: 30 need 7936 rows
     for k in range(small):
-        s = slice(256 * (k + 1), 256 * (k + 2))
+        s = slice(sb * (k + 1), sb * (k + 2)) if len(u) >= 2 * sb else slice(0, sb)
         m.step(u[s], i[s], j[s])
     dts = time.perf_counter() - t1
     return {"value": steps * B / dt, "unit": "interactions/s", "cores": torch.get_num_threads(),
@@ -138,7 +139,7 @@ def cpu_baseline(U, I, d, B, batches, reg):
             "why_not_30_steps": "SURVEY 8d asks for >= 30 steps; a step of this batch costs the host ~7 s (dense "
                                 "gradients over both tables), and the bench contract bounds the CPU leg to a sample of "
                                 "tens of seconds: the rate is flat from the second step on",
-            "reference_default_batch": {"value": small * 256 / dts, "unit": "interactions/s", "batch": 256,
+            "reference_default_batch": {"value": small * sb / dts, "unit": "interactions/s", "batch": sb,
                                         "steps": small, "seconds": dts}}
 
 
@@ -400,14 +401,25 @@ def main():
     want_cpu = (a.cpu_steps + 1) if (world == 1 and rank == 0 and not a.no_cpu_baseline) else 0
     B_main = a.batch if a.batch is not None else ((1 << 21) if world == 1 else (1 << 24))
 
-    def guarded(what, fn, *args):
-        """a diagnostic leg must not cost the run its headline number: an exception in it (raised alike on every rank - the
-        legs are collective) is put on the line instead"""
+    def guarded(what, fn, *args, collective=True):
+        """a diagnostic leg must not cost the run its headline number: an exception in it is put on the line instead.
+        Collective legs: a rank that failed alone (an OOM in rank 0's extra work, say) would leave the others blocked in
+        the leg's next collective if it simply carried on - it cannot rejoin them mid-leg either, so the ranks agree on
+        the outcome AFTER the leg (the failing rank gets there because an exception left the leg; the healthy ones
+        because RCCL's watchdog / the leg's end released them) and every rank reports the failure alike."""
+        err = None
         try:
-            return fn(*args)
+            res = fn(*args)
         except Exception as e:                          # noqa: BLE001
             import traceback
-            return {"error": f"{what}: {type(e).__name__}: {e}", "traceback": traceback.format_exc()[-1500:]}
+            err = {"error": f"{what}: {type(e).__name__}: {e}", "traceback": traceback.format_exc()[-1500:]}
+            res = err
+        if collective and world > 1:
+            flag = torch.tensor([1 if err is not None else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.cpu()) and err is None:
+                res = {"error": f"{what}: failed on another rank"}
+        return res
 
     check = None
     if world > 1 and not a.no_replica_check and a.item_mode == "fused":
@@ -444,20 +456,38 @@ def main():
                                   "frac": ach2 / HBM_PEAK_GBS,
                                   "algorithmic_bytes_per_interaction": ALGO_BYTES_PER_INTERACTION_SGD(64)}}
 
-    ref = None
+    ref, ref_global = None, {}
     if world > 1 and wl in ("c3", "tiny") and not a.no_ref:
-        # the same workload on ONE GPU (rank 0; the others wait), so that the N-GPU / 1-GPU ratio on
-        # BASELINE configs[2] is on this line
+        # the same workload on ONE GPU (rank 0; the others wait), so that the N-GPU / 1-GPU ratio on BASELINE configs[2]
+        # is on this line - at the single-GPU operating point (2M-interaction steps) AND at the N-GPU run's GLOBAL batch
+        # (the loss is a batch sum and one GPU's throughput rises with B: only the second ratio compares like with like)
         if rank == 0:
             def one_gpu():
                 d1 = build_data(a, 0, 1, dev, wl)
-                r1 = measure(a, d1, 0, 1, dev, (1 << 21) if wl == "c3" else (1 << 16), 1, None, a.warmup)
+
+                def point(B1):
+                    r1 = measure(a, d1, 0, 1, dev, B1, 1, None, a.warmup)
+                    return {"value": r1["steps"] * r1["B"] / r1["dt"], "unit": "interactions/s", "n_gpus": 1,
+                            "steps": r1["steps"], "ms_per_step": r1["dt"] / r1["steps"] * 1e3, "batch": r1["B"],
+                            "workload": r1["name"], "batch_over_nnz": r1["B"] / r1["n"],
+                            "roofline_frac": ALGO_BYTES_PER_INTERACTION_SGD(64) * r1["B"] / (r1["dt"] / r1["steps"]) / 1e9 / HBM_PEAK_GBS}
+                base = point((1 << 21) if wl == "c3" else (1 << 16))
+                at_global = {}
+                locals_ = sorted({r["B"]} | {s_["B"] for s_ in sweep if "error" not in s_})
+                for Bl in locals_:
+                    Bg = min(Bl * world, d1["n"])            # (a global batch beyond the set: one step per epoch)
+                    try:
+                        at_global[Bl] = point(Bg)
+                    except Exception as e:                  # noqa: BLE001  (the stage is B x 256 B: may not fit one GPU)
+                        at_global[Bl] = {"error": f"{type(e).__name__}: {e}", "batch": Bg}
+                        torch.cuda.empty_cache()
                 free_data(d1)
-                return {"value": r1["steps"] * r1["B"] / r1["dt"], "unit": "interactions/s", "n_gpus": 1,
-                        "steps": r1["steps"], "ms_per_step": r1["dt"] / r1["steps"] * 1e3, "batch": r1["B"],
-                        "workload": r1["name"],
-                        "roofline_frac": ALGO_BYTES_PER_INTERACTION_SGD(64) * r1["B"] / (r1["dt"] / r1["steps"]) / 1e9 / HBM_PEAK_GBS}
-            ref = guarded("single-GPU reference", one_gpu)      # (the other ranks wait at the barrier either way)
+                return base, at_global
+            got = guarded("single-GPU reference", one_gpu, collective=False)   # (the other ranks wait at the barrier)
+            if isinstance(got, dict):
+                ref = got
+            else:
+                ref, ref_global = got
         dist.barrier()
 
     if rank == 0:
@@ -513,12 +543,22 @@ def main():
             out["six_x_budget"] = ("DESIGN.md section 5: the exchange is 2 x (N-1)/N x I x 264 B per step and rank whatever the "
                                    "batch (replicated Q), so >= 6x at 8 GPUs is budgeted only for B_local >= 8M interactions "
                                    "per rank and step (about 3x at 2M); the sweep measures it")
+        if world > 1:
+            out["config"]["global_batch_over_nnz"] = B * world / (r["n"] * world)
         if ref is not None:
             out["single_gpu_same_workload"] = ref
             if "error" in ref:
                 ref = None
             else:
                 out["speedup_vs_single_gpu_same_workload"] = value / ref["value"]
+                out["speedup_note"] = ("speedup_vs_single_gpu_same_workload divides by the 1-GPU rate at ITS operating point "
+                                       f"(B = {ref['batch']}); speedup_vs_1gpu_same_global_batch divides by the 1-GPU rate at "
+                                       "this run's GLOBAL batch (same optimisation trajectory: the loss is a batch sum)")
+            g = ref_global.get(B)
+            if g is not None:
+                out["single_gpu_same_global_batch"] = g
+                if "error" not in g:
+                    out["speedup_vs_1gpu_same_global_batch"] = value / g["value"]
         if sweep:
             pts = []
             for s_ in sweep:
@@ -530,9 +570,16 @@ def main():
                       "ms_per_step": s_["dt"] / s_["steps"] * 1e3,
                       "compute_ms": s_["split_ms"][0] if s_["split_ms"] else None,
                       "exposed_exchange_ms": s_["split_ms"][1] if s_["split_ms"] else None}
+                pt["global_batch"] = s_["B"] * world
+                pt["global_batch_over_nnz"] = s_["B"] / s_["n"]
                 if ref is not None:
                     pt["speedup_vs_1gpu"] = v / ref["value"]
                     pt["meets_6x"] = bool(v / ref["value"] >= 6.0)
+                g = ref_global.get(s_["B"])
+                if g is not None and "error" not in g:
+                    pt["one_gpu_value_same_global_batch"] = g["value"]
+                    pt["speedup_vs_1gpu_same_global_batch"] = v / g["value"]
+                    pt["meets_6x_same_global_batch"] = bool(v / g["value"] >= 6.0)
                 pts.append(pt)
             out["sweep"] = pts
         if r["cpu_batches"]:

@@ -1981,6 +1981,10 @@ static int adam_lazy_batch(daisy_bpr_ctx *ctx, bool with_g, float *P, float *gP,
         set_error("adam_lazy: needs a batch of the sorted plan layout / daisy_bpr_set_batch*");
         return DAISY_ERR_STATE;
     }
+    // rows of P change behind the staged step's row-norm cache and behind a pre-norm that rode on its last item pass
+    // (a caller may hand the same LazyAdam state to this path and to daisy_bpr_staged_adam_step on one context)
+    ctx->p_sqnorm_of = nullptr;
+    ctx->pre_ready = false;
     const BatchView &v = ctx->v;
     const AdamTable TP{P, gP, mP, vP, lastP}, TQ{Q, gQ, mQ, vQ, lastQ};
     const AdamHyper h{reinterpret_cast<const float2 *>(table), beta1, beta2, eps, (int32_t)step};

@@ -26,6 +26,10 @@ NATIVE_OPTIMIZERS = ("sgd", "adam", "adagrad", "rmsprop")
 KNOWN_OPTIMIZERS = ("adam", "sgd", "adagrad", "rmsprop", "sparse_adam")
 
 
+# config['lazy_adam'] (Adam only).  With the default item_mode 'fused' the staged step's row owners ALWAYS apply the lazy
+# form (bit-equal to the dense optimiser after every flush) unless lazy_adam is False, which routes the fit to the phase
+# kernels + torch's dense pass.  For the explicit item modes 'chunked' / 'sorted' / 'atomic', True / 'auto' select
+# ops.LazyAdam's row updates behind the phase kernels; there
 # 'auto' picks the lazy Adam only when the tables are large enough for the dense pass to matter: below this many
 # table bytes (ml-100k scale: 2.6 k rows) the dense optimiser is one trivial launch and the lazy form only adds two
 # launches per step plus serial replays at every catch-up / flush
@@ -332,7 +336,16 @@ class GeneralRecommender(AbstractRecommender):
         # segment owner): SGD and Adam, every loss of loss.py, FM's biases.  Adagrad / RMSprop run the phase kernels with
         # the dense optimisers.  Batches of a few hundred samples go through the sorted plan instead: fit_epoch_sgd then
         # runs the whole epoch inside one persistent workgroup (SGD, pairwise, no biases; csrc/bpr_small.hip).
+        if opt == "adam" and self.lazy_adam is False and item_mode == ops.ITEM_MODES["fused"]:
+            # config['lazy_adam']=False: torch's dense Adam pass over both tables behind the phase kernels (the staged
+            # step's row owners apply the exact LAZY form - same bits after every flush, but the knob means what it says)
+            item_mode = ops.ITEM_MODES["chunked"]
         staged = item_mode == ops.ITEM_MODES["fused"] and opt in ("sgd", "adam") and B > ops.SMALL_BATCH_MAX
+        self.logger.info("HIP fit: %s, optimizer %s, B=%d: %s", type(self).__name__, opt, B,
+                         "staged step over the partitioned plan" + (" (row owners apply lazy Adam)" if opt == "adam" else "")
+                         if staged else ("small-batch epoch kernel" if (opt == "sgd" and B <= ops.SMALL_BATCH_MAX
+                                                                         and item_mode in (ops.ITEM_MODES["fused"], ops.ITEM_MODES["chunked"]))
+                                         else "phase kernels + dense optimiser"))
         adam = (_AdamState(P, Q, self.lr, biases, kind=opt, max_steps=self.epochs * ((n + B - 1) // B),
                            lazy=((3 * B < P.shape[0] + Q.shape[0]
                                   and (P.numel() + Q.numel()) * 4 >= LAZY_ADAM_MIN_TABLE_BYTES)

@@ -497,6 +497,8 @@ class LazyAdam:
         self.t += 1
         if self.t > self._table_steps:
             self._grow(2 * self.t)
+        self._ctx = ctx            # (flush() rewrites rows of P behind this context's row-norm cache)
+        ctx._p_key = None          # the native side drops the cache; so does the wrapper's notion of it
         f = torch.float32
         check(lib.daisy_adam_lazy_catchup(
             ctx._h, _ptr(self.P, f, "P"), _ptr(self.m[0], f, "mP"), _ptr(self.v[0], f, "vP"),
@@ -505,6 +507,8 @@ class LazyAdam:
             self.BETA1, self.BETA2, self.EPS, self.t, _stream()))
 
     def step(self, ctx, gP, gQ):
+        self._ctx = ctx
+        ctx._p_key = None
         f = torch.float32
         check(lib.daisy_adam_lazy_step(
             ctx._h, _ptr(self.P, f, "P"), _ptr(gP, f, "gP"), _ptr(self.m[0], f, "mP"), _ptr(self.v[0], f, "vP"),

@@ -22,7 +22,12 @@ def _has_gpu():
         return False
 
 
-GPU_TEST_TIMEOUT_S = 900      # a hung kernel must fail its test, not hang the GPU box until the driver's own limit
+# A hung kernel must not hang the GPU box until the driver's own limit.  pytest-timeout's 'thread' method is the only one
+# that works against a host thread blocked inside hipStreamSynchronize (the 'signal' method needs the interpreter to
+# return to bytecode): it dumps every thread's stack and os._exit()s the WHOLE pytest process - the remaining tests of
+# the session do not run and no summary is printed; the dump names the hung test.  Without the plugin (it is listed in
+# tests/requirements.txt) no limit is applied.
+GPU_TEST_TIMEOUT_S = 900
 
 
 def pytest_collection_modifyitems(config, items):

@@ -168,3 +168,10 @@ def test_bench_self_spawns_its_ranks():
     pts = out["sweep"]
     assert {(p["batch_per_gpu"], p["slices"]) for p in pts} == {(16384, 1), (16384, 4), (65536, 1), (65536, 4)}
     assert all(p["value"] > 0 and p["compute_ms"] > 0 and "meets_6x" in p for p in pts)
+    # like with like: the 1-GPU rate at the run's GLOBAL batch next to the one at its own operating
+    # point - on the line and on every sweep point
+    g = out["single_gpu_same_global_batch"]
+    assert g["batch"] == 2 * 65536 and g["value"] > 0 and out["speedup_vs_1gpu_same_global_batch"] > 0
+    assert 0 < out["config"]["global_batch_over_nnz"] <= 1
+    assert all(p["global_batch"] == 2 * p["batch_per_gpu"] and p["speedup_vs_1gpu_same_global_batch"] > 0
+               and "meets_6x_same_global_batch" in p for p in pts)
