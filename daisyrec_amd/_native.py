@@ -29,7 +29,7 @@ ST_LOSS_DATA, ST_L1_U, ST_L1_I, ST_L1_J, ST_SQ_U, ST_SQ_I, ST_SQ_J = range(7)
 ST_LOSS, ST_NORM_U, ST_NORM_I, ST_NORM_J = 7, 8, 9, 10
 ST_SUM_COEF = 12
 ST_SQ_U_PRE = 13
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _p = C.c_void_p
 _i32, _i64, _u64, _f32, _sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
@@ -76,6 +76,7 @@ SIGNATURES = {
     "daisy_epoch_plan_build_positions": (C.c_int, [_p, _p, _p, _i64, _i64, _p]),
     "daisy_epoch_plan_batch_rows": (_i64, [_p, _i64]),
     "daisy_bpr_ctx_invalidate_cache": (C.c_int, [_p]),
+    "daisy_bpr_ctx_set_p_stream": (C.c_int, [_p, C.c_int32]),
     "daisy_bpr_staged_prenorm": (C.c_int, [_p, _p, _p, _p]),
     "daisy_bpr_staged_user": (C.c_int, [_p, _p, _p, _i32, _f32, _f32, _f32, _f32, _p, _p]),
     "daisy_bpr_staged_item": (C.c_int, [_p, _i32, _p, _p, _p, _f32, _f32, _f32, _p, _p]),

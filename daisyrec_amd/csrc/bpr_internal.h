@@ -44,26 +44,40 @@ __device__ __forceinline__ bool halted(const double *halt) { return halt != null
 
 // What the STAGED step (bpr_staged.hip) sees of the current batch.  Either layout of the epoch plan
 // can feed it:
-//   sample s in [0,B):  user = s_user[s] & umask, (pos item, neg item) = s_ij[s], samples of one user contiguous;
-//                       stage slot of the sample = s_pos ? s_pos[s] - pos_base : s      (a bijection onto [0,B))
-//   entry  q in [0,E):  item = (e_key[q] & imask) >> 1, negative slot = e_key[q] & 1 (ascending, stable);
+//   sample s in [0,B):  partitioned layout: s_rec[s] = {user, pos item, neg item, epoch position}, stage slot of the sample
+//                       = position - pos_base;   sorted layout (s_rec == NULL): user = s_user[s] & umask, (pos item, neg
+//                       item) = s_ij[s], stage slot = s.  Samples of one user are contiguous; the slots are a bijection
+//                       onto [0,B)
+//   entry  q in [0,E):  item = (e_key[q*e_kstride] & imask) >> 1, negative slot = e_key[..] & 1 (ascending, stable);
 //                       stage slot of the sample it belongs to = (e_pos[q*e_stride] & ~kNegBit) - pos_base
+//                       (partitioned layout: 8-byte records {key, position}, both strides 2)
 namespace daisy {
 struct StreamView {
+    const uint4 *s_rec;
     const uint32_t *s_user;
     const int2 *s_ij;
-    const uint32_t *s_pos;
     const uint32_t *e_key;
     const uint32_t *e_pos;
     uint32_t umask, imask;
-    int32_t e_stride;
+    int32_t e_kstride, e_stride;
     uint32_t pos_base;
     int64_t B, E;
     const double *halt;      // see BatchView::halt
     int32_t pointwise;       // rows are (user, item, label): E = B entries in the partitioned layout; the sorted
                              // layout keeps an inert negative slot per sample (E = 2B)
-    int32_t p_stream;        // the user pass reads P with nontemporal loads (set by the host for tables >> the caches)
+    int32_t p_stream;        // the user pass reads and writes P past the caches (tables far beyond them: set by the host)
 };
+// the sample as {user, pos item, neg item, stage slot} / the user alone / an entry's key  (any layout; the hot kernels
+// read the layout they were compiled for directly)
+__device__ __forceinline__ uint4 sv_sample(const StreamView &v, int64_t s) {
+    if (v.s_rec) { uint4 r = v.s_rec[s]; r.w -= v.pos_base; return r; }
+    const int2 ij = v.s_ij[s];
+    return make_uint4(v.s_user[s] & v.umask, (uint32_t)ij.x, (uint32_t)ij.y, (uint32_t)s);
+}
+__device__ __forceinline__ uint32_t sv_user(const StreamView &v, int64_t s) {
+    return v.s_rec ? v.s_rec[s].x : (v.s_user[s] & v.umask);
+}
+__device__ __forceinline__ uint32_t sv_key(const StreamView &v, int64_t e) { return v.e_key[e * v.e_kstride] & v.imask; }
 }  // namespace daisy
 
 // Static index of a training set (built once per fit): the triples in CSR (user-sorted) order and
@@ -113,16 +127,12 @@ struct daisy_epoch_plan {
     // kind 1 buffers (allocated by the first daisy_epoch_plan_build_indexed): record set [x] of the LSD passes
     void *parena;
     size_t parena_bytes, ptemp_bytes;
-    uint32_t *p_user[2], *p_pos[2];     // [n]   samples: user, epoch position
-    int2 *p_ij[2];                      // [n]            (pos item, neg item)
-    uint32_t *p_ekey[2], *p_epos[2];    // [2n]  entries: item << 1 | slot, epoch position of the sample
-    uint32_t *p_tmp_pos;                // [2n]  positions computed by the counting pass
+    uint4 *p_srec[2];                   // [n]   sample records {user, pos item, neg item / label, epoch position}
+    uint2 *p_erec[2];                   // [2n]  entry records {item << 1 | slot, epoch position of the sample}
     uint32_t *p_counts, *p_offsets;     // [ndig * ntiles] per-tile digit counts / their exclusive scan
     uint32_t *p_inv;                    // [n]   inverse of an explicit permutation (DAISY_ORDER_PERM)
     void *ptemp;                        // rocPRIM scan scratch
     void *parena2;                      // second record set (plans with more than 256 batches: LSD passes ping-pong)
-    void *p_onepass;                    // look-back words + tickets of the one-pass partition (DAISY_PLAN_ONEPASS=1)
-    size_t p_onepass_bytes;
     int32_t p_cur;                      // record set holding the finished plan
     uint64_t build_gen;                 // id of the build the plan currently holds, unique in the process (what a
                                         // batch index refers to: a context that computed something ahead for "batch k+1"
@@ -171,6 +181,7 @@ struct daisy_bpr_ctx {
     const daisy_epoch_plan *pre_plan; int64_t pre_k; uint64_t pre_gen;
     const float *pre_P; const double *pre_stats; int pre_n;     // pre_n > 0: partial sums in `partials`; 0: stats[SQ_U_PRE]
     bool pre_ready;
+    int32_t p_stream_mode;      // daisy_bpr_ctx_set_p_stream: -1 automatic (by table size), 0 off, 1 on
 };
 
 

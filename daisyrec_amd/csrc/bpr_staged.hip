@@ -78,8 +78,12 @@ static inline hipStream_t S(daisy_stream_t s) { return reinterpret_cast<hipStrea
 // partitioned epoch plan
 // =============================================================================
 constexpr int kPartThreads = 256;
-constexpr int kPartK = 8;                              // records per thread per sub-tile
-constexpr int kPartSub = kPartThreads * kPartK;        // 2048 records sorted in LDS at a time
+constexpr int kPartK = 8;                              // records per thread per sub-tile: samples (16-byte records)
+constexpr int kPartKE = 8;                             //   entries (8-byte records; 16 per thread measured 1.56 against
+                                                       //   1.30 ms per epoch at BASELINE configs[1]: two workgroups per CU
+                                                       //   less, and every lane walks twice as many positions in a row)
+constexpr int kPartSub = kPartThreads * kPartK;        // 2048 records: the counting kernels' staging unit
+constexpr int kPartMaxTiles = 16384;                   // most tiles (workgroups) of a partition
 constexpr int kPartWaves = kPartThreads / kWave;
 
 struct PosFn {            // position of triple t in the epoch order
@@ -112,14 +116,19 @@ __device__ __forceinline__ uint32_t batch_of(uint32_t p, const BatchDiv &bd) {
     return q;
 }
 
+// Records of the partitioned plan (array of structures: a bucket piece of a sub-tile leaves as ONE contiguous run of
+// 16-byte / 8-byte records - round 3's three separate arrays left as ~85-record pieces of 340 / 680 / 340 B, and the
+// counters showed the scatter writing 2.1x its records in partial lines):
+//   sample record  uint4 {user, pos item, neg item (or label), epoch position}
+//   entry record   uint2 {item << 1 | slot, epoch position of its sample}
 struct PartSrc {
     const int32_t *triples; int32_t user_base;          // samples, static source (CSR-ordered triples)
-    const uint32_t *user; const int2 *ij;               // samples, record source (LSD pass >= 1)
     const uint32_t *ent_t;                              // entries, static source: triple index | slot << 31
-    const uint32_t *key;                                // entries: item << 1 | slot
-    const uint32_t *pos;                                // epoch positions (record source, or the counting pass's scratch)
+    const uint32_t *ent_key;                            //                         item << 1 | slot
+    const uint4 *srec;                                  // samples, record source (LSD pass >= 1)
+    const uint2 *erec;                                  // entries, record source
 };
-struct PartDst { uint32_t *user; int2 *ij; uint32_t *key; uint32_t *pos; };
+struct PartDst { uint4 *srec; uint2 *erec; };
 
 // lanes of this wave that hold the same digit (the AMD counterpart of match.any: one ballot per digit bit)
 __device__ __forceinline__ uint64_t match_digit(uint32_t dgt, bool valid, int nbits) {
@@ -132,21 +141,21 @@ __device__ __forceinline__ uint64_t match_digit(uint32_t dgt, bool valid, int nb
     return peers;
 }
 
-// KIND 0: samples from the static source   1: entries from the static source   2: records of a previous pass
-// (pos read).  The static kinds compute the epoch position and park it in pos_out (when given) for the
-// scatter pass: the Feistel evaluation is the ALU bound of the plan build.
+// Digit histogram of every tile.  KIND 0: samples from the static source   1: entries from the static source (their
+// epoch positions are computed here and again by the scatter pass - round 3 parked them in memory for it: 12 B per
+// record of traffic for ALU work that hides under the scatter's memory time; measured a tie to slightly faster,
+// profiles/r04_plan_variants.txt "variant 3")   2 / 3: sample / entry records of a previous LSD pass.
 template <int KIND>
 __global__ __launch_bounds__(kPartThreads) void k_part_count(PartSrc src, PosFn pf, BatchDiv bd, int64_t n,
                                                              int shift, int nbits, int ndig, int64_t tile_elems,
-                                                             int64_t ntiles, uint32_t *__restrict__ pos_out,
-                                                             uint32_t *__restrict__ counts) {
+                                                             int64_t ntiles, uint32_t *__restrict__ counts) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t lds_t[KIND == 1 ? kPartSub : 1];
     hist[threadIdx.x] = 0;
     __syncthreads();
     const int64_t lo = (int64_t)blockIdx.x * tile_elems;
     const int64_t hi = (lo + tile_elems < n) ? lo + tile_elems : n;
-    if (KIND != 2 && pf.mode == DAISY_ORDER_FEISTEL) {
+    if (KIND < 2 && pf.mode == DAISY_ORDER_FEISTEL) {
         // Cycle walking inside a lock-step wave costs the MAXIMUM walk length of its 64 lanes per element
         // (~3.5 network passes instead of the 1.34 average at n = 0.75 * 2^2h).  So every lane owns a strip of
         // elements and steps through it at its own pace: each trip of the loop is one useful network pass for
@@ -175,7 +184,6 @@ __global__ __launch_bounds__(kPartThreads) void k_part_count(PartSrc src, PosFn 
             while (active) {
                 x = feistel_once(x, pf.fk);
                 if (x < nn) {
-                    if (pos_out) pos_out[e] = x;
                     atomicAdd(&hist[(batch_of(x, bd) >> shift) & 255u], 1u);
                     ++j;
                     e += kPartThreads;
@@ -193,8 +201,8 @@ __global__ __launch_bounds__(kPartThreads) void k_part_count(PartSrc src, PosFn 
             if (valid) {
                 if constexpr (KIND == 0) p = pos_of(pf, (uint32_t)e);
                 else if constexpr (KIND == 1) p = pos_of(pf, src.ent_t[e] & ~kNegBit);
-                else p = src.pos[e];
-                if constexpr (KIND != 2) { if (pos_out) pos_out[e] = p; }
+                else if constexpr (KIND == 2) p = src.srec[e].w;
+                else p = src.erec[e].y;
             }
             const uint32_t dgt = (batch_of(p, bd) >> shift) & 255u;
             const uint64_t peers = match_digit(dgt, valid, nbits);          // one LDS atomic per digit per wave
@@ -205,114 +213,95 @@ __global__ __launch_bounds__(kPartThreads) void k_part_count(PartSrc src, PosFn 
     if ((int)threadIdx.x < ndig) counts[(int64_t)threadIdx.x * ntiles + blockIdx.x] = hist[threadIdx.x];
 }
 
-// Stable scatter of one LSD digit.  A tile is cut into sub-tiles of 2048 records; a wave takes 512
-// consecutive records of the sub-tile in 8 rounds of 64 (coalesced reads, and the round order = the record
-// order, so ranks are stable), the sub-tile is sorted by digit in LDS and leaves as one contiguous piece per
-// bucket.  SAMPLES: records (user, i, j, pos); else (key, pos).  STATIC: samples come from the triple array
-// and their position is src.pos (parked by the counting pass) or recomputed (entries always carry theirs in src.pos).
-// WALK (DAISY_PLAN_ONEPASS=3, compiled but not yet run): nothing was parked by the counting pass - the sub-tile's
-// positions are computed here, every lane walking its own eight records (k_part_count's strip walk) into LDS, so the
-// Feistel ALU work hides under the scatter's memory time and 8 B per record of parked-position traffic disappear.
-template <bool SAMPLES, bool STATIC, bool WALK = false>
+// Stable scatter of one LSD digit.  A tile is cut into sub-tiles of 256 * K records; a wave takes 64 * K consecutive
+// records of the sub-tile in K rounds of 64 (coalesced reads, and the round order = the record order, so ranks are
+// stable), the sub-tile is sorted by digit in LDS and every bucket leaves as one contiguous piece of whole records.
+// STATIC: the records are formed from the static index and their epoch positions are computed here - every lane walks
+// the Feistel network over its own K records (k_part_count's strip walk) into LDS while the other workgroups of the CU
+// are in their memory phases.
+template <bool SAMPLES, bool STATIC, int K>
 __global__ __launch_bounds__(kPartThreads) void k_part_scatter(PartSrc src, PosFn pf, BatchDiv bd, int64_t n,
                                                                int shift, int nbits, int ndig,
                                                                int64_t tile_elems, int64_t ntiles,
-                                                               const uint32_t *__restrict__ offsets,
+                                                               const uint32_t *__restrict__ offsets, uint32_t off_base,
                                                                PartDst dst) {
-    static_assert(!WALK || STATIC, "only the static source lacks positions");
-    __shared__ uint4 rec4[SAMPLES ? kPartSub : 1];
-    __shared__ uint2 rec2[SAMPLES ? 1 : kPartSub];
-    __shared__ uint32_t lp[WALK ? kPartSub : 1];
-    __shared__ uint8_t sdig[kPartSub];
+    constexpr int SUB = kPartThreads * K;
+    // the sorted records; before that (STATIC) the sub-tile's epoch positions, 4 B per record, read back by the thread
+    // that wrote them and dead by the time the first record is stored (two barriers in between)
+    __shared__ __attribute__((aligned(16))) uint32_t recw[SUB * (SAMPLES ? 4 : 2)];
+    __shared__ uint8_t sdig[SUB];
     __shared__ uint32_t wcnt[kPartWaves][256];
     __shared__ uint32_t tstart[256], goff[256], tot[256];
     __shared__ uint32_t wsum[kPartWaves];
+    uint4 *rec4 = reinterpret_cast<uint4 *>(recw);
+    uint2 *rec2 = reinterpret_cast<uint2 *>(recw);
+    uint32_t *lp = recw;
 
     const int tid = threadIdx.x, wave = tid / kWave, wl = tid % kWave;
     const uint64_t lt_mask = ((uint64_t)1 << wl) - 1;
-    goff[tid] = (tid < ndig) ? offsets[(int64_t)tid * ntiles + blockIdx.x] : 0u;
+    goff[tid] = (tid < ndig) ? offsets[(int64_t)tid * ntiles + blockIdx.x] - off_base : 0u;
     const int64_t lo = (int64_t)blockIdx.x * tile_elems;
     const int64_t hi = (lo + tile_elems < n) ? lo + tile_elems : n;
 
-    for (int64_t sub = lo; sub < hi; sub += kPartSub) {
+    for (int64_t sub = lo; sub < hi; sub += SUB) {
 #pragma unroll
         for (int w = 0; w < kPartWaves; ++w) wcnt[w][tid] = 0;
-        __syncthreads();
-        uint32_t r_a[kPartK], r_b[kPartK], r_c[kPartK], r_p[kPartK], r_rank[kPartK], r_dig[kPartK];
-        const int64_t wbase = sub + (int64_t)wave * (kWave * kPartK);
-        if constexpr (WALK) {
-            // slot of the record this thread holds in round r: wave*512 + r*64 + wl (read back by this thread only)
-            const int xw = wave * (kWave * kPartK) + wl;
-            if constexpr (!SAMPLES) {
+        uint32_t r_a[K], r_b[SAMPLES ? K : 1], r_c[SAMPLES ? K : 1], r_p[K], r_rank[K], r_dig[K];
+        const int64_t wbase = sub + (int64_t)wave * (kWave * K);
+        // ---- the records of this thread (round r: record wbase + r*64 + wl); all loads are issued before the walk
 #pragma unroll
-                for (int r = 0; r < kPartK; ++r) {
-                    const int64_t e = wbase + r * kWave + wl;
-                    if (e < hi) lp[xw + r * kWave] = src.ent_t[e] & ~kNegBit;
+        for (int r = 0; r < K; ++r) {
+            const int64_t e = wbase + r * kWave + wl;
+            const int64_t ec = (e < hi) ? e : hi - 1;
+            if constexpr (!STATIC) {
+                if constexpr (SAMPLES) {
+                    const uint4 q = src.srec[ec];
+                    r_a[r] = q.x; r_b[r] = q.y; r_c[r] = q.z; r_p[r] = q.w;
+                } else {
+                    const uint2 q = src.erec[ec];
+                    r_a[r] = q.x; r_p[r] = q.y;
                 }
+            } else if constexpr (SAMPLES) {
+                const int32_t *row = src.triples + 3 * ec;
+                r_a[r] = (uint32_t)(row[0] - src.user_base);
+                r_b[r] = (uint32_t)row[1];
+                r_c[r] = (uint32_t)row[2];
+                r_p[r] = (uint32_t)ec;                      // (the triple whose position is wanted)
+            } else {
+                r_a[r] = src.ent_key[ec];
+                r_p[r] = src.ent_t[ec] & ~kNegBit;
             }
-            auto first = [&](int r, int64_t e) -> uint32_t {
-                uint32_t t;
-                if constexpr (SAMPLES) t = (uint32_t)e;
-                else t = lp[xw + r * kWave];
-                return t;
-            };
+        }
+        if constexpr (STATIC) {
+            // slot of the record this thread holds in round r: wave*64*K + r*64 + wl
+            const int xw = wave * (kWave * K) + wl;
             if (pf.mode == DAISY_ORDER_FEISTEL) {
                 const uint32_t nn = (uint32_t)pf.n;
+#pragma unroll
+                for (int r = 0; r < K; ++r) lp[xw + r * kWave] = pf.orig ? pf.orig[r_p[r]] : r_p[r];
                 int r = 0;
-                int64_t e = wbase + wl;
-                bool active = e < hi;
-                uint32_t v = 0;
-                if (active) { v = first(0, e); if (pf.orig) v = pf.orig[v]; }
+                bool active = wbase + wl < hi;
+                uint32_t v = active ? lp[xw] : 0u;
                 while (active) {
                     v = feistel_once(v, pf.fk);
                     if (v < nn) {
                         lp[xw + r * kWave] = v;
                         ++r;
-                        e += kWave;
-                        active = (r < kPartK) && (e < hi);
-                        if (active) { v = first(r, e); if (pf.orig) v = pf.orig[v]; }
+                        active = (r < K) && (wbase + r * kWave + wl < hi);
+                        if (active) v = lp[xw + r * kWave];
                     }
                 }
+#pragma unroll
+                for (int r = 0; r < K; ++r) r_p[r] = lp[xw + r * kWave];
             } else {
-                for (int r = 0; r < kPartK; ++r) {
-                    const int64_t e = wbase + r * kWave + wl;
-                    if (e < hi) lp[xw + r * kWave] = pos_of(pf, first(r, e));
-                }
+#pragma unroll
+                for (int r = 0; r < K; ++r) r_p[r] = pos_of(pf, r_p[r]);
             }
         }
+        __syncthreads();              // (wcnt is zero; nobody is still reading the previous sub-tile's records)
 #pragma unroll
-        for (int r = 0; r < kPartK; ++r) {
-            const int64_t e = wbase + r * kWave + wl;
-            const bool valid = e < hi;
-            const int64_t ec = valid ? e : hi - 1;
-            if constexpr (WALK) {
-                if constexpr (SAMPLES) {
-                    const int32_t *row = src.triples + 3 * ec;
-                    r_a[r] = (uint32_t)(row[0] - src.user_base);
-                    r_b[r] = (uint32_t)row[1];
-                    r_c[r] = (uint32_t)row[2];
-                } else {
-                    r_a[r] = src.key[ec];
-                }
-                r_p[r] = valid ? lp[wave * (kWave * kPartK) + r * kWave + wl] : 0u;
-            } else if constexpr (SAMPLES) {
-                if constexpr (STATIC) {
-                    const int32_t *row = src.triples + 3 * ec;
-                    r_a[r] = (uint32_t)(row[0] - src.user_base);
-                    r_b[r] = (uint32_t)row[1];
-                    r_c[r] = (uint32_t)row[2];
-                    r_p[r] = src.pos ? src.pos[ec] : pos_of(pf, (uint32_t)ec);
-                } else {
-                    const int2 ij = src.ij[ec];
-                    r_a[r] = src.user[ec];
-                    r_b[r] = (uint32_t)ij.x;
-                    r_c[r] = (uint32_t)ij.y;
-                    r_p[r] = src.pos[ec];
-                }
-            } else {
-                r_a[r] = src.key[ec];
-                r_p[r] = src.pos[ec];
-            }
+        for (int r = 0; r < K; ++r) {
+            const bool valid = wbase + r * kWave + wl < hi;
             const uint32_t dgt = (batch_of(r_p[r], bd) >> shift) & 255u;
             const uint64_t peers = match_digit(dgt, valid, nbits);
             const uint32_t base = wcnt[wave][dgt];                  // all lanes read ...
@@ -341,7 +330,7 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(PartSrc src, PosF
         tstart[tid] = wprefix + inc - t;
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < kPartK; ++r) {
+        for (int r = 0; r < K; ++r) {
             if (r_dig[r] != 0xFFFFFFFFu) {
                 const uint32_t x = tstart[r_dig[r]] + wcnt[wave][r_dig[r]] + r_rank[r];
                 if constexpr (SAMPLES) rec4[x] = make_uint4(r_a[r], r_b[r], r_c[r], r_p[r]);
@@ -350,268 +339,12 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(PartSrc src, PosF
             }
         }
         __syncthreads();
-        const int cnt = (int)((hi - sub < kPartSub) ? (hi - sub) : kPartSub);
+        const int cnt = (int)((hi - sub < SUB) ? (hi - sub) : SUB);
         for (int x = tid; x < cnt; x += kPartThreads) {
             const uint32_t dg = sdig[x];
             const int64_t o = (int64_t)goff[dg] + (x - tstart[dg]);
-#ifdef DAISY_PART_NOSTORE
-            if (o != 0x7fffffffffff) continue;
-#endif
-            if constexpr (SAMPLES) {
-                const uint4 q = rec4[x];
-                dst.user[o] = q.x;
-                dst.ij[o] = make_int2((int)q.y, (int)q.z);
-                dst.pos[o] = q.w;
-            } else {
-                const uint2 q = rec2[x];
-                dst.key[o] = q.x;
-                dst.pos[o] = q.y;
-            }
-        }
-        __syncthreads();
-        goff[tid] += tot[tid];
-    }
-}
-
-// ---- one-pass partition (opt-in: DAISY_PLAN_ONEPASS=1) ----------------------------------------------------------
-// The counting pass, the scan and the scatter of one digit in ONE launch: a workgroup draws a tile of 8192 records
-// by ticket, computes the tile's epoch positions into LDS (the Feistel walk: ALU only, it overlaps the memory phase of
-// the other workgroup on the CU), publishes the tile's digit counts, finds its offsets by a decoupled look-back over
-// the tiles before it (Merrill & Garland; one 8-byte {flag, count} word per tile and digit, relaxed agent-scope
-// atomics on both sides: MI355X_MICROARCH "8-B agent atomics both sides"), and scatters sub-tile by sub-tile exactly
-// like k_part_scatter.  Against the three-launch form it saves the parked positions (4 B written + 4 B read per
-// record) and the serial ALU-bound counting launches.  Tickets make the look-back deadlock-free: every tile a
-// workgroup waits for was drawn earlier, is therefore resident, and publishes its counts before it waits itself.
-// Only for one LSD pass (<= 256 batches) over a whole epoch (bucket k starts at k * records-per-batch).
-// State (profiles/r03_onepass_check.txt): record-for-record identical to the three-launch build in every order
-// (tests/test_gpu_staged.py runs both), but SLOWER today - 0.99 against 0.66 ms at 20 M samples - and therefore off:
-// 58 / 74 KB of LDS leave two workgroups per CU (the scatter kernel runs three), too few loads in flight for pass B.
-constexpr int kOneSubs = 4;
-constexpr int kOneTile = kOneSubs * kPartSub;           // 8192 records per workgroup
-constexpr int kOnePer = kOneTile / kPartThreads;        // 32 records per thread
-constexpr uint64_t kOneAgg = (uint64_t)1 << 62, kOnePrefix = (uint64_t)2 << 62, kOneVal = ((uint64_t)1 << 62) - 1;
-
-struct OnePass {
-    uint64_t *state;        // [ndig][tile_stride]  flag << 62 | count   (0 = not published; zeroed before the launch)
-    uint32_t *ticket;       // [1] zeroed before the launch
-    int64_t tile_stride;
-    int64_t bucket_elems;   // records of a full bucket (entries per sample x batch size): bucket k starts at k * this
-};
-
-__device__ __forceinline__ uint64_t wave_sum_u64(uint64_t x) {
-#pragma unroll
-    for (int off = kWave / 2; off > 0; off >>= 1) {
-        const uint32_t lo = __shfl_xor((uint32_t)x, off, kWave), hi = __shfl_xor((uint32_t)(x >> 32), off, kWave);
-        x += ((uint64_t)hi << 32) | lo;
-    }
-    return x;
-}
-
-// FRONT (DAISY_PLAN_ONEPASS=2, written after the round's GPU budget - compiled, never run): every record of the tile is
-// loaded into registers before the Feistel walk (32 or 96 loads per lane in flight, two workgroups per CU leave 256
-// VGPRs per lane), so pass B has no global loads left: reads overlap the ALU phase instead of depending on occupancy.
-template <bool SAMPLES, bool FRONT>
-__global__ __launch_bounds__(kPartThreads) void k_part_onepass(PartSrc src, PosFn pf, BatchDiv bd, int64_t n, int nbits,
-                                                               int ndig, OnePass op, PartDst dst) {
-    __shared__ uint32_t lpos[kOneTile];                  // entries: triple index, then (both) the epoch position
-    __shared__ uint4 rec4[SAMPLES ? kPartSub : 1];
-    __shared__ uint2 rec2[SAMPLES ? 1 : kPartSub];
-    __shared__ uint8_t sdig[kPartSub];
-    __shared__ uint32_t wcnt[kPartWaves][256];
-    __shared__ uint32_t tstart[256], goff[256], tot[256], hist[256];
-    __shared__ uint32_t wsum[kPartWaves];
-    __shared__ uint32_t s_tile;
-
-    const int tid = threadIdx.x, wave = tid / kWave, wl = tid % kWave;
-    const uint64_t lt_mask = ((uint64_t)1 << wl) - 1;
-    if (tid == 0) s_tile = atomicAdd(op.ticket, 1u);
-    hist[tid] = 0;
-    goff[tid] = 0;
-    __syncthreads();
-    const int64_t tile = (int64_t)s_tile;
-    const int64_t lo = tile * kOneTile;
-    const int64_t hi = (lo + kOneTile < n) ? lo + kOneTile : n;
-    const int cnt_tile = (int)(hi - lo);                 // >= 1: the grid has ceil(n / kOneTile) workgroups
-
-    // ---- pass A: positions and digit counts.  Thread (wave, wl) owns the slots sub*2048 + wave*512 + r*64 + wl - the
-    // records pass B will hold in round r of sub-tile sub; its k-th slot (k = sub*8 + r) grows with k
-    auto slot = [&](int k) -> int { return ((k >> 3) << 11) + (wave << 9) + ((k & 7) << 6) + wl; };
-    if constexpr (!SAMPLES) {
-#pragma unroll 8
-        for (int k = 0; k < kOnePer; ++k) {
-            const int x = slot(k);
-            if (x < cnt_tile) lpos[x] = src.ent_t[lo + x] & ~kNegBit;      // read back by this thread only
-        }
-    }
-    uint32_t q_a[FRONT ? kOnePer : 1], q_b[(FRONT && SAMPLES) ? kOnePer : 1], q_c[(FRONT && SAMPLES) ? kOnePer : 1];
-    if constexpr (FRONT) {
-#pragma unroll
-        for (int k = 0; k < kOnePer; ++k) {
-            const int x = slot(k);
-            const int64_t ec = lo + ((x < cnt_tile) ? x : cnt_tile - 1);
-            if constexpr (SAMPLES) {
-                const int32_t *row = src.triples + 3 * ec;
-                q_a[k] = (uint32_t)(row[0] - src.user_base);
-                q_b[k] = (uint32_t)row[1];
-                q_c[k] = (uint32_t)row[2];
-            } else {
-                q_a[k] = src.key[ec];
-            }
-        }
-    }
-    if (pf.mode == DAISY_ORDER_FEISTEL) {                // every lane walks its own strip (see k_part_count)
-        const uint32_t nn = (uint32_t)pf.n;
-        int k = 0, x = slot(0);
-        bool active = x < cnt_tile;
-        auto first = [&]() -> uint32_t {
-            uint32_t t;
-            if constexpr (SAMPLES) t = (uint32_t)(lo + x);
-            else t = lpos[x];
-            return pf.orig ? pf.orig[t] : t;
-        };
-        uint32_t v = active ? first() : 0u;
-        while (active) {
-            v = feistel_once(v, pf.fk);
-            if (v < nn) {
-                lpos[x] = v;
-                atomicAdd(&hist[batch_of(v, bd) & 255u], 1u);
-                ++k;
-                active = false;
-                if (k < kOnePer) {
-                    x = slot(k);
-                    active = x < cnt_tile;
-                    if (active) v = first();
-                }
-            }
-        }
-    } else {
-        for (int k = 0; k < kOnePer; ++k) {
-            const int x = slot(k);
-            if (x < cnt_tile) {
-                uint32_t t;
-                if constexpr (SAMPLES) t = (uint32_t)(lo + x);
-                else t = lpos[x];
-                const uint32_t v = pos_of(pf, t);
-                lpos[x] = v;
-                atomicAdd(&hist[batch_of(v, bd) & 255u], 1u);
-            }
-        }
-    }
-    __syncthreads();
-
-    // ---- publish the tile's counts, then look back for the records of every digit in the tiles before this one
-    if (tid < ndig) {
-        uint64_t *w = op.state + (int64_t)tid * op.tile_stride + tile;
-        __hip_atomic_store(w, (tile == 0 ? kOnePrefix : kOneAgg) | (uint64_t)hist[tid], __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-    }
-    for (int dg = wave; dg < ndig; dg += kPartWaves) {   // wave-uniform loop: one digit per wave and trip
-        uint64_t *row = op.state + (int64_t)dg * op.tile_stride;
-        uint64_t excl = 0;
-        int64_t base = tile - 1;                         // lane l looks at tile base - l
-        while (base >= 0) {
-            const int64_t idx = base - wl;
-            uint64_t st = kOnePrefix;                    // before tile 0: a prefix of nothing
-            if (idx >= 0) st = __hip_atomic_load(row + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t flag = (uint32_t)(st >> 62);
-            const uint64_t m_pref = __ballot(flag == 2u), m_empty = __ballot(flag == 0u);
-            const int fp = m_pref ? (int)__builtin_ctzll(m_pref) : 64;     // nearest tile that already knows its prefix
-            const uint64_t need = (fp >= 63) ? ~(uint64_t)0 : (((uint64_t)1 << (fp + 1)) - 1);
-            if (m_empty & need) {                        // somebody up to there has not published yet: poll again
-                __builtin_amdgcn_s_sleep(4);
-                continue;
-            }
-            excl += wave_sum_u64((wl <= fp) ? (st & kOneVal) : 0);
-            if (fp < 64) break;
-            base -= kWave;
-        }
-        if (wl == 0) {
-            goff[dg] = (uint32_t)((uint64_t)dg * (uint64_t)op.bucket_elems + excl);
-            if (tile > 0)
-                __hip_atomic_store(row + tile, kOnePrefix | (excl + (uint64_t)hist[dg]), __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __syncthreads();
-
-    // ---- pass B: the stable scatter of k_part_scatter, sub-tile by sub-tile, positions from LDS
-#pragma unroll
-    for (int sb = 0; sb < kOneSubs; ++sb) {              // (unrolled: FRONT indexes its record registers by sb*8 + r)
-        if (sb * kPartSub >= cnt_tile) break;
-        const int64_t sub = lo + (int64_t)sb * kPartSub;
-#pragma unroll
-        for (int w = 0; w < kPartWaves; ++w) wcnt[w][tid] = 0;
-        __syncthreads();
-        uint32_t r_a[kPartK], r_b[kPartK], r_c[kPartK], r_p[kPartK], r_rank[kPartK], r_dig[kPartK];
-        const int xbase = sb * kPartSub + wave * (kWave * kPartK);
-#pragma unroll
-        for (int r = 0; r < kPartK; ++r) {
-            const int x = xbase + r * kWave + wl;
-            const bool valid = x < cnt_tile;
-            const int xc = valid ? x : cnt_tile - 1;
-            const int64_t ec = lo + xc;
-            if constexpr (FRONT) {
-                r_a[r] = q_a[sb * kPartK + r];
-                if constexpr (SAMPLES) { r_b[r] = q_b[sb * kPartK + r]; r_c[r] = q_c[sb * kPartK + r]; }
-            } else if constexpr (SAMPLES) {
-                const int32_t *row = src.triples + 3 * ec;
-                r_a[r] = (uint32_t)(row[0] - src.user_base);
-                r_b[r] = (uint32_t)row[1];
-                r_c[r] = (uint32_t)row[2];
-            } else {
-                r_a[r] = src.key[ec];
-            }
-            r_p[r] = lpos[xc];
-            const uint32_t dgt = batch_of(r_p[r], bd) & 255u;
-            const uint64_t peers = match_digit(dgt, valid, nbits);
-            const uint32_t base = wcnt[wave][dgt];
-            const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
-            if (valid && rank == 0) wcnt[wave][dgt] = base + (uint32_t)__popcll(peers);
-            r_rank[r] = base + rank;
-            r_dig[r] = valid ? dgt : 0xFFFFFFFFu;
-        }
-        __syncthreads();
-        uint32_t t = 0;
-#pragma unroll
-        for (int w = 0; w < kPartWaves; ++w) { const uint32_t c = wcnt[w][tid]; wcnt[w][tid] = t; t += c; }
-        tot[tid] = t;
-        uint32_t inc = t;
-#pragma unroll
-        for (int off = 1; off < kWave; off <<= 1) {
-            const uint32_t up = __shfl_up(inc, off, kWave);
-            if (wl >= off) inc += up;
-        }
-        if (wl == kWave - 1) wsum[wave] = inc;
-        __syncthreads();
-        uint32_t wprefix = 0;
-#pragma unroll
-        for (int w = 0; w < kPartWaves; ++w) if (w < wave) wprefix += wsum[w];
-        tstart[tid] = wprefix + inc - t;
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < kPartK; ++r) {
-            if (r_dig[r] != 0xFFFFFFFFu) {
-                const uint32_t x = tstart[r_dig[r]] + wcnt[wave][r_dig[r]] + r_rank[r];
-                if constexpr (SAMPLES) rec4[x] = make_uint4(r_a[r], r_b[r], r_c[r], r_p[r]);
-                else rec2[x] = make_uint2(r_a[r], r_p[r]);
-                sdig[x] = (uint8_t)r_dig[r];
-            }
-        }
-        __syncthreads();
-        const int cnt = (int)((hi - sub < kPartSub) ? (hi - sub) : kPartSub);
-        for (int x = tid; x < cnt; x += kPartThreads) {
-            const uint32_t dg = sdig[x];
-            const int64_t o = (int64_t)goff[dg] + (x - tstart[dg]);
-            if constexpr (SAMPLES) {
-                const uint4 q = rec4[x];
-                dst.user[o] = q.x;
-                dst.ij[o] = make_int2((int)q.y, (int)q.z);
-                dst.pos[o] = q.w;
-            } else {
-                const uint2 q = rec2[x];
-                dst.key[o] = q.x;
-                dst.pos[o] = q.y;
-            }
+            if constexpr (SAMPLES) dst.srec[o] = rec4[x];
+            else dst.erec[o] = rec2[x];
         }
         __syncthreads();
         goff[tid] += tot[tid];
@@ -638,13 +371,13 @@ __global__ void k_positions_u32(const int64_t *__restrict__ pos, int64_t n, int6
 }
 
 // off[k] = first record of batch k in the partitioned sample records (their batch ids never decrease)
-__global__ void k_batch_offsets(const uint32_t *__restrict__ pos, int64_t n, BatchDiv bd, int64_t nb,
+__global__ void k_batch_offsets(const uint4 *__restrict__ srec, int64_t n, BatchDiv bd, int64_t nb,
                                 int64_t *__restrict__ off) {
     for (int64_t k = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; k <= nb; k += (int64_t)gridDim.x * blockDim.x) {
         int64_t lo = 0, hi = n;                       // first index whose batch id >= k
         while (lo < hi) {
             const int64_t mid = (lo + hi) >> 1;
-            if ((int64_t)batch_of(pos[mid], bd) < k) lo = mid + 1; else hi = mid;
+            if ((int64_t)batch_of(srec[mid].w, bd) < k) lo = mid + 1; else hi = mid;
         }
         off[k] = lo;
     }
@@ -688,11 +421,12 @@ __global__ void k_read_partitioned(StreamView v, int32_t *__restrict__ u, int32_
                                    uint32_t *__restrict__ ent_s, int32_t *__restrict__ ent_u) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < v.E; e += (int64_t)gridDim.x * blockDim.x) {
         if (e < v.B) {
-            u[e] = (int32_t)(v.s_user[e] & v.umask);
-            i[e] = v.s_ij[e].x;
-            j[e] = v.s_ij[e].y;
+            const uint4 r = sv_sample(v, e);
+            u[e] = (int32_t)r.x;
+            i[e] = (int32_t)r.y;
+            j[e] = (int32_t)r.z;
         }
-        const uint32_t k = v.e_key[e] & v.imask;
+        const uint32_t k = sv_key(v, e);
         if (ent_item) ent_item[e] = (int32_t)(k >> 1);
         if (ent_s) ent_s[e] = ((v.e_pos[e * v.e_stride] & ~kNegBit) - v.pos_base) | ((k & 1u) ? kNegBit : 0u);
         if (ent_u) ent_u[e] = -1;          // this layout does not carry the user with the entry
@@ -708,12 +442,12 @@ StreamView plan_stream_view(const daisy_epoch_plan *p, int64_t k) {
     if (p->h_off) { lo = p->h_off[k]; v.B = p->h_off[k + 1] - lo; }      // a rank's share of the epoch
     const int64_t epl = p->pointwise ? 1 : 2;          // entries per sample (point-wise rows have no negative item)
     v.E = epl * v.B;
-    v.s_user = p->p_user[c] + lo;
-    v.s_ij = p->p_ij[c] + lo;
-    v.s_pos = p->p_pos[c] + lo;
-    v.e_key = p->p_ekey[c] + epl * lo;
-    v.e_pos = p->p_epos[c] + epl * lo;
-    v.e_stride = 1;
+    v.s_rec = p->p_srec[c] + lo;
+    v.s_user = nullptr; v.s_ij = nullptr;
+    v.e_key = reinterpret_cast<const uint32_t *>(p->p_erec[c] + epl * lo);      // record {key, pos}: both at stride 2
+    v.e_pos = v.e_key + 1;
+    v.e_kstride = 2;
+    v.e_stride = 2;
     v.umask = v.imask = 0xFFFFFFFFu;
     v.pos_base = pos_base;
     v.halt = nullptr;
@@ -733,19 +467,18 @@ int plan_read_batch_partitioned(const daisy_epoch_plan *plan, int64_t k, int32_t
     return DAISY_OK;
 }
 
-// record set x of the partitioned layout lives in one allocation: user[n] pos[n] ij[n] ekey[2n] epos[2n]
+// record set x of the partitioned layout lives in one allocation: sample records [n] x 16 B, entry records [2n] x 8 B
 static int plan_need_partitioned(daisy_epoch_plan *p, int set) {
     void **slot = set ? &p->parena2 : &p->parena;
     if (*slot) return DAISY_OK;
     const size_t n = (size_t)p->max_triples;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
-    const size_t o_u = take(n * 4), o_p = take(n * 4);   // adjacent: together they are the 2n-word scratch of the entry pass
-    const size_t o_ij = take(n * 8), o_ek = take(n * 8), o_ep = take(n * 8);
+    const size_t o_s = take(n * 16), o_e = take(n * 16);
     size_t o_cnt = 0, o_tmp = 0, o_inv = 0, cnt_elems = 0;
     if (set == 0) {
         const int64_t max_tiles = (2 * (int64_t)n + kPartSub - 1) / kPartSub;
-        const int64_t tiles = max_tiles < 16384 ? max_tiles : 16384 + 1;
+        const int64_t tiles = max_tiles < kPartMaxTiles ? max_tiles : kPartMaxTiles + 1;
         cnt_elems = (size_t)256 * (size_t)(tiles + 1);
         p->ptemp_bytes = exclusive_scan_u32_temp_bytes((int64_t)cnt_elems);
         o_cnt = take(cnt_elems * 4 * 2);   // counts, then their exclusive scan
@@ -761,11 +494,8 @@ static int plan_need_partitioned(daisy_epoch_plan *p, int set) {
     *slot = mem;
     p->parena_bytes += off;
     char *b = (char *)mem;
-    p->p_user[set] = (uint32_t *)(b + o_u);
-    p->p_pos[set] = (uint32_t *)(b + o_p);
-    p->p_ij[set] = (int2 *)(b + o_ij);
-    p->p_ekey[set] = (uint32_t *)(b + o_ek);
-    p->p_epos[set] = (uint32_t *)(b + o_ep);
+    p->p_srec[set] = (uint4 *)(b + o_s);
+    p->p_erec[set] = (uint2 *)(b + o_e);
     if (set == 0) {
         p->p_counts = (uint32_t *)(b + o_cnt);
         p->p_offsets = p->p_counts + cnt_elems;
@@ -775,16 +505,17 @@ static int plan_need_partitioned(daisy_epoch_plan *p, int set) {
     return DAISY_OK;
 }
 
-static void part_tiling(int64_t n, int64_t &tile_elems, int64_t &ntiles) {
-    // at most this many tiles (workgroups): fewer, longer tiles write consecutive pieces of a bucket from the same
-    // workgroup a few microseconds apart (the partial lines at the piece boundaries merge in L2) - a sweep that is
-    // still to be run (the counters say the scatter writes 2.1x its records); 16384 is the count every measurement
-    // so far was taken with
-    const int64_t cap_env = getenv("DAISY_PART_TILES") ? atoll(getenv("DAISY_PART_TILES")) : 16384;   // (per build)
-    const int64_t cap = cap_env < 256 ? 256 : (cap_env > 16384 ? 16384 : cap_env);      // (the count buffers hold 16384 + 1)
-    int64_t subs = (n + (int64_t)kPartSub * cap - 1) / ((int64_t)kPartSub * cap);
+// tiles (workgroups) of a partition over n records whose sub-tiles hold `sub` records: at most kPartMaxTiles (the count
+// buffers hold that many; fewer, longer tiles measured slower - profiles/r04_plan_variants.txt)
+static void part_tiling(int64_t n, int64_t sub, int64_t &tile_elems, int64_t &ntiles) {
+    // DAISY_PART_TILES: fewer tiles than the buffers hold (read per build).  Tiles of several sub-tiles otherwise need
+    // more than 67 M records: the tests use it to walk that loop on small plans
+    const char *env = getenv("DAISY_PART_TILES");
+    int64_t cap = env ? atoll(env) : kPartMaxTiles;
+    cap = cap < 1 ? 1 : (cap > kPartMaxTiles ? kPartMaxTiles : cap);
+    int64_t subs = (n + sub * cap - 1) / (sub * cap);
     if (subs < 1) subs = 1;
-    tile_elems = subs * kPartSub;
+    tile_elems = subs * sub;
     ntiles = (n + tile_elems - 1) / tile_elems;
 }
 
@@ -832,69 +563,12 @@ static int plan_build_partitioned(daisy_epoch_plan *p, const daisy_train_index *
     }
     const BatchDiv bd = make_batch_div(batch_size);
 
-    // 0 (default): count (positions parked) / scan / scatter.  1, 2: k_part_onepass (2: front-loaded).  3: count / scan /
-    // scatter with nothing parked - the scatter walks the positions itself (k_part_scatter<.., WALK>)
-    const int tune_onepass = getenv("DAISY_PLAN_ONEPASS") ? atoi(getenv("DAISY_PLAN_ONEPASS")) : 0;
-    const bool walk = tune_onepass == 3;
-    if ((tune_onepass == 1 || tune_onepass == 2) && passes == 1 && !subset) {
-        // ---- one launch per record kind (k_part_onepass); its look-back words and tickets are zeroed by one memset
-        const int64_t nt_e = (ix->n_ent + kOneTile - 1) / kOneTile, nt_s = (n + kOneTile - 1) / kOneTile;
-        const int ndig = (int)nb;
-        const size_t words = (size_t)ndig * (size_t)(nt_e + nt_s);
-        const size_t bytes = words * 8 + 64;
-        if (p->p_onepass_bytes < bytes) {
-            if (p->p_onepass) (void)hipFree(p->p_onepass);
-            p->p_onepass = nullptr; p->p_onepass_bytes = 0;
-            // room for every batch size of this plan: 256 digits, the tiles of max_triples
-            const size_t cap_tiles = (size_t)((2 * p->max_triples + kOneTile - 1) / kOneTile + (p->max_triples + kOneTile - 1) / kOneTile);
-            size_t cap = (size_t)256 * cap_tiles * 8 + 64;
-            if (cap < bytes) cap = bytes;
-            hipError_t e = hipMalloc(&p->p_onepass, cap);
-            if (e != hipSuccess) {
-                set_error("epoch_plan_build_indexed: hipMalloc(%zu) failed: %s", cap, hipGetErrorString(e));
-                p->p_onepass = nullptr;
-                return DAISY_ERR_HIP;
-            }
-            p->p_onepass_bytes = cap;
-        }
-        DAISY_HIP(hipMemsetAsync(p->p_onepass, 0, bytes, s));
-        uint64_t *st = (uint64_t *)p->p_onepass;
-        uint32_t *tickets = (uint32_t *)(st + words);
-        PartSrc src;
-        memset(&src, 0, sizeof(src));
-        src.triples = ix->triples; src.user_base = ix->user_base;
-        src.ent_t = ix->ent_t; src.key = ix->ent_key;
-        PartDst dst;
-        dst.user = p->p_user[0]; dst.ij = p->p_ij[0]; dst.key = p->p_ekey[0];
-        OnePass op;
-        op.state = st; op.ticket = tickets; op.tile_stride = nt_e;
-        op.bucket_elems = (ix->pointwise ? 1 : 2) * batch_size;
-        dst.pos = p->p_epos[0];
-        if (tune_onepass == 2)
-            hipLaunchKernelGGL((k_part_onepass<false, true>), dim3((unsigned)nt_e), dim3(kPartThreads), 0, s, src, pf, bd,
-                               ix->n_ent, bbits, ndig, op, dst);
-        else
-            hipLaunchKernelGGL((k_part_onepass<false, false>), dim3((unsigned)nt_e), dim3(kPartThreads), 0, s, src, pf, bd,
-                               ix->n_ent, bbits, ndig, op, dst);
-        DAISY_LAUNCH_CHECK();
-        op.state = st + (size_t)ndig * (size_t)nt_e; op.ticket = tickets + 1; op.tile_stride = nt_s;
-        op.bucket_elems = batch_size;
-        dst.pos = p->p_pos[0];
-        if (tune_onepass == 2)
-            hipLaunchKernelGGL((k_part_onepass<true, true>), dim3((unsigned)nt_s), dim3(kPartThreads), 0, s, src, pf, bd, n,
-                               bbits, ndig, op, dst);
-        else
-            hipLaunchKernelGGL((k_part_onepass<true, false>), dim3((unsigned)nt_s), dim3(kPartThreads), 0, s, src, pf, bd, n,
-                               bbits, ndig, op, dst);
-        DAISY_LAUNCH_CHECK();
-    } else
-    // ---- entries first: their counting pass parks the positions in the (still unused) sample arrays of
-    // the destination set; then the samples
+    // per record kind (entries, then samples) and LSD digit: histogram of every tile, exclusive scan, stable scatter
     for (int what = 0; what < 2; ++what) {
         const bool entries = (what == 0);
         const int64_t m = entries ? ix->n_ent : n;
         int64_t tile_elems, ntiles;
-        part_tiling(m, tile_elems, ntiles);
+        part_tiling(m, kPartThreads * (entries ? kPartKE : kPartK), tile_elems, ntiles);
         for (int pass = 0; pass < passes; ++pass) {
             const int shift = 8 * pass;
             const int bits_here = (bbits - shift < 8) ? (bbits - shift) : 8;
@@ -905,52 +579,26 @@ static int plan_build_partitioned(daisy_epoch_plan *p, const daisy_train_index *
             const int sset = dset ^ 1;
             PartSrc src;
             memset(&src, 0, sizeof(src));
-            PartDst dst;
-            dst.user = p->p_user[dset]; dst.ij = p->p_ij[dset];
-            dst.key = p->p_ekey[dset];
-            dst.pos = entries ? p->p_epos[dset] : p->p_pos[dset];
-            uint32_t *scratch_pos = p->p_user[dset];            // 2n words: p_user | p_pos of the destination set
-            if (pass == 0) {
-                src.triples = ix->triples; src.user_base = ix->user_base;
-                src.ent_t = ix->ent_t; src.key = ix->ent_key;
-                if (entries) {
-                    uint32_t *park = walk ? nullptr : scratch_pos;
-                    src.pos = park;
-                    hipLaunchKernelGGL((k_part_count<1>), dim3((unsigned)ntiles), dim3(kPartThreads), 0, s, src, pf,
-                                       bd, m, shift, bits_here, ndig, tile_elems, ntiles, park, p->p_counts);
-                } else {
-                    // the Feistel positions of the samples are parked in the (otherwise unused) inverse-permutation
-                    // buffer; identity / explicit orders are a load or nothing, so they are simply re-evaluated
-                    uint32_t *park = (order_mode == DAISY_ORDER_FEISTEL && !walk) ? p->p_inv : nullptr;
-                    src.pos = park;
-                    hipLaunchKernelGGL((k_part_count<0>), dim3((unsigned)ntiles), dim3(kPartThreads), 0, s, src, pf,
-                                       bd, m, shift, bits_here, ndig, tile_elems, ntiles, park, p->p_counts);
-                }
-            } else {
-                src.user = p->p_user[sset]; src.ij = p->p_ij[sset]; src.key = p->p_ekey[sset];
-                src.pos = entries ? p->p_epos[sset] : p->p_pos[sset];
-                hipLaunchKernelGGL((k_part_count<2>), dim3((unsigned)ntiles), dim3(kPartThreads), 0, s, src, pf, bd,
-                                   m, shift, bits_here, ndig, tile_elems, ntiles, (uint32_t *)nullptr, p->p_counts);
-            }
+            src.triples = ix->triples; src.user_base = ix->user_base;
+            src.ent_t = ix->ent_t; src.ent_key = ix->ent_key;
+            src.srec = p->p_srec[sset]; src.erec = p->p_erec[sset];
+            const PartDst dst{p->p_srec[dset], p->p_erec[dset]};
+            const dim3 g((unsigned)ntiles), b(kPartThreads);
+#define DAISY_PART_COUNT(KIND)                                                                                      \
+    hipLaunchKernelGGL((k_part_count<KIND>), g, b, 0, s, src, pf, bd, m, shift, bits_here, ndig, tile_elems, ntiles, \
+                       p->p_counts)
+            if (pass == 0) { if (entries) DAISY_PART_COUNT(1); else DAISY_PART_COUNT(0); }
+            else { if (entries) DAISY_PART_COUNT(3); else DAISY_PART_COUNT(2); }
+#undef DAISY_PART_COUNT
             DAISY_LAUNCH_CHECK();
             rc = exclusive_scan_u32(p->ptemp, p->ptemp_bytes, p->p_counts, p->p_offsets, (int64_t)ndig * ntiles, s);
             if (rc) return rc;
-            const dim3 g((unsigned)ntiles), b(kPartThreads);
-            if (pass == 0 && walk && entries)
-                hipLaunchKernelGGL((k_part_scatter<false, true, true>), g, b, 0, s, src, pf, bd, m, shift, bits_here, ndig,
-                                   tile_elems, ntiles, p->p_offsets, dst);
-            else if (pass == 0 && walk)
-                hipLaunchKernelGGL((k_part_scatter<true, true, true>), g, b, 0, s, src, pf, bd, m, shift, bits_here, ndig,
-                                   tile_elems, ntiles, p->p_offsets, dst);
-            else if (entries)
-                hipLaunchKernelGGL((k_part_scatter<false, false>), g, b, 0, s, src, pf, bd, m, shift, bits_here, ndig,
-                                   tile_elems, ntiles, p->p_offsets, dst);
-            else if (pass == 0)
-                hipLaunchKernelGGL((k_part_scatter<true, true>), g, b, 0, s, src, pf, bd, m, shift, bits_here, ndig,
-                                   tile_elems, ntiles, p->p_offsets, dst);
-            else
-                hipLaunchKernelGGL((k_part_scatter<true, false>), g, b, 0, s, src, pf, bd, m, shift, bits_here, ndig,
-                                   tile_elems, ntiles, p->p_offsets, dst);
+#define DAISY_PART_SCATTER(SAMPLES, STATIC, KK)                                                                      \
+    hipLaunchKernelGGL((k_part_scatter<SAMPLES, STATIC, KK>), g, b, 0, s, src, pf, bd, m, shift, bits_here, ndig,      \
+                       tile_elems, ntiles, p->p_offsets, 0u, dst)
+            if (entries) { if (pass == 0) DAISY_PART_SCATTER(false, true, kPartKE); else DAISY_PART_SCATTER(false, false, kPartKE); }
+            else { if (pass == 0) DAISY_PART_SCATTER(true, true, kPartK); else DAISY_PART_SCATTER(true, false, kPartK); }
+#undef DAISY_PART_SCATTER
             DAISY_LAUNCH_CHECK();
         }
     }
@@ -959,7 +607,7 @@ static int plan_build_partitioned(daisy_epoch_plan *p, const daisy_train_index *
     p->pointwise = ix->pointwise;
     p->kind = 1;
     if (subset) {          // where every batch starts: one small copy and one host sync per epoch
-        hipLaunchKernelGGL(k_batch_offsets, dim3(grid_for(nb + 1, kBlock)), dim3(kBlock), 0, s, p->p_pos[0], n, bd, nb,
+        hipLaunchKernelGGL(k_batch_offsets, dim3(grid_for(nb + 1, kBlock)), dim3(kBlock), 0, s, p->p_srec[0], n, bd, nb,
                            p->d_off);
         DAISY_LAUNCH_CHECK();
         int bad_host[2] = {0, 0};
@@ -1035,7 +683,7 @@ __global__ __launch_bounds__(kBlock) void k_unorm(const float *__restrict__ p_sq
     double acc = 0.0;
     for (int64_t s = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; s < v.B;
          s += (int64_t)gridDim.x * blockDim.x)
-        acc += (double)p_sqnorm[v.s_user[s] & v.umask];
+        acc += (double)p_sqnorm[sv_user(v, s)];
     __shared__ double sm[kBlock / kWave];
     const double w = wave_sum_f64(acc);
     if ((threadIdx.x % kWave) == 0) sm[threadIdx.x / kWave] = w;
@@ -1067,7 +715,7 @@ __global__ __launch_bounds__(kBlock) void k_unorm_reduce(const double *__restric
 // partial sums (RideReduce) - two launches less per step (k_unorm, k_unorm_reduce: ~12 us of kernels and two
 // kernel boundaries of a 0.57 ms step, one of five launches below ~130 k samples).
 struct RideUnorm {
-    const float *p_sqnorm; const uint32_t *s_user; uint32_t umask; int64_t B;
+    const float *p_sqnorm; const uint4 *s_rec; int64_t B;        // the sample records of the NEXT batch (partitioned plan)
     double *partials; int first_block, nblocks;      // nblocks == 0: nothing rides
 };
 struct RideReduce { const double *partials; int n; double *stats; };    // n == 0: nothing rides
@@ -1075,7 +723,7 @@ struct RideReduce { const double *partials; int n; double *stats; };    // n == 
 __device__ __forceinline__ void unorm_block(const RideUnorm &r, int b) {
     double acc = 0.0;
     for (int64_t s = (int64_t)b * blockDim.x + threadIdx.x; s < r.B; s += (int64_t)r.nblocks * blockDim.x)
-        acc += (double)r.p_sqnorm[r.s_user[s] & r.umask];
+        acc += (double)r.p_sqnorm[r.s_rec[s].x];
     __shared__ double sm_ride[kBlock / kWave];
     const double w = wave_sum_f64(acc);
     if ((threadIdx.x % kWave) == 0) sm_ride[threadIdx.x / kWave] = w;
@@ -1183,13 +831,18 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((C::NE <= 4
         // unconditional on a clamped address (a branch around a load drains vmcnt first)
         const int64_t last = n - 1;
         const int64_t il = (t0 + lane < n) ? (t0 + lane) : last;
-        const uint32_t k_me = v.s_user[il] & v.umask;
-        const int2 ij_me = v.s_ij[il];
-        uint32_t slot_me = (uint32_t)il;
-        if constexpr (HAS_POS) slot_me = v.s_pos[il] - v.pos_base;
-        const uint32_t k_prev = v.s_user[(t0 > 0) ? ((t0 - 1 < n) ? t0 - 1 : last) : 0] & v.umask;
-        const uint32_t k_next = v.s_user[(t1 < n) ? t1 : last] & v.umask;
-        const uint32_t k_cprev = v.s_user[(c0 > 0) ? c0 - 1 : 0] & v.umask;
+        const int64_t i_prev = (t0 > 0) ? ((t0 - 1 < n) ? t0 - 1 : last) : 0, i_next = (t1 < n) ? t1 : last;
+        const int64_t i_cprev = (c0 > 0) ? c0 - 1 : 0;
+        uint32_t k_me, slot_me, k_prev, k_next, k_cprev;
+        int2 ij_me;
+        if constexpr (HAS_POS) {            // partitioned plan: one 16-byte record per sample
+            const uint4 rec = v.s_rec[il];
+            k_me = rec.x; ij_me = make_int2((int)rec.y, (int)rec.z); slot_me = rec.w - v.pos_base;
+            k_prev = v.s_rec[i_prev].x; k_next = v.s_rec[i_next].x; k_cprev = v.s_rec[i_cprev].x;
+        } else {
+            k_me = v.s_user[il] & v.umask; ij_me = v.s_ij[il]; slot_me = (uint32_t)il;
+            k_prev = v.s_user[i_prev] & v.umask; k_next = v.s_user[i_next] & v.umask; k_cprev = v.s_user[i_cprev] & v.umask;
+        }
         const int32_t my_user = (lane < cnt) ? (int32_t)k_me : -1;
         const int2 my_ij = (lane < cnt) ? ij_me : make_int2(0, 0);
         const int32_t user_prev = (cnt > 0 && t0 > 0) ? (int32_t)k_prev : -1;
@@ -1480,7 +1133,8 @@ struct QWindow { const float *lds; int32_t first, rows; };
 // what the owner of a finished segment does with  g = sum_e w_e * stage[slot(e)]  and the entry counts:
 //   APPLY:  regulariser reg_1*(np+nn)*sign(q) + reg_2*(np/|Q[i]|_F + nn/|Q[j]|_F)*q  (MFRecommender.py:88-89), then the
 //           optimiser's step on Q[item] in place; FM: i_bias[item] follows with the sum of the coefficients
-//   else:   gQ[item] = g (data term), cnt[item] = (np, nn): what a multi-GPU step reduce-scatters
+//   else:   gQ[item] = g (data term), cnt[item] = (np, nn): what a multi-GPU step reduce-scatters (FM: g_i_bias[item] =
+//           the sum of the coefficients, which the ranks all-reduce)
 template <class C, bool APPLY, bool ADAM>
 __device__ __forceinline__ void item_commit(float *__restrict__ Qo, float *__restrict__ cnt_out, int64_t item,
                                             const Row<C> &g, float np, float nn, float sb, int lane, int d,
@@ -1516,7 +1170,10 @@ __device__ __forceinline__ void item_commit(float *__restrict__ Qo, float *__res
         }
     } else {
         g.store(Qo + item * d, lane, d);
-        if (lane == 0) { cnt_out[2 * item] = np; cnt_out[2 * item + 1] = nn; }
+        if (lane == 0) {
+            cnt_out[2 * item] = np; cnt_out[2 * item + 1] = nn;
+            if (fm.bi) fm.g_bi[item] = sb;       // FM under a multi-GPU step: dL/d i_bias[item] travels like gQ's rows
+        }
     }
 }
 
@@ -1546,7 +1203,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(ADAM ? 2 : 
     // pass into such slices so that a finished slice can be exchanged while the next one is reduced.
     if (erange) {
         const int64_t lo = erange[0];
-        v.e_key += lo;
+        v.e_key += lo * v.e_kstride;
         v.e_pos += lo * v.e_stride;
         v.E = erange[1] - lo;
     }
@@ -1586,11 +1243,11 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(ADAM ? 2 : 
         // ---- hop 1: the run's metadata, lane x <- entry x, plus the entries around the run
         const int64_t last = n - 1;
         const int64_t il = (t0 + lane < n) ? (t0 + lane) : last;
-        const uint32_t k_me = v.e_key[il] & v.imask;
+        const uint32_t k_me = sv_key(v, il);
         const uint32_t slot_me = (v.e_pos[il * v.e_stride] & ~kNegBit) - v.pos_base;
-        const uint32_t k_prev = v.e_key[(t0 > 0) ? ((t0 - 1 < n) ? t0 - 1 : last) : 0] & v.imask;
-        const uint32_t k_next = v.e_key[(t1 < n) ? t1 : last] & v.imask;
-        const uint32_t k_cprev = v.e_key[(c0 > 0) ? c0 - 1 : 0] & v.imask;
+        const uint32_t k_prev = sv_key(v, (t0 > 0) ? ((t0 - 1 < n) ? t0 - 1 : last) : 0);
+        const uint32_t k_next = sv_key(v, (t1 < n) ? t1 : last);
+        const uint32_t k_cprev = sv_key(v, (c0 > 0) ? c0 - 1 : 0);
         const int32_t my_item = (lane < cnt) ? (int32_t)(k_me >> 1) : -1;
         const int32_t my_neg = (int32_t)(k_me & 1u);
         const int32_t item_prev = (cnt > 0 && t0 > 0) ? (int32_t)(k_prev >> 1) : -1;
@@ -1599,8 +1256,8 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(ADAM ? 2 : 
         QWindow win{qwin, 0, 0};
         if constexpr (WIN) {
             const int64_t c1 = (c0 + E < n) ? (c0 + E) : n;
-            win.first = (int32_t)((v.e_key[c0] & v.imask) >> 1);
-            const int32_t item_hi = (int32_t)((v.e_key[c1 - 1] & v.imask) >> 1);
+            win.first = (int32_t)(sv_key(v, c0) >> 1);
+            const int32_t item_hi = (int32_t)(sv_key(v, c1 - 1) >> 1);
             const int32_t cap = WINF / d;
             win.rows = (item_hi - win.first + 1 < cap) ? (item_hi - win.first + 1) : cap;
             const int units = win.rows * (d >> 2);                      // 16-byte units, contiguous in Q
@@ -1647,7 +1304,13 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(ADAM ? 2 : 
                 else p[x].zero();
             }
         }
-        if constexpr (WIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the window has landed before anyone reads it
+        // the window has landed before anyone reads it.  (Round 4 tried the counted form - the LDS-DMA issued from an asm
+        // statement so that the compiler keeps no LDS write pending on the VM counter, s_waitcnt vmcnt(RUN * NV) here,
+        // the window read as a proper ds_read_b128 instead of the flat load a generic pointer yields - so that the
+        // reduction starts on the first stage rows while the last are in flight: 24 B of scratch at the 128-register
+        // cap, and within +-1.5 % of this form at both BASELINE shapes, same box: profiles/r04_item_plan_variants.txt.
+        // The pass is not bound by this wait.)
+        if constexpr (WIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
 
         if (cnt > 0) {
@@ -1882,7 +1545,7 @@ __global__ void k_slice_ranges(StreamView v, SliceBounds bounds, int S, int64_t 
     const uint32_t want = (uint32_t)bounds.b[s];
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
-        if (((v.e_key[mid] & v.imask) >> 1) < want) lo = mid + 1; else hi = mid;
+        if ((sv_key(v, mid) >> 1) < want) lo = mid + 1; else hi = mid;
     }
     rng[s] = lo;
 }
@@ -2001,9 +1664,9 @@ static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_ty
     StreamView v = ctx->sv;
     const int d = ctx->d;
     const int mode = staged_mode(ctx, loss_type);
-    const bool has_pos = v.s_pos != nullptr;
-    static const int tune_ps = getenv("DAISY_STAGED_PSTREAM") ? atoi(getenv("DAISY_STAGED_PSTREAM")) : -1;
-    v.p_stream = (tune_ps >= 0) ? tune_ps : ((size_t)ctx->U * (size_t)d * 4 > kStreamTableBytes ? 1 : 0);
+    const bool has_pos = v.s_rec != nullptr;       // (the partitioned plan: the slot comes with the record)
+    v.p_stream = (ctx->p_stream_mode >= 0) ? (ctx->p_stream_mode != 0)
+                                           : ((size_t)ctx->U * (size_t)d * 4 > kStreamTableBytes ? 1 : 0);
     UserEdges ed{ctx->edge_vec, ctx->edge_user, ctx->edge_n, ctx->edge_whole};
     const PreNorm pre{ctx->partials + (size_t)kMaxGrid * 8, n_pre};
     const RowOpt opt = row_opt(lr, adam, true);
@@ -2058,7 +1721,7 @@ static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_ty
 static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_out, bool apply, float lr,
                        float reg_1, float reg_2, const double *stats, hipStream_t s, int slice = -1,
                        const StagedAdam *adam = nullptr, bool bias_grad_out = false,
-                       RideUnorm ride = RideUnorm{nullptr, nullptr, 0u, 0, nullptr, 0, 0},
+                       RideUnorm ride = RideUnorm{nullptr, nullptr, 0, nullptr, 0, 0},
                        RideReduce rr = RideReduce{nullptr, 0, nullptr}) {
     const int64_t *erange = (slice >= 0) ? ctx->slice_rng + slice : nullptr;
     const StreamView &v = ctx->sv;
@@ -2120,7 +1783,7 @@ int staged_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int loss_type, float
     else if ((rc = staged_prenorm(ctx, P, stats, false, &n_pre, s))) return rc;
     if ((rc = staged_user(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, stats, &gu, n_pre, true, epoch_acc, step_loss, s))) return rc;
     // the next batch of the same plan: its pre-norm rides on this step's item pass
-    RideUnorm ride{nullptr, nullptr, 0u, 0, nullptr, 0, 0};
+    RideUnorm ride{nullptr, nullptr, 0, nullptr, 0, 0};
     RideReduce rr{nullptr, 0, nullptr};
     const daisy_epoch_plan *pl = ctx->cur_plan;
     if (tune_ride && pl && pl->kind == 1 && ctx->cur_gen == pl->build_gen && ctx->cur_k + 1 < pl->num_batches &&
@@ -2128,7 +1791,7 @@ int staged_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int loss_type, float
         const StreamView nv = plan_stream_view(pl, ctx->cur_k + 1);
         const int gn = grid_for(nv.B, kBlock * 4);
         const bool fold = gn <= kPreBlocks / 2;              // (the same rule as staged_prenorm)
-        ride.p_sqnorm = ctx->p_sqnorm; ride.s_user = nv.s_user; ride.umask = nv.umask; ride.B = nv.B;
+        ride.p_sqnorm = ctx->p_sqnorm; ride.s_rec = nv.s_rec; ride.B = nv.B;
         ride.partials = fold ? ctx->partials + (size_t)kMaxGrid * 8 : ctx->partials;
         ride.nblocks = gn;
         if (!fold) { rr.partials = ride.partials; rr.n = gn; rr.stats = stats; }
@@ -2158,12 +1821,12 @@ __global__ __launch_bounds__(kBlock) void k_staged_adam_catchup(StreamView v, in
         const bool user_side = x < v.B;
         int64_t row;
         if (user_side) {
-            row = (int64_t)(v.s_user[x] & v.umask);
-            if (x > 0 && (int64_t)(v.s_user[x - 1] & v.umask) == row) continue;
+            row = (int64_t)sv_user(v, x);
+            if (x > 0 && (int64_t)sv_user(v, x - 1) == row) continue;
         } else {
             const int64_t e = x - v.B;
-            row = (int64_t)((v.e_key[e] & v.imask) >> 1);
-            if (e > 0 && (int64_t)((v.e_key[e - 1] & v.imask) >> 1) == row) continue;
+            row = (int64_t)(sv_key(v, e) >> 1);
+            if (e > 0 && (int64_t)(sv_key(v, e - 1) >> 1) == row) continue;
         }
         float *W = user_side ? P : Q, *M = user_side ? a.mP : a.mQ, *V = user_side ? a.vP : a.vQ;
         int32_t *last = user_side ? a.lastP : a.lastQ;
@@ -2363,6 +2026,13 @@ int daisy_bpr_ctx_invalidate_cache(daisy_bpr_ctx *ctx) {
     DAISY_CHECK_ARG(ctx != nullptr, "ctx_invalidate_cache: NULL context");
     ctx->p_sqnorm_of = nullptr;
     ctx->pre_ready = false;       // the next batch's pre-norm that rode on the last item pass was summed from the old cache
+    return DAISY_OK;
+}
+
+int daisy_bpr_ctx_set_p_stream(daisy_bpr_ctx *ctx, int32_t mode) {
+    DAISY_CHECK_ARG(ctx != nullptr, "ctx_set_p_stream: NULL context");
+    DAISY_CHECK_ARG(mode >= -1 && mode <= 1, "ctx_set_p_stream: mode %d not in -1 (automatic), 0, 1", mode);
+    ctx->p_stream_mode = mode;
     return DAISY_OK;
 }
 

@@ -1208,7 +1208,6 @@ static int plan_free(daisy_epoch_plan *p) {
         if (p->k64[k]) (void)hipFree(p->k64[k]);
     if (p->parena) (void)hipFree(p->parena);
     if (p->parena2) (void)hipFree(p->parena2);
-    if (p->p_onepass) (void)hipFree(p->p_onepass);
     if (p->d_off) (void)hipFree(p->d_off);
     free(p->h_off);
     delete p;
@@ -1352,8 +1351,8 @@ int launch_reduce_partials(const double *partials, int nblocks, double *stats, b
 // the same batch as the staged step reads it (stage slot = grouped sample position)
 static StreamView stream_view_of(const BatchView &v) {
     StreamView sv;
-    sv.s_user = v.ukey; sv.s_ij = v.ij; sv.s_pos = nullptr;
-    sv.e_key = v.ekey; sv.e_pos = reinterpret_cast<const uint32_t *>(v.esu); sv.e_stride = 2;
+    sv.s_rec = nullptr; sv.s_user = v.ukey; sv.s_ij = v.ij;
+    sv.e_key = v.ekey; sv.e_kstride = 1; sv.e_pos = reinterpret_cast<const uint32_t *>(v.esu); sv.e_stride = 2;
     sv.umask = v.umask; sv.imask = v.imask; sv.pos_base = 0;
     sv.B = v.B; sv.E = 2 * v.B;
     sv.halt = nullptr;
@@ -1544,6 +1543,7 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
     c->bu = c->bi = c->b0 = c->g_bu = c->g_bi = c->g_b0 = nullptr;
     c->cur_plan = c->pre_plan = nullptr; c->cur_k = c->pre_k = -1; c->cur_gen = c->pre_gen = 0;
     c->pre_P = nullptr; c->pre_stats = nullptr; c->pre_n = 0; c->pre_ready = false;
+    c->p_stream_mode = -1;
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     const size_t o_coef = take((size_t)max_batch * 8);

@@ -223,7 +223,7 @@ class GeneralRecommender(AbstractRecommender):
         inv[perm] = torch.arange(n, dtype=torch.int64, device=row_ids.device)
         return inv[row_ids].contiguous()
 
-    def _fit_sharded(self, train_loader, triples, n, B, loss_id, opt="sgd"):
+    def _fit_sharded(self, train_loader, triples, n, B, loss_id, opt="sgd", biases=None):
         """`fit` over the ranks of a torch.distributed job (one process per GPU).  Every rank calls it
         with the same loader and the same seeds.  Users - with their interactions and their rows of P - are split
         into contiguous ranges; Q is replicated.  Batch k of rank r = its rows among positions [k*B, (k+1)*B) of
@@ -250,6 +250,11 @@ class GeneralRecommender(AbstractRecommender):
                              "(the reference raises IndexError in nn.Embedding, MFRecommender.py:64-65)")
         P_loc = P[lo:hi]
         ctx = ops.BprContext(B, d, hi - lo, I, device=P.device)        # stage slots are positions inside a GLOBAL batch
+        if biases is not None:             # FM: the rank's slice of u_bias, the replicated i_bias / bias_ (sharding.py)
+            for b in biases:
+                dist.broadcast(b, 0)
+            ctx.set_bias(biases[0].view(-1)[lo:hi], biases[1], biases[2],
+                         g_i_bias=torch.zeros(I, dtype=torch.float32, device=P.device))
         index = plan = None
         trainer = UserShardedBprTrainer(ctx, P_loc, Q, lo, self.lr, self.reg_1, self.reg_2, loss_type=loss_id,
                                         item_mode=ops.ITEM_MODES["fused"], slices=self.exchange_slices,
@@ -292,6 +297,8 @@ class GeneralRecommender(AbstractRecommender):
                 a, b = user_range(U, world, r)
                 if b > a:
                     dist.broadcast(P[a:b], r)
+                    if biases is not None:                             # (and with every user's bias)
+                        dist.broadcast(biases[0].view(-1)[a:b], r)
         finally:
             torch.cuda.synchronize()
             ctx.close()
@@ -357,11 +364,11 @@ class GeneralRecommender(AbstractRecommender):
                          g_bias=adam.g[2] if adam is not None else None)
         user_sorted = ops.triples_user_sorted(triples[:n])
         if self._sharded_world() > 1:
-            if item_mode == ops.ITEM_MODES["fused"] and opt in ("sgd", "adam") and biases is None:
+            if item_mode == ops.ITEM_MODES["fused"] and (opt == "sgd" or (opt == "adam" and biases is None)):
                 ctx.close()
                 plan.close()
-                return self._fit_sharded(train_loader, triples, n, B, loss_id, opt)
-            self.logger.info("torch.distributed is initialised, but only SGD / Adam without FM biases + item_mode 'fused' "
+                return self._fit_sharded(train_loader, triples, n, B, loss_id, opt, biases)
+            self.logger.info("torch.distributed is initialised, but only SGD (MF, FM) / Adam (MF) with item_mode 'fused' "
                              "shards the users over the ranks: every rank trains the whole model")
         if item_mode == ops.ITEM_MODES["fused"] and not staged and B > ops.SMALL_BATCH_MAX:
             item_mode = ops.ITEM_MODES["chunked"]

@@ -232,6 +232,11 @@ class BprContext:
         check(lib.daisy_bpr_ctx_invalidate_cache(self._h))
         self._p_key = None
 
+    def set_p_stream(self, mode="auto"):
+        """staged step: user rows read / written past the caches ('auto': by table size - beyond 512 MB; True / False)"""
+        m = -1 if mode in ("auto", None, -1) else (1 if mode else 0)
+        check(lib.daisy_bpr_ctx_set_p_stream(self._h, m))
+
     # -- the staged step in phases (multi-GPU form) ------------------------------------------------
     def staged_prenorm(self, P):
         self._sync_norm_cache(P)

@@ -84,11 +84,15 @@ class UserShardedBprTrainer:
         # issue the collectives even in a group of one rank (they are identities there): lets a single-GPU box
         # drive the real RCCL entry points
         self.collective = self.world > 1 or (bool(always_collective) and dist.is_initialized())
-        if getattr(ctx, "_bias", None) is not None:
-            # FM's bias gradients (stats[SUM_COEF], g_i_bias) are not part of either exchange: the replicas
-            # would drift apart silently
-            raise NotImplementedError("UserShardedBprTrainer: contexts with FM biases are not supported")
         self.staged = self.item_mode == N.ITEM_FUSED and hasattr(ctx, "staged_user")
+        # FM (FMRecommender.py:61-95) on the staged protocol, SGD: u_bias rows live with their users (the user pass
+        # updates the rank's slice in place), i_bias is replicated like Q - its gradient (one float per item, written
+        # by the item pass next to gQ) is all-reduced and every rank applies the same update -, bias_ follows from the
+        # all-reduced sum of the coefficients.  Without these exchanges the replicas would drift apart silently.
+        self.fm = getattr(ctx, "_bias", None)
+        if self.fm is not None and (not self.staged or adam_steps):
+            raise NotImplementedError("UserShardedBprTrainer: FM biases need the staged protocol (item_mode 'fused') "
+                                      "with SGD")
         if self.item_mode == N.ITEM_FUSED and not self.staged:
             self.item_mode = N.ITEM_CHUNKED
         # collectives the backend lacks are emulated with the ones it has (gloo: no reduce_scatter);
@@ -216,6 +220,8 @@ class UserShardedBprTrainer:
         else:
             c.staged_user(self.P, self.Q, self.lr, self.reg_1, self.reg_2, self.loss_type, self.gamma)
         w0 = self._all_reduce(c.stats[:7], async_op=self.overlap)
+        if self.fm is not None:                          # FM: dL/d bias_ = the sum of the coefficients over the GLOBAL batch
+            self._all_reduce(c.stats[N.ST_SUM_COEF:N.ST_SUM_COEF + 1])
         if self.slices == 1:
             c.staged_item(self.lr, self.reg_1, self.reg_2, gQ=self.gQ[:I], cnt=self.cnt[:I],
                           loss_type=self.loss_type)      # overlaps the 56-byte all-reduce
@@ -223,6 +229,7 @@ class UserShardedBprTrainer:
                 w0.wait()
             c.finalize(self.reg_1, self.reg_2)           # every rank: the GLOBAL loss and norms
             self._mark(1)
+            self._fm_bias_step()
             out = self._exchange_items()
             self._mark(2)
             return out
@@ -237,9 +244,21 @@ class UserShardedBprTrainer:
                 c.finalize(self.reg_1, self.reg_2)
             self._exchange_slice(s_)
         self._mark(1)
+        self._fm_bias_step()
         self._join_side()
         self._mark(2)
         return c.stats
+
+    def _fm_bias_step(self):
+        """FM: i_bias -= lr * (all-reduced item-bias gradient), bias_ -= lr * (all-reduced coefficient sum) - the same
+        arithmetic on every rank, so the replicas stay identical (FMRecommender.py:61-68; SGD)"""
+        if self.fm is None:
+            return
+        _, i_bias, bias, _, g_i_bias, _ = self.fm
+        self._all_reduce(g_i_bias)
+        i_bias.view(-1).sub_(g_i_bias, alpha=self.lr)
+        g_i_bias.zero_()
+        bias.view(-1).sub_((self.lr * self.ctx.stats[N.ST_SUM_COEF]).to(bias.dtype))
 
     def _on_side(self):
         """context: the side stream, ordered behind everything queued on the current stream so far"""
@@ -301,8 +320,11 @@ class UserShardedBprTrainer:
         c.stats.zero_()
         self._all_reduce(c.stats[N.ST_SQ_U_PRE:N.ST_SQ_U_PRE + 1])
         self._all_reduce(c.stats[:7])
+        if self.fm is not None:
+            self._all_reduce(c.stats[N.ST_SUM_COEF:N.ST_SUM_COEF + 1])
         c.finalize(self.reg_1, self.reg_2)
         self._mark(1)
+        self._fm_bias_step()
         out = self._exchange_items()
         self._mark(2)
         return out

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DAISY_ABI_VERSION 4
+#define DAISY_ABI_VERSION 5
 
 typedef void *daisy_stream_t; /* hipStream_t */
 
@@ -231,6 +231,13 @@ int64_t daisy_epoch_plan_batch_rows(const daisy_epoch_plan *plan, int64_t k);
 /* The staged step keeps |P[u]|^2 of every row in the context; every entry point that writes P through the
  * context keeps it current or drops it.  A caller that changes P by other means calls this first. */
 int daisy_bpr_ctx_invalidate_cache(daisy_bpr_ctx *ctx);
+
+/* Staged step, user pass: rows of P read and written PAST the caches (nontemporal loads + owner stores) - for user
+ * tables so far beyond the 256 MB Infinity Cache that a row returns only once every few steps (then the cache is left to
+ * Q and the stage).  mode -1 (default): automatic, on for tables > 512 MB (measured: -3.4 ... -5.1 % per step at
+ * 10 M x 64, +0.7 ... +3 % at 1 M x 64); 0: off; 1: on.  Same arithmetic either way (MFRecommender.py:63-97): only the
+ * cache policy of the accesses changes. */
+int daisy_bpr_ctx_set_p_stream(daisy_bpr_ctx *ctx, int32_t mode);
 
 /* The staged step in phases (what daisy_bpr_sgd_step(DAISY_ITEM_FUSED) runs back to back), so that a
  * multi-GPU step can put its collectives between them:

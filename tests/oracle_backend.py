@@ -12,6 +12,11 @@ class OracleContext:
         self.stats = torch.zeros(16, dtype=torch.float64)
         self.epoch_acc = torch.zeros(2, dtype=torch.float64)
         self.gQ = torch.zeros(item_num, d, dtype=torch.float32)
+        self._bias = None
+
+    def set_bias(self, u_bias=None, i_bias=None, bias=None, g_u_bias=None, g_i_bias=None, g_bias=None):
+        """FM (FMRecommender.py:61-68): score += u_bias[u] + i_bias[item] + bias_"""
+        self._bias = None if u_bias is None else (u_bias, i_bias, bias, g_u_bias, g_i_bias, g_bias)
 
     def set_batch_from_triples(self, triples, idx=None, start=0, B=None, user_base=0, validate=True):
         t = triples.numpy() if isinstance(triples, torch.Tensor) else triples
@@ -25,10 +30,15 @@ class OracleContext:
     def forward(self, P, Q, loss_type=0, gamma=1e-10):
         P64, Q64 = P.numpy().astype(np.float64), Q.numpy().astype(np.float64)
         pu, qi, qj = P64[self.u], Q64[self.i], Q64[self.j]
-        terms, cp, cn = O.pair_loss_coef((pu * qi).sum(1), (pu * qj).sum(1), loss_type, gamma)
+        sp, sn = (pu * qi).sum(1), (pu * qj).sum(1)
+        if self._bias is not None:
+            bu, bi, b0 = (x.numpy().astype(np.float64).reshape(-1) for x in self._bias[:3])
+            sp, sn = sp + bu[self.u] + bi[self.i] + b0[0], sn + bu[self.u] + bi[self.j] + b0[0]
+        terms, cp, cn = O.pair_loss_coef(sp, sn, loss_type, gamma)
         self.cp, self.cn = cp, cn
         s = self.stats
         s[0] = terms.sum()
+        s[12] = (cp + cn).sum()                # dL/d bias_ over the LOCAL samples (FM)
         s[1], s[2], s[3] = np.abs(pu).sum(), np.abs(qi).sum(), np.abs(qj).sum()
         s[4], s[5], s[6] = (pu * pu).sum(), (qi * qi).sum(), (qj * qj).sum()
 
@@ -97,6 +107,10 @@ class OracleContext:
         np.add.at(g, self.u, self.cp[:, None] * qi + self.cn[:, None] * qj + reg_1 * np.sign(self.pu_pre)
                   + reg_2 * self._fro(self.pu_pre, nU))
         P.copy_(torch.from_numpy((P64 - lr * g).astype(np.float32)))
+        if self._bias is not None:             # the rank's slice of u_bias follows its users (SGD, in place)
+            gb = np.zeros(P64.shape[0])
+            np.add.at(gb, self.u, self.cp + self.cn)
+            self._bias[0].view(-1).sub_(torch.from_numpy((lr * gb).astype(np.float32)))
 
     def staged_item(self, lr, reg_1, reg_2, Q=None, gQ=None, cnt=None, loss_type=0):
         assert Q is None, "the oracle backend only restates the gradient-output form"
@@ -106,6 +120,11 @@ class OracleContext:
         np.add.at(g, self.j, self.cn[:, None] * self.pu_pre)
         np.add.at(c[:, 0], self.i, 1.0)
         np.add.at(c[:, 1], self.j, 1.0)
+        if self._bias is not None:             # dL/d i_bias of the LOCAL samples, all-reduced by the trainer
+            gb = np.zeros(self.item_num)
+            np.add.at(gb, self.i, self.cp)
+            np.add.at(gb, self.j, self.cn)
+            self._bias[4].copy_(torch.from_numpy(gb.astype(np.float32)))
         gQ += torch.from_numpy(g.astype(np.float32))
         cnt += torch.from_numpy(c.astype(np.float32))
 

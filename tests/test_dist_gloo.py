@@ -209,3 +209,65 @@ def test_row_sharded_lightgcn_product_on_cpu(tmp_path, world, pieces):
         o = np.load(os.path.join(str(tmp_path), f"lg{r}.npz"))
         np.testing.assert_allclose(o["y1"], want1, atol=1e-6)
         np.testing.assert_allclose(o["y2"], want2, atol=1e-5)
+
+
+def _fm_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from daisyrec_amd.sharding import UserShardedBprTrainer, shard_triples, user_range
+    from daisyrec_amd import _native as N
+    from oracle_backend import OracleContext
+    P0, Q0, batches = _data(True)
+    bu0, bi0, b00 = _fm_biases()
+    lo, hi = user_range(U, world, rank)
+    P, Q = torch.from_numpy(P0[lo:hi].copy()), torch.from_numpy(Q0.copy())
+    bu, bi, b0 = torch.from_numpy(bu0[lo:hi].copy()), torch.from_numpy(bi0.copy()), torch.from_numpy(b00.copy())
+    ctx = OracleContext(B, D, hi - lo, I)
+    ctx.set_bias(bu, bi, b0, g_i_bias=torch.zeros(I))
+    tr = UserShardedBprTrainer(ctx, P, Q, lo, LR, R1, R2, item_mode=N.ITEM_FUSED, slices=1 + rank % 1)
+    assert tr.staged and tr.fm is not None
+    losses = []
+    for b in batches:
+        mine = shard_triples(b, U, world, rank)
+        stats = tr.step_from_plan(None, 0) if len(mine) == 0 else tr.step_from_triples(torch.from_numpy(mine))
+        losses.append(float(stats[7]))
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), P=P.numpy(), Q=Q.numpy(), bu=bu.numpy(), bi=bi.numpy(), b0=b0.numpy(),
+             lo=lo, hi=hi, losses=np.array(losses))
+    dist.destroy_process_group()
+
+
+def _fm_biases():
+    rng = np.random.default_rng(21)
+    return ((rng.standard_normal(U) * 0.1).astype(np.float32), (rng.standard_normal(I) * 0.1).astype(np.float32),
+            np.array([0.05], np.float32))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_fm_user_sharding_equals_single_process(tmp_path, world):
+    """FM's three bias parameters through the sharded protocol: u_bias rows with their users, the
+    item-bias gradient all-reduced, bias_ from the all-reduced coefficient sum; one step leaves ranks without samples
+    (they still join the bias exchanges) - against oracle.fm_numpy.fm_sgd_step on the union batches"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle import fm_numpy as F
+    mp.spawn(_fm_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    P, Q, batches = _data(True)
+    cur = [P, Q, *_fm_biases()]
+    ref_losses = []
+    for b in batches:
+        loss, *cur = F.fm_sgd_step(*cur, b[:, 0], b[:, 1], b[:, 2], LR, R1, R2)
+        ref_losses.append(loss)
+    P, Q, bu, bi, b0 = cur
+    outs = [np.load(os.path.join(str(tmp_path), f"r{r}.npz")) for r in range(world)]
+    for o in outs:
+        lo, hi = int(o["lo"]), int(o["hi"])
+        np.testing.assert_allclose(o["losses"], ref_losses, rtol=1e-6)
+        np.testing.assert_allclose(o["Q"], Q, atol=3e-6)
+        np.testing.assert_allclose(o["P"], P[lo:hi], atol=3e-6)
+        np.testing.assert_allclose(o["bu"], np.asarray(bu).reshape(-1)[lo:hi], atol=3e-6)
+        np.testing.assert_allclose(o["bi"], np.asarray(bi).reshape(-1), atol=3e-6)
+        np.testing.assert_allclose(o["b0"], np.asarray(b0).reshape(-1), atol=3e-6)
+    for o in outs[1:]:
+        np.testing.assert_array_equal(outs[0]["bi"], o["bi"])
+        np.testing.assert_array_equal(outs[0]["b0"], o["b0"])
+

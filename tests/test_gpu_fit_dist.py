@@ -45,9 +45,10 @@ def _config(shuffle_mode, shape=None):
 
 def _fit(shuffle_mode, shuffle, shape=None):
     from daisyrec_amd.model.MFRecommender import MF
+    from daisyrec_amd.model.FMRecommender import FM
     from daisyrec_amd.utils.dataset import BasicDataset, get_dataloader
     torch.manual_seed(123)
-    model = MF(_config(shuffle_mode, shape))
+    model = (FM if os.environ.get("DAISY_TEST_MODEL") == "fm" else MF)(_config(shuffle_mode, shape))
     loader = get_dataloader(BasicDataset(_triples(shape)), batch_size=(shape or (0, 0, 0, 0, B))[4], shuffle=shuffle,
                             num_workers=0)
     torch.manual_seed(321)                           # the loader's permutations
@@ -66,8 +67,15 @@ def _worker(rank, world, port, out_dir, shuffle_mode, shuffle, backend="gloo", s
         dist.init_process_group("gloo", rank=rank, world_size=world)
     model = _fit(shuffle_mode, shuffle, shape)
     np.savez(os.path.join(out_dir, f"r{rank}.npz"), P=model.embed_user.weight.data.cpu().numpy(),
-             Q=model.embed_item.weight.data.cpu().numpy(), losses=np.array(model.epoch_losses))
+             Q=model.embed_item.weight.data.cpu().numpy(), losses=np.array(model.epoch_losses), **_bias_arrays(model))
     dist.destroy_process_group()
+
+
+def _bias_arrays(model):
+    if not hasattr(model, "u_bias"):
+        return {}
+    return {"bu": model.u_bias.weight.data.cpu().numpy().reshape(-1), "bi": model.i_bias.weight.data.cpu().numpy().reshape(-1),
+            "b0": model.bias_.data.cpu().numpy().reshape(-1)}
 
 
 def _free_port():
@@ -87,6 +95,8 @@ def _compare(tmp_path, world, shuffle_mode, shuffle, shape=None, atol=5e-6):
         np.testing.assert_allclose(o["losses"], ref.epoch_losses, rtol=2e-6)
         np.testing.assert_allclose(o["Q"], Q, atol=atol)          # (fp32 summation order differs: typically 1e-7)
         np.testing.assert_allclose(o["P"], P, atol=atol)          # every rank ends with the WHOLE user table
+        for k, v in _bias_arrays(ref).items():                    # FM: every user's bias, the replicated item biases, bias_
+            np.testing.assert_allclose(o[k], v, atol=atol, err_msg=k)
 
 
 @pytest.mark.parametrize("shuffle_mode,shuffle", [("loader", True), ("device", True), ("loader", False)])
@@ -117,6 +127,18 @@ def test_adam_fit_over_three_ranks_equals_the_single_process_fit(tmp_path, loss,
     world = 3
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "device", True), nprocs=world, join=True)
     _compare(tmp_path, world, "device", True, atol=1e-4)
+
+
+@pytest.mark.parametrize("loss,shape", [("BPR", None), ("CL", None), ("TL", SMALL)])
+def test_fm_fit_over_three_ranks_equals_the_single_process_fit(tmp_path, loss, shape, monkeypatch):
+    """FM (FMRecommender.py:61-95) sharded by user: u_bias rows travel with their users, the item-bias gradient is
+    all-reduced next to the item exchange, bias_ follows from the all-reduced coefficient sum - against the
+    single-process FM fit: losses, both tables, all three bias parameters.  SMALL: ranks without a sample in many steps"""
+    monkeypatch.setenv("DAISY_TEST_LOSS", loss)
+    monkeypatch.setenv("DAISY_TEST_MODEL", "fm")
+    world = 3
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "device", True, "gloo", shape), nprocs=world, join=True)
+    _compare(tmp_path, world, "device", True, shape)
 
 
 def test_fit_over_ranks_with_small_lopsided_batches(tmp_path):

@@ -31,12 +31,13 @@ def _plan_batches(plan, nb, B):
                                           (513, 1000, 50, 70, False), (7, 1, 5, 5, False),
                                           (70000, 100, 900, 1200, False),        # 700 batches: two LSD passes
                                           (300000, 4096, 20000, 3000, True)])
-@pytest.mark.parametrize("onepass", [0, 1])
-def test_partitioned_plan_bit_exact(n, B, U, I, sort, onepass, monkeypatch):
-    """onepass = 1: the opt-in single-launch partition with a decoupled look-back (k_part_onepass; plans of at most 256
-    batches, others take the three-launch build) must produce the very same records"""
+@pytest.mark.parametrize("tiles", [0, 3])
+def test_partitioned_plan_bit_exact(n, B, U, I, sort, tiles, monkeypatch):
+    """tiles = 3: at most three tiles (workgroups) per partition, so that a tile walks SEVERAL sub-tiles - what plans
+    beyond 67 M records do with the default 16384 tiles - and ends in a partial one"""
     from daisyrec_amd import ops
-    monkeypatch.setenv("DAISY_PLAN_ONEPASS", str(onepass))
+    if tiles:
+        monkeypatch.setenv("DAISY_PART_TILES", str(tiles))
     tri = _triples(n, U, I, n, sort)
     t_dev = torch.from_numpy(tri).to(DEV)
     index = ops.TrainIndex(t_dev, U, I)
@@ -66,12 +67,13 @@ def test_partitioned_plan_bit_exact(n, B, U, I, sort, onepass, monkeypatch):
 
 
 @pytest.mark.parametrize("n,B,U,I", [(1000, 64, 300, 200), (4097, 256, 300, 200), (70000, 100, 900, 1200)])
-@pytest.mark.parametrize("onepass", [0, 1])
-def test_partitioned_plan_pointwise_bit_exact(n, B, U, I, onepass, monkeypatch):
+@pytest.mark.parametrize("tiles", [0, 2])
+def test_partitioned_plan_pointwise_bit_exact(n, B, U, I, tiles, monkeypatch):
     """point-wise rows (user, item, label): ONE item entry per row in the static index and in every batch of the plan;
     the label travels in the sample's third column and is not an id (it may exceed nothing: no range check)"""
     from daisyrec_amd import ops
-    monkeypatch.setenv("DAISY_PLAN_ONEPASS", str(onepass))
+    if tiles:
+        monkeypatch.setenv("DAISY_PART_TILES", str(tiles))
     tri = _triples(n, U, I, n + 1)
     tri[:, 2] = np.random.default_rng(n).integers(0, 2, n)              # labels
     tri[::7, 2] = I + 5                                                 # (not an item id: must not be validated as one)
@@ -144,6 +146,118 @@ def test_staged_epoch_matches_oracle(d, loss):
         assert abs(float(sl[k].cpu()) - want) <= 1e-5 * abs(want), (k, float(sl[k].cpu()), want)
     assert np.abs(P.cpu().numpy() - Pn).max() < 5e-6 and np.abs(Q.cpu().numpy() - Qn).max() < 5e-6
     ctx.close(); plan.close(); index.close()
+
+
+@pytest.mark.parametrize("d", [32, 64, 100])
+@pytest.mark.parametrize("opt", ["sgd", "adam"])
+def test_p_stream_user_rows_match_the_oracle(d, opt):
+    """StreamView::p_stream - user rows read with nontemporal loads and written with nontemporal owner stores (what the
+    host switches on for user tables beyond 512 MB, i.e. the code path of bench.py's `secondary` number) - forced on
+    through daisy_bpr_ctx_set_p_stream on heavily colliding batches: only the cache policy may differ, so the epoch must
+    equal the oracle's (MFRecommender.py:63-97) like the default path does, and the default path bit for bit."""
+    from daisyrec_amd import ops
+    from daisyrec_amd.model.AbstractRecommender import _AdamState
+    U, I, n, B = 37, 23, 1500, 400
+    tri = _triples(n, U, I, d + 11)
+    tri[:300, 0] = 5                       # a run that crosses chunks (edge records: their owners store too)
+    P0, Q0 = _tables(U, I, d, d + 12)
+    t_dev = torch.from_numpy(tri).to(DEV)
+    index, plan = ops.TrainIndex(t_dev, U, I), ops.EpochPlan(n, U, I)
+    plan.build_indexed(index, B, order="feistel", seed=5, epoch=1)
+    nb = plan.num_batches
+    batches = _plan_batches(plan, nb, B)
+    lid, lr = ops.LOSS_IDS["BPR"], (0.05 if opt == "sgd" else 0.01)
+    outs = {}
+    for mode in (False, True):
+        P, Q = torch.from_numpy(P0).to(DEV), torch.from_numpy(Q0).to(DEV)
+        ctx = ops.BprContext(B, d, U, I)
+        ctx.set_p_stream(mode)
+        sl = torch.zeros(nb, dtype=torch.float64, device=DEV)
+        if opt == "sgd":
+            ctx.fit_epoch_sgd(plan, P, Q, lr, 1e-3, 2e-3, loss_type=lid, item_mode=ops.ITEM_MODES["fused"], step_losses=sl)
+        else:
+            adam = _AdamState(P, Q, lr, None, kind="adam", max_steps=4)
+            for k in range(nb):
+                ctx.set_batch_from_plan(plan, k)
+                adam.step(ctx, P, Q, 1e-3, 2e-3, lid, ops.ITEM_MODES["fused"])
+                sl[k] = ctx.stats[7]
+            adam.flush()
+        torch.cuda.synchronize()
+        outs[mode] = (P.cpu().numpy(), Q.cpu().numpy(), sl.cpu().numpy())
+        ctx.close()
+    assert np.array_equal(outs[True][0], outs[False][0]) and np.array_equal(outs[True][1], outs[False][1])
+    assert np.array_equal(outs[True][2], outs[False][2])
+    Pn, Qn = P0.astype(np.float64), Q0.astype(np.float64)
+    ref = O.DenseAdam([P0.shape, Q0.shape], lr)
+    for k, (rows, _, _) in enumerate(batches):
+        if opt == "sgd":
+            want, Pn, Qn = O.mf_sgd_step(Pn, Qn, rows[:, 0], rows[:, 1], rows[:, 2], lr, 1e-3, 2e-3, loss_type=lid)
+        else:
+            want, gP, gQ = O.mf_pair_grad(Pn, Qn, rows[:, 0], rows[:, 1], rows[:, 2], 1e-3, 2e-3, lid)
+            Pn, Qn = ref.step([Pn, Qn], [gP, gQ])
+        assert abs(outs[True][2][k] - want) <= 2e-5 * abs(want), (k, outs[True][2][k], want)
+    for got, want_t in ((outs[True][0], Pn), (outs[True][1], Qn)):
+        diff = np.abs(got - want_t)
+        if opt == "sgd":
+            assert diff.max() < 5e-6
+        else:       # (Adam: see test_staged_adam_epochs_match_the_dense_oracle for the tolerance)
+            assert (diff > 2e-5).mean() < 2e-3 and np.median(diff) < 1e-7
+    plan.close(); index.close()
+
+
+def test_p_stream_step_at_ten_million_users():
+    """The regime the switch exists for: a 10 M x 64 user table (2.56 GB, ten Infinity Caches) - one 1 M-sample staged
+    step with the AUTOMATIC setting (on by table size) against a plain torch fp32 restatement of the closed form on the
+    GPU, like test_c2_scale_step_properties; then the same step with the switch forced off: identical bits."""
+    from daisyrec_amd import ops
+    U, I, d, B = 10_000_000, 1_000_000, 64, 1 << 20
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(7)
+    P = torch.randn(U, d, device=DEV, generator=gen) * 0.01
+    Q = torch.randn(I, d, device=DEV, generator=gen) * 0.01
+    u = torch.randint(0, U, (B,), device=DEV, generator=gen, dtype=torch.int32)
+    u[:50_000] = u[0]                      # a run across many chunks
+    i = torch.randint(0, I, (B,), device=DEV, generator=gen, dtype=torch.int32)
+    j = torch.randint(0, I, (B,), device=DEV, generator=gen, dtype=torch.int32)
+    lr, r1, r2 = 0.01, 1e-3, 1e-3
+    ul, il, jl = u.long(), i.long(), j.long()
+    pu, qi, qj = P[ul], Q[il], Q[jl]
+    x = (pu * qi).sum(-1) - (pu * qj).sum(-1)
+    s = torch.sigmoid(x)
+    loss = -(1e-10 + s).log().double().sum()
+    nU, nI, nJ = (t.double().pow(2).sum().sqrt() for t in (pu, qi, qj))
+    loss = loss + r1 * (pu.abs().double().sum() + qi.abs().double().sum() + qj.abs().double().sum()) + r2 * (nU + nI + nJ)
+    c = (-(s * (1 - s)) / (1e-10 + s)).unsqueeze(1)
+    dP = -lr * (c * (qi - qj) + r1 * pu.sign() + r2 * pu / nU.float())
+    Qn = Q.clone()
+    Qn.index_add_(0, il, -lr * (c * pu + r1 * qi.sign() + r2 * qi / nI.float()))
+    Qn.index_add_(0, jl, -lr * (-c * pu + r1 * qj.sign() + r2 * qj / nJ.float()))
+    del qi, qj, x, s
+    res = []
+    for mode in ("auto", False):
+        P1, Q1 = P.clone(), Q.clone()
+        ctx = ops.BprContext(B, d, U, I)
+        ctx.set_p_stream(mode)
+        sl = torch.zeros(1, dtype=torch.float64, device=DEV)
+        ctx.set_batch(u, i, j)
+        ctx.sgd_step(P1, Q1, lr, r1, r2, item_mode=ops.ITEM_MODES["fused"], step_loss=sl)
+        torch.cuda.synchronize()
+        assert abs(float(sl.cpu()) - float(loss.cpu())) <= 1e-5 * float(loss.cpu())
+        res.append((P1, Q1))
+        ctx.close()
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    P1, Q1 = res[0]
+    assert float((Q1 - Qn).abs().max().cpu()) < 1e-6
+    Pn = P.clone()
+    Pn.index_add_(0, ul, dP)
+    dPmax = (P1 - Pn).abs()
+    long_user = int(ul[0])                 # (its 50 000 terms of ~1e-4 meet in another order: a few fp32 ulps of the sum)
+    assert float(dPmax[long_user].max().cpu()) < 2e-5
+    dPmax[long_user] = 0
+    assert float(dPmax.max().cpu()) < 1e-6
+    untouched = torch.ones(U, dtype=torch.bool, device=DEV)
+    untouched[ul] = False
+    assert torch.equal(P1[untouched], P[untouched])
 
 
 @pytest.mark.parametrize("d,loss", [(64, "BPR"), (32, "TL"), (100, "BPR"), (64, "CL"), (20, "SL"), (128, "HL")])

@@ -1,9 +1,9 @@
 #!/usr/bin/env python
-"""Round-3 kernel probe: one workload (c2 = BASELINE configs[1]; c3s = configs[2] table shapes with the interaction
-count cut to 100 M), the staged step through the Python step loop of bench.py, HIP-event timings of the plan build
-and of the steps alone.  Run it under `rocprofv3 --kernel-trace --stats` for the per-kernel split; knobs of the
-library are environment variables (see the getenv calls in csrc/bpr_staged.hip); PROBE_PLAN_VARIANTS=0,2,3,1
-times the plan-build variants (DAISY_PLAN_ONEPASS) one after the other in this process, twice each."""
+"""Kernel probe: one workload (c2 = BASELINE configs[1]; c3s = configs[2] table shapes with the interaction count cut
+to 100 M; c3r = one rank's share of configs[2]), the staged step through the Python step loop of bench.py, HIP-event
+timings of the plan build and of the steps alone.  Run it under `rocprofv3 --kernel-trace --stats` for the per-kernel
+split (tools/probe_run.sh); knobs of the library are environment variables or -D flags of a development
+build selected with DAISY_LIB_OVERRIDE (tools/devlib.sh)."""
 import os
 import sys
 
@@ -40,6 +40,8 @@ def main():
     Q = torch.empty(I, d, device=dev).normal_(0.0, 0.01, generator=g)
     P = torch.empty(U, d, device=dev).normal_(0.0, 0.01, generator=g)
     ctx = ops.BprContext(B, d, U, I, device=dev)
+    if os.environ.get("PROBE_PSTREAM"):          # 0 / 1: force the nontemporal user rows off / on (default: by table size)
+        ctx.set_p_stream(bool(int(os.environ["PROBE_PSTREAM"])))
     index = ops.TrainIndex(triples, U, I, user_sorted=True)
     plan = ops.EpochPlan(n, U, I, device=dev)
     ep = [0]
@@ -108,21 +110,6 @@ def main():
         tot_ov = a.elapsed_time(b) / (E * nb)
         print(f"[{wl} {tag}] overlap={ov}: {tot_ov * 1e3:.1f} us/step incl. plan  frac(total) {1548 * B / (tot_ov * 1e-3) / 8e12:.3f}  "
               f"(sequential: {(ms + plan_ms / nb) * 1e3:.1f})", flush=True)
-    variants = os.environ.get("PROBE_PLAN_VARIANTS", "")   # e.g. "0,2,3,1": DAISY_PLAN_ONEPASS values (read per build), twice each
-    if variants:
-        for v in variants.split(",") * 2:                   # "flag" or "flag:tiles" (DAISY_PART_TILES, three-launch forms)
-            flag, _, tiles = v.partition(":")
-            os.environ["DAISY_PLAN_ONEPASS"] = flag
-            if tiles:
-                os.environ["DAISY_PART_TILES"] = tiles
-            else:
-                os.environ.pop("DAISY_PART_TILES", None)
-            build()
-            t = ev_time(build, 3)
-            print(f"[{wl} {tag}] plan variant {v}: {t:.3f} ms/epoch = {t / nb * 1e3:.1f} us/step  "
-                  f"-> frac(total) {1548 * B / ((ms + t / nb) * 1e-3) / 8e12:.3f}", flush=True)
-        os.environ.pop("DAISY_PLAN_ONEPASS", None)
-        os.environ.pop("DAISY_PART_TILES", None)
     loss, bad = (float(x) for x in ctx.epoch_acc.cpu())
     per_step_plan = plan_ms / nb
     tot = ms + per_step_plan
