@@ -648,7 +648,13 @@ struct StagedUserCfg {
     static constexpr int G = BLK / C::LPR;
     static constexpr int E = G * RUN;
 };
-template <class C, int BLK = kBlock>
+// SPARSE: few entries per item (small batches, or huge item tables): nearly every entry ends a segment, and each end is a
+// commit that needs the item's row of Q - a DEPENDENT read inside the reduction loop wherever the row is not in the LDS
+// window (which holds a contiguous item range and therefore only helps dense batches).  At B = 4096 over 100 K items the
+// 16 commits of a 16-entry run were 16 trips to memory one after the other: 14 us for a pass that moves 2 MB.  The sparse
+// flavour takes runs of 4 entries (four times the workgroups: these batches do not fill the chip anyway) and gathers
+// the Q row of EVERY entry together with its staged row, so a commit waits for nothing.
+template <class C, int BLK = kBlock, bool SPARSE = false>
 struct StagedItemCfg {
 #ifndef DAISY_ITEM_RUN8
 #define DAISY_ITEM_RUN8 8
@@ -657,7 +663,8 @@ struct StagedItemCfg {
 #define DAISY_ITEM_RUN16 4
 #endif
     // staged rows in flight per lane group: 64 row registers in every shape (16 x 4 floats, 8 x 8, 4 x 16)
-    static constexpr int RUN_BY_REGS = (C::NE <= 4) ? 16 : ((C::NE <= 8) ? DAISY_ITEM_RUN8 : DAISY_ITEM_RUN16);
+    static constexpr int RUN_BY_REGS = SPARSE ? ((C::NE <= 8) ? 4 : 2)
+                                              : ((C::NE <= 4) ? 16 : ((C::NE <= 8) ? DAISY_ITEM_RUN8 : DAISY_ITEM_RUN16));
     static constexpr int RUN = RUN_BY_REGS < C::LPR ? RUN_BY_REGS : C::LPR;
     static constexpr int G = BLK / C::LPR;
     static constexpr int E = G * RUN;
@@ -800,7 +807,10 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((C::NE <= 4
     RowOpt opt, float reg_1, float reg_2, int loss_type, float gamma, float *__restrict__ stage,
     float2 *__restrict__ coef, float *__restrict__ p_sqnorm, double *__restrict__ partials, UserEdges ed,
     PreNorm pre, StagedBias fm) {
-    if (halted(v.halt)) return;            // an earlier step of this epoch had a non-finite loss: the epoch has stopped
+    // an earlier step of this epoch had a non-finite loss: the epoch has stopped.  The word is requested here and looked
+    // at behind the first chunk's gathers (before anything is stored): a launch-bound step - a few thousand samples -
+    // is a chain of dependent trips to memory, and this one now travels with the metadata instead of in front of it
+    const double halt_word = v.halt ? *v.halt : 0.0;
     constexpr int G = StagedUserCfg<C, BLK>::G, RUN = StagedUserCfg<C, BLK>::RUN, E = StagedUserCfg<C, BLK>::E;
     constexpr int ROWF = C::NE * C::LPR;
     constexpr bool PAIR = MODE != kModePoint;
@@ -902,6 +912,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((C::NE <= 4
                 }
             }
         }
+        if (halt_word > 0.0) return;           // (uniform over the grid; nothing has been written yet)
         __syncthreads();
 
         if (cnt > 0) {
@@ -1139,11 +1150,15 @@ template <class C, bool APPLY, bool ADAM>
 __device__ __forceinline__ void item_commit(float *__restrict__ Qo, float *__restrict__ cnt_out, int64_t item,
                                             const Row<C> &g, float np, float nn, float sb, int lane, int d,
                                             const RowOpt &opt, float reg_1, float rI, float rJ, const StagedBias &fm,
-                                            const QWindow win = QWindow{nullptr, 0, 0}) {
+                                            const QWindow win = QWindow{nullptr, 0, 0},
+                                            const Row<C> *qpre = nullptr) {
     if constexpr (APPLY) {
         Row<C> q;
         bool in_lds = false;
-        if constexpr (C::VEC == 4) {
+        if (qpre) {                                    // (compile-time at every call site) gathered with the stage rows
+            q = *qpre;
+            in_lds = true;
+        } else if constexpr (C::VEC == 4) {
             const uint32_t off = (uint32_t)((int32_t)item - win.first);
             if (off < (uint32_t)win.rows) {            // the row waits in LDS: no dependent trip to memory
                 in_lds = true;
@@ -1183,7 +1198,7 @@ __device__ __forceinline__ void item_commit(float *__restrict__ Qo, float *__res
 // MODE (see k_staged_user): premul - entry weight +/-1; plain - the sample's (dL/dpos, dL/dneg) gathered from coef;
 // point - weight 1 (a negative slot, which only the sorted layout's point-wise batches have, is inert: weight 0, not
 // counted).
-template <class C, int BLK, int MODE, bool APPLY, bool ADAM>
+template <class C, int BLK, int MODE, bool APPLY, bool ADAM, bool SPARSE>
 __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(ADAM ? 2 : 4, 8))) void k_staged_item(const float *__restrict__ stage,
                                                         const float2 *__restrict__ coef, StreamView v, int d,
                                                         float *__restrict__ Qo, float *__restrict__ cnt_out,
@@ -1191,13 +1206,17 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(ADAM ? 2 : 
                                                         float reg_1, float reg_2, ItemEdges2 ed,
                                                         const int64_t *__restrict__ erange, StagedBias fm,
                                                         RideUnorm ride) {
-    if (halted(v.halt)) return;            // this step's loss (reduced behind the user pass) or an earlier one was not finite
+    // this step's loss (reduced behind the user pass) or an earlier one was not finite: nothing may be written.  Requested
+    // here, looked at behind the first chunk's gathers (see k_staged_user)
+    const double halt_word = v.halt ? *v.halt : 0.0;
     if (ride.nblocks && (int)blockIdx.x >= ride.first_block) {      // the next batch's pre-norm rides on this launch
+        if (halt_word > 0.0) return;
         unorm_block(ride, (int)blockIdx.x - ride.first_block);
         return;
     }
     const int item_grid = ride.nblocks ? ride.first_block : (int)gridDim.x;
-    constexpr int G = StagedItemCfg<C, BLK>::G, RUN = StagedItemCfg<C, BLK>::RUN, E = StagedItemCfg<C, BLK>::E;
+    using Cfg = StagedItemCfg<C, BLK, SPARSE>;
+    constexpr int G = Cfg::G, RUN = Cfg::RUN, E = Cfg::E;
     // erange: only the entries [erange[0], erange[1]) - an item range of the batch (the entries are sorted by item, so
     // no segment crosses the cut and the piece is reduced exactly like a whole batch).  Multi-GPU steps cut the item
     // pass into such slices so that a finished slice can be exchanged while the next one is reduced.
@@ -1218,7 +1237,8 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(ADAM ? 2 : 
     // a commit inside the reduction then costs no dependent trip to memory (at a few entries per item - 10 M x 1 M
     // shapes - 355 -> 320 us per pass).  Only for d % 4 == 0 (16-byte units); rows past the window (sparse batches: few
     // entries spread over many items) are loaded directly.
-    constexpr bool WIN = APPLY && C::VEC == 4 && C::NE <= 8 && DAISY_ITEM_WINDOW;
+    constexpr bool WIN = APPLY && C::VEC == 4 && C::NE <= 8 && DAISY_ITEM_WINDOW && !SPARSE;
+    constexpr bool QPRE = APPLY && SPARSE;                 // the Q row of every entry rides with its staged row
     constexpr int WINF = (C::NE <= 4) ? kItemWinFloats : (kItemWinFloats * 2 / 3);
     __shared__ __attribute__((aligned(16))) float qwin[WIN ? WINF : 4];
 
@@ -1292,16 +1312,25 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(ADAM ? 2 : 
             my_w = (lane < cnt && !my_neg) ? 1.f : 0.f;
             if (has_bias) my_c = (lane < cnt && !my_neg) ? coef[slot_me].x : 0.f;
         }
-        Row<C> p[RUN];
+        Row<C> p[RUN], qe[QPRE ? RUN : 1];
         if (__all(cnt == RUN)) {        // wave-uniform: every run of this wave is full
 #pragma unroll
-            for (int x = 0; x < RUN; ++x) DAISY_STAGE_LOAD(p[x], stage + (int64_t)group_bcast<C>(slot_me, x) * d, lane, d);
+            for (int x = 0; x < RUN; ++x) {
+                DAISY_STAGE_LOAD(p[x], stage + (int64_t)group_bcast<C>(slot_me, x) * d, lane, d);
+                if constexpr (QPRE) qe[x].load(Qo + (int64_t)group_bcast<C>(my_item, x) * d, lane, d);
+            }
         } else {
 #pragma unroll
             for (int x = 0; x < RUN; ++x) {
                 const uint32_t sx = group_bcast<C>(slot_me, x);
-                if (x < cnt) DAISY_STAGE_LOAD(p[x], stage + (int64_t)sx * d, lane, d);
-                else p[x].zero();
+                const int32_t ix = group_bcast<C>(my_item, x);
+                if (x < cnt) {
+                    DAISY_STAGE_LOAD(p[x], stage + (int64_t)sx * d, lane, d);
+                    if constexpr (QPRE) qe[x].load(Qo + (int64_t)ix * d, lane, d);
+                } else {
+                    p[x].zero();
+                    if constexpr (QPRE) qe[x].zero();
+                }
             }
         }
         // the window has landed before anyone reads it.  (Round 4 tried the counted form - the LDS-DMA issued from an asm
@@ -1311,6 +1340,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(ADAM ? 2 : 
         // cap, and within +-1.5 % of this form at both BASELINE shapes, same box: profiles/r04_item_plan_variants.txt.
         // The pass is not bound by this wait.)
         if constexpr (WIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (halt_word > 0.0) return;           // (uniform over the grid; nothing has been written yet)
         __syncthreads();
 
         if (cnt > 0) {
@@ -1330,9 +1360,12 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(ADAM ? 2 : 
             Row<C> acc;
             acc.zero();
             float np = 0.f, nn = 0.f, sb = 0.f;
+            Row<C> qcur;                            // QPRE: the pre-step row of the current segment's item
+            if constexpr (QPRE) qcur = qe[0];
             auto finish = [&](bool ends_here, bool to_next_chunk) {
                 if (cur_slot < 0 && ends_here) {    // interior: this group owns the item's row
-                    item_commit<C, APPLY, ADAM>(Qo, cnt_out, cur_item, acc, np, nn, sb, lane, d, opt, reg_1, rI, rJ, fm, win);
+                    item_commit<C, APPLY, ADAM>(Qo, cnt_out, cur_item, acc, np, nn, sb, lane, d, opt, reg_1, rI, rJ, fm, win,
+                                                QPRE ? &qcur : nullptr);
                 } else {                            // crosses a run boundary: park it for the slot's finisher
                     const int s = (cur_slot >= 0) ? cur_slot : group + 1;
                     const int q = group * 2 + ((cur_slot >= 0) ? 0 : 1);
@@ -1361,6 +1394,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(ADAM ? 2 : 
                         cur_slot = -1;
                         acc.zero();
                         np = 0.f; nn = 0.f; sb = 0.f;
+                        if constexpr (QPRE) qcur = qe[x];
                     }
 #pragma unroll
                     for (int k = 0; k < C::NE; ++k) acc.v[k] = fmaf(wx, p[x].v[k], acc.v[k]);
@@ -1732,23 +1766,43 @@ static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_
     const StagedBias fm = staged_bias(ctx, bias_grad_out);
     if (adam && !apply) { set_error("staged item pass: the Adam owner update needs the in-place form"); return DAISY_ERR_ARG; }
     static const int tune_ig = getenv("DAISY_STAGED_IGRID") ? atoi(getenv("DAISY_STAGED_IGRID")) : 16384;
+    // DAISY_STAGED_SPARSE (read per call: the tests switch it): 0 / 1 force the dense / sparse flavour of the SGD item pass
+    const char *env_sparse = getenv("DAISY_STAGED_SPARSE");
+    const int tune_sparse = env_sparse ? atoi(env_sparse) : -1;
     bool overflow = false;
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
         constexpr int BLK = kStagedItemBlock;        // (128-thread workgroups measured the same, r02 / r03)
-        const int64_t nchunks = (v.E + StagedItemCfg<C, BLK>::E - 1) / StagedItemCfg<C, BLK>::E;
+        // the sparse flavour (StagedItemCfg) when a dense chunk's item range would not fit the LDS window: expected
+        // items under a chunk = chunk entries x items / entries  >  rows of the window
+        constexpr int E_dense = StagedItemCfg<C, BLK>::E, E_sparse = StagedItemCfg<C, BLK, true>::E;
+        constexpr int win_rows = kItemWinFloats / (C::NE * C::LPR);
+        bool sparse = apply && !adam && (double)v.E * win_rows < (double)E_dense * (double)ctx->I;
+        if (tune_sparse >= 0) sparse = apply && !adam && tune_sparse != 0;
+        if (sparse && (v.E + E_sparse - 1) / E_sparse > ctx->edge_chunks) sparse = false;
+        const int chunk_e = sparse ? E_sparse : E_dense;
+        const int64_t nchunks = (v.E + chunk_e - 1) / chunk_e;
         if (nchunks > ctx->edge_chunks) { overflow = true; return DAISY_OK; }
-        const int gi = grid_for(v.E, StagedItemCfg<C, BLK>::E, tune_ig);
+        const int gi = grid_for(v.E, chunk_e, tune_ig);
         RideUnorm ru = ride;
         ru.first_block = gi;                 // the riding workgroups follow the item pass's own
         const dim3 g(gi + ru.nblocks), b(BLK), ge(grid_for(nchunks, C::GROUPS_PER_BLOCK) + (rr.n ? 1 : 0));
         auto launch = [&](auto mode_tag, auto ap_tag, auto adam_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
             constexpr bool AP = decltype(ap_tag)::value, AD = decltype(adam_tag)::value;
-            hipLaunchKernelGGL((k_staged_item<C, BLK, MODE, AP, AD>), g, b, 0, s, ctx->p_stage, ctx->coef, v, d, Qo, cnt_out,
-                               stats, opt, reg_1, reg_2, ed, erange, fm, ru);
+            if constexpr (AP && !AD) {
+                if (sparse)
+                    hipLaunchKernelGGL((k_staged_item<C, BLK, MODE, true, false, true>), g, b, 0, s, ctx->p_stage, ctx->coef, v,
+                                       d, Qo, cnt_out, stats, opt, reg_1, reg_2, ed, erange, fm, ru);
+                else
+                    hipLaunchKernelGGL((k_staged_item<C, BLK, MODE, true, false, false>), g, b, 0, s, ctx->p_stage, ctx->coef, v,
+                                       d, Qo, cnt_out, stats, opt, reg_1, reg_2, ed, erange, fm, ru);
+            } else {
+                hipLaunchKernelGGL((k_staged_item<C, BLK, MODE, AP, AD, false>), g, b, 0, s, ctx->p_stage, ctx->coef, v, d, Qo,
+                                   cnt_out, stats, opt, reg_1, reg_2, ed, erange, fm, ru);
+            }
             hipLaunchKernelGGL((k_staged_item_edges<C, AP, AD>), ge, dim3(kBlock), 0, s, ed, nchunks, d, Qo, cnt_out, stats,
-                               opt, reg_1, reg_2, erange, StagedItemCfg<C, BLK>::E, v.halt, fm, rr);
+                               opt, reg_1, reg_2, erange, chunk_e, v.halt, fm, rr);
         };
         auto by_apply = [&](auto mode_tag) {
             if (apply && adam) launch(mode_tag, std::true_type{}, std::true_type{});

@@ -119,11 +119,17 @@ def _tables(U, I, d, seed, scale=0.1):
 
 @pytest.mark.parametrize("d", [64, 32, 8, 20, 128, 100, 7, 256])
 @pytest.mark.parametrize("loss", ["BPR", "HL", "TL", "CL", "SL"])
-def test_staged_epoch_matches_oracle(d, loss):
+@pytest.mark.parametrize("sparse", [None, "1"])
+def test_staged_epoch_matches_oracle(d, loss, sparse, monkeypatch):
     """A whole epoch through the partitioned plan + fit_epoch_sgd(fused), replayed by the oracle on the
     batches the plan serves: hot users/items, runs that cross lane groups and chunks, a partial batch.
-    CL / SL: point-wise rows (user, item, label), one entry per row."""
+    CL / SL: point-wise rows (user, item, label), one entry per row.
+    sparse = "1": the sparse flavour of the item pass (runs of 4 entries, the Q row of every entry gathered with its
+    staged row) forced onto these DENSE batches - long segments across runs and chunks, which it meets rarely where
+    the library picks it by itself."""
     from daisyrec_amd import ops
+    if sparse:
+        monkeypatch.setenv("DAISY_STAGED_SPARSE", sparse)
     U, I, n, B = 37, 23, 1500, 400         # heavy collisions: every row is shared inside a batch
     tri = _triples(n, U, I, d)
     point = loss in ("CL", "SL")
@@ -143,6 +149,36 @@ def test_staged_epoch_matches_oracle(d, loss):
     Pn, Qn = P0.astype(np.float64), Q0.astype(np.float64)
     for k, (rows, _, _) in enumerate(_plan_batches(plan, nb, B)):
         want, Pn, Qn = O.mf_sgd_step(Pn, Qn, rows[:, 0], rows[:, 1], rows[:, 2], 0.05, 1e-3, 2e-3, loss_type=lid)
+        assert abs(float(sl[k].cpu()) - want) <= 1e-5 * abs(want), (k, float(sl[k].cpu()), want)
+    assert np.abs(P.cpu().numpy() - Pn).max() < 5e-6 and np.abs(Q.cpu().numpy() - Qn).max() < 5e-6
+    ctx.close(); plan.close(); index.close()
+
+
+@pytest.mark.parametrize("d,B,I", [(64, 3000, 9000), (32, 1024, 4000), (100, 777, 50000), (64, 6000, 100000)])
+@pytest.mark.parametrize("sparse", [None, "0"])
+def test_sparse_batches_match_the_oracle(d, B, I, sparse, monkeypatch):
+    """Few entries per item - what every batch of the reference's size range (basic.yaml:23: 256 ... a few thousand) is
+    over a real item table: the library takes the sparse flavour of the item pass by itself (sparse=None); "0" forces
+    the dense one onto the same batches (its LDS window covers none of their rows).  Two steps against the oracle."""
+    from daisyrec_amd import ops
+    if sparse:
+        monkeypatch.setenv("DAISY_STAGED_SPARSE", sparse)
+    U, n = 5000, 2 * B
+    rng = np.random.default_rng(d + B)
+    tri = np.stack([rng.integers(0, U, n), rng.integers(0, I, n), rng.integers(0, I, n)], 1).astype(np.int32)
+    tri[:40, 1] = 7                        # one segment across runs even here
+    P0, Q0 = _tables(U, I, d, d + 3)
+    t_dev = torch.from_numpy(tri).to(DEV)
+    index, plan = ops.TrainIndex(t_dev, U, I), ops.EpochPlan(n, U, I)
+    plan.build_indexed(index, B, order="feistel", seed=3, epoch=1)
+    P, Q = torch.from_numpy(P0).to(DEV), torch.from_numpy(Q0).to(DEV)
+    ctx = ops.BprContext(B, d, U, I)
+    sl = torch.zeros(2, dtype=torch.float64, device=DEV)
+    ctx.fit_epoch_sgd(plan, P, Q, 0.05, 1e-3, 2e-3, item_mode=ops.ITEM_MODES["fused"], step_losses=sl)
+    torch.cuda.synchronize()
+    Pn, Qn = P0.astype(np.float64), Q0.astype(np.float64)
+    for k, (rows, _, _) in enumerate(_plan_batches(plan, 2, B)):
+        want, Pn, Qn = O.mf_sgd_step(Pn, Qn, rows[:, 0], rows[:, 1], rows[:, 2], 0.05, 1e-3, 2e-3)
         assert abs(float(sl[k].cpu()) - want) <= 1e-5 * abs(want), (k, float(sl[k].cpu()), want)
     assert np.abs(P.cpu().numpy() - Pn).max() < 5e-6 and np.abs(Q.cpu().numpy() - Qn).max() < 5e-6
     ctx.close(); plan.close(); index.close()
