@@ -234,7 +234,7 @@ class GeneralRecommender(AbstractRecommender):
         from torch.utils.data import SequentialSampler
         from ..sharding import UserShardedBprTrainer, user_range
         world, rank = dist.get_world_size(), dist.get_rank()
-        P, Q = self.embed_user.weight.data, self.embed_item.weight.data
+        P, Q = self._tables()
         U, I, d = P.shape[0], Q.shape[0], P.shape[1]
         dist.broadcast(P, 0)               # replicas start from rank 0's tables (same seeds make this a no-op)
         dist.broadcast(Q, 0)
@@ -334,7 +334,7 @@ class GeneralRecommender(AbstractRecommender):
                     break
             return
         B = min(B, n)            # fewer rows than one batch: a single partial batch, like the DataLoader
-        P, Q = self.embed_user.weight.data, self.embed_item.weight.data
+        P, Q = self._tables()    # (the padded buffers behind embed_*.weight where the model trains on a row pitch)
         ctx = ops.BprContext(B, P.shape[1], P.shape[0], Q.shape[0], device=P.device)
         plan = ops.EpochPlan(n, P.shape[0], Q.shape[0], device=P.device)
         biases = self._biases() if hasattr(self, "_biases") else None     # FM: (u_bias, i_bias, bias_)

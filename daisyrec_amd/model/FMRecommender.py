@@ -39,6 +39,8 @@ class FM(MF):
         self.initializer = config["init_method"] if config["init_method"] != "default" else "normal"
         self.early_stop = config["early_stop"]
         self.topk = config["topk"]
+        self.row_pitch = config.get("row_pitch", "auto")
+        self._padded = {}
 
         self.apply(self._init_weight)
         nn.init.constant_(self.u_bias.weight, 0.0)

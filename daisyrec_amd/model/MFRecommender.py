@@ -15,6 +15,20 @@ from .. import ops
 from .AbstractRecommender import GeneralRecommender
 
 
+def padded_factors(d: int, row_pitch="auto") -> int:
+    """columns of the tables the kernels train on for a d-factor model.  'auto': the next multiple of 32 (128-byte rows)
+    where that was measured to pay - up to 64 columns and at most a third more of them (d = 24 -> 32: 0.433 -> 0.402 ms per
+    2 M-sample step, d = 50 -> 64: 0.698 -> 0.603; but d = 100 -> 128: 1.131 -> 1.203, d = 200 -> 256: 2.56 -> 2.69 -
+    profiles/r03_factor_sweep.txt); 0 / False: never; an integer: pad to its next multiple."""
+    if row_pitch in (0, False, None, "0", "off", "none"):
+        return d
+    if row_pitch == "auto":
+        dp = (d + 31) // 32 * 32
+        return dp if (dp <= 64 and 4 * d >= 3 * dp) else d
+    m = int(row_pitch)
+    return (d + m - 1) // m * m
+
+
 class MF(GeneralRecommender):
     def __init__(self, config):
         """Config keys as in MFRecommender.py:44-59:
@@ -36,15 +50,38 @@ class MF(GeneralRecommender):
         self.optimizer = config["optimizer"] if config["optimizer"] != "default" else "sgd"
         self.initializer = config["init_method"] if config["init_method"] != "default" else "normal"
         self.early_stop = config["early_stop"]
+        self.row_pitch = config.get("row_pitch", "auto")
+        self._padded = {}
 
         self.apply(self._init_weight)
 
     # -- tables as the kernels see them ------------------------------------------
     def _tables(self):
+        """(P, Q) as the kernels see them.  Row pitch (config['row_pitch'], default 'auto'): a factor count whose rows
+        are not whole 128-byte lines (d = 50: 200-byte rows straddle lines and leave 3 of 16 lanes idle) trains on tables
+        PADDED to the next multiple of 32 columns, the extra columns zero: they stay exactly zero under every update
+        (their data gradient is c * 0, sign(0) = 0, the Frobenius and Adam terms are multiples of the element), so scores,
+        norms, losses and gradients are those of the d-column model, while a row costs what the aligned row costs
+        (profiles/r04_factor_sweep.txt).  `embed_*.weight` stays an [n, d] tensor - a strided view of the padded buffer -
+        for state_dict() and every consumer of the reference's attribute."""
         self._require_device()
         if not self.embed_user.weight.is_cuda:
             self.to(self.device)
-        return self.embed_user.weight.data, self.embed_item.weight.data
+        d = self.embed_user.weight.shape[1]
+        dp = padded_factors(d, self.row_pitch)
+        if dp == d:
+            return self.embed_user.weight.data, self.embed_item.weight.data
+        out = []
+        for name in ("embed_user", "embed_item"):
+            w = getattr(self, name).weight
+            buf = self._padded.get(name)
+            if buf is None or buf.device != w.device or w.data.data_ptr() != buf.data_ptr() or tuple(w.data.stride()) != (dp, 1):
+                buf = torch.zeros(w.shape[0], dp, dtype=w.dtype, device=w.device)     # (re)home the weights: after the
+                buf[:, :d].copy_(w.data)                                              # first .to(device), a load, ...
+                w.data = buf[:, :d]
+                self._padded[name] = buf
+            out.append(buf)
+        return out[0], out[1]
 
     def _biases(self):
         """None for MF; FM returns (u_bias, i_bias, bias_) device tensors (FMRecommender.py:49-53)."""

@@ -1,0 +1,100 @@
+"""Row pitch (daisyrec_amd/model/MFRecommender.py::padded_factors): a factor count whose rows are not whole 128-byte lines
+trains on tables padded with ZERO columns to the next multiple of 32.  The padded model must BE the d-column model
+(MFRecommender.py:63-97: scores, L1 / Frobenius norms and every gradient are unchanged by zero columns, which stay zero),
+and `embed_*.weight` must remain the [n, d] tensor the reference's consumers read."""
+import logging
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bpr_mf_numpy as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("d,dp", [(50, 64), (24, 32), (57, 64)])
+@pytest.mark.parametrize("loss", ["BPR", "CL"])
+def test_zero_padded_tables_train_like_the_unpadded_oracle(d, dp, loss):
+    """kernel level: an epoch of the staged step on [n, dp] tables whose columns d.. are zero against the oracle on the
+    [n, d] tables - same losses, same first d columns, the padding still exactly zero"""
+    from daisyrec_amd import ops
+    U, I, n, B = 61, 47, 1800, 500
+    rng = np.random.default_rng(d)
+    tri = np.stack([rng.integers(0, U, n), rng.integers(0, I, n), rng.integers(0, I, n)], 1).astype(np.int32)
+    point = loss == "CL"
+    if point:
+        tri[:, 2] = rng.integers(0, 2, n)
+    P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    Pp, Qp = np.zeros((U, dp), np.float32), np.zeros((I, dp), np.float32)
+    Pp[:, :d], Qp[:, :d] = P0, Q0
+    t_dev = torch.from_numpy(tri).to(DEV)
+    index, plan = ops.TrainIndex(t_dev, U, I, pointwise=point), ops.EpochPlan(n, U, I)
+    plan.build_indexed(index, B, order="feistel", seed=2, epoch=1)
+    nb = plan.num_batches
+    P, Q = torch.from_numpy(Pp).to(DEV), torch.from_numpy(Qp).to(DEV)
+    ctx = ops.BprContext(B, dp, U, I)
+    sl = torch.zeros(nb, dtype=torch.float64, device=DEV)
+    lid = ops.LOSS_IDS[loss]
+    ctx.fit_epoch_sgd(plan, P, Q, 0.05, 1e-3, 2e-3, loss_type=lid, item_mode=ops.ITEM_MODES["fused"], step_losses=sl)
+    torch.cuda.synchronize()
+    Pn, Qn = P0.astype(np.float64), Q0.astype(np.float64)
+    for k in range(nb):
+        u, i, j = (t.cpu().numpy().astype(np.int64) for t in plan.read_batch(k, B)[:3])
+        want, Pn, Qn = O.mf_sgd_step(Pn, Qn, u, i, j, 0.05, 1e-3, 2e-3, loss_type=lid)
+        assert abs(float(sl[k].cpu()) - want) <= 1e-5 * abs(want), (k, float(sl[k].cpu()), want)
+    Pg, Qg = P.cpu().numpy(), Q.cpu().numpy()
+    assert np.abs(Pg[:, :d] - Pn).max() < 5e-6 and np.abs(Qg[:, :d] - Qn).max() < 5e-6
+    assert not Pg[:, d:].any() and not Qg[:, d:].any()           # exactly zero (no -0.0 either: .any() is on the bits' value)
+    ctx.close(); plan.close(); index.close()
+
+
+def _config(d, opt, pitch):
+    return {"gpu": "0", "logger": logging.getLogger("t"), "lr": 0.05 if opt == "sgd" else 0.01, "reg_1": 0.001, "reg_2": 0.002,
+            "epochs": 2, "topk": 10, "user_num": 157, "item_num": 211, "factors": d, "loss_type": "BPR", "optimizer": opt,
+            "init_method": "default", "early_stop": False, "progress": False, "seed": 7, "row_pitch": pitch}
+
+
+@pytest.mark.parametrize("d,opt", [(50, "sgd"), (24, "sgd"), (50, "adam")])
+def test_fit_on_a_row_pitch_equals_the_fit_without(d, opt):
+    """model level: MF.fit with the automatic pitch against the same fit with row_pitch=0 (same seeds, same loader
+    order): epoch losses, weights - [n, d] tensors either way -, ranked lists; the padded buffers keep zero padding;
+    state_dict round trip through the strided views"""
+    from daisyrec_amd.model.MFRecommender import MF, padded_factors
+    from daisyrec_amd.utils.dataset import BasicDataset, get_dataloader, CandidatesDataset
+    assert padded_factors(d) != d and padded_factors(100) == 100 and padded_factors(64) == 64 and padded_factors(d, 0) == d
+    rng = np.random.default_rng(5)
+    tri = np.stack([np.sort(rng.integers(0, 157, 6000)), rng.integers(0, 211, 6000), rng.integers(0, 211, 6000)], 1).astype(np.int32)
+    models = []
+    for pitch in ("auto", 0):
+        torch.manual_seed(123)
+        m = MF(_config(d, opt, pitch))
+        torch.manual_seed(321)
+        m.fit(get_dataloader(BasicDataset(tri), batch_size=700, shuffle=True, num_workers=0))
+        models.append(m)
+    a, b = models
+    assert tuple(a.embed_user.weight.shape) == (157, d) and tuple(a.embed_item.weight.shape) == (211, d)
+    np.testing.assert_allclose(a.epoch_losses, b.epoch_losses, rtol=2e-6)
+    tol = 5e-6 if opt == "sgd" else 1e-4        # (Adam: a last-bit difference in a tiny gradient moves a step by up to lr)
+    np.testing.assert_allclose(a.embed_user.weight.data.cpu().numpy(), b.embed_user.weight.data.cpu().numpy(), atol=tol)
+    np.testing.assert_allclose(a.embed_item.weight.data.cpu().numpy(), b.embed_item.weight.data.cpu().numpy(), atol=tol)
+    Pp, Qp = a._tables()
+    assert Pp.shape[1] == padded_factors(d) and Pp.data_ptr() == a.embed_user.weight.data.data_ptr()
+    assert float(Pp[:, d:].abs().max().cpu()) == 0.0 and float(Qp[:, d:].abs().max().cpu()) == 0.0
+    # scores through the reference's methods agree (rank kernels run on the padded tables)
+    us = torch.arange(20)
+    cands = torch.from_numpy(rng.integers(0, 211, (20, 60)))
+    ra = a.rank([(us, cands)])
+    rb = b.rank([(us, cands)])
+    assert (ra == rb).mean() > 0.97
+    assert abs(a.predict(3, 5) - b.predict(3, 5)) < 1e-5
+    # state_dict: [n, d] tensors; loading them into a fresh padded model reproduces the scores
+    sd = {k: v.clone() for k, v in a.state_dict().items()}
+    assert tuple(sd["embed_user.weight"].shape) == (157, d)
+    c = MF(_config(d, opt, "auto"))
+    c.load_state_dict(sd)
+    assert abs(c.predict(3, 5) - a.predict(3, 5)) < 1e-7
+    Pc, _ = c._tables()
+    assert Pc.shape[1] == padded_factors(d) and float(Pc[:, d:].abs().max().cpu()) == 0.0

@@ -24,12 +24,17 @@ if MODE == "fused":
     plan.build_indexed(index, B, order="feistel", seed=1, epoch=0)
 else:
     plan.build(triples, B, order="feistel", seed=1, epoch=0, user_sorted=True)
+from daisyrec_amd.model.MFRecommender import padded_factors  # noqa: E402
+PITCH = os.environ.get("PITCH", "auto")          # what MF / FM train on (config['row_pitch']); PITCH=0: the bare row shapes
 for d in [int(x) for x in sys.argv[1:]] or [64, 100, 128, 96, 50, 32, 24, 200, 256]:
     g = torch.Generator(device=dev)
     g.manual_seed(1)
-    Q = torch.empty(I, d, device=dev).normal_(0.0, 0.01, generator=g)
-    P = torch.empty(U, d, device=dev).normal_(0.0, 0.01, generator=g)
-    ctx = ops.BprContext(B, d, U, I, device=dev)
+    dp = padded_factors(d, 0 if PITCH == "0" else PITCH)
+    Q = torch.zeros(I, dp, device=dev)
+    P = torch.zeros(U, dp, device=dev)
+    Q[:, :d].normal_(0.0, 0.01, generator=g)
+    P[:, :d].normal_(0.0, 0.01, generator=g)
+    ctx = ops.BprContext(B, dp, U, I, device=dev)
     k = [0]
 
     def step():
@@ -41,6 +46,6 @@ for d in [int(x) for x in sys.argv[1:]] or [64, 100, 128, 96, 50, 32, 24, 200, 2
         step()
     ms = ev_time(step, 20)
     alg = 24 * d + 12            # bytes per interaction: 6 row touches of 4d bytes + the (u, i, j) record
-    print(f"d={d:4d}  {ms:.4f} ms/step  {B / ms / 1e6:.3f} G inter/s  {alg * B / (ms * 1e-3) / 1e12:.2f} TB/s algorithmic "
+    print(f"d={d:4d}{'' if dp == d else f' (rows padded to {dp})':20s}  {ms:.4f} ms/step  {B / ms / 1e6:.3f} G inter/s  {alg * B / (ms * 1e-3) / 1e12:.2f} TB/s algorithmic "
           f"({alg * B / (ms * 1e-3) / 8e12:.3f} of 8 TB/s)", flush=True)
     ctx.close()
