@@ -1893,6 +1893,12 @@ __global__ __launch_bounds__(kBlock) void k_staged_adam_catchup(StreamView v, in
             const float2 c = table[st];
             adam_row<C>(w, m, vv, g, c.x, c.y, a.beta1, a.beta2, a.eps);
         }
+        // (Round 4, measured and rejected - profiles/r04_bench_adam_fused_catchup_rejected.txt, r04_adam_prefetch_ab.txt:
+        // NOT writing the users back and replaying the same steps in the user pass, which then gathers each sample's
+        // moments - three row transfers per stale user less, but the replay is ~60 VALU cycles per element and step
+        // (sqrt, two divides) and doing it twice cost more than the traffic: 2.80 -> 3.62 ms per step at 10 M x 1 M.
+        // Gathering the moments with the rows WITHOUT the replay, so that a run's owner commits from registers: no
+        // change either way (1.293 / 1.291 and 3.032 / 3.039 ms, same box) at 180 instead of 161 VGPRs.)
         w.store(W + row * d, lane, d); m.store(M + row * d, lane, d); vv.store(V + row * d, lane, d);
         if (lane == 0) last[row] = a.t - 1;
         if (user_side) {
