@@ -146,6 +146,7 @@ struct daisy_epoch_plan {
 
 constexpr int kMaxItemSlices = 16;  // daisy_bpr_staged_item_slices
 constexpr int kPreBlocks = 256;   // workgroups (= partial sums) of the staged step's pre-norm pass
+constexpr int64_t kMergeMaxBatch = 131072;   // largest batch of the three-launch staged step (see staged_sgd_step)
 
 struct daisy_bpr_ctx {
     int64_t max_batch, U, I;
@@ -168,6 +169,10 @@ struct daisy_bpr_ctx {
     daisy::StreamView sv;  // the same batch as the staged step sees it
     int32_t batch_kind;   // layout of the plan the current batch comes from (0: v and sv valid, 1: only sv)
     int64_t edge_chunks;  // chunks the edge-record arrays hold (two records per chunk)
+    // a second, small set of edge records: the three-launch form of the staged step (batches up to kMergeMaxBatch
+    // samples) runs the user pass's edge chains and the item pass in ONE launch, so the two cannot share theirs
+    float *edge2_vec; int32_t *edge2_item; float *edge2_cnt; int32_t *edge2_whole;
+    int64_t edge2_chunks;
     float *edge_cnt;      // staged step, edge records of the item pass: [2*nchunks][2] (n_pos, n_neg)
     int64_t *slice_rng;   // staged step in item slices (multi-GPU pipelining): entry range of slice s = [slice_rng[s], slice_rng[s+1])
     int32_t n_slices;     //   of the current batch (0: not prepared)
@@ -207,16 +212,20 @@ int launch_reduce_partials(const double *partials, int nblocks, double *stats, b
                            float reg_2, double *epoch_acc, double *step_loss, hipStream_t s);
 // shared device helpers
 // MFRecommender.py:88-89,94-95: loss += reg_1*(L1 terms) + reg_2*(Frobenius terms)
+// the step's loss and the three Frobenius norms from the seven batch sums (indexed like stats[0..6])
+__device__ __forceinline__ double loss_from_sums(const double *__restrict__ s7, float reg_1, float reg_2, double &nU,
+                                                 double &nI, double &nJ) {
+    nU = sqrt(s7[DAISY_ST_SQ_U]);
+    nI = sqrt(s7[DAISY_ST_SQ_I]);
+    nJ = sqrt(s7[DAISY_ST_SQ_J]);
+    return s7[DAISY_ST_LOSS_DATA] + (double)reg_1 * (s7[DAISY_ST_L1_I] + s7[DAISY_ST_L1_J]) + (double)reg_2 * (nI + nJ) +
+           (double)reg_1 * s7[DAISY_ST_L1_U] + (double)reg_2 * nU;
+}
 __device__ __forceinline__ void finalize_stats(double *__restrict__ stats, float reg_1, float reg_2,
                                                double *__restrict__ epoch_acc,
                                                double *__restrict__ step_loss) {
-    const double nU = sqrt(stats[DAISY_ST_SQ_U]);
-    const double nI = sqrt(stats[DAISY_ST_SQ_I]);
-    const double nJ = sqrt(stats[DAISY_ST_SQ_J]);
-    const double loss = stats[DAISY_ST_LOSS_DATA] +
-                        (double)reg_1 * (stats[DAISY_ST_L1_I] + stats[DAISY_ST_L1_J]) +
-                        (double)reg_2 * (nI + nJ) + (double)reg_1 * stats[DAISY_ST_L1_U] +
-                        (double)reg_2 * nU;
+    double nU, nI, nJ;
+    const double loss = loss_from_sums(stats, reg_1, reg_2, nU, nI, nJ);
     stats[DAISY_ST_LOSS] = loss;
     stats[DAISY_ST_NORM_U] = nU;
     stats[DAISY_ST_NORM_I] = nI;
@@ -229,12 +238,12 @@ __device__ __forceinline__ void finalize_stats(double *__restrict__ stats, float
 }
 
 
-// one workgroup of kBlock threads: stats[0..7] = column sums of partials[nblocks][8], in a fixed order
-__device__ __forceinline__ void reduce_partials_block(const double *__restrict__ partials, int nblocks,
-                                                      double *__restrict__ stats, bool finalize, float reg_1,
-                                                      float reg_2, double *__restrict__ epoch_acc,
-                                                      double *__restrict__ step_loss) {
-    __shared__ double sm[kBlock][8];
+// one workgroup of kBlock threads: the column sums of partials[nblocks][8] in a fixed order - thread b adds rows b,
+// b + kBlock, ..., every wave adds its 64 threads' sums (DPP steps in registers), the four wave sums are added in wave
+// order - returned in LDS: (*sums)[k] for k < 8, readable by every thread after the call (which ends in its only
+// barrier; round 3's eight-level LDS tree cost eight, on the critical path of every step's reduction).
+__device__ __forceinline__ const double (*partials_sums(const double *__restrict__ partials, int nblocks))[8] {
+    __shared__ double sm[kBlock / kWave + 1][8];
     double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int b = threadIdx.x;
     for (; b + kBlock < nblocks; b += 2 * kBlock) {          // two rows (16 loads) in flight per thread
@@ -248,18 +257,31 @@ __device__ __forceinline__ void reduce_partials_block(const double *__restrict__
 #pragma unroll
         for (int k = 0; k < 8; ++k) t[k] += partials[(int64_t)b * 8 + k];
     }
+    const int wave = threadIdx.x / kWave;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) sm[threadIdx.x][k] = t[k];
-    __syncthreads();
-    for (int off = kBlock / 2; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) sm[threadIdx.x][k] += sm[threadIdx.x + off][k];
-        }
-        __syncthreads();
+    for (int k = 0; k < 8; ++k) {
+        const double w = wave_sum_f64_dpp(t[k]);
+        if ((threadIdx.x % kWave) == 0) sm[wave][k] = w;
     }
-    if (threadIdx.x < 7) stats[threadIdx.x] = sm[0][threadIdx.x];
-    if (threadIdx.x == 7) stats[DAISY_ST_SUM_COEF] = sm[0][7];
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        double tot = sm[0][threadIdx.x];
+#pragma unroll
+        for (int w = 1; w < kBlock / kWave; ++w) tot += sm[w][threadIdx.x];
+        sm[kBlock / kWave][threadIdx.x] = tot;
+    }
+    __syncthreads();
+    return reinterpret_cast<const double (*)[8]>(&sm[kBlock / kWave]);
+}
+
+// stats[0..6, SUM_COEF] = those sums; finalize: also the norms and the loss (finalize_stats)
+__device__ __forceinline__ void reduce_partials_block(const double *__restrict__ partials, int nblocks,
+                                                      double *__restrict__ stats, bool finalize, float reg_1,
+                                                      float reg_2, double *__restrict__ epoch_acc,
+                                                      double *__restrict__ step_loss) {
+    const double (*sums)[8] = partials_sums(partials, nblocks);
+    if (threadIdx.x < 7) stats[threadIdx.x] = (*sums)[threadIdx.x];
+    if (threadIdx.x == 7) stats[DAISY_ST_SUM_COEF] = (*sums)[7];
     if (finalize) {
         __syncthreads();
         if (threadIdx.x == 0) finalize_stats(stats, reg_1, reg_2, epoch_acc, step_loss);

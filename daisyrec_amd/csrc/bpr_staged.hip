@@ -1086,15 +1086,11 @@ struct ReduceJob {
     double *stats, *epoch_acc, *step_loss;
 };
 template <class C, bool ADAM>
-__global__ __launch_bounds__(kBlock) void k_staged_user_edges(float *__restrict__ P, int64_t nchunks, int d,
-                                                              const double *__restrict__ stats, RowOpt opt,
-                                                              float reg_1, float reg_2, UserEdges ed,
-                                                              float *__restrict__ p_sqnorm, PreNorm pre,
-                                                              ReduceJob red, const double *__restrict__ halt,
-                                                              StagedBias fm) {
-    if (halted(halt)) return;              // (the riding reduction too: the epoch's sums stay at the offending step)
+__device__ __forceinline__ void user_edges_block(unsigned bid, unsigned nb, float *__restrict__ P, int64_t nchunks, int d,
+                                                 const double *__restrict__ stats, const RowOpt &opt, float reg_1,
+                                                 float reg_2, const UserEdges &ed, float *__restrict__ p_sqnorm,
+                                                 const PreNorm &pre, const ReduceJob &red, const StagedBias &fm) {
     const double sq_pre = prenorm_sum(stats, pre);
-    unsigned nb = gridDim.x, bid = blockIdx.x;
     if (red.nblocks > 0) {            // workgroup 0 (dispatched first: its chain of dependent loads is the longest)
         if (bid == 0) {
             reduce_partials_block(red.partials, red.nblocks, red.stats, true, reg_1, reg_2, red.epoch_acc, red.step_loss);
@@ -1130,6 +1126,29 @@ __global__ __launch_bounds__(kBlock) void k_staged_user_edges(float *__restrict_
         user_bias_commit(fm, uu, sb, opt.lr, lane);
     }
 }
+
+template <class C, bool ADAM>
+__global__ __launch_bounds__(kBlock) void k_staged_user_edges(float *__restrict__ P, int64_t nchunks, int d,
+                                                              const double *__restrict__ stats, RowOpt opt,
+                                                              float reg_1, float reg_2, UserEdges ed,
+                                                              float *__restrict__ p_sqnorm, PreNorm pre,
+                                                              ReduceJob red, const double *__restrict__ halt,
+                                                              StagedBias fm) {
+    if (halted(halt)) return;              // (the riding reduction too: the epoch's sums stay at the offending step)
+    user_edges_block<C, ADAM>(blockIdx.x, gridDim.x, P, nchunks, d, stats, opt, reg_1, reg_2, ed, p_sqnorm, pre, red, fm);
+}
+
+// The THREE-LAUNCH form of the step (batches up to kMergeMaxBatch samples, where a step is a chain of launches of ~4.5 us
+// each and not bytes): the user pass's edge chains + the reduction of its sums, and the item pass, touch disjoint data
+// - the chains write rows of P and the norm cache, the item pass reads the stage and Q - once the item workgroups stop
+// waiting for the reduced norms: every one of them adds the user pass's per-workgroup sums itself (partials_sums: the
+// same loads in the same order as the reduction, so the same bits).  The item launch then carries the chains and the
+// reduction as extra workgroups behind its own; the next batch's pre-norm, which needs the chains' rows, moves on to the
+// item-edge launch.
+struct MergedJob {
+    float *P; int64_t u_nchunks; UserEdges ued; float *p_sqnorm; PreNorm pre; ReduceJob red;
+    int n_ue;                    // workgroups for the user pass's edge chains (the reduction's workgroup not counted)
+};
 
 struct ItemEdges2 {
     float *vec;          // [2*nchunks][d]  partial gradient rows; [2c] head edge (inherited), [2c+1] tail edge
@@ -1198,23 +1217,44 @@ __device__ __forceinline__ void item_commit(float *__restrict__ Qo, float *__res
 // MODE (see k_staged_user): premul - entry weight +/-1; plain - the sample's (dL/dpos, dL/dneg) gathered from coef;
 // point - weight 1 (a negative slot, which only the sorted layout's point-wise batches have, is inert: weight 0, not
 // counted).
-template <class C, int BLK, int MODE, bool APPLY, bool ADAM, bool SPARSE>
-__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(ADAM ? 2 : 4, 8))) void k_staged_item(const float *__restrict__ stage,
+// MERGED (three-launch form, see MergedJob; SGD in place only): the launch also carries the user pass's edge chains and
+// the reduction of its sums, as workgroups behind the item pass's own, and every item workgroup derives the norms (and
+// whether this step's loss is finite) from the user pass's per-workgroup sums itself.
+template <class C, int BLK, int MODE, bool APPLY, bool ADAM, bool SPARSE, bool MERGED = false>
+__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((ADAM || MERGED) ? 2 : 4, 8))) void k_staged_item(const float *__restrict__ stage,
                                                         const float2 *__restrict__ coef, StreamView v, int d,
                                                         float *__restrict__ Qo, float *__restrict__ cnt_out,
                                                         const double *__restrict__ stats, RowOpt opt,
                                                         float reg_1, float reg_2, ItemEdges2 ed,
                                                         const int64_t *__restrict__ erange, StagedBias fm,
-                                                        RideUnorm ride) {
+                                                        RideUnorm ride, MergedJob mj) {
+    static_assert(!MERGED || (APPLY && !ADAM && BLK == kBlock), "the three-launch form: SGD in place, 256-thread workgroups");
     // this step's loss (reduced behind the user pass) or an earlier one was not finite: nothing may be written.  Requested
     // here, looked at behind the first chunk's gathers (see k_staged_user)
-    const double halt_word = v.halt ? *v.halt : 0.0;
+    double halt_word = v.halt ? *v.halt : 0.0;
     if (ride.nblocks && (int)blockIdx.x >= ride.first_block) {      // the next batch's pre-norm rides on this launch
         if (halt_word > 0.0) return;
         unorm_block(ride, (int)blockIdx.x - ride.first_block);
         return;
     }
-    const int item_grid = ride.nblocks ? ride.first_block : (int)gridDim.x;
+    int item_grid = ride.nblocks ? ride.first_block : (int)gridDim.x;
+    float rI = 0.f, rJ = 0.f;
+    if constexpr (MERGED) {
+        item_grid = (int)gridDim.x - mj.n_ue - 1;
+        if ((int)blockIdx.x >= item_grid) {                         // the user pass's edge chains and its reduction
+            if (halt_word > 0.0) return;
+            user_edges_block<C, false>(blockIdx.x - item_grid, mj.n_ue + 1, mj.P, mj.u_nchunks, d, stats, opt, reg_1, reg_2,
+                                       mj.ued, mj.p_sqnorm, mj.pre, mj.red, fm);
+            return;
+        }
+        // what the reduction workgroup will write to stats, formed here from the same sums in the same order
+        const double (*sums)[8] = partials_sums(mj.red.partials, mj.red.nblocks);
+        double nU, nI, nJ;
+        const double loss = loss_from_sums(&(*sums)[0], reg_1, reg_2, nU, nI, nJ);
+        if (!(loss == loss) || isinf(loss)) halt_word = 1.0;        // this step's loss is not finite: the epoch stops here
+        rI = inv_or_zero(nI, reg_2);
+        rJ = inv_or_zero(nJ, reg_2);
+    }
     using Cfg = StagedItemCfg<C, BLK, SPARSE>;
     constexpr int G = Cfg::G, RUN = Cfg::RUN, E = Cfg::E;
     // erange: only the entries [erange[0], erange[1]) - an item range of the batch (the entries are sorted by item, so
@@ -1248,8 +1288,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu(ADAM ? 2 : 
     const int64_t n = v.E;
     const int64_t nchunks = (n + E - 1) / E;
     const bool has_bias = BIAS && fm.bi != nullptr;
-    float rI = 0.f, rJ = 0.f;
-    if constexpr (APPLY) {
+    if constexpr (APPLY && !MERGED) {
         rI = inv_or_zero(stats[DAISY_ST_NORM_I], reg_2);
         rJ = inv_or_zero(stats[DAISY_ST_NORM_J], reg_2);
     }
@@ -1458,9 +1497,13 @@ __global__ __launch_bounds__(kBlock) void k_staged_item_edges(ItemEdges2 ed, int
                                                               float reg_1, float reg_2,
                                                               const int64_t *__restrict__ erange, int chunk_entries,
                                                               const double *__restrict__ halt, StagedBias fm,
-                                                              RideReduce rr) {
+                                                              RideReduce rr, RideUnorm ride) {
     if (halted(halt)) return;
-    unsigned nb = gridDim.x;
+    if (ride.nblocks && (int)blockIdx.x >= ride.first_block) {     // three-launch form: the next batch's pre-norm rides HERE
+        unorm_block(ride, (int)blockIdx.x - ride.first_block);     // (the user pass's edge chains ran in the item launch)
+        return;
+    }
+    unsigned nb = ride.nblocks ? (unsigned)ride.first_block : gridDim.x;
     if (rr.n) {                            // the last workgroup adds the next batch's pre-norm partial sums (k_unorm_reduce)
         nb -= 1;
         if (blockIdx.x == nb) {
@@ -1693,7 +1736,8 @@ struct StagedUserBlk {
 static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_type, float gamma, float lr,
                        float reg_1, float reg_2, double *stats, int *grid_out, int n_pre, bool ride_reduce,
                        double *epoch_acc, double *step_loss, hipStream_t s, const StagedAdam *adam = nullptr,
-                       bool bias_grad_out = false) {
+                       bool bias_grad_out = false, MergedJob *hand_over = nullptr) {
+    // hand_over != NULL (three-launch form): the edge launch is NOT issued; *hand_over describes its work for the item launch
     ctx->pre_ready = false;                // (P is about to change: a pre-norm computed ahead of this pass is stale)
     StreamView v = ctx->sv;
     const int d = ctx->d;
@@ -1736,6 +1780,10 @@ static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_ty
         else by_pos(std::integral_constant<int, kModePoint>{});
         const ReduceJob red{ctx->partials, ride_reduce ? *grid_out : 0, stats, epoch_acc, step_loss};
         const dim3 ge(grid_for(nchunks_out, C::GROUPS_PER_BLOCK) + (ride_reduce ? 1 : 0));
+        if (hand_over) {
+            *hand_over = MergedJob{P, nchunks_out, ed, ctx->p_sqnorm, pre, red, grid_for(nchunks_out, C::GROUPS_PER_BLOCK)};
+            return DAISY_OK;
+        }
         if (adam)
             hipLaunchKernelGGL((k_staged_user_edges<C, true>), ge, dim3(kBlock), 0, s, P, nchunks_out, d, stats, opt, reg_1,
                                reg_2, ed, ctx->p_sqnorm, pre, red, v.halt, fm);
@@ -1750,18 +1798,38 @@ static int staged_user(daisy_bpr_ctx *ctx, float *P, const float *Q, int loss_ty
     return DAISY_OK;
 }
 
+// the user pass's edge launch from a MergedJob that was not merged after all (SGD)
+static int staged_user_edges_launch(daisy_bpr_ctx *ctx, const MergedJob &mj, float lr, float reg_1, float reg_2,
+                                    const double *stats, hipStream_t s) {
+    const RowOpt opt = row_opt(lr, nullptr, true);
+    const StagedBias fm = staged_bias(ctx, false);
+    int rc = dispatch_d(ctx->d, [&](auto cfg) {
+        using C = decltype(cfg);
+        hipLaunchKernelGGL((k_staged_user_edges<C, false>), dim3(mj.n_ue + (mj.red.nblocks > 0 ? 1 : 0)), dim3(kBlock), 0, s, mj.P,
+                           mj.u_nchunks, ctx->d, stats, opt, reg_1, reg_2, mj.ued, mj.p_sqnorm, mj.pre, mj.red, ctx->sv.halt, fm);
+        return DAISY_OK;
+    });
+    if (rc) return rc;
+    DAISY_LAUNCH_CHECK();
+    return DAISY_OK;
+}
+
 // apply != 0: Qo = Q, updated in place; else Qo = gQ (data term), cnt_out f32[I][2]
 // slice >= 0: only the entries of item slice `slice` (daisy_bpr_staged_item_slices has run for this batch)
 static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_out, bool apply, float lr,
                        float reg_1, float reg_2, const double *stats, hipStream_t s, int slice = -1,
                        const StagedAdam *adam = nullptr, bool bias_grad_out = false,
                        RideUnorm ride = RideUnorm{nullptr, nullptr, 0, nullptr, 0, 0},
-                       RideReduce rr = RideReduce{nullptr, 0, nullptr}) {
+                       RideReduce rr = RideReduce{nullptr, 0, nullptr}, const MergedJob *merged = nullptr) {
+    // merged != NULL (three-launch form; apply, SGD): the item launch carries the user pass's edge work, the item pass
+    // keeps its edge records in the context's second set, and `ride` rides on the item-EDGE launch
     const int64_t *erange = (slice >= 0) ? ctx->slice_rng + slice : nullptr;
     const StreamView &v = ctx->sv;
     const int d = ctx->d;
     const int mode = staged_mode(ctx, loss_type);
     ItemEdges2 ed{ctx->edge_vec, ctx->edge_user, ctx->edge_cnt, ctx->edge_whole};
+    if (merged) ed = ItemEdges2{ctx->edge2_vec, ctx->edge2_item, ctx->edge2_cnt, ctx->edge2_whole};
+    const int64_t edge_cap = merged ? ctx->edge2_chunks : ctx->edge_chunks;
     const RowOpt opt = row_opt(lr, adam, false);
     const StagedBias fm = staged_bias(ctx, bias_grad_out);
     if (adam && !apply) { set_error("staged item pass: the Adam owner update needs the in-place form"); return DAISY_ERR_ARG; }
@@ -1779,30 +1847,38 @@ static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_
         constexpr int win_rows = kItemWinFloats / (C::NE * C::LPR);
         bool sparse = apply && !adam && (double)v.E * win_rows < (double)E_dense * (double)ctx->I;
         if (tune_sparse >= 0) sparse = apply && !adam && tune_sparse != 0;
-        if (sparse && (v.E + E_sparse - 1) / E_sparse > ctx->edge_chunks) sparse = false;
+        if (sparse && (v.E + E_sparse - 1) / E_sparse > edge_cap) sparse = false;
         const int chunk_e = sparse ? E_sparse : E_dense;
         const int64_t nchunks = (v.E + chunk_e - 1) / chunk_e;
-        if (nchunks > ctx->edge_chunks) { overflow = true; return DAISY_OK; }
+        if (nchunks > edge_cap) { overflow = true; return DAISY_OK; }
         const int gi = grid_for(v.E, chunk_e, tune_ig);
-        RideUnorm ru = ride;
+        const int ge_own = grid_for(nchunks, C::GROUPS_PER_BLOCK) + (rr.n ? 1 : 0);
+        RideUnorm ru = ride, ru_edge = RideUnorm{nullptr, nullptr, 0, nullptr, 0, 0};
+        MergedJob mj{};
+        if (merged) {                        // the ride moves to the edge launch; the user pass's edge work joins this one
+            ru_edge = ride;
+            ru_edge.first_block = ge_own;
+            ru.nblocks = 0;
+            mj = *merged;
+        }
         ru.first_block = gi;                 // the riding workgroups follow the item pass's own
-        const dim3 g(gi + ru.nblocks), b(BLK), ge(grid_for(nchunks, C::GROUPS_PER_BLOCK) + (rr.n ? 1 : 0));
+        const dim3 g(gi + ru.nblocks + (merged ? mj.n_ue + 1 : 0)), b(BLK), ge(ge_own + ru_edge.nblocks);
         auto launch = [&](auto mode_tag, auto ap_tag, auto adam_tag) {
             constexpr int MODE = decltype(mode_tag)::value;
             constexpr bool AP = decltype(ap_tag)::value, AD = decltype(adam_tag)::value;
             if constexpr (AP && !AD) {
-                if (sparse)
-                    hipLaunchKernelGGL((k_staged_item<C, BLK, MODE, true, false, true>), g, b, 0, s, ctx->p_stage, ctx->coef, v,
-                                       d, Qo, cnt_out, stats, opt, reg_1, reg_2, ed, erange, fm, ru);
-                else
-                    hipLaunchKernelGGL((k_staged_item<C, BLK, MODE, true, false, false>), g, b, 0, s, ctx->p_stage, ctx->coef, v,
-                                       d, Qo, cnt_out, stats, opt, reg_1, reg_2, ed, erange, fm, ru);
+#define DAISY_ITEM_LAUNCH(SP, MG)                                                                                          \
+    hipLaunchKernelGGL((k_staged_item<C, BLK, MODE, true, false, SP, MG>), g, b, 0, s, ctx->p_stage, ctx->coef, v, d, Qo, \
+                       cnt_out, stats, opt, reg_1, reg_2, ed, erange, fm, ru, mj)
+                if (merged) { if (sparse) DAISY_ITEM_LAUNCH(true, true); else DAISY_ITEM_LAUNCH(false, true); }
+                else { if (sparse) DAISY_ITEM_LAUNCH(true, false); else DAISY_ITEM_LAUNCH(false, false); }
+#undef DAISY_ITEM_LAUNCH
             } else {
                 hipLaunchKernelGGL((k_staged_item<C, BLK, MODE, AP, AD, false>), g, b, 0, s, ctx->p_stage, ctx->coef, v, d, Qo,
-                                   cnt_out, stats, opt, reg_1, reg_2, ed, erange, fm, ru);
+                                   cnt_out, stats, opt, reg_1, reg_2, ed, erange, fm, ru, mj);
             }
             hipLaunchKernelGGL((k_staged_item_edges<C, AP, AD>), ge, dim3(kBlock), 0, s, ed, nchunks, d, Qo, cnt_out, stats,
-                               opt, reg_1, reg_2, erange, chunk_e, v.halt, fm, rr);
+                               opt, reg_1, reg_2, erange, chunk_e, v.halt, fm, rr, ru_edge);
         };
         auto by_apply = [&](auto mode_tag) {
             if (apply && adam) launch(mode_tag, std::true_type{}, std::true_type{});
@@ -1835,13 +1911,28 @@ int staged_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int loss_type, float
     ctx->pre_ready = false;                  // consumed, or stale
     if (have_pre) n_pre = ctx->pre_n;        // > 0: partial sums wait behind the user pass's own; 0: stats[SQ_U_PRE] holds the sum
     else if ((rc = staged_prenorm(ctx, P, stats, false, &n_pre, s))) return rc;
-    if ((rc = staged_user(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, stats, &gu, n_pre, true, epoch_acc, step_loss, s))) return rc;
-    // the next batch of the same plan: its pre-norm rides on this step's item pass
+    // THREE launches (MergedJob) for batches whose user pass leaves at most kMergeMaxPartials rows of partial sums (every
+    // item workgroup adds them itself): B <= 16384 at d = 64.  DAISY_STAGED_MERGE (read per call: the tests switch it):
+    // 0 never, 1 whenever the buffers allow it
+    const char *env_merge = getenv("DAISY_STAGED_MERGE");
+    const int tune_merge = env_merge ? atoi(env_merge) : -1;
+    constexpr int64_t kMergeMaxPartials = 512;
+    const daisy_epoch_plan *pl = ctx->cur_plan;
+    const bool ride_next = tune_ride && pl && pl->kind == 1 && ctx->cur_gen == pl->build_gen &&
+                           ctx->cur_k + 1 < pl->num_batches && daisy_epoch_plan_batch_rows(pl, ctx->cur_k + 1) > 0;
+    bool merge = tune_merge != 0 && ctx->edge2_vec != nullptr && ctx->sv.B <= kMergeMaxBatch &&
+                 (!ride_next || grid_for(plan_stream_view(pl, ctx->cur_k + 1).B, kBlock * 4) <= kPreBlocks / 2);
+    MergedJob mj{};
+    if ((rc = staged_user(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, stats, &gu, n_pre, true, epoch_acc, step_loss, s,
+                          nullptr, false, merge ? &mj : nullptr))) return rc;
+    if (merge && tune_merge < 0 && gu > kMergeMaxPartials) merge = false;
+    if (!merge && mj.P != nullptr) {         // (decided against it after all: issue the edge launch that was held back)
+        if ((rc = staged_user_edges_launch(ctx, mj, lr, reg_1, reg_2, stats, s))) return rc;
+    }
+    // the next batch of the same plan: its pre-norm rides on this step's item pass (three-launch form: on the item-edge launch)
     RideUnorm ride{nullptr, nullptr, 0, nullptr, 0, 0};
     RideReduce rr{nullptr, 0, nullptr};
-    const daisy_epoch_plan *pl = ctx->cur_plan;
-    if (tune_ride && pl && pl->kind == 1 && ctx->cur_gen == pl->build_gen && ctx->cur_k + 1 < pl->num_batches &&
-        daisy_epoch_plan_batch_rows(pl, ctx->cur_k + 1) > 0) {
+    if (ride_next) {
         const StreamView nv = plan_stream_view(pl, ctx->cur_k + 1);
         const int gn = grid_for(nv.B, kBlock * 4);
         const bool fold = gn <= kPreBlocks / 2;              // (the same rule as staged_prenorm)
@@ -1852,7 +1943,8 @@ int staged_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int loss_type, float
         ctx->pre_plan = pl; ctx->pre_k = ctx->cur_k + 1; ctx->pre_gen = ctx->cur_gen;
         ctx->pre_P = P; ctx->pre_stats = stats; ctx->pre_n = fold ? gn : 0;
     }
-    if ((rc = staged_item(ctx, loss_type, Q, nullptr, true, lr, reg_1, reg_2, stats, s, -1, nullptr, false, ride, rr))) return rc;
+    if ((rc = staged_item(ctx, loss_type, Q, nullptr, true, lr, reg_1, reg_2, stats, s, -1, nullptr, false, ride, rr,
+                          merge ? &mj : nullptr))) return rc;
     ctx->pre_ready = ride.nblocks > 0;
     ctx->fwd_done = false;
     return DAISY_OK;

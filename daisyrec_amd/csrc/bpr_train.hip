@@ -1566,6 +1566,11 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
     const size_t o_ev = take(n_edge * (size_t)d * 4), o_eu = take(n_edge * 4), o_en = take(n_edge * 8);
     const size_t o_ew = take(n_edge * 4);
     const size_t o_ec = take(n_edge * 16);        // staged item pass: (n_pos, n_neg, coefficient sum, -) per edge record
+    // the item pass's own edge records in the three-launch form (its chunks are at least 2 entries x 16 lane groups)
+    const size_t merge_b = (size_t)(max_batch < kMergeMaxBatch ? max_batch : kMergeMaxBatch);
+    const size_t chunks2 = 2 * merge_b / 32 + 2, n_edge2 = 2 * chunks2;
+    const size_t o_e2v = take(n_edge2 * (size_t)d * 4), o_e2i = take(n_edge2 * 4), o_e2c = take(n_edge2 * 16);
+    const size_t o_e2w = take(n_edge2 * 4);
     const size_t o_sr = take((kMaxItemSlices + 1) * 8);
     const size_t o_ps = take((size_t)max_batch * (size_t)d * 4);
     const size_t o_pn = take((size_t)user_num * 4);
@@ -1585,6 +1590,9 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
     c->edge_n = (float *)(base + o_en);
     c->edge_whole = (int32_t *)(base + o_ew);
     c->edge_cnt = (float *)(base + o_ec);
+    c->edge2_vec = (float *)(base + o_e2v); c->edge2_item = (int32_t *)(base + o_e2i);
+    c->edge2_cnt = (float *)(base + o_e2c); c->edge2_whole = (int32_t *)(base + o_e2w);
+    c->edge2_chunks = (int64_t)chunks2;
     c->slice_rng = (int64_t *)(base + o_sr);
     c->n_slices = 0;
     c->batch_kind = 0;

@@ -293,6 +293,27 @@ __device__ __forceinline__ float wave_sum_f32_dpp(float x) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// The same for a double: the DPP steps move the two halves (no LDS crossbar: wave_sum_f64's twelve ds_bpermute per sum
+// are a microsecond where eight sums meet on the critical path of a launch-bound step).
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = dpp_i32<CTRL>((int)(b & 0xFFFFFFFFll)), hi = dpp_i32<CTRL>((int)(b >> 32));
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+    const long long b = __builtin_bit_cast(long long, x);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xFFFFFFFFll), lane), hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_f64_dpp(double x) {
+    x += dpp_f64<kDppQuadXor1>(x);
+    x += dpp_f64<kDppQuadXor2>(x);
+    x += dpp_f64<kDppHalfMirror>(x);
+    x += dpp_f64<kDppMirror>(x);
+    return (readlane_f64(x, 0) + readlane_f64(x, 16)) + (readlane_f64(x, 32) + readlane_f64(x, 48));
+}
+
 // Pick the fragment shape for a runtime d.  F is a generic lambda taking a RowCfg tag.
 template <class F>
 inline int dispatch_d(int d, F &&f) {

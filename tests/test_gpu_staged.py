@@ -119,8 +119,8 @@ def _tables(U, I, d, seed, scale=0.1):
 
 @pytest.mark.parametrize("d", [64, 32, 8, 20, 128, 100, 7, 256])
 @pytest.mark.parametrize("loss", ["BPR", "HL", "TL", "CL", "SL"])
-@pytest.mark.parametrize("sparse", [None, "1"])
-def test_staged_epoch_matches_oracle(d, loss, sparse, monkeypatch):
+@pytest.mark.parametrize("sparse,merge", [(None, None), ("1", None), (None, "0"), ("1", "0")])
+def test_staged_epoch_matches_oracle(d, loss, sparse, merge, monkeypatch):
     """A whole epoch through the partitioned plan + fit_epoch_sgd(fused), replayed by the oracle on the
     batches the plan serves: hot users/items, runs that cross lane groups and chunks, a partial batch.
     CL / SL: point-wise rows (user, item, label), one entry per row.
@@ -130,6 +130,8 @@ def test_staged_epoch_matches_oracle(d, loss, sparse, monkeypatch):
     from daisyrec_amd import ops
     if sparse:
         monkeypatch.setenv("DAISY_STAGED_SPARSE", sparse)
+    if merge:        # "0": four launches per step; default at this size: three (the item launch carries the user pass's edge work)
+        monkeypatch.setenv("DAISY_STAGED_MERGE", merge)
     U, I, n, B = 37, 23, 1500, 400         # heavy collisions: every row is shared inside a batch
     tri = _triples(n, U, I, d)
     point = loss in ("CL", "SL")
@@ -381,10 +383,15 @@ def test_staged_fm_epoch_matches_oracle(d, loss):
     ctx.close(); plan.close(); index.close()
 
 
-def test_staged_large_batch_against_chunked_and_reproducible():
+@pytest.mark.parametrize("merge", [None, "1"])
+def test_staged_large_batch_against_chunked_and_reproducible(merge, monkeypatch):
     """Throughput shapes (runs across chunks on both sides): the staged step equals the phase kernels to
-    round-off, touches the same rows, and two runs give identical bits."""
+    round-off, touches the same rows, and two runs give identical bits.  merge = "1": the three-launch form forced onto
+    this 131 072-sample batch (2048 rows of partial sums for every item workgroup to add; by itself the library stops
+    at 512)."""
     from daisyrec_amd import ops
+    if merge:
+        monkeypatch.setenv("DAISY_STAGED_MERGE", merge)
     U, I, d, n, B = 20000, 3000, 64, 400000, 131072
     tri = _triples(n, U, I, 3, sort=True)
     tri[:5000, 0] = 7                      # one very long user run
