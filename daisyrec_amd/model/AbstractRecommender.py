@@ -334,7 +334,7 @@ class GeneralRecommender(AbstractRecommender):
                     break
             return
         B = min(B, n)            # fewer rows than one batch: a single partial batch, like the DataLoader
-        P, Q = self._tables()    # (the padded buffers behind embed_*.weight where the model trains on a row pitch)
+        P, Q = self._tables(batch=B)    # (the padded buffers behind embed_*.weight where the model trains on a row pitch)
         ctx = ops.BprContext(B, P.shape[1], P.shape[0], Q.shape[0], device=P.device)
         plan = ops.EpochPlan(n, P.shape[0], Q.shape[0], device=P.device)
         biases = self._biases() if hasattr(self, "_biases") else None     # FM: (u_bias, i_bias, bias_)

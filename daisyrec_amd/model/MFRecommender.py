@@ -15,16 +15,19 @@ from .. import ops
 from .AbstractRecommender import GeneralRecommender
 
 
-def padded_factors(d: int, row_pitch="auto") -> int:
+def padded_factors(d: int, row_pitch="auto", batch=None) -> int:
     """columns of the tables the kernels train on for a d-factor model.  'auto': the next multiple of 32 (128-byte rows)
     where that was measured to pay - up to 64 columns and at most a third more of them (d = 24 -> 32: 0.433 -> 0.402 ms per
     2 M-sample step, d = 50 -> 64: 0.698 -> 0.603; but d = 100 -> 128: 1.131 -> 1.203, d = 200 -> 256: 2.56 -> 2.69 -
-    profiles/r03_factor_sweep.txt); 0 / False: never; an integer: pad to its next multiple."""
+    profiles/r03_factor_sweep.txt); for batches of the reference's default size (<= 256, basic.yaml:23), where a step is a
+    chain of dependent phases and not bytes, also beyond 64 columns: the default d = 100 runs as 128 (21.3 -> 17.3 us per
+    step, profiles/r02_small_epoch.txt).  0 / False: never; an integer: pad to its next multiple."""
     if row_pitch in (0, False, None, "0", "off", "none"):
         return d
     if row_pitch == "auto":
         dp = (d + 31) // 32 * 32
-        return dp if (dp <= 64 and 4 * d >= 3 * dp) else d
+        small = batch is not None and batch <= ops.SMALL_BATCH_MAX
+        return dp if ((dp <= 64 or (small and dp <= 128)) and 4 * d >= 3 * dp) else d
     m = int(row_pitch)
     return (d + m - 1) // m * m
 
@@ -56,31 +59,39 @@ class MF(GeneralRecommender):
         self.apply(self._init_weight)
 
     # -- tables as the kernels see them ------------------------------------------
-    def _tables(self):
+    def _tables(self, batch=None):
         """(P, Q) as the kernels see them.  Row pitch (config['row_pitch'], default 'auto'): a factor count whose rows
         are not whole 128-byte lines (d = 50: 200-byte rows straddle lines and leave 3 of 16 lanes idle) trains on tables
         PADDED to the next multiple of 32 columns, the extra columns zero: they stay exactly zero under every update
         (their data gradient is c * 0, sign(0) = 0, the Frobenius and Adam terms are multiples of the element), so scores,
         norms, losses and gradients are those of the d-column model, while a row costs what the aligned row costs
         (profiles/r04_factor_sweep.txt).  `embed_*.weight` stays an [n, d] tensor - a strided view of the padded buffer -
-        for state_dict() and every consumer of the reference's attribute."""
+        for state_dict() and every consumer of the reference's attribute.  `batch`: the batch size of the fit about to
+        run (the pitch that pays depends on it); None keeps the tables as they are homed."""
         self._require_device()
         if not self.embed_user.weight.is_cuda:
             self.to(self.device)
         d = self.embed_user.weight.shape[1]
-        dp = padded_factors(d, self.row_pitch)
-        if dp == d:
-            return self.embed_user.weight.data, self.embed_item.weight.data
+        want = padded_factors(d, self.row_pitch, batch)
         out = []
         for name in ("embed_user", "embed_item"):
             w = getattr(self, name).weight
             buf = self._padded.get(name)
-            if buf is None or buf.device != w.device or w.data.data_ptr() != buf.data_ptr() or tuple(w.data.stride()) != (dp, 1):
-                buf = torch.zeros(w.shape[0], dp, dtype=w.dtype, device=w.device)     # (re)home the weights: after the
-                buf[:, :d].copy_(w.data)                                              # first .to(device), a load, ...
+            homed = (buf is not None and buf.device == w.device and w.data.data_ptr() == buf.data_ptr()
+                     and tuple(w.data.stride()) == (buf.shape[1], 1))
+            if homed and (batch is None or buf.shape[1] == want):
+                out.append(buf)
+            elif want == d:                                     # bare rows: the weight itself, contiguous
+                if homed or not w.data.is_contiguous():
+                    w.data = w.data.contiguous()
+                self._padded.pop(name, None)
+                out.append(w.data)
+            else:                                               # (re)home the weights: after the first .to(device), a
+                buf = torch.zeros(w.shape[0], want, dtype=w.dtype, device=w.device)    # load, another batch regime, ...
+                buf[:, :d].copy_(w.data)
                 w.data = buf[:, :d]
                 self._padded[name] = buf
-            out.append(buf)
+                out.append(buf)
         return out[0], out[1]
 
     def _biases(self):

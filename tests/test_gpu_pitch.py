@@ -57,14 +57,16 @@ def _config(d, opt, pitch):
             "init_method": "default", "early_stop": False, "progress": False, "seed": 7, "row_pitch": pitch}
 
 
-@pytest.mark.parametrize("d,opt", [(50, "sgd"), (24, "sgd"), (50, "adam")])
-def test_fit_on_a_row_pitch_equals_the_fit_without(d, opt):
+@pytest.mark.parametrize("d,opt,B", [(50, "sgd", 700), (24, "sgd", 700), (50, "adam", 700), (100, "sgd", 256)])
+def test_fit_on_a_row_pitch_equals_the_fit_without(d, opt, B):
     """model level: MF.fit with the automatic pitch against the same fit with row_pitch=0 (same seeds, same loader
     order): epoch losses, weights - [n, d] tensors either way -, ranked lists; the padded buffers keep zero padding;
     state_dict round trip through the strided views"""
     from daisyrec_amd.model.MFRecommender import MF, padded_factors
     from daisyrec_amd.utils.dataset import BasicDataset, get_dataloader, CandidatesDataset
-    assert padded_factors(d) != d and padded_factors(100) == 100 and padded_factors(64) == 64 and padded_factors(d, 0) == d
+    # (the reference's default d = 100 only at its default batch: one persistent workgroup per epoch, bound by phases not bytes)
+    assert padded_factors(d, "auto", B) != d and padded_factors(100) == 100 and padded_factors(100, "auto", 256) == 128
+    assert padded_factors(64) == 64 and padded_factors(d, 0) == d
     rng = np.random.default_rng(5)
     tri = np.stack([np.sort(rng.integers(0, 157, 6000)), rng.integers(0, 211, 6000), rng.integers(0, 211, 6000)], 1).astype(np.int32)
     models = []
@@ -72,7 +74,7 @@ def test_fit_on_a_row_pitch_equals_the_fit_without(d, opt):
         torch.manual_seed(123)
         m = MF(_config(d, opt, pitch))
         torch.manual_seed(321)
-        m.fit(get_dataloader(BasicDataset(tri), batch_size=700, shuffle=True, num_workers=0))
+        m.fit(get_dataloader(BasicDataset(tri), batch_size=B, shuffle=True, num_workers=0))
         models.append(m)
     a, b = models
     assert tuple(a.embed_user.weight.shape) == (157, d) and tuple(a.embed_item.weight.shape) == (211, d)
@@ -81,7 +83,7 @@ def test_fit_on_a_row_pitch_equals_the_fit_without(d, opt):
     np.testing.assert_allclose(a.embed_user.weight.data.cpu().numpy(), b.embed_user.weight.data.cpu().numpy(), atol=tol)
     np.testing.assert_allclose(a.embed_item.weight.data.cpu().numpy(), b.embed_item.weight.data.cpu().numpy(), atol=tol)
     Pp, Qp = a._tables()
-    assert Pp.shape[1] == padded_factors(d) and Pp.data_ptr() == a.embed_user.weight.data.data_ptr()
+    assert Pp.shape[1] == padded_factors(d, "auto", B) and Pp.data_ptr() == a.embed_user.weight.data.data_ptr()
     assert float(Pp[:, d:].abs().max().cpu()) == 0.0 and float(Qp[:, d:].abs().max().cpu()) == 0.0
     # scores through the reference's methods agree (rank kernels run on the padded tables)
     us = torch.arange(20)
@@ -96,5 +98,9 @@ def test_fit_on_a_row_pitch_equals_the_fit_without(d, opt):
     c = MF(_config(d, opt, "auto"))
     c.load_state_dict(sd)
     assert abs(c.predict(3, 5) - a.predict(3, 5)) < 1e-7
-    Pc, _ = c._tables()
-    assert Pc.shape[1] == padded_factors(d) and float(Pc[:, d:].abs().max().cpu()) == 0.0
+    Pc, _ = c._tables(batch=B)
+    assert Pc.shape[1] == padded_factors(d, "auto", B) and float(Pc[:, d:].abs().max().cpu()) == 0.0
+    # another batch regime re-homes the tables (d = 100: bare rows for large batches), the weights unchanged
+    before = c.embed_user.weight.data.clone()
+    Pl, _ = c._tables(batch=1 << 20)
+    assert Pl.shape[1] == padded_factors(d, "auto", 1 << 20) and torch.equal(c.embed_user.weight.data, before)
