@@ -448,13 +448,26 @@ def main():
         r2 = measure(a, d2, rank, world, dev, 1 << 21, 1, None, a.warmup)
         free_data(d2)
         ach2, gpu2 = roofline_of(r2, 1)
+        traffic2, traffic2_src = None, None
+        t2path = os.path.join(ROOT, "profiles", "pmc_traffic_c3shapes.json")
+        if os.path.exists(t2path):
+            try:        # the committed PMC passes of this very leg (bench.py --workload c3 --nnz 100000000)
+                t2 = json.load(open(t2path))
+                traffic2 = t2["hbm_bytes_per_interaction"] * r2["B"]
+                traffic2_src = t2.get("source", "profiles/pmc_traffic_c3shapes.json")
+            except Exception:
+                traffic2 = None
         secondary = {"workload": r2["name"] + " - the pure-HBM regime of configs[2] on ONE GPU (P 2.56 GB, Q 256 MB: "
                                               "both beyond the 256 MB Infinity Cache)",
                      "value": r2["steps"] * r2["B"] / r2["dt"], "unit": "interactions/s", "steps": r2["steps"],
                      "batch": r2["B"], "ms_per_step": r2["dt"] / r2["steps"] * 1e3, "gpu_ms_per_step_events": gpu2,
                      "roofline": {"bound": "hbm", "achieved": ach2, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": ach2 / HBM_PEAK_GBS,
-                                  "algorithmic_bytes_per_interaction": ALGO_BYTES_PER_INTERACTION_SGD(64)}}
+                                  "frac": ach2 / HBM_PEAK_GBS, "traffic": traffic2, "traffic_source": traffic2_src,
+                                  "algorithmic_bytes_per_interaction": ALGO_BYTES_PER_INTERACTION_SGD(64),
+                                  "ceiling_note": "at these table shapes a step really moves ~1.38x the algorithmic bytes "
+                                                  "(every P row read and written once per sample, a quarter of the Q rows "
+                                                  "updated in place per step, the stage written once and read twice): at the "
+                                                  "~6.3 TB/s the fabric delivers frac cannot exceed ~0.57 with this design"}}
 
     ref, ref_global = None, {}
     if world > 1 and wl in ("c3", "tiny") and not a.no_ref:
@@ -505,7 +518,8 @@ def main():
             except Exception:
                 traffic = None
         if r["staged"]:
-            chain = ("one SGD step = k_unorm (+reduce) + k_staged_user + its edge kernel (which also reduces the batch sums) + k_staged_item (+edges)"
+            chain = ("one SGD step = k_staged_user (forward + user rows) + its edge kernel (which also reduces the batch sums) + "
+                     "k_staged_item (item rows in place; the next batch's pre-norm rides on it) + its edge kernel"
                      + (" + RCCL reduce-scatter / k_item_apply_counts / all-gather" if world > 1 else ""))
         else:
             chain = "one SGD step = k_fwd + k_reduce_partials + k_item_grad_" + a.item_mode + " + k_user + k_item_apply"
