@@ -47,14 +47,15 @@ template <class KeyT>
 __global__ void k_plan_keys(const int32_t *__restrict__ triples, const int64_t *__restrict__ perm,
                             int order_mode, FeistelKey fk, int64_t n, int64_t start, int64_t B,
                             int32_t user_base, int ubits, int64_t U, int64_t I, int pointwise,
-                            int *__restrict__ bad, KeyT *__restrict__ key, uint64_t *__restrict__ val) {
+                            int *__restrict__ bad, KeyT *__restrict__ key, uint64_t *__restrict__ val,
+                            int64_t perm_limit) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n;
          e += (int64_t)gridDim.x * blockDim.x) {
         int64_t t, p;
         if (order_mode == 1) { p = e; t = perm[e]; }
         else if (order_mode == 2) { t = e; p = (int64_t)feistel_position((uint64_t)e, (uint64_t)n, fk); }
         else { t = e; p = e; }
-        if (order_mode == 1 && (t < 0 || t >= n)) { atomicOr(bad, 2); t = 0; }
+        if (order_mode == 1 && (t < 0 || t >= perm_limit)) { atomicOr(bad, 2); t = 0; }     // (rows the entry may name)
         const int32_t *row = triples + 3 * (t + start);
         int64_t uu = (int64_t)row[0] - user_base;
         int32_t ri = row[1], rj = row[2];
@@ -1232,9 +1233,13 @@ static int plan_need_k64(daisy_epoch_plan *p) {
 }
 
 // flags: DAISY_PLAN_TRIPLES_USER_SORTED -> the samples only need a stable partition by batch
+// perm_limit: rows of `triples` a permutation entry may name (n for a permutation of the n rows; the whole array when the
+// entries SELECT n of its rows: daisy_bpr_set_batch_from_triples - whose range check compared against n until round 4, so
+// that a selection naming a row >= its own length was refused)
 static int plan_build(daisy_epoch_plan *p, const int32_t *triples, int64_t n, int64_t start,
                       const int64_t *perm, int order_mode, uint64_t seed, uint64_t epoch,
-                      int64_t batch_size, int32_t user_base, int32_t flags, hipStream_t s) {
+                      int64_t batch_size, int32_t user_base, int32_t flags, hipStream_t s, int64_t perm_limit = -1) {
+    if (perm_limit < 0) perm_limit = n;
     const int ubits = bits_for(p->U), ibits = bits_for(p->I);
     const int64_t nb = (n + batch_size - 1) / batch_size;
     const int bbits = (nb > 1) ? bits_for(nb) : 0;
@@ -1253,7 +1258,7 @@ static int plan_build(daisy_epoch_plan *p, const int32_t *triples, int64_t n, in
     if (!wide) {
         hipLaunchKernelGGL((k_plan_keys<uint32_t>), dim3(g1), dim3(kBlock), 0, s, triples, perm,
                            order_mode, fk, n, start, batch_size, user_base, ubits, p->U, p->I, pointwise, p->bad,
-                           p->k32[0], p->v64[0]);
+                           p->k32[0], p->v64[0], perm_limit);
         DAISY_LAUNCH_CHECK();
         if (ubits + bbits > s_begin) {
             rc = sort_pairs_u32_u64(p->temp, p->temp_bytes, p->k32[0], p->ukey, p->v64[0], p->uval, n,
@@ -1281,7 +1286,7 @@ static int plan_build(daisy_epoch_plan *p, const int32_t *triples, int64_t n, in
         if ((rc = plan_need_k64(p))) return rc;
         hipLaunchKernelGGL((k_plan_keys<uint64_t>), dim3(g1), dim3(kBlock), 0, s, triples, perm,
                            order_mode, fk, n, start, batch_size, user_base, ubits, p->U, p->I, pointwise, p->bad,
-                           p->k64[0], p->v64[0]);
+                           p->k64[0], p->v64[0], perm_limit);
         DAISY_LAUNCH_CHECK();
         rc = sort_pairs_u64_u64(p->temp, p->temp_bytes, p->k64[0], p->k64[1], p->v64[0], p->uval, n,
                                 s_begin, ubits + bbits, s);
@@ -1692,7 +1697,7 @@ int daisy_bpr_set_batch_from_triples(daisy_bpr_ctx *ctx, const int32_t *triples,
     if (rc) return rc;
     // a one-batch plan over the selected rows
     rc = plan_build(ctx->own_plan, triples, B, idx ? 0 : start, idx, idx ? DAISY_ORDER_PERM : DAISY_ORDER_IDENTITY,
-                    0, 0, B, user_base, ctx->pointwise ? DAISY_PLAN_POINTWISE : 0, S(stream));
+                    0, 0, B, user_base, ctx->pointwise ? DAISY_PLAN_POINTWISE : 0, S(stream), idx ? n_triples : -1);
     if (rc) return rc;
     ctx->v = plan_view(ctx->own_plan, 0);
     ctx->sv = stream_view_of(ctx->v);

@@ -250,25 +250,39 @@ class GeneralRecommender(AbstractRecommender):
                              "(the reference raises IndexError in nn.Embedding, MFRecommender.py:64-65)")
         P_loc = P[lo:hi]
         ctx = ops.BprContext(B, d, hi - lo, I, device=P.device)        # stage slots are positions inside a GLOBAL batch
+        # Adagrad / RMSprop, and Adam with FM's biases: the dense-optimiser protocol (phase kernels + torch's dense
+        # optimisers: sharding.py); SGD (MF, FM) and Adam (MF): the staged protocol
+        dense = opt in ("adagrad", "rmsprop") or (opt == "adam" and biases is not None)
         if biases is not None:             # FM: the rank's slice of u_bias, the replicated i_bias / bias_ (sharding.py)
             for b in biases:
                 dist.broadcast(b, 0)
-            ctx.set_bias(biases[0].view(-1)[lo:hi], biases[1], biases[2],
-                         g_i_bias=torch.zeros(I, dtype=torch.float32, device=P.device))
+            zeros = lambda m: torch.zeros(m, dtype=torch.float32, device=P.device)      # noqa: E731
+            ctx.set_bias(biases[0].view(-1)[lo:hi], biases[1], biases[2], g_u_bias=zeros(hi - lo) if dense else None,
+                         g_i_bias=zeros(I), g_bias=zeros(1) if dense else None)
+        if pointwise_rows := (loss_id in ops.POINTWISE_LOSSES):
+            ctx.set_pointwise(True)
         index = plan = None
         trainer = UserShardedBprTrainer(ctx, P_loc, Q, lo, self.lr, self.reg_1, self.reg_2, loss_type=loss_id,
                                         item_mode=ops.ITEM_MODES["fused"], slices=self.exchange_slices,
-                                        adam_steps=(self.epochs * ((n + B - 1) // B)) if opt == "adam" else 0)
+                                        adam_steps=(self.epochs * ((n + B - 1) // B)) if (opt == "adam" and not dense) else 0,
+                                        dense_opt=ops.DenseOptimizer(opt, self.lr) if dense else None)
         acc = torch.zeros(2, dtype=torch.float64, device=P.device)
         nb = (n + B - 1) // B
         last_loss = 0.0
         try:
-            if n_loc:
-                index = ops.TrainIndex(mine, hi - lo, I, user_base=lo, pointwise=loss_id in ops.POINTWISE_LOSSES)
+            if n_loc and not dense:
+                index = ops.TrainIndex(mine, hi - lo, I, user_base=lo, pointwise=pointwise_rows)
                 plan = ops.EpochPlan(n_loc, hi - lo, I, device=P.device)
             for epoch in range(1, self.epochs + 1):
                 self.train()
-                if n_loc:
+                if n_loc and dense:
+                    # the phase kernels read one sorted batch at a time: the rank's rows in epoch order, cut where the
+                    # global batches end
+                    pos_loc = self._epoch_positions(train_loader, n, epoch, row_ids)
+                    order = torch.argsort(pos_loc)
+                    cuts = torch.searchsorted(pos_loc[order].contiguous(),
+                                              torch.arange(nb + 1, device=P.device, dtype=torch.int64) * B).cpu().tolist()
+                elif n_loc:
                     plan.build_positions(index, self._epoch_positions(train_loader, n, epoch, row_ids), n, B)
                 elif not (self.shuffle_mode == "device" and not isinstance(train_loader.sampler, SequentialSampler)):
                     # a rank without rows: the replayed DataLoader pass draws from the torch RNG, which has to stay in
@@ -276,7 +290,10 @@ class GeneralRecommender(AbstractRecommender):
                     self._epoch_order(train_loader, len(train_loader.dataset))
                 acc.zero_()
                 for k in range(nb):
-                    stats = trainer.step_from_plan(plan, k)
+                    if dense and n_loc and cuts[k + 1] > cuts[k]:
+                        stats = trainer.step_from_triples(mine, idx=order[cuts[k]:cuts[k + 1]].contiguous(), validate=(epoch == 1))
+                    else:
+                        stats = trainer.step_from_plan(plan, k)        # (plan None / no row of batch k: the rank only joins the exchanges)
                     loss = stats[ops.N.ST_LOSS]
                     acc[0] += loss
                     acc[1] += (~torch.isfinite(loss)).to(torch.float64)
@@ -364,12 +381,12 @@ class GeneralRecommender(AbstractRecommender):
                          g_bias=adam.g[2] if adam is not None else None)
         user_sorted = ops.triples_user_sorted(triples[:n])
         if self._sharded_world() > 1:
-            if item_mode == ops.ITEM_MODES["fused"] and (opt == "sgd" or (opt == "adam" and biases is None)):
+            if item_mode == ops.ITEM_MODES["fused"] or opt in ("adagrad", "rmsprop"):
                 ctx.close()
                 plan.close()
                 return self._fit_sharded(train_loader, triples, n, B, loss_id, opt, biases)
-            self.logger.info("torch.distributed is initialised, but only SGD (MF, FM) / Adam (MF) with item_mode 'fused' "
-                             "shards the users over the ranks: every rank trains the whole model")
+            self.logger.info("torch.distributed is initialised, but SGD / Adam with an explicit item_mode other than "
+                             "'fused' do not shard the users over the ranks: every rank trains the whole model")
         if item_mode == ops.ITEM_MODES["fused"] and not staged and B > ops.SMALL_BATCH_MAX:
             item_mode = ops.ITEM_MODES["chunked"]
         index = None

@@ -39,6 +39,13 @@ r owns the r-th block of every range.  Every rank must use the same S.
 PHASE protocol (item modes 'chunked' / 'sorted', or a backend without the staged phases):
 forward -> all_reduce(stats) -> item_grad -> all_reduce(gQ) overlapped with user_sgd -> dense
 item_sgd_apply.  Kept for the modes the staged step does not cover.
+
+DENSE-OPTIMISER protocol (`dense_opt=`: torch's Adagrad / RMSprop, and Adam for FM - AbstractRecommender.py:48-67): the
+phase protocol with gradients instead of updates - forward -> all_reduce(stats) -> item_grad -> all_reduce(gQ)
+overlapped with user_grad -> the dense optimiser on the rank's rows of P (its own state) and on the replicated Q (every
+rank the same gradient, the same state, the same step).  FM: u_bias with its users, the item-bias gradient and the
+coefficient sum all-reduced.  The wire volume is a dense all-reduce of gQ per step: the slow path, for the optimisers
+the staged step does not apply.
 """
 from __future__ import annotations
 
@@ -70,7 +77,7 @@ class UserShardedBprTrainer:
 
     def __init__(self, ctx, P_local, Q, user_lo, lr, reg_1, reg_2, loss_type=N.LOSS_BPR,
                  gamma=1e-10, item_mode=N.ITEM_FUSED, group=None, overlap=True, always_collective=False, slices=1,
-                 adam_steps=0):
+                 adam_steps=0, dense_opt=None):
         """adam_steps > 0: torch.optim.Adam instead of SGD (staged protocol only; the value sizes the table of per-step
         constants, it grows on demand): lazy on the rank's rows of P, dense on its own block(s) of Q (ops.ShardedAdam)"""
         self.ctx, self.P, self.Q = ctx, P_local, Q
@@ -84,15 +91,21 @@ class UserShardedBprTrainer:
         # issue the collectives even in a group of one rank (they are identities there): lets a single-GPU box
         # drive the real RCCL entry points
         self.collective = self.world > 1 or (bool(always_collective) and dist.is_initialized())
-        self.staged = self.item_mode == N.ITEM_FUSED and hasattr(ctx, "staged_user")
+        # dense_opt: an `ops.DenseOptimizer` (next_step() / step(W, g): consumes and clears g) - the dense-optimiser protocol
+        self.dense = dense_opt
+        if dense_opt is not None:
+            if self.item_mode == N.ITEM_FUSED:
+                self.item_mode = N.ITEM_CHUNKED
+            self.gP = torch.zeros_like(P_local)
+        self.staged = dense_opt is None and self.item_mode == N.ITEM_FUSED and hasattr(ctx, "staged_user")
         # FM (FMRecommender.py:61-95) on the staged protocol, SGD: u_bias rows live with their users (the user pass
         # updates the rank's slice in place), i_bias is replicated like Q - its gradient (one float per item, written
         # by the item pass next to gQ) is all-reduced and every rank applies the same update -, bias_ follows from the
         # all-reduced sum of the coefficients.  Without these exchanges the replicas would drift apart silently.
         self.fm = getattr(ctx, "_bias", None)
-        if self.fm is not None and (not self.staged or adam_steps):
+        if self.fm is not None and self.dense is None and (not self.staged or adam_steps):
             raise NotImplementedError("UserShardedBprTrainer: FM biases need the staged protocol (item_mode 'fused') "
-                                      "with SGD")
+                                      "with SGD, or a dense optimiser (dense_opt)")
         if self.item_mode == N.ITEM_FUSED and not self.staged:
             self.item_mode = N.ITEM_CHUNKED
         # collectives the backend lacks are emulated with the ones it has (gloo: no reduce_scatter);
@@ -205,7 +218,42 @@ class UserShardedBprTrainer:
         return self._step()
 
     def _step(self):
+        if self.dense is not None:
+            return self._step_dense(False)
         return self._step_staged() if self.staged else self._step_phases()
+
+    def _step_dense(self, empty):
+        """dense-optimiser protocol; `empty`: this rank holds no sample of the step (it contributes zero sums and zero
+        gradients, and its rows still take the optimiser's step: Adam's and RMSprop's state moves without a gradient)"""
+        c = self.ctx
+        self.dense.next_step()
+        if empty:
+            c.stats.zero_()
+        else:
+            c.forward(self.P, self.Q, self.loss_type, self.gamma)
+        self._all_reduce(c.stats[:7])
+        c.finalize(self.reg_1, self.reg_2)                     # every rank: the GLOBAL loss and norms
+        if not empty:
+            c.item_grad(self.P, self.Q, self.reg_1, self.reg_2, self.item_mode)     # -> c.gQ (FM: g_i_bias)
+        work = self._all_reduce(c.gQ, async_op=self.overlap)
+        if not empty:
+            c.user_grad(self.P, self.Q, self.reg_1, self.reg_2, self.gP)            # overlaps the all-reduce (FM: g_u_bias, g_bias)
+        if work is not None:
+            work.wait()
+        if self.P.numel():
+            self.dense.step(self.P, self.gP)
+        self.dense.step(self.Q, c.gQ)
+        if self.fm is not None:
+            u_bias, i_bias, bias, g_u, g_i, g_b = self.fm
+            if empty and g_b is not None:
+                g_b.zero_()
+            self._all_reduce(g_i)
+            self._all_reduce(g_b)
+            if u_bias.numel():
+                self.dense.step(u_bias, g_u)
+            self.dense.step(i_bias, g_i)
+            self.dense.step(bias, g_b)
+        return c.stats
 
     def _step_staged(self):
         c, I = self.ctx, self.Q.shape[0]
@@ -310,7 +358,9 @@ class UserShardedBprTrainer:
         return self.ctx.stats
 
     def _step_empty(self):
-        """This rank's part of a global step to which it contributes no sample (staged protocol)."""
+        """This rank's part of a global step to which it contributes no sample (staged / dense-optimiser protocol)."""
+        if self.dense is not None:
+            return self._step_dense(True)
         if not self.staged:
             raise NotImplementedError("an empty local batch is only supported by the staged protocol")
         c = self.ctx

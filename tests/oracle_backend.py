@@ -88,6 +88,16 @@ class OracleContext:
                   + reg_2 * self._fro(pu, nU))
         P.copy_(torch.from_numpy((P64 - lr * g).astype(np.float32)))
 
+    def user_grad(self, P, Q, reg_1, reg_2, gP):
+        """dL/dP of the local samples into gP (rows of this rank's users), regulariser from the GLOBAL norm"""
+        P64, Q64 = P.numpy().astype(np.float64), Q.numpy().astype(np.float64)
+        pu, qi, qj = P64[self.u], Q64[self.i], Q64[self.j]
+        nU = float(self.stats[8])
+        g = np.zeros_like(P64)
+        np.add.at(g, self.u, self.cp[:, None] * qi + self.cn[:, None] * qj + reg_1 * np.sign(pu)
+                  + reg_2 * self._fro(pu, nU))
+        gP += torch.from_numpy(g.astype(np.float32))
+
     def item_sgd_apply(self, Q, lr, dense=False, gQ=None):
         Q.sub_(lr * self.gQ)
         self.gQ.zero_()
@@ -217,3 +227,24 @@ class OracleGraph:
         full = self.LG.spmm(self.csr, X.numpy().astype(np.float64))
         Yrows[1:1 + row_hi - row_lo] = torch.from_numpy(full[row_lo:row_hi].astype(np.float32))
         return Yrows[1:1 + row_hi - row_lo]
+
+
+class OracleDense:
+    """CPU stand-in for `daisyrec_amd.ops.DenseOptimizer` (next_step() / step(W, g): consumes and clears g) on the oracle's
+    dense optimisers, one state per parameter tensor"""
+
+    def __init__(self, kind, lr):
+        self.kind, self.lr, self.t, self._state = kind, lr, 0, {}
+
+    def next_step(self):
+        self.t += 1
+
+    def step(self, W, g):
+        st = self._state.get(W.data_ptr())
+        if st is None:
+            cls = {"adam": O.DenseAdam, "adagrad": O.DenseAdagrad, "rmsprop": O.DenseRMSprop}[self.kind]
+            st = self._state[W.data_ptr()] = cls([tuple(W.shape)], self.lr)
+        (Wn,) = st.step([W.numpy()], [g.numpy().astype(np.float64)])
+        W.copy_(torch.from_numpy(Wn))
+        g.zero_()
+

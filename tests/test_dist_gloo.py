@@ -271,3 +271,50 @@ def test_fm_user_sharding_equals_single_process(tmp_path, world):
         np.testing.assert_array_equal(outs[0]["bi"], o["bi"])
         np.testing.assert_array_equal(outs[0]["b0"], o["b0"])
 
+
+def _dense_worker(rank, world, port, out_dir, kind):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from daisyrec_amd.sharding import UserShardedBprTrainer, shard_triples, user_range
+    from daisyrec_amd import _native as N
+    from oracle_backend import OracleContext, OracleDense
+    P0, Q0, batches = _data(True)
+    lo, hi = user_range(U, world, rank)
+    P, Q = torch.from_numpy(P0[lo:hi].copy()), torch.from_numpy(Q0.copy())
+    ctx = OracleContext(B, D, hi - lo, I)
+    tr = UserShardedBprTrainer(ctx, P, Q, lo, 0.01, R1, R2, item_mode=N.ITEM_FUSED, overlap=(rank % 2 == 0),
+                               dense_opt=OracleDense(kind, 0.01))
+    assert not tr.staged and tr.dense is not None
+    losses = []
+    for b in batches:
+        mine = shard_triples(b, U, world, rank)
+        stats = tr.step_from_plan(None, 0) if len(mine) == 0 else tr.step_from_triples(torch.from_numpy(mine))
+        losses.append(float(stats[7]))
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), P=P.numpy(), Q=Q.numpy(), lo=lo, hi=hi, losses=np.array(losses))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,world", [("adagrad", 2), ("rmsprop", 4), ("adam", 3)])
+def test_dense_optimiser_protocol_equals_single_process(tmp_path, kind, world):
+    """the dense-optimiser protocol of the sharded trainer (torch's Adagrad / RMSprop / dense Adam behind the phase kernels:
+    all-reduce of the dense item gradient, the optimiser on the rank's rows of P and on the replicated Q; a rank without a
+    sample still steps its rows - RMSprop's and Adam's state moves without a gradient) against the oracle's dense
+    optimisers on the union batches"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    mp.spawn(_dense_worker, args=(world, _free_port(), str(tmp_path), kind), nprocs=world, join=True)
+    P, Q, batches = _data(True)
+    opt = {"adam": O.DenseAdam, "adagrad": O.DenseAdagrad, "rmsprop": O.DenseRMSprop}[kind]([P.shape, Q.shape], 0.01)
+    ref_losses = []
+    for b in batches:
+        loss, gP, gQ = O.mf_pair_grad(P, Q, b[:, 0], b[:, 1], b[:, 2], R1, R2)
+        P, Q = opt.step([P, Q], [gP, gQ])
+        ref_losses.append(loss)
+    outs = [np.load(os.path.join(str(tmp_path), f"r{r}.npz")) for r in range(world)]
+    for o in outs:
+        np.testing.assert_allclose(o["losses"], ref_losses, rtol=1e-6)
+        np.testing.assert_allclose(o["Q"], Q, atol=2e-5)
+        np.testing.assert_allclose(o["P"], P[int(o["lo"]):int(o["hi"])], atol=2e-5)
+    for o in outs[1:]:
+        np.testing.assert_array_equal(outs[0]["Q"], o["Q"])
+

@@ -37,7 +37,7 @@ def _triples(shape=None):
 def _config(shuffle_mode, shape=None):
     import logging
     U_, I_, D_, _, _ = shape or (U, I, D, N_ROWS, B)
-    return {"gpu": "0", "logger": logging.getLogger("t"), "lr": 0.05, "reg_1": 0.001, "reg_2": 0.002,
+    return {"gpu": "0", "logger": logging.getLogger("t"), "lr": float(os.environ.get("DAISY_TEST_LR", "0.05")), "reg_1": 0.001, "reg_2": 0.002,
             "epochs": EPOCHS, "topk": 10, "user_num": U_, "item_num": I_, "factors": D_, "loss_type": _loss(),
             "optimizer": os.environ.get("DAISY_TEST_OPT", "sgd"), "init_method": "default", "early_stop": False, "shuffle_mode": shuffle_mode,
             "progress": False, "seed": 7}
@@ -86,17 +86,28 @@ def _free_port():
     return p
 
 
-def _compare(tmp_path, world, shuffle_mode, shuffle, shape=None, atol=5e-6):
+def _close(got, want, atol, outliers, what=""):
+    """|got - want| <= atol everywhere; outliers > 0: all but that fraction of the elements (optimisers that divide by
+    the root of a DECAYING state - RMSprop - turn the round-off of a near-zero gradient into a step of up to ~10 lr on
+    that element, in both implementations; the bulk still agrees to atol and the rest stays within 0.02)"""
+    diff = np.abs(np.asarray(got, np.float64) - np.asarray(want, np.float64))
+    if outliers:
+        assert (diff > atol).mean() <= outliers and diff.max() < 0.02, (what, float((diff > atol).mean()), float(diff.max()))
+    else:
+        np.testing.assert_allclose(got, want, atol=atol, err_msg=what)
+
+
+def _compare(tmp_path, world, shuffle_mode, shuffle, shape=None, atol=5e-6, outliers=0.0):
     ref = _fit(shuffle_mode, shuffle, shape)         # no process group here: the single-device path
     P, Q = ref.embed_user.weight.data.cpu().numpy(), ref.embed_item.weight.data.cpu().numpy()
     assert len(ref.epoch_losses) == EPOCHS
     for r in range(world):
         o = np.load(os.path.join(str(tmp_path), f"r{r}.npz"))
         np.testing.assert_allclose(o["losses"], ref.epoch_losses, rtol=2e-6)
-        np.testing.assert_allclose(o["Q"], Q, atol=atol)          # (fp32 summation order differs: typically 1e-7)
-        np.testing.assert_allclose(o["P"], P, atol=atol)          # every rank ends with the WHOLE user table
+        _close(o["Q"], Q, atol, outliers, "Q")                    # (fp32 summation order differs: typically 1e-7)
+        _close(o["P"], P, atol, outliers, "P")                    # every rank ends with the WHOLE user table
         for k, v in _bias_arrays(ref).items():                    # FM: every user's bias, the replicated item biases, bias_
-            np.testing.assert_allclose(o[k], v, atol=atol, err_msg=k)
+            _close(o[k], v, atol, outliers, k)
 
 
 @pytest.mark.parametrize("shuffle_mode,shuffle", [("loader", True), ("device", True), ("loader", False)])
@@ -139,6 +150,22 @@ def test_fm_fit_over_three_ranks_equals_the_single_process_fit(tmp_path, loss, s
     world = 3
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "device", True, "gloo", shape), nprocs=world, join=True)
     _compare(tmp_path, world, "device", True, shape)
+
+
+@pytest.mark.parametrize("opt,model,shape", [("adagrad", "mf", None), ("rmsprop", "mf", None), ("adam", "fm", None),
+                                             ("adagrad", "fm", SMALL)])
+def test_dense_optimiser_fit_over_three_ranks_equals_the_single_process_fit(tmp_path, opt, model, shape, monkeypatch):
+    """torch's Adagrad / RMSprop (AbstractRecommender.py:56-61), and Adam with FM's biases, sharded by user through the
+    dense-optimiser protocol (sharding.py: phase kernels, all-reduce of the dense item gradient, the dense optimiser on the
+    rank's rows of P and on the replicated Q) against the single-process fit with the same optimiser.  These optimisers
+    divide by the root of their state: a last-bit difference in a tiny gradient moves a step by up to lr, hence 1e-4.
+    SMALL: 37-sample batches, ranks without a sample in many steps (their rows still take the optimiser's step)."""
+    monkeypatch.setenv("DAISY_TEST_OPT", opt)
+    monkeypatch.setenv("DAISY_TEST_MODEL", model)
+    monkeypatch.setenv("DAISY_TEST_LR", {"adagrad": "0.02", "rmsprop": "0.002", "adam": "0.01"}[opt])   # (RMSprop's first steps are 10 lr)
+    world = 3
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), "device", True, "gloo", shape), nprocs=world, join=True)
+    _compare(tmp_path, world, "device", True, shape, atol=1e-4, outliers=5e-3 if opt == "rmsprop" else 0.0)
 
 
 def test_fit_over_ranks_with_small_lopsided_batches(tmp_path):

@@ -309,3 +309,32 @@ def test_epoch_stops_at_the_first_non_finite_loss(ops, path):
         assert np.array_equal(P_bad[keep], P_ok[keep])
     else:
         assert np.array_equal(P_bad, P_ok)
+
+
+@pytest.mark.parametrize("mode", ["fused", "chunked"])
+def test_set_batch_from_triples_selects_rows_anywhere_in_the_array(ops, mode):
+    """daisy_bpr_set_batch_from_triples(idx=...): a batch of B rows SELECTED from a larger triple array - what one rank's
+    share of a global batch is in the dense-optimiser protocol (sharding.py).  The range check of the selection compared
+    its entries against B instead of the array's length until round 4, so any row >= B was refused."""
+    rng = np.random.default_rng(17)
+    U, I, d, n, B = 300, 200, 64, 5000, 257
+    tri = np.stack([rng.integers(0, U, n), rng.integers(0, I, n), rng.integers(0, I, n)], 1).astype(np.int32)
+    idx = rng.choice(n, B, replace=False).astype(np.int64)
+    idx[0], idx[1] = n - 1, 0                                      # both ends of the array
+    P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    rows = tri[idx]
+    want, Pn, Qn = O.mf_sgd_step(P0, Q0, rows[:, 0], rows[:, 1], rows[:, 2], 0.01, 1e-3, 1e-3)
+    P, Q = _t(P0), _t(Q0)
+    ctx = ops.BprContext(B, d, U, I)
+    sl = torch.zeros(1, dtype=torch.float64, device="cuda")
+    ctx.set_batch_from_triples(_t(tri), idx=_t(idx))
+    ctx.sgd_step(P, Q, 0.01, 1e-3, 1e-3, item_mode=ops.ITEM_MODES[mode], step_loss=sl)
+    torch.cuda.synchronize()
+    assert abs(float(sl.cpu()) - want) <= 1e-5 * abs(want)
+    assert np.abs(P.cpu().numpy() - Pn).max() < 3e-6 and np.abs(Q.cpu().numpy() - Qn).max() < 3e-6
+    bad = idx.copy()
+    bad[5] = n                                                     # one past the array
+    with pytest.raises(ValueError, match="out of range"):
+        ctx.set_batch_from_triples(_t(tri), idx=_t(bad))
+    ctx.close()
