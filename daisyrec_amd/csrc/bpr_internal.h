@@ -240,10 +240,14 @@ __device__ __forceinline__ void finalize_stats(double *__restrict__ stats, float
 
 // one workgroup of kBlock threads: the column sums of partials[nblocks][8] in a fixed order - thread b adds rows b,
 // b + kBlock, ..., every wave adds its 64 threads' sums (DPP steps in registers), the four wave sums are added in wave
-// order - returned in LDS: (*sums)[k] for k < 8, readable by every thread after the call (which ends in its only
-// barrier; round 3's eight-level LDS tree cost eight, on the critical path of every step's reduction).
+// order - returned in LDS: (*sums)[k] for k < 8, readable by every thread after the call (two barriers: the wave sums,
+// then their total; round 3's eight-level LDS tree cost eight, on the critical path of every step's reduction).
+// Contract: called by ALL threads of a workgroup of exactly kBlock threads (the row loop strides by kBlock, sm holds
+// kBlock / kWave wave sums); the returned pointer aims at a function-static LDS array, so it is valid only until the
+// workgroup's next call (callers that need the sums longer copy them).
 __device__ __forceinline__ const double (*partials_sums(const double *__restrict__ partials, int nblocks))[8] {
     __shared__ double sm[kBlock / kWave + 1][8];
+    if (blockDim.x != kBlock) __builtin_trap();      // (uniform, one compare: a violated contract must not pass silently)
     double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int b = threadIdx.x;
     for (; b + kBlock < nblocks; b += 2 * kBlock) {          // two rows (16 loads) in flight per thread

@@ -64,8 +64,27 @@ namespace daisy {
 #ifndef DAISY_ITEM_WINDOW
 #define DAISY_ITEM_WINDOW 1
 #endif
+// development probes of the item pass (dev builds only: the results of a probe build are WRONG by design).  Bit 0: the
+// gathers alone - hop 1 (metadata), hop 2 (stage rows), one add per element to keep them alive, no reduction, no commit,
+// no barrier: the ceiling of this access pattern inside this launch shape; bit 1: without the LDS window of Q rows; bit 2:
+// the slot of an entry computed from its index instead of loaded (no dependent hop)
+#ifndef DAISY_ITEM_PROBE
+#define DAISY_ITEM_PROBE 0
+#endif
+#ifndef DAISY_ITEM_TOUCH
+#define DAISY_ITEM_TOUCH 1
+#endif
+#ifndef DAISY_ITEM_RUN4
+#define DAISY_ITEM_RUN4 16
+#endif
+#ifndef DAISY_ITEM_WINF
+#define DAISY_ITEM_WINF 6144
+#endif
+#ifndef DAISY_ITEM_WAVES
+#define DAISY_ITEM_WAVES 4
+#endif
 constexpr size_t kStreamTableBytes = (size_t)512 << 20;   // user tables beyond this are read past the caches (k_staged_user)
-constexpr int kItemWinFloats = 6144;      // 24 KB of Q rows per workgroup of the item pass (96 rows at d = 64); rows of two
+constexpr int kItemWinFloats = DAISY_ITEM_WINF;     // 24 KB of Q rows per workgroup of the item pass (96 rows at d = 64); rows of two
                                           // float4 per lane get 16 KB, wider ones none (their partial-sum slots already
                                           // take the LDS that four workgroups per CU leave)
 
@@ -664,7 +683,7 @@ struct StagedItemCfg {
 #endif
     // staged rows in flight per lane group: 64 row registers in every shape (16 x 4 floats, 8 x 8, 4 x 16)
     static constexpr int RUN_BY_REGS = SPARSE ? ((C::NE <= 8) ? 4 : 2)
-                                              : ((C::NE <= 4) ? 16 : ((C::NE <= 8) ? DAISY_ITEM_RUN8 : DAISY_ITEM_RUN16));
+                                              : ((C::NE <= 4) ? DAISY_ITEM_RUN4 : ((C::NE <= 8) ? DAISY_ITEM_RUN8 : DAISY_ITEM_RUN16));
     static constexpr int RUN = RUN_BY_REGS < C::LPR ? RUN_BY_REGS : C::LPR;
     static constexpr int G = BLK / C::LPR;
     static constexpr int E = G * RUN;
@@ -818,6 +837,10 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((C::NE <= 4
     __shared__ float part_acc[2 * G * ROWF];
     __shared__ float part_n[2 * G], part_b[2 * G];
     __shared__ int part_slot[2 * G];
+    // the pre-step row of P of a run that leaves its group through the TAIL: the slot's finisher commits from it.  (Until
+    // round 5 the finisher loaded the row again - a dependent trip to memory behind this chunk's row and stage STORES, which
+    // the vector-memory counter also counts: s_waitcnt vmcnt(0) in front of the commit waited for all of them.)
+    __shared__ float part_p[G * ROWF];
     __shared__ int slot_user[G + 1], slot_next[G + 1];
     __shared__ int run_first[G], run_last[G];
 
@@ -978,6 +1001,11 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((C::NE <= 4
                     float *dst = part_acc + q * ROWF;
 #pragma unroll
                     for (int k = 0; k < C::NE; ++k) dst[k * C::LPR + lane] = acc.v[k];
+                    if (cur_slot < 0) {              // the run began here: its pre-step row for slot group + 1's finisher
+                        float *pd = part_p + group * ROWF;
+#pragma unroll
+                        for (int k = 0; k < C::NE; ++k) pd[k * C::LPR + lane] = prow.v[k];
+                    }
                     if (lane == 0) {
                         part_slot[q] = s;
                         part_n[q] = cn_;
@@ -1033,18 +1061,23 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((C::NE <= 4
             Row<C> g;
             g.zero();
             float ns = 0.f, sb = 0.f;
-            for (int q = 0; q < 2 * G; ++q) {
-                if (part_slot[q] != s) continue;
+            auto add_part = [&](int q) {
                 const float *src = part_acc + q * ROWF;
 #pragma unroll
                 for (int k = 0; k < C::NE; ++k) g.v[k] += src[k * C::LPR + lane];
                 ns += part_n[q];
                 sb += part_b[q];
-            }
+            };
+            // slot s in group order: the tail of group s - 1 (where the run began), then the heads of the groups s, s + 1,
+            // ... it runs through (see k_staged_item: the same chain instead of a scan over all 2 G parked sums)
+            if (s > 0 && part_slot[2 * s - 1] == s) add_part(2 * s - 1);
+            for (int q = 2 * s; q < 2 * G && part_slot[q] == s; q += 2) add_part(q);
             const bool from_prev = (s == 0), to_next = slot_next[s] != 0;
             if (!from_prev && !to_next) {
-                Row<C> p;
-                p.load(P + (int64_t)uu * d, lane, d);
+                Row<C> p;                            // (s >= 1: the tail of group s - 1 parked the row)
+                const float *ps = part_p + (s - 1) * ROWF;
+#pragma unroll
+                for (int k = 0; k < C::NE; ++k) p.v[k] = ps[k * C::LPR + lane];
                 user_commit<C, ADAM>(P, p_sqnorm, uu, p, g, ns, reg_1, rU, opt, lane, d);
                 if constexpr (BIAS) user_bias_commit(fm, uu, sb, opt.lr, lane);
             } else {
@@ -1158,7 +1191,12 @@ struct ItemEdges2 {
 };
 
 // pre-step rows of Q staged in LDS for the commits of one chunk (k_staged_item): rows [first, first + rows)
-struct QWindow { const float *lds; int32_t first, rows; };
+// (the pointer is an LDS-address-space pointer on purpose: as a generic pointer the commit's row read - window or memory,
+// chosen per row - was if-converted into ONE flat_load of a selected address, and a pending FLAT access makes the compiler
+// wait for vmcnt(0) AND lgkmcnt(0): every commit then waited for the previous commit's row STORE to land in L2, a full
+// trip to memory inside the reduction loop - round 5, profiles/r05_item_pass_counters.txt)
+typedef __attribute__((address_space(3))) const float lds_cfloat;
+struct QWindow { lds_cfloat *lds; int32_t first, rows; };
 
 // what the owner of a finished segment does with  g = sum_e w_e * stage[slot(e)]  and the entry counts:
 //   APPLY:  regulariser reg_1*(np+nn)*sign(q) + reg_2*(np/|Q[i]|_F + nn/|Q[j]|_F)*q  (MFRecommender.py:88-89), then the
@@ -1169,7 +1207,7 @@ template <class C, bool APPLY, bool ADAM>
 __device__ __forceinline__ void item_commit(float *__restrict__ Qo, float *__restrict__ cnt_out, int64_t item,
                                             const Row<C> &g, float np, float nn, float sb, int lane, int d,
                                             const RowOpt &opt, float reg_1, float rI, float rJ, const StagedBias &fm,
-                                            const QWindow win = QWindow{nullptr, 0, 0},
+                                            const QWindow win = QWindow{(lds_cfloat *)nullptr, 0, 0},
                                             const Row<C> *qpre = nullptr) {
     if constexpr (APPLY) {
         Row<C> q;
@@ -1181,17 +1219,24 @@ __device__ __forceinline__ void item_commit(float *__restrict__ Qo, float *__res
             const uint32_t off = (uint32_t)((int32_t)item - win.first);
             if (off < (uint32_t)win.rows) {            // the row waits in LDS: no dependent trip to memory
                 in_lds = true;
-                const float *src = win.lds + (size_t)off * d;
+                lds_cfloat *src = win.lds + off * (uint32_t)d;
+                typedef float v4f __attribute__((ext_vector_type(4)));
 #pragma unroll
                 for (int c = 0; c < C::NV; ++c) {
                     const int e = (c * C::LPR + lane) * 4;
-                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (C::EXACT || e < d) t = *reinterpret_cast<const float4 *>(src + e);
+                    v4f t = {0.f, 0.f, 0.f, 0.f};
+                    if (C::EXACT || e < d) t = *reinterpret_cast<__attribute__((address_space(3))) const v4f *>(src + e);
                     q.v[c * 4 + 0] = t.x; q.v[c * 4 + 1] = t.y; q.v[c * 4 + 2] = t.z; q.v[c * 4 + 3] = t.w;
                 }
             }
         }
-        if (!in_lds) q.load(Qo + item * d, lane, d);
+        if (!in_lds) {
+            q.load(Qo + item * d, lane, d);
+            // the wait for THIS load stays inside this branch (a "use" of its registers): behind the join the compiler
+            // would wait for vmcnt(0) on every path, i.e. also where the row came from LDS and only STORES are in flight
+#pragma unroll
+            for (int k = 0; k < C::NE; ++k) asm volatile("" : "+v"(q.v[k]));
+        }
         const float w1 = reg_1 * (np + nn), w2 = np * rI + nn * rJ;
         Row<C> gg;
 #pragma unroll
@@ -1221,7 +1266,7 @@ __device__ __forceinline__ void item_commit(float *__restrict__ Qo, float *__res
 // the reduction of its sums, as workgroups behind the item pass's own, and every item workgroup derives the norms (and
 // whether this step's loss is finite) from the user pass's per-workgroup sums itself.
 template <class C, int BLK, int MODE, bool APPLY, bool ADAM, bool SPARSE, bool MERGED = false>
-__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((ADAM || MERGED) ? 2 : 4, 8))) void k_staged_item(const float *__restrict__ stage,
+__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((ADAM || MERGED) ? 2 : DAISY_ITEM_WAVES, 8))) void k_staged_item(const float *__restrict__ stage,
                                                         const float2 *__restrict__ coef, StreamView v, int d,
                                                         float *__restrict__ Qo, float *__restrict__ cnt_out,
                                                         const double *__restrict__ stats, RowOpt opt,
@@ -1251,7 +1296,10 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((ADAM || ME
         const double (*sums)[8] = partials_sums(mj.red.partials, mj.red.nblocks);
         double nU, nI, nJ;
         const double loss = loss_from_sums(&(*sums)[0], reg_1, reg_2, nU, nI, nJ);
-        if (!(loss == loss) || isinf(loss)) halt_word = 1.0;        // this step's loss is not finite: the epoch stops here
+        // this step's loss is not finite: the epoch stops here - when the caller gave a halt word at all; a bare step
+        // (no epoch accumulator) applies the whole step in the four-launch form, and so must this one: its edge launch
+        // and the user pass's edge chains have no word to look at
+        if (v.halt && (!(loss == loss) || isinf(loss))) halt_word = 1.0;
         rI = inv_or_zero(nI, reg_2);
         rJ = inv_or_zero(nJ, reg_2);
     }
@@ -1277,10 +1325,13 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((ADAM || ME
     // a commit inside the reduction then costs no dependent trip to memory (at a few entries per item - 10 M x 1 M
     // shapes - 355 -> 320 us per pass).  Only for d % 4 == 0 (16-byte units); rows past the window (sparse batches: few
     // entries spread over many items) are loaded directly.
-    constexpr bool WIN = APPLY && C::VEC == 4 && C::NE <= 8 && DAISY_ITEM_WINDOW && !SPARSE;
+    constexpr bool WIN = APPLY && C::VEC == 4 && C::NE <= 8 && DAISY_ITEM_WINDOW && !SPARSE && !(DAISY_ITEM_PROBE & 2);
     constexpr bool QPRE = APPLY && SPARSE;                 // the Q row of every entry rides with its staged row
     constexpr int WINF = (C::NE <= 4) ? kItemWinFloats : (kItemWinFloats * 2 / 3);
     __shared__ __attribute__((aligned(16))) float qwin[WIN ? WINF : 4];
+    // sparse flavour: the pre-step row of Q of a segment that leaves its run through the TAIL, for the slot's finisher (a
+    // load there would sit behind this chunk's row stores: k_staged_user's part_p has the story)
+    __shared__ float part_q[QPRE ? G * ROWF : 4];
 
     const int tid = threadIdx.x;
     const int lane = tid % C::LPR;
@@ -1303,7 +1354,11 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((ADAM || ME
         const int64_t last = n - 1;
         const int64_t il = (t0 + lane < n) ? (t0 + lane) : last;
         const uint32_t k_me = sv_key(v, il);
+#if DAISY_ITEM_PROBE & 4
+        const uint32_t slot_me = (uint32_t)(((uint64_t)il * 2654435761ull) % (uint64_t)v.B);
+#else
         const uint32_t slot_me = (v.e_pos[il * v.e_stride] & ~kNegBit) - v.pos_base;
+#endif
         const uint32_t k_prev = sv_key(v, (t0 > 0) ? ((t0 - 1 < n) ? t0 - 1 : last) : 0);
         const uint32_t k_next = sv_key(v, (t1 < n) ? t1 : last);
         const uint32_t k_cprev = sv_key(v, (c0 > 0) ? c0 - 1 : 0);
@@ -1311,12 +1366,13 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((ADAM || ME
         const int32_t my_neg = (int32_t)(k_me & 1u);
         const int32_t item_prev = (cnt > 0 && t0 > 0) ? (int32_t)(k_prev >> 1) : -1;
         const int32_t item_next = (cnt > 0 && t1 < n) ? (int32_t)(k_next >> 1) : -1;
-        const int32_t chunk_prev_item = (c0 > 0) ? (int32_t)(k_cprev >> 1) : -1;
-        QWindow win{qwin, 0, 0};
+        // (workgroup-uniform values that come out of a vector load: as scalars they cost no vector register)
+        const int32_t chunk_prev_item = (c0 > 0) ? __builtin_amdgcn_readfirstlane((int32_t)(k_cprev >> 1)) : -1;
+        QWindow win{(lds_cfloat *)qwin, 0, 0};
         if constexpr (WIN) {
             const int64_t c1 = (c0 + E < n) ? (c0 + E) : n;
-            win.first = (int32_t)(sv_key(v, c0) >> 1);
-            const int32_t item_hi = (int32_t)(sv_key(v, c1 - 1) >> 1);
+            win.first = __builtin_amdgcn_readfirstlane((int32_t)(sv_key(v, c0) >> 1));
+            const int32_t item_hi = __builtin_amdgcn_readfirstlane((int32_t)(sv_key(v, c1 - 1) >> 1));
             const int32_t cap = WINF / d;
             win.rows = (item_hi - win.first + 1 < cap) ? (item_hi - win.first + 1) : cap;
             const int units = win.rows * (d >> 2);                      // 16-byte units, contiguous in Q
@@ -1379,7 +1435,39 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((ADAM || ME
         // cap, and within +-1.5 % of this form at both BASELINE shapes, same box: profiles/r04_item_plan_variants.txt.
         // The pass is not bound by this wait.)
         if constexpr (WIN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if DAISY_ITEM_TOUCH
+        // (the same for the window: one LDS read that may alias the LDS-DMA's destination makes the compiler's own wait for
+        // the DMA happen HERE, once, instead of in front of every commit's window read)
+        if constexpr (WIN) {
+            float w0 = ((lds_cfloat *)qwin)[tid & 3];
+            asm volatile("" : "+v"(w0));
+        }
+        // every gathered row register is "used" here, so the COMPILER waits for the gathers here and knows they are done:
+        // with the wait hidden in the asm statement above it kept all of them pending in its scoreboard, and since the
+        // vector-memory counter also counts stores, the first use of a row behind a commit's store (data-dependent
+        // control flow, merged states) became s_waitcnt vmcnt(0) - the reduction waited for every row store it issued
+#pragma unroll
+        for (int x = 0; x < RUN; ++x) {
+#pragma unroll
+            for (int k = 0; k < C::NE; ++k) asm volatile("" : "+v"(p[x].v[k]));
+            if constexpr (QPRE) {
+#pragma unroll
+                for (int k = 0; k < C::NE; ++k) asm volatile("" : "+v"(qe[x].v[k]));
+            }
+        }
+#endif
         if (halt_word > 0.0) return;           // (uniform over the grid; nothing has been written yet)
+#if DAISY_ITEM_PROBE & 1
+        {
+            float a = (float)(my_item + (int32_t)my_w);
+#pragma unroll
+            for (int x = 0; x < RUN; ++x)
+#pragma unroll
+                for (int k = 0; k < C::NE; ++k) a += p[x].v[k];
+            if (a == 123.456f) Qo[tid] = a + qwin[tid & 3];
+            continue;
+        }
+#endif
         __syncthreads();
 
         if (cnt > 0) {
@@ -1411,6 +1499,13 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((ADAM || ME
                     float *dst = part_acc + q * ROWF;
 #pragma unroll
                     for (int k = 0; k < C::NE; ++k) dst[k * C::LPR + lane] = acc.v[k];
+                    if constexpr (QPRE) {
+                        if (cur_slot < 0) {
+                            float *qd = part_q + group * ROWF;
+#pragma unroll
+                            for (int k = 0; k < C::NE; ++k) qd[k * C::LPR + lane] = qcur.v[k];
+                        }
+                    }
                     if (lane == 0) {
                         part_slot[q] = s;
                         part_np[q] = np;
@@ -1460,15 +1555,20 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((ADAM || ME
             Row<C> g;
             g.zero();
             float sp = 0.f, sn = 0.f, sc = 0.f;
-            for (int q = 0; q < 2 * G; ++q) {
-                if (part_slot[q] != s) continue;
+            auto add_part = [&](int q) {
                 const float *src = part_acc + q * ROWF;
 #pragma unroll
                 for (int k = 0; k < C::NE; ++k) g.v[k] += src[k * C::LPR + lane];
                 sp += part_np[q];
                 sn += part_nn[q];
                 sc += part_b[q];
-            }
+            };
+            // the partial sums of slot s, in group order: the TAIL of group s - 1 (the run the segment began in; slot 0
+            // came from the previous chunk and has none), then the HEADS of the groups s, s + 1, ... it runs through -
+            // consecutive by construction.  (Until round 5 a scan over all 2 G parked slots: 32 dependent LDS reads per
+            // finisher where two or three are needed - 1.3 of the ~1.8 us a chunk spends behind its gathers.)
+            if (s > 0 && part_slot[2 * s - 1] == s) add_part(2 * s - 1);
+            for (int q = 2 * s; q < 2 * G && part_slot[q] == s; q += 2) add_part(q);
             const bool from_prev = (s == 0), to_next = slot_shared[s] != 0;
             if (from_prev || to_next) {
                 const int64_t e = 2 * chunk + (from_prev ? 0 : 1);
@@ -1480,6 +1580,12 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((ADAM || ME
                     ed.cnt[4 * e + 2] = sc;
                     if (from_prev && to_next) ed.whole[chunk] = 1;
                 }
+            } else if constexpr (QPRE) {             // (s >= 1 here: the tail of group s - 1 parked the pre-step row)
+                Row<C> qrow;
+                const float *qs = part_q + (s - 1) * ROWF;
+#pragma unroll
+                for (int k = 0; k < C::NE; ++k) qrow.v[k] = qs[k * C::LPR + lane];
+                item_commit<C, APPLY, ADAM>(Qo, cnt_out, r, g, sp, sn, sc, lane, d, opt, reg_1, rI, rJ, fm, win, &qrow);
             } else {
                 item_commit<C, APPLY, ADAM>(Qo, cnt_out, r, g, sp, sn, sc, lane, d, opt, reg_1, rI, rJ, fm, win);
             }
@@ -2265,6 +2371,45 @@ int daisy_bpr_staged_adam_step(daisy_bpr_ctx *ctx, float *P, float *Q, int32_t l
     }
     return staged_adam_step(ctx, P, Q, loss_type, gamma, reg_1, reg_2, a, table, bias_grad_out, stats, epoch_acc,
                             step_loss, S(stream));
+}
+
+// The epoch loop of GeneralRecommender.fit (AbstractRecommender.py:118-128) with torch.optim.Adam
+// (AbstractRecommender.py:54): every batch of a built plan through the staged Adam step, enqueued natively - steps
+// first_step, first_step + 1, ... - and, flush != 0, the rows no batch referenced brought up to the epoch's last step
+// (daisy_adam_lazy_flush on both tables), so the tables are current when the call's work has drained.
+int daisy_bpr_fit_epoch_adam(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, float *P, float *Q, int32_t loss_type,
+                             float gamma, float lr, float reg_1, float reg_2, float *mP, float *vP, int32_t *lastP,
+                             float *mQ, float *vQ, int32_t *lastQ, const float *table, int64_t table_steps, float beta1,
+                             float beta2, float eps, int64_t first_step, int32_t flush, double *stats, double *epoch_acc,
+                             double *step_losses, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(ctx && plan && P && Q && mP && vP && lastP && mQ && vQ && lastQ && table && stats && first_step >= 1,
+                    "fit_epoch_adam: bad argument");
+    if (!plan->built) { set_error("fit_epoch_adam: plan has not been built"); return DAISY_ERR_STATE; }
+    DAISY_CHECK_ARG(loss_type >= DAISY_LOSS_BPR && loss_type <= DAISY_LOSS_SL, "Invalid loss type: %d", loss_type);
+    DAISY_CHECK_ARG(first_step + plan->num_batches - 1 <= table_steps,
+                    "fit_epoch_adam: the constants table holds %lld steps, the epoch ends at step %lld",
+                    (long long)table_steps, (long long)(first_step + plan->num_batches - 1));
+    if (ctx->bu) {          // FM: the biases step through the caller's dense optimiser between two steps
+        set_error("fit_epoch_adam: contexts with FM biases are driven step by step (daisy_bpr_staged_adam_step)");
+        return DAISY_ERR_ARG;
+    }
+    for (int64_t k = 0; k < plan->num_batches; ++k) {
+        int rc = daisy_bpr_set_batch_from_plan(ctx, plan, k, stream);
+        if (rc) return rc;
+        rc = daisy_bpr_staged_adam_step(ctx, P, Q, loss_type, gamma, lr, reg_1, reg_2, mP, vP, lastP, mQ, vQ, lastQ, table,
+                                        beta1, beta2, eps, first_step + k, stats, epoch_acc,
+                                        step_losses ? step_losses + k : nullptr, stream);
+        if (rc) return rc;
+    }
+    if (flush && plan->num_batches > 0) {
+        const int64_t t = first_step + plan->num_batches - 1;
+        int rc = daisy_adam_lazy_flush(P, mP, vP, lastP, ctx->U, ctx->d, table, beta1, beta2, eps, t, stream);
+        if (rc) return rc;
+        if ((rc = daisy_adam_lazy_flush(Q, mQ, vQ, lastQ, ctx->I, ctx->d, table, beta1, beta2, eps, t, stream))) return rc;
+        ctx->p_sqnorm_of = nullptr;          // the flush rewrote rows of P behind the row-norm cache
+        ctx->pre_ready = false;
+    }
+    return DAISY_OK;
 }
 
 int daisy_bpr_staged_adam_catchup_users(daisy_bpr_ctx *ctx, float *P, float *mP, float *vP, int32_t *lastP,

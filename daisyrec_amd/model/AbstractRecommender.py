@@ -223,7 +223,7 @@ class GeneralRecommender(AbstractRecommender):
         inv[perm] = torch.arange(n, dtype=torch.int64, device=row_ids.device)
         return inv[row_ids].contiguous()
 
-    def _fit_sharded(self, train_loader, triples, n, B, loss_id, opt="sgd", biases=None):
+    def _fit_sharded(self, train_loader, triples, n, B, loss_id, opt="sgd", biases=None, dense_adam=False):
         """`fit` over the ranks of a torch.distributed job (one process per GPU).  Every rank calls it
         with the same loader and the same seeds.  Users - with their interactions and their rows of P - are split
         into contiguous ranges; Q is replicated.  Batch k of rank r = its rows among positions [k*B, (k+1)*B) of
@@ -252,7 +252,8 @@ class GeneralRecommender(AbstractRecommender):
         ctx = ops.BprContext(B, d, hi - lo, I, device=P.device)        # stage slots are positions inside a GLOBAL batch
         # Adagrad / RMSprop, and Adam with FM's biases: the dense-optimiser protocol (phase kernels + torch's dense
         # optimisers: sharding.py); SGD (MF, FM) and Adam (MF): the staged protocol
-        dense = opt in ("adagrad", "rmsprop") or (opt == "adam" and biases is not None)
+        # (config['lazy_adam']=False with Adam: torch's dense pass, i.e. the dense-optimiser protocol as well)
+        dense = opt in ("adagrad", "rmsprop") or (opt == "adam" and (biases is not None or dense_adam))
         if biases is not None:             # FM: the rank's slice of u_bias, the replicated i_bias / bias_ (sharding.py)
             for b in biases:
                 dist.broadcast(b, 0)
@@ -351,6 +352,10 @@ class GeneralRecommender(AbstractRecommender):
                     break
             return
         B = min(B, n)            # fewer rows than one batch: a single partial batch, like the DataLoader
+        if self._sharded_world() > 1 and getattr(self, "row_pitch", None) == "auto":
+            # a sharded fit moves whole table rows over the wire (broadcasts, the item exchange): the automatic row pitch
+            # would ship its zero columns too (+28 % at d = 50), so it stays off there; an explicit pitch is honoured
+            self.row_pitch = 0
         P, Q = self._tables(batch=B)    # (the padded buffers behind embed_*.weight where the model trains on a row pitch)
         ctx = ops.BprContext(B, P.shape[1], P.shape[0], Q.shape[0], device=P.device)
         plan = ops.EpochPlan(n, P.shape[0], Q.shape[0], device=P.device)
@@ -381,10 +386,16 @@ class GeneralRecommender(AbstractRecommender):
                          g_bias=adam.g[2] if adam is not None else None)
         user_sorted = ops.triples_user_sorted(triples[:n])
         if self._sharded_world() > 1:
-            if item_mode == ops.ITEM_MODES["fused"] or opt in ("adagrad", "rmsprop"):
+            dense_adam = opt == "adam" and self.lazy_adam is False and self.item_mode == "fused"
+            if item_mode == ops.ITEM_MODES["fused"] or opt in ("adagrad", "rmsprop") or dense_adam:
                 ctx.close()
                 plan.close()
-                return self._fit_sharded(train_loader, triples, n, B, loss_id, opt, biases)
+                if (opt in ("adagrad", "rmsprop") or dense_adam or (opt == "adam" and biases is not None)) \
+                        and Q.numel() * 4 > 64 * B * Q.shape[1]:
+                    self.logger.warning("sharded fit with a dense optimiser: every step all-reduces the dense item gradient "
+                                        "(%d MB) for a batch of %d rows - at this ratio the unsharded fit "
+                                        "(config['shard_users']=False) is likely faster", Q.numel() * 4 >> 20, B)
+                return self._fit_sharded(train_loader, triples, n, B, loss_id, opt, biases, dense_adam=dense_adam)
             self.logger.info("torch.distributed is initialised, but SGD / Adam with an explicit item_mode other than "
                              "'fused' do not shard the users over the ranks: every rank trains the whole model")
         if item_mode == ops.ITEM_MODES["fused"] and not staged and B > ops.SMALL_BATCH_MAX:
@@ -421,6 +432,10 @@ class GeneralRecommender(AbstractRecommender):
                 if adam is None:
                     ctx.fit_epoch_sgd(plan, P, Q, self.lr, self.reg_1, self.reg_2, loss_type=loss_id,
                                       item_mode=item_mode)
+                elif adam.kind == "adam" and staged and biases is None:
+                    # the epoch as ONE enqueue (daisy_bpr_fit_epoch_adam), like the SGD loop: at the reference's batch
+                    # sizes a host round trip per batch would bound the fit
+                    adam.staged_epoch(ctx, plan, self.reg_1, self.reg_2, loss_id)
                 else:
                     for k in range(plan.num_batches):
                         ctx.set_batch_from_plan(plan, k)
@@ -511,6 +526,14 @@ class _AdamState:
         self.opt.step(Q, ctx.gQ)          # also zeroes gQ
         for w, g in zip(self.w, self.g):
             self.opt.step(w, g)
+
+    def staged_epoch(self, ctx, plan, reg_1, reg_2, loss_id):
+        """one epoch of the staged Adam step in one native call, the lazy rows flushed at its end (MF; see `step`)"""
+        if self.lazy_staged is None:
+            self.lazy_staged = self.lazy if self.lazy is not None else ops.LazyAdam(*self._lazy_args)
+            self.lazy = None
+        self.opt.t += plan.num_batches          # (the dense optimiser's shared step count: FM-free fits never read it)
+        self.lazy_staged.fit_epoch(ctx, plan, reg_1, reg_2, loss_id)
 
     def flush(self):
         """every row up to the current step (end of an epoch: before the tables are read by anything but a step)"""

@@ -55,8 +55,20 @@ class MF(GeneralRecommender):
         self.early_stop = config["early_stop"]
         self.row_pitch = config.get("row_pitch", "auto")
         self._padded = {}
+        # a table homed on a row pitch is an [n, d] VIEW of a padded buffer: torch.save(state_dict()) would write the
+        # whole padded storage (up to a third more bytes, and not byte-comparable with the reference's checkpoint), so
+        # the state dict carries contiguous [n, d] copies of such tables
+        self._register_state_dict_hook(MF._contiguous_state)
 
         self.apply(self._init_weight)
+
+    @staticmethod
+    def _contiguous_state(module, state_dict, prefix, local_metadata):
+        for name in ("embed_user.weight", "embed_item.weight"):
+            t = state_dict.get(prefix + name)
+            if t is not None and not t.is_contiguous():
+                state_dict[prefix + name] = t.contiguous()
+        return state_dict
 
     # -- tables as the kernels see them ------------------------------------------
     def _tables(self, batch=None):

@@ -541,6 +541,25 @@ class LazyAdam:
             _ptr(ctx.epoch_acc, torch.float64, "epoch_acc") if accumulate else None,
             _ptr(step_loss, torch.float64, "step_loss"), _stream()))
 
+    def fit_epoch(self, ctx, plan, reg_1, reg_2, loss_type=N.LOSS_BPR, gamma=1e-10, flush=True, step_losses=None):
+        """Every batch of a built plan through the staged Adam step, enqueued by ONE native call (daisy_bpr_fit_epoch_adam:
+        the loop of AbstractRecommender.py:118-128 without a host round trip per batch), then - flush - the rows no batch
+        referenced brought up to the epoch's last step.  MF contexts only (FM's biases step between two steps)."""
+        nb = plan.num_batches
+        if self.t + nb > self._table_steps:
+            self._grow(2 * (self.t + nb))
+        ctx._sync_norm_cache(self.P)
+        self._ctx = ctx
+        f = torch.float32
+        check(lib.daisy_bpr_fit_epoch_adam(
+            ctx._h, plan._h, _ptr(self.P, f, "P"), _ptr(self.Q, f, "Q"), int(loss_type), float(gamma), self.lr,
+            float(reg_1), float(reg_2), _ptr(self.m[0], f, "mP"), _ptr(self.v[0], f, "vP"),
+            _ptr(self.last[0], torch.int32, "lastP"), _ptr(self.m[1], f, "mQ"), _ptr(self.v[1], f, "vQ"),
+            _ptr(self.last[1], torch.int32, "lastQ"), _ptr(self._table, f, "table"), self._table_steps, self.BETA1,
+            self.BETA2, self.EPS, self.t + 1, 1 if flush else 0, _ptr(ctx.stats, torch.float64, "stats"),
+            _ptr(ctx.epoch_acc, torch.float64, "epoch_acc"), _ptr(step_losses, torch.float64, "step_losses"), _stream()))
+        self.t += nb
+
     def flush(self):
         f = torch.float32
         for W, m, v, last in ((self.P, self.m[0], self.v[0], self.last[0]), (self.Q, self.m[1], self.v[1], self.last[1])):
@@ -548,8 +567,11 @@ class LazyAdam:
                                             _ptr(last, torch.int32, "last"), W.shape[0], W.shape[1],
                                             _ptr(self._table, f, "table"), self.BETA1, self.BETA2, self.EPS, self.t,
                                             _stream()))
-        if getattr(self, "_ctx", None) is not None:      # the flush rewrote rows of P behind the staged step's row-norm cache
-            self._ctx.invalidate_cache()
+        ctx = getattr(self, "_ctx", None)              # the flush rewrote rows of P behind the staged step's row-norm cache
+        if ctx is not None and getattr(ctx, "_h", None) is not None and ctx._h.value:
+            ctx.invalidate_cache()
+        else:                                          # (a context that was closed in the meantime has no cache to drop)
+            self._ctx = None
 
 
 class ShardedAdam:

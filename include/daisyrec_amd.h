@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DAISY_ABI_VERSION 5
+#define DAISY_ABI_VERSION 6
 
 typedef void *daisy_stream_t; /* hipStream_t */
 
@@ -384,6 +384,19 @@ int daisy_bpr_fit_epoch_sgd(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, fl
                             int32_t loss_type, float gamma, float lr, float reg_1, float reg_2,
                             float *gQ, double *stats, double *epoch_acc, double *step_losses,
                             int32_t item_mode, daisy_stream_t stream);
+
+/* The same loop with torch.optim.Adam (AbstractRecommender.py:54,118-128; ABI 6): every batch of a built plan through
+ * daisy_bpr_staged_adam_step - steps first_step, first_step + 1, ... (the constants table must hold table_steps >=
+ * first_step + num_batches - 1 steps) - enqueued natively: a reference run at its default batch (256 ... a few thousand
+ * rows) is not bound by one host round trip per batch.  flush != 0: the rows no batch referenced are brought up to the
+ * epoch's last step (daisy_adam_lazy_flush on both tables), i.e. both tables equal the dense optimiser's after the
+ * epoch.  MF only: contexts with FM biases are driven step by step (their biases step through the caller's dense
+ * optimiser between two steps) and are refused. */
+int daisy_bpr_fit_epoch_adam(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, float *P, float *Q, int32_t loss_type,
+                             float gamma, float lr, float reg_1, float reg_2, float *mP, float *vP, int32_t *lastP,
+                             float *mQ, float *vQ, int32_t *lastQ, const float *table, int64_t table_steps, float beta1,
+                             float beta2, float eps, int64_t first_step, int32_t flush, double *stats,
+                             double *epoch_acc, double *step_losses, daisy_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Scoring / ranking  (MFRecommender.py:99-133)

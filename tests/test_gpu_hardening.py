@@ -338,3 +338,37 @@ def test_set_batch_from_triples_selects_rows_anywhere_in_the_array(ops, mode):
     with pytest.raises(ValueError, match="out of range"):
         ctx.set_batch_from_triples(_t(tri), idx=_t(bad))
     ctx.close()
+
+
+@pytest.mark.parametrize("B", [512, 4096])
+def test_bare_step_with_a_non_finite_loss_is_the_same_in_both_launch_forms(ops, B, monkeypatch):
+    """a step WITHOUT an epoch accumulator has no halt word; the four-launch form then applies the whole step
+    whatever its loss, and the three-launch form (batches up to 16 384 samples) has to do the same - its item workgroups
+    used to stop themselves on a non-finite loss while the edge launches, which have no word to look at, still committed:
+    a half-updated Q that depended on the batch size."""
+    rng = np.random.default_rng(8)
+    U, I, d = 300, 90, 64
+    u = np.sort(rng.integers(0, U, B)).astype(np.int32)
+    i = rng.integers(0, I - 1, B).astype(np.int32)
+    j = rng.integers(0, I - 1, B).astype(np.int32)
+    i[7] = I - 1                                              # one sample meets the poisoned row
+    P0 = (rng.standard_normal((U, d)) * 0.1).astype(np.float32)
+    Q0 = (rng.standard_normal((I, d)) * 0.1).astype(np.float32)
+    Q0[I - 1] = np.inf
+    out = []
+    for merge in ("0", "1"):
+        monkeypatch.setenv("DAISY_STAGED_MERGE", merge)
+        P, Q = _t(P0), _t(Q0)
+        ctx = ops.BprContext(B, d, U, I)
+        ctx.set_batch(_t(u), _t(i), _t(j))
+        sl = torch.zeros(1, dtype=torch.float64, device="cuda")
+        ctx.sgd_step(P, Q, 0.05, 1e-3, 1e-3, item_mode=ops.ITEM_MODES["fused"], step_loss=sl, accumulate=False)
+        torch.cuda.synchronize()
+        assert not np.isfinite(float(sl.cpu()))
+        out.append((P.cpu().numpy(), Q.cpu().numpy()))
+        ctx.close()
+    # same rows written in both forms (NaN / inf patterns included: compare the bits)
+    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
+    assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+    moved = (out[0][1][: I - 1] != Q0[: I - 1]).any(axis=1)
+    assert moved.sum() > (I - 1) // 2                           # the step WAS applied (no halt word: nothing may stop it)

@@ -578,3 +578,96 @@ def test_small_batch_epoch_in_one_workgroup(d, B, loss):
         assert np.abs(P - Pn).max() < tol and np.abs(Q - Qn).max() < tol
     assert np.abs(res[0][0] - res[1][0]).max() < 2e-6 and np.abs(res[0][1] - res[1][1]).max() < 2e-6
     plan.close()
+
+
+@pytest.mark.parametrize("d,loss,B", [(64, "BPR", 400), (32, "CL", 256), (100, "HL", 1300)])
+def test_adam_epoch_in_one_call_equals_the_step_by_step_loop(d, loss, B):
+    """daisy_bpr_fit_epoch_adam (ABI 6; the loop of AbstractRecommender.py:118-128 with torch.optim.Adam, one enqueue per
+    epoch) against the same epochs driven step by step through daisy_bpr_staged_adam_step + the flush: both tables, both
+    moments, the stamps, the epoch accumulator and every step loss bit for bit, over two epochs (the second starts from
+    step nb + 1 with another plan)."""
+    from daisyrec_amd import ops
+    U, I, n = 61, 43, 1300
+    tri = _triples(n, U, I, d + 5)
+    tri[:300, 0] = 5
+    point = loss in ("CL", "SL")
+    if point:
+        tri[:, 2] = np.random.default_rng(d).integers(0, 2, n)
+    P0, Q0 = _tables(U, I, d, d + 1)
+    t_dev = torch.from_numpy(tri).to(DEV)
+    lid = ops.LOSS_IDS[loss]
+    res = []
+    for one_call in (False, True):
+        index, plan = ops.TrainIndex(t_dev, U, I, pointwise=point), ops.EpochPlan(n, U, I)
+        P, Q = torch.from_numpy(P0).to(DEV), torch.from_numpy(Q0).to(DEV)
+        ctx = ops.BprContext(B, d, U, I)
+        adam = ops.LazyAdam(P, Q, 0.01, 2)                 # (a table of 2 steps: both paths have to grow it)
+        losses, accs = [], []
+        for epoch in (1, 2):
+            plan.build_indexed(index, B, order="feistel", seed=4, epoch=epoch)
+            nb = plan.num_batches
+            sl = torch.zeros(nb, dtype=torch.float64, device=DEV)
+            ctx.epoch_acc.zero_()
+            if one_call:
+                adam.fit_epoch(ctx, plan, 1e-3, 2e-3, lid, step_losses=sl)
+            else:
+                for k in range(nb):
+                    ctx.set_batch_from_plan(plan, k)
+                    adam.staged_step(ctx, 1e-3, 2e-3, lid, step_loss=sl[k:k + 1])
+                adam.flush()
+            torch.cuda.synchronize()
+            losses.append(sl.clone())
+            accs.append(ctx.epoch_acc.clone())
+        assert adam.t == 2 * nb
+        res.append((P.clone(), Q.clone(), [x.clone() for x in adam.m + adam.v + adam.last], losses, accs))
+        ctx.close(); plan.close(); index.close()
+    a, b = res
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert all(torch.equal(x, y) for x, y in zip(a[2], b[2]))
+    assert all(torch.equal(x, y) for x, y in zip(a[3], b[3])) and all(torch.equal(x, y) for x, y in zip(a[4], b[4]))
+    assert float(a[4][1][0].cpu()) > 0 and float(a[4][1][1].cpu()) == 0
+
+
+def test_adam_fit_runs_the_epoch_call():
+    """MF.fit with Adam takes the one-enqueue epoch (daisy_bpr_fit_epoch_adam) and equals the fit driven step by step:
+    the same epoch losses, the same tables."""
+    import logging
+    from daisyrec_amd import ops
+    from daisyrec_amd.model.MFRecommender import MF
+    from daisyrec_amd.utils.dataset import BasicDataset, get_dataloader
+    U, I, n, B, d = 300, 120, 5000, 512, 32
+    tri = _triples(n, U, I, 77)
+    cfg = {"gpu": "0", "logger": logging.getLogger("t"), "lr": 0.01, "reg_1": 0.001, "reg_2": 0.001, "epochs": 2,
+           "topk": 10, "user_num": U, "item_num": I, "factors": d, "loss_type": "BPR", "optimizer": "adam",
+           "init_method": "default", "early_stop": False, "progress": False, "seed": 7}
+    out = []
+    for one_call in (True, False):
+        torch.manual_seed(5)
+        m = MF(cfg)
+        calls = []
+        orig = ops.LazyAdam.fit_epoch
+        if one_call:
+            ops.LazyAdam.fit_epoch = lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1]
+        else:                                  # force the step-by-step loop of round 4
+            from daisyrec_amd.model import AbstractRecommender as AR
+            saved = AR._AdamState.staged_epoch
+
+            def stepwise(self, ctx, plan, reg_1, reg_2, loss_id):
+                for k in range(plan.num_batches):
+                    ctx.set_batch_from_plan(plan, k)
+                    self.step(ctx, self._P, self.lazy_staged.Q if self.lazy_staged else self._lazy_args[1], reg_1, reg_2,
+                              loss_id, ops.ITEM_MODES["fused"])
+                self.flush()
+            AR._AdamState.staged_epoch = stepwise
+        try:
+            torch.manual_seed(11)
+            m.fit(get_dataloader(BasicDataset(tri), batch_size=B, shuffle=True, num_workers=0))
+        finally:
+            ops.LazyAdam.fit_epoch = orig
+            if not one_call:
+                AR._AdamState.staged_epoch = saved
+        if one_call:
+            assert len(calls) == 2
+        out.append((list(m.epoch_losses), m.embed_user.weight.data.clone(), m.embed_item.weight.data.clone()))
+    assert out[0][0] == out[1][0]
+    assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
