@@ -72,10 +72,19 @@ def parse():
     ap.add_argument("--overlap-plan", type=int, default=0,
                     help="build the next epoch's plan on a side stream (two plans in ping-pong; measured: no gain, the "
                          "plan build and the steps compete for the same memory system)")
-    ap.add_argument("--cpu-steps", type=int, default=10)
-    ap.add_argument("--slices", type=int, default=1,
+    ap.add_argument("--cpu-steps", type=int, default=3,
+                    help="timed CPU steps at the headline batch (a step of 2M interactions costs the host ~7 s); the "
+                         ">= 30 steps of SURVEY 8(d) run at B = 65536 on the same tables")
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="timed regions of --steps steps each on the headline leg; `value` is their median (boxes and "
+                         "passes differ by a few per cent)")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N=1: skip the `extra` legs (Zipf ids, Adam, B = 65536, NeuMF at ml-1m shapes, LightGCN at "
+                         "Amazon-Book shapes)")
+    ap.add_argument("--slices", type=int, default=0,
                     help="N>1: cut the item pass into this many item ranges and exchange a finished range on a side "
-                         "stream while the next one is reduced (1: one exchange after the whole pass)")
+                         "stream while the next one is reduced (1: one exchange after the whole pass; 0 = automatic: "
+                         "sharding.auto_exchange_slices, from the exchange bytes, an assumed bus rate and the batch)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 code path on one GPU)")
     return ap.parse_args()
@@ -110,37 +119,43 @@ def synth_triples(U, I, nnz, seed, device, dist_kind="uniform"):
 
 def cpu_baseline(U, I, d, B, batches, reg):
     """The reference's CPU/PyTorch path (oracle/torch_port.py restates it with the same stock ops; the
-    reference checkout does not exist on the GPU box) timed on this host's cores on a bounded sample:
-    the first len(batches)-1 batches of the GPU run's own epoch (same triples, same B), one more as warm-up.
-    Plus, as context, the reference's DEFAULT batch (B=256, basic.yaml:23) for 30 steps on the same tables."""
+    reference checkout does not exist on the GPU box) timed on this host's cores on a bounded sample of the GPU run's
+    own epoch (same triples): len(batches) steps at the headline batch B; the >= 30 steps SURVEY 8(d) asks for at
+    B = 65536 (rows of the same batches), where a step costs the host a quarter of a second instead of seven; and, as
+    context, the reference's DEFAULT batch (B = 256, basic.yaml:23) on the same tables."""
     from oracle.torch_port import TorchMFBPR
     torch.manual_seed(2022)
     m = TorchMFBPR(U, I, d, 0.01, reg, reg)
-    m.step(*batches[0])                                    # warm-up (allocations, thread pool)
+    u, i, j = batches[0]
+
+    def leg(sb, steps):
+        steps = max(1, min(steps, len(u) // sb - 1))          # slices [sb*(k+1), sb*(k+2)) must exist
+        m.step(u[:sb], i[:sb], j[:sb])                        # warm-up (allocations, thread pool)
+        t0 = time.perf_counter()
+        for k in range(steps):
+            sl = slice(sb * (k + 1), sb * (k + 2)) if len(u) >= 2 * sb else slice(0, sb)
+            m.step(u[sl], i[sl], j[sl])
+        dt = time.perf_counter() - t0
+        return {"value": steps * sb / dt, "unit": "interactions/s", "batch": sb, "steps": steps, "seconds": dt}
+
+    mid = leg(min(65536, len(u)), 30)                         # also warms the pool up for the big steps
     t0 = time.perf_counter()
-    for b in batches[1:]:
+    for b in batches:
         m.step(*b)
     dt = time.perf_counter() - t0
-    steps = len(batches) - 1
-    u, i, j = batches[0]
-    sb = min(256, len(u))                                   # (a --batch below 256: the whole batch)
-    m.step(u[:sb], i[:sb], j[:sb])
-    t1 = time.perf_counter()
-    small = max(1, min(30, len(u) // sb - 1))               # slices [sb*(k+1), sb*(k+2)) must exist: 30 need 7936 rows
-    for k in range(small):
-        s = slice(sb * (k + 1), sb * (k + 2)) if len(u) >= 2 * sb else slice(0, sb)
-        m.step(u[s], i[s], j[s])
-    dts = time.perf_counter() - t1
+    steps = len(batches)
+    small = leg(min(256, len(u)), 10)
     return {"value": steps * B / dt, "unit": "interactions/s", "cores": torch.get_num_threads(),
             "kind": "port",
             "sample": f"{steps} SGD steps at B={B} on the first batches of the GPU run's epoch (U={U}, I={I}, d={d}; "
                       f"oracle/torch_port.py: nn.Embedding + autograd + optim.SGD, dense grads like the reference), "
                       f"{dt:.1f}s",
-            "why_not_30_steps": "SURVEY 8d asks for >= 30 steps; a step of this batch costs the host ~7 s (dense "
-                                "gradients over both tables), and the bench contract bounds the CPU leg to a sample of "
-                                "tens of seconds: the rate is flat from the second step on",
-            "reference_default_batch": {"value": small * sb / dts, "unit": "interactions/s", "batch": sb,
-                                        "steps": small, "seconds": dts}}
+            "why_not_30_steps_at_this_batch": "a step of this batch costs the host ~7 s (dense gradients over both "
+                                              "tables) and the bench contract bounds the CPU leg to tens of seconds; "
+                                              "the 30 steps of SURVEY 8(d) are in `steps30_b65536` (same tables, "
+                                              "same triples), the rate is flat from the second step on",
+            "steps30_b65536": mid,
+            "reference_default_batch": small}
 
 
 def build_data(a, rank, world, dev, wl, nnz_override=None):
@@ -184,8 +199,10 @@ def free_data(data):
     torch.cuda.empty_cache()
 
 
-def measure(a, data, rank, world, dev, B, slices, steps, warmup, want_cpu_batches=0):
-    """warmup + `steps` timed steps of batch size B (per rank) over `data`; max over ranks of the wall time"""
+def measure(a, data, rank, world, dev, B, slices, steps, warmup, want_cpu_batches=0, repeats=1):
+    """warmup + `steps` timed steps of batch size B (per rank) over `data`; max over ranks of the wall time.
+    repeats > 1: that many timed regions of `steps` steps, each bracketed like the first; the result is the region
+    with the MEDIAN wall time, the others are listed in `repeats`."""
     from daisyrec_amd import ops
     from daisyrec_amd.sharding import UserShardedBprTrainer
     d, n, U_loc, I = data["d"], data["n"], data["U"], data["I"]
@@ -194,7 +211,9 @@ def measure(a, data, rank, world, dev, B, slices, steps, warmup, want_cpu_batche
     lr, reg = 0.01, a.reg
     ctx = ops.BprContext(B, d, U_loc, I, device=dev)
     item_mode = ops.ITEM_MODES[a.item_mode]
-    trainer = UserShardedBprTrainer(ctx, P, Q, 0, lr, reg, reg, item_mode=item_mode, slices=slices) if world > 1 else None
+    trainer = UserShardedBprTrainer(ctx, P, Q, 0, lr, reg, reg, item_mode=item_mode, slices=slices or "auto") if world > 1 else None
+    if trainer is not None:
+        slices = trainer.slices                # (0 / 'auto' resolved: the same on every rank by construction)
     if trainer is not None:
         trainer.enable_timing()
     full_batches = n // B                      # the bench steps over full batches only (fixed B per step)
@@ -254,27 +273,31 @@ def measure(a, data, rank, world, dev, B, slices, steps, warmup, want_cpu_batche
 
     for _ in range(warmup):
         step()
-    # start the timed region on an epoch boundary: every timed epoch then contains exactly one plan build
-    state["k"] = full_batches if (a.overlap_plan and state["k"] is not None) else None
-    if trainer is not None and trainer.timeline is not None:
-        trainer.timeline.clear()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(steps):
-        ev[k][0].record()
-        step()
-        ev[k][1].record()
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.cpu())
+    regions = []
+    for rep in range(max(1, repeats)):
+        # start the timed region on an epoch boundary: every timed epoch then contains exactly one plan build
+        state["k"] = full_batches if (a.overlap_plan and state["k"] is not None) else None
+        if trainer is not None and trainer.timeline is not None:
+            trainer.timeline.clear()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            ev[k][0].record()
+            step()
+            ev[k][1].record()
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.cpu())
+        regions.append((dt, sorted(s_.elapsed_time(e_) for s_, e_ in ev), trainer.step_split() if trainer is not None else None))
     loss_sum, nan_cnt = (float(x) for x in ctx.epoch_acc.cpu())
     assert nan_cnt == 0 and loss_sum == loss_sum, "NaN loss during the benchmark"
-    step_ms = sorted(s.elapsed_time(e) for s, e in ev)
-    split = trainer.step_split() if trainer is not None else None
+    order = sorted(range(len(regions)), key=lambda r_: regions[r_][0])
+    dt, step_ms, split = regions[order[len(order) // 2]]
+    all_dt = [r_[0] for r_ in regions]
     cpu_batches = []
     if want_cpu_batches:                       # the first batches of the last built epoch, for the CPU leg
         for k in range(min(want_cpu_batches, full_batches)):
@@ -284,7 +307,7 @@ def measure(a, data, rank, world, dev, B, slices, steps, warmup, want_cpu_batche
            "dt": dt, "lr": lr, "reg": reg, "step_ms": step_ms, "plan_kind": data["plan_kind"], "cpu_batches": cpu_batches,
            "plan_bytes": sum(p.nbytes for p in plans), "index_bytes": index.nbytes if index is not None else 0,
            "staged": trainer.staged if trainer is not None else (a.item_mode == "fused"), "slices": slices,
-           "split_ms": split, "loss_sum": loss_sum}
+           "split_ms": split, "loss_sum": loss_sum, "all_dt": all_dt}
     ctx.close()
     for p in plans:
         p.close()
@@ -298,6 +321,264 @@ def roofline_of(r, world):
     eff_ms = max(gpu_ms_mean, r["dt"] / r["steps"] * 1e3) if world == 1 else gpu_ms_mean
     achieved = ALGO_BYTES_PER_INTERACTION_SGD(r["d"]) * r["B"] / (eff_ms * 1e-3) / 1e9
     return achieved, gpu_ms_mean
+
+
+ADAM_BYTES_PER_INTERACTION = lambda d: 72 * d + 12        # + m, v read and written for the three rows
+MFMA_PEAK_TF = {"fp32": 157.3, "bf16": 2500.0}            # MI355X_MICROARCH.md: dense MFMA peaks (no sparsity)
+
+
+def _timed(fn, reps):
+    """(wall seconds, HIP-event ms) of `reps` calls of fn, bracketed by synchronisations"""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, e0.elapsed_time(e1)
+
+
+def _hbm_roof(bytes_per_unit, units, seconds, note=None):
+    ach = bytes_per_unit * units / seconds / 1e9
+    r = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+         "traffic": None, "algorithmic_bytes_per_interaction": bytes_per_unit}
+    if note:
+        r["note"] = note
+    return r
+
+
+def extra_mf_epoch_loop(data, dev, B, reg, cpu_ref=None):
+    """SURVEY 8(d)'s mid-size batch: whole epochs through daisy_bpr_fit_epoch_sgd (the C loop `MF.fit` runs: one
+    enqueue per epoch), the plan build of every epoch inside the timed region"""
+    from daisyrec_amd import ops
+    n = min(data["n"], B * 800) // B * B
+    tr = data["triples"][:n].contiguous()
+    index = ops.TrainIndex(tr, data["U"], data["I"], user_sorted=True)
+    plan = ops.EpochPlan(n, data["U"], data["I"], device=dev)
+    ctx = ops.BprContext(B, data["d"], data["U"], data["I"], device=dev)
+    P, Q = data["P"].clone(), data["Q"].clone()
+    ep = [0]
+
+    def epoch():
+        ep[0] += 1
+        plan.build_indexed(index, B, order="feistel", seed=2022, epoch=ep[0])
+        ctx.fit_epoch_sgd(plan, P, Q, 0.01, reg, reg, item_mode=ops.ITEM_MODES["fused"])
+
+    epoch()
+    wall, ms = _timed(epoch, 2)
+    loss, bad = (float(x) for x in ctx.epoch_acc.cpu())
+    assert bad == 0 and loss == loss
+    nb = n // B
+    ctx.close(); plan.close(); index.close()
+    out = {"workload": f"MF+BPR SGD, configs[1] tables, B = {B} through daisy_bpr_fit_epoch_sgd ({nb} steps per epoch, "
+                       "plan builds timed)", "batch": B, "steps": 2 * nb, "value": 2 * n / wall, "unit": "interactions/s",
+           "us_per_step": wall / (2 * nb) * 1e6, "gpu_us_per_step_events": ms / (2 * nb) * 1e3,
+           "roofline": _hbm_roof(ALGO_BYTES_PER_INTERACTION_SGD(data["d"]), 2 * n, wall)}
+    if cpu_ref is not None:
+        out["cpu_baseline"] = dict(cpu_ref, cores=torch.get_num_threads(), kind="port",
+                                   sample=f"{cpu_ref['steps']} SGD steps at B = {cpu_ref['batch']} on the same tables "
+                                          "(oracle/torch_port.py)")
+    return out
+
+
+def extra_mf_adam(data, dev, B, reg):
+    """MF + torch.optim.Adam (AbstractRecommender.py:54): the staged step whose row owners apply the exact lazy form,
+    one epoch per enqueue (daisy_bpr_fit_epoch_adam), flush and plan build inside the timed region; priced by SURVEY
+    8(d)'s Adam byte model (72 d + 12 B per interaction)"""
+    from daisyrec_amd import ops
+    n, U, I, d = data["n"], data["U"], data["I"], data["d"]
+    plan = ops.EpochPlan(n, U, I, device=dev)
+    ctx = ops.BprContext(B, d, U, I, device=dev)
+    P, Q = data["P"].clone(), data["Q"].clone()
+    nb = n // B
+    adam = ops.LazyAdam(P, Q, 0.001, 4 * (nb + 1))
+    ep = [0]
+
+    def epoch():
+        ep[0] += 1
+        plan.build_indexed(data["index"], B, order="feistel", seed=2022, epoch=ep[0])
+        adam.fit_epoch(ctx, plan, reg, reg)
+
+    epoch()
+    wall, ms = _timed(epoch, 1)
+    loss, bad = (float(x) for x in ctx.epoch_acc.cpu())
+    assert bad == 0 and loss == loss
+    steps = plan.num_batches
+    ctx.close(); plan.close()
+    del adam
+    return {"workload": f"MF+BPR with torch.optim.Adam semantics (lazy rows, exact), tables {U} x {I}, B = {B}, one epoch "
+                        f"= {steps} steps + flush + plan build", "batch": B, "steps": steps, "value": n / wall,
+            "unit": "interactions/s", "ms_per_step": wall / steps * 1e3, "gpu_ms_per_step_events": ms / steps,
+            "roofline": _hbm_roof(ADAM_BYTES_PER_INTERACTION(d), n, wall,
+                                  "SURVEY 8(d): 72 d + 12 B per interaction (rows + both moments read and written), no "
+                                  "credit for duplicate rows - which is generous where a batch holds several samples per "
+                                  "user and item (configs[1] tables at B = 2 M: 2.3 per touched user, 42 per item; the lazy "
+                                  "form moves a touched row's moments once): read the figure at configs[2] table shapes "
+                                  "(`mf_adam_c3shapes`) as the honest one")}
+
+
+def extra_neumf(dev, want_cpu):
+    """BASELINE configs[3]: NeuMF (GMF + 3-layer MLP) at ml-1m shapes, d = 64; a step = daisy_neumf_step_grads + one
+    dense Adam pass.  The tower is GEMM work: priced against the dense MFMA peak of the mode's input type (fp32 = the
+    reference's arithmetic and the parity mode; bf16 storage = the throughput mode configs[3] names)"""
+    from daisyrec_amd import ops
+    U, I, D, L = 6040, 3706, 64, 3
+    g = torch.Generator(device=dev)
+    g.manual_seed(0)
+    dm = D << (L - 1)
+    shapes = {"uG": (U, D), "iG": (I, D), "uM": (U, dm), "iM": (I, dm)}
+    w, macs = 2 * dm, 0
+    for l in range(1, L + 1):
+        shapes[f"W{l}"], shapes[f"b{l}"] = (w // 2, w), (w // 2,)
+        macs += w * (w // 2)
+        w //= 2
+    shapes["Wp"], shapes["bp"] = (1, 2 * D), (1,)
+    names = ops.neumf_param_names(L)
+    numel = lambda k: int(torch.tensor(shapes[k]).prod())     # noqa: E731
+    flat = torch.randn(sum(numel(k) for k in names), device=dev, generator=g) * 0.05
+    gflat, m, v = torch.zeros_like(flat), torch.zeros_like(flat), torch.zeros_like(flat)
+    p, gr, off = {}, {}, 0
+    for k in names:
+        p[k], gr[k] = flat[off:off + numel(k)].view(shapes[k]), gflat[off:off + numel(k)].view(shapes[k])
+        off += numel(k)
+    flops_per_sample = 2 * macs * 3 * 2            # x2 flop/MAC, x3 GEMMs (forward, d-input, d-weight), x2 rows (pos, neg)
+    out = {"workload": "BASELINE configs[3] shapes: NeuMF (GMF + 512-256-128-64 MLP) on ml-1m sizes U=6040, I=3706, d=64, "
+                       "pairwise BPR rows (u, i, j), Adam; synthetic ids, random-init weights", "points": []}
+    for B, prec, steps in ((65536, 0, 8), (262144, 0, 4), (65536, 2, 8), (262144, 2, 6)):
+        u, i, j = (torch.randint(0, hi, (B,), device=dev, generator=g, dtype=torch.int32) for hi in (U, I, I))
+        ctx = ops.NeumfContext(2 * B, D, L, U, I)
+        ctx.set_precision(prec)
+        t = [0]
+
+        def step():
+            t[0] += 1
+            ctx.step_grads(p, gr, u, i, j, 0, 1e-3, 1e-3, dropout=0.0, seed=t[0])
+            ops.adam_dense(flat, gflat, m, v, 1e-3, t[0])
+
+        for _ in range(2):
+            step()
+        wall, ms = _timed(step, steps)
+        ctx.close()
+        name = "fp32" if prec == 0 else "bf16"
+        tf = flops_per_sample * B * steps / wall / 1e12
+        out["points"].append({"batch": B, "precision": {0: "fp32 (parity mode)", 2: "bf16 storage, fp32 accumulation"}[prec],
+                              "steps": steps, "value": B * steps / wall, "unit": "samples/s", "ms_per_step": wall / steps * 1e3,
+                              "gpu_ms_per_step_events": ms / steps,
+                              "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TF[name], "unit": "TFLOP/s",
+                                           "frac": tf / MFMA_PEAK_TF[name], "traffic": None,
+                                           "flops_counted": "the three GEMMs per layer x 2 rows per sample; gathers, "
+                                                            "scatter and Adam are not counted"}})
+    best = max(out["points"], key=lambda q: q["value"])
+    out["value"], out["unit"] = best["value"], "samples/s"
+    if want_cpu:
+        from oracle.torch_port import TorchNeuMF
+        torch.manual_seed(0)
+        mdl = TorchNeuMF(U, I, D, L)
+        gh = torch.Generator()
+        gh.manual_seed(1)
+        Bc, cs = 16384, 3
+        bt = [tuple(torch.randint(0, hi, (Bc,), generator=gh) for hi in (U, I, I)) for _ in range(cs + 1)]
+        mdl.step(*bt[0])
+        t0 = time.perf_counter()
+        for b in bt[1:]:
+            mdl.step(*b)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": cs * Bc / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{cs} Adam steps at B = {Bc} (oracle/torch_port.py: TorchNeuMF, stock "
+                                         f"nn.Embedding / Linear / autograd / optim.Adam), {dt:.1f}s"}
+    return out
+
+
+def extra_lightgcn(dev, want_cpu):
+    """BASELINE configs[4] shapes on ONE GPU: LightGCN, 3 layers, Amazon-Book sizes; the sparse x dense products are
+    HBM-bound (per stored entry one 4 d-byte row gather + 20 B of entry metadata, per node a memset and a row write)"""
+    import logging
+    import numpy as np
+    import scipy.sparse as sp
+    from daisyrec_amd import ops
+    from daisyrec_amd.model.LightGCNRecommender import LightGCN
+    U, I, NNZ, D, L = 52643, 91599, 2380730, 64, 3
+    rng = np.random.default_rng(0)
+    w = 1.0 / np.arange(1, I + 1) ** 0.8                       # popularity-skewed items
+    cdf = np.cumsum(w / w.sum())
+    gi = np.minimum(np.searchsorted(cdf, rng.random(NNZ)), I - 1).astype(np.int64)
+    gu = rng.integers(0, U, NNZ).astype(np.int64)
+    cfg = dict(gpu="0", logger=logging.getLogger("bench"), epochs=1, lr=0.01, topk=50, user_num=U, item_num=I,
+               inter_matrix=sp.coo_matrix((np.ones(NNZ, np.float32), (gu, gi)), shape=(U, I)), factors=D,
+               num_layers=L, reg_1=0.0, reg_2=0.0, loss_type="BPR", optimizer="default", init_method="default",
+               early_stop=False, progress=False)
+    torch.manual_seed(0)
+    model = LightGCN(cfg)
+    E0 = model._ego()
+    graph = model._adj()
+    X = torch.randn(U + I, D, device=dev)
+    graph.spmm(X)
+    wall, _ = _timed(lambda: graph.spmm(X), 20)
+    spmm_s = wall / 20
+    alg = graph.nnz * (4 * D + 20) + (U + I) * 4 * D * 2
+    out = {"workload": f"BASELINE configs[4] shapes on one GPU: LightGCN {L} layers, Amazon-Book sizes U={U}, I={I}, "
+                       f"{NNZ} interactions -> {graph.nnz} stored adjacency entries, d={D}; the propagation is "
+                       "recomputed for every batch like the reference (LightGCNRecommender.py:117-129,141)",
+           "spmm": {"ms": spmm_s * 1e3, "G_row_gathers_per_s": graph.nnz / spmm_s / 1e9,
+                    "roofline": {"bound": "hbm", "achieved": alg / spmm_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": alg / spmm_s / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                 "algorithmic_bytes": alg,
+                                 "note": "the 37 MB table is Infinity-Cache resident: cache-assisted"}},
+           "points": []}
+    loss_id = ops.loss_id("BPR")
+    o_, G, dE0 = torch.empty_like(E0), torch.empty_like(E0), torch.zeros_like(E0)
+    m, v = torch.zeros_like(model._flat), torch.zeros_like(model._flat)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    for B, steps in ((4096, 20), (65536, 20)):
+        u, i, j = (torch.randint(0, hi, (B,), device=dev, generator=g, dtype=torch.int32) for hi in (U, I, I))
+        ctx = ops.BprContext(B, D, U, I)
+        t = [0]
+
+        def step():
+            t[0] += 1
+            model._batch_grads(ctx, E0, o_, G, dE0, u, i, j, loss_id)
+            ops.adam_dense(model._flat, dE0.view(-1), m, v, 0.01, t[0])
+
+        for _ in range(2):
+            step()
+        wall, ms = _timed(step, steps)
+        ctx.close()
+        out["points"].append({"batch": B, "steps": steps, "value": B * steps / wall, "unit": "samples/s",
+                              "ms_per_step": wall / steps * 1e3, "gpu_ms_per_step_events": ms / steps,
+                              "propagation_share": 2 * L * spmm_s / (wall / steps),
+                              "roofline": {"bound": "hbm", "achieved": 2 * L * alg / (wall / steps) / 1e9, "peak": HBM_PEAK_GBS,
+                                           "unit": "GB/s", "frac": 2 * L * alg / (wall / steps) / 1e9 / HBM_PEAK_GBS,
+                                           "traffic": None,
+                                           "note": "algorithmic bytes of the step's 2 L products only (the batch part and "
+                                                   "the dense Adam pass are not counted) / the whole step's time"}})
+    out["value"], out["unit"] = out["points"][-1]["value"], "samples/s"
+    if want_cpu:
+        from oracle import lightgcn_numpy as LG
+        from oracle.torch_port import TorchLightGCN
+        indptr, col, val = LG.norm_adj_csr(gu, gi, U, I)
+        rows = np.repeat(np.arange(U + I), np.diff(indptr))
+        adj = torch.sparse_coo_tensor(torch.as_tensor(np.stack([rows, col.astype(np.int64)])), torch.as_tensor(val),
+                                      (U + I, U + I)).coalesce()
+        torch.manual_seed(0)
+        mdl = TorchLightGCN(U, I, D, L, adj)
+        gh = torch.Generator()
+        gh.manual_seed(1)
+        Bc, cs = 4096, 2
+        bt = [tuple(torch.randint(0, hi, (Bc,), generator=gh) for hi in (U, I, I)) for _ in range(cs + 1)]
+        mdl.step(*bt[0])
+        t0 = time.perf_counter()
+        for b in bt[1:]:
+            mdl.step(*b)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": cs * Bc / dt, "unit": "samples/s", "ms_per_step": dt / cs * 1e3,
+                               "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{cs} Adam steps at B = {Bc} (oracle/torch_port.py: TorchLightGCN, "
+                                         f"torch.sparse.mm propagation per batch), {dt:.1f}s"}
+    graph.close()
+    return out
 
 
 def replica_check(a, rank, world, dev):
@@ -398,7 +679,7 @@ def main():
                 "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
 
     wl = a.workload if a.workload != "auto" else ("c2" if world == 1 else "c3")
-    want_cpu = (a.cpu_steps + 1) if (world == 1 and rank == 0 and not a.no_cpu_baseline) else 0
+    want_cpu = a.cpu_steps if (world == 1 and rank == 0 and not a.no_cpu_baseline) else 0
     B_main = a.batch if a.batch is not None else ((1 << 21) if world == 1 else (1 << 24))
 
     def guarded(what, fn, *args, collective=True):
@@ -426,7 +707,22 @@ def main():
         check = guarded("replica_check", replica_check, a, rank, world, dev)
 
     data = build_data(a, rank, world, dev, wl)
-    r = measure(a, data, rank, world, dev, B_main, a.slices, a.steps, a.warmup, want_cpu)
+    r = measure(a, data, rank, world, dev, B_main, a.slices, a.steps, a.warmup, want_cpu, repeats=a.repeats)
+    # N = 1: the other operating points of SURVEY 8(d) and the other BASELINE configs, on the same JSON line as `extra`
+    # (each a guarded leg: an exception lands on the line instead of costing the headline number)
+    want_extras = (world == 1 and wl == "c2" and not a.no_extras and a.item_mode == "fused" and a.batch is None
+                   and a.nnz is None and a.dist == "uniform")
+    extra = {}
+    cpu_mid = [None]
+    if want_extras:
+        if r["cpu_batches"]:            # the CPU leg first: its 30-step B = 65536 figure pairs with the GPU leg at that batch
+            cpu_res = guarded("cpu_baseline", cpu_baseline, r["U"], r["I"], r["d"], r["B"], r["cpu_batches"], r["reg"],
+                              collective=False)
+            r["cpu_result"] = cpu_res
+            cpu_mid[0] = cpu_res.get("steps30_b65536") if isinstance(cpu_res, dict) else None
+        extra["mf_b65536"] = guarded("extra mf_b65536", extra_mf_epoch_loop, data, dev, 65536, a.reg, cpu_mid[0],
+                                     collective=False)
+        extra["mf_adam"] = guarded("extra mf_adam", extra_mf_adam, data, dev, 1 << 21, a.reg, collective=False)
     sweep = []
     if world > 1 and wl in ("c3", "tiny") and not a.no_sweep and a.item_mode == "fused" and (a.batch is None or wl == "tiny"):
         # the regimes of DESIGN.md section 5 in one launch: the exchange is a fixed 2 x 231 MB per step and rank, so
@@ -446,6 +742,8 @@ def main():
     if world == 1 and wl == "c2" and not a.no_secondary and a.item_mode == "fused" and a.batch is None and a.nnz is None:
         d2 = build_data(a, rank, world, dev, "c3", nnz_override=SECONDARY_NNZ)
         r2 = measure(a, d2, rank, world, dev, 1 << 21, 1, None, a.warmup)
+        if want_extras:      # Adam where the byte model has no duplicate rows to be generous about: ~1.1 samples per touched user
+            extra["mf_adam_c3shapes"] = guarded("extra mf_adam_c3shapes", extra_mf_adam, d2, dev, 1 << 21, a.reg, collective=False)
         free_data(d2)
         ach2, gpu2 = roofline_of(r2, 1)
         traffic2, traffic2_src = None, None
@@ -468,6 +766,31 @@ def main():
                                                   "(every P row read and written once per sample, a quarter of the Q rows "
                                                   "updated in place per step, the stage written once and read twice): at the "
                                                   "~6.3 TB/s the fabric delivers frac cannot exceed ~0.57 with this design"}}
+
+    if want_extras:
+        def zipf_leg():
+            az = argparse.Namespace(**vars(a))
+            az.dist = "zipf"
+            dz = build_data(az, rank, world, dev, "c2")
+            try:
+                rz = measure(az, dz, rank, world, dev, 1 << 21, 1, a.steps, a.warmup)
+            finally:
+                free_data(dz)
+            achz, gpuz = roofline_of(rz, 1)
+            return {"workload": "configs[1] sizes with Zipf(1.0) item popularity (SURVEY 8d's skewed distribution), "
+                                "B = 2097152, SGD", "batch": rz["B"], "steps": rz["steps"],
+                    "value": rz["steps"] * rz["B"] / rz["dt"], "unit": "interactions/s",
+                    "ms_per_step": rz["dt"] / rz["steps"] * 1e3, "gpu_ms_per_step_events": gpuz,
+                    "roofline": {"bound": "hbm", "achieved": achz, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": achz / HBM_PEAK_GBS, "traffic": None,
+                                 "algorithmic_bytes_per_interaction": ALGO_BYTES_PER_INTERACTION_SGD(64)}}
+        extra["mf_zipf"] = guarded("extra mf_zipf", zipf_leg, collective=False)
+        want_cpu_x = not a.no_cpu_baseline
+        extra["neumf_ml1m"] = guarded("extra neumf_ml1m", extra_neumf, dev, want_cpu_x, collective=False)
+        torch.cuda.empty_cache()
+        extra["lightgcn_amazon_book"] = guarded("extra lightgcn_amazon_book", extra_lightgcn, dev, want_cpu_x,
+                                                collective=False)
+        torch.cuda.empty_cache()
 
     ref, ref_global = None, {}
     if world > 1 and wl in ("c3", "tiny") and not a.no_ref:
@@ -542,6 +865,12 @@ def main():
                          "algorithmic_bytes_per_interaction": ALGO_BYTES_PER_INTERACTION_SGD(d),
                          "gpu_ms_per_step_events": gpu_ms_mean, "gpu_ms_per_step_median": step_ms[len(step_ms) // 2]},
         }
+        if len(r["all_dt"]) > 1:          # every timed region of `steps` steps; `value` / `ms_per_step` are the median one's
+            out["repeats"] = [steps * B * world / t_ for t_ in r["all_dt"]]
+            out["repeats_note"] = (f"{len(r['all_dt'])} timed regions of {steps} steps each, every one bracketed by barrier + "
+                                   "synchronize; value = the median region")
+        if extra:
+            out["extra"] = extra
         if secondary is not None:
             out["secondary"] = secondary
         if world > 1:
@@ -596,7 +925,9 @@ def main():
                     pt["meets_6x_same_global_batch"] = bool(v / g["value"] >= 6.0)
                 pts.append(pt)
             out["sweep"] = pts
-        if r["cpu_batches"]:
+        if r.get("cpu_result") is not None:
+            out["cpu_baseline"] = r["cpu_result"]
+        elif r["cpu_batches"]:
             out["cpu_baseline"] = cpu_baseline(r["U"], r["I"], d, B, r["cpu_batches"], r["reg"])
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -88,7 +88,14 @@ constexpr int kItemWinFloats = DAISY_ITEM_WINF;     // 24 KB of Q rows per workg
                                           // float4 per lane get 16 KB, wider ones none (their partial-sum slots already
                                           // take the LDS that four workgroups per CU leave)
 
-constexpr int kStagedUserBlock = 128, kStagedItemBlock = 256;    // threads per workgroup of the two passes (measured:
+// threads per workgroup of the item pass outside the three-launch form.  Its four barriers per chunk make a workgroup as
+// slow as its slowest wave's gathers; two waves per workgroup instead of four (round 5, same box): 222 -> 216 us at
+// BASELINE configs[1], 296 -> 285 us at 10 M x 1 M shapes; one wave (64 threads: four times the chunks, edge records and
+// finishers) loses again (227 / 307 us).  Rounds 2 / 3 had measured 128 "the same" - with the commit stalls still in.
+#ifndef DAISY_ITEM_BLK
+#define DAISY_ITEM_BLK 128
+#endif
+constexpr int kStagedUserBlock = 128, kStagedItemBlock = DAISY_ITEM_BLK;    // threads per workgroup of the two passes (measured:
                                                                  // user pass 387 -> 360 us at 128, item pass indifferent)
 
 static inline hipStream_t S(daisy_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
@@ -582,6 +589,10 @@ static int plan_build_partitioned(daisy_epoch_plan *p, const daisy_train_index *
     }
     const BatchDiv bd = make_batch_div(batch_size);
 
+    // (Round 5 ran the two partitions of a build - entry records, sample records - side by side on two streams, hoping
+    // the VALU-bound counting kernels would hide under the scatters: every kernel took twice as long and the build as long
+    // as before, 1.33 -> 1.36 ms per epoch at BASELINE configs[1] (profiles/r05_notes.txt).  The scatters are bound by
+    // instruction issue like the counts - ranking by ballots, LDS sort - not by memory; deleted.)
     // per record kind (entries, then samples) and LSD digit: histogram of every tile, exclusive scan, stable scatter
     for (int what = 0; what < 2; ++what) {
         const bool entries = (what == 0);
@@ -1327,7 +1338,8 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((ADAM || ME
     // entries spread over many items) are loaded directly.
     constexpr bool WIN = APPLY && C::VEC == 4 && C::NE <= 8 && DAISY_ITEM_WINDOW && !SPARSE && !(DAISY_ITEM_PROBE & 2);
     constexpr bool QPRE = APPLY && SPARSE;                 // the Q row of every entry rides with its staged row
-    constexpr int WINF = (C::NE <= 4) ? kItemWinFloats : (kItemWinFloats * 2 / 3);
+    // (24 KB per 256 threads: the CU's LDS is shared by 256 / BLK times as many workgroups, a chunk covers BLK / 256 of the items)
+    constexpr int WINF = ((C::NE <= 4) ? kItemWinFloats : (kItemWinFloats * 2 / 3)) * BLK / kBlock;
     __shared__ __attribute__((aligned(16))) float qwin[WIN ? WINF : 4];
     // sparse flavour: the pre-step row of Q of a segment that leaves its run through the TAIL, for the slot's finisher (a
     // load there would sit behind this chunk's row stores: k_staged_user's part_p has the story)
@@ -1939,25 +1951,26 @@ static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_
     const RowOpt opt = row_opt(lr, adam, false);
     const StagedBias fm = staged_bias(ctx, bias_grad_out);
     if (adam && !apply) { set_error("staged item pass: the Adam owner update needs the in-place form"); return DAISY_ERR_ARG; }
-    static const int tune_ig = getenv("DAISY_STAGED_IGRID") ? atoi(getenv("DAISY_STAGED_IGRID")) : 16384;
+    static const int tune_ig = getenv("DAISY_STAGED_IGRID") ? atoi(getenv("DAISY_STAGED_IGRID")) : 0;    // 0: 16 384 x 256 threads
     // DAISY_STAGED_SPARSE (read per call: the tests switch it): 0 / 1 force the dense / sparse flavour of the SGD item pass
     const char *env_sparse = getenv("DAISY_STAGED_SPARSE");
     const int tune_sparse = env_sparse ? atoi(env_sparse) : -1;
     bool overflow = false;
     int rc = dispatch_d(d, [&](auto cfg) {
         using C = decltype(cfg);
-        constexpr int BLK = kStagedItemBlock;        // (128-thread workgroups measured the same, r02 / r03)
+      auto with_block = [&](auto blk_tag) {
+        constexpr int BLK = decltype(blk_tag)::value;        // (128-thread workgroups measured the same, r02 / r03)
         // the sparse flavour (StagedItemCfg) when a dense chunk's item range would not fit the LDS window: expected
         // items under a chunk = chunk entries x items / entries  >  rows of the window
         constexpr int E_dense = StagedItemCfg<C, BLK>::E, E_sparse = StagedItemCfg<C, BLK, true>::E;
-        constexpr int win_rows = kItemWinFloats / (C::NE * C::LPR);
+        constexpr int win_rows = (kItemWinFloats * BLK / kBlock) / (C::NE * C::LPR);
         bool sparse = apply && !adam && (double)v.E * win_rows < (double)E_dense * (double)ctx->I;
         if (tune_sparse >= 0) sparse = apply && !adam && tune_sparse != 0;
         if (sparse && (v.E + E_sparse - 1) / E_sparse > edge_cap) sparse = false;
         const int chunk_e = sparse ? E_sparse : E_dense;
         const int64_t nchunks = (v.E + chunk_e - 1) / chunk_e;
         if (nchunks > edge_cap) { overflow = true; return DAISY_OK; }
-        const int gi = grid_for(v.E, chunk_e, tune_ig);
+        const int gi = grid_for(v.E, chunk_e, tune_ig > 0 ? tune_ig : 16384 * kBlock / BLK);
         const int ge_own = grid_for(nchunks, C::GROUPS_PER_BLOCK) + (rr.n ? 1 : 0);
         RideUnorm ru = ride, ru_edge = RideUnorm{nullptr, nullptr, 0, nullptr, 0, 0};
         MergedJob mj{};
@@ -1976,8 +1989,10 @@ static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_
 #define DAISY_ITEM_LAUNCH(SP, MG)                                                                                          \
     hipLaunchKernelGGL((k_staged_item<C, BLK, MODE, true, false, SP, MG>), g, b, 0, s, ctx->p_stage, ctx->coef, v, d, Qo, \
                        cnt_out, stats, opt, reg_1, reg_2, ed, erange, fm, ru, mj)
-                if (merged) { if (sparse) DAISY_ITEM_LAUNCH(true, true); else DAISY_ITEM_LAUNCH(false, true); }
-                else { if (sparse) DAISY_ITEM_LAUNCH(true, false); else DAISY_ITEM_LAUNCH(false, false); }
+                if constexpr (BLK == kBlock) {
+                    if (merged) { if (sparse) DAISY_ITEM_LAUNCH(true, true); else DAISY_ITEM_LAUNCH(false, true); }
+                }
+                if (!merged) { if (sparse) DAISY_ITEM_LAUNCH(true, false); else DAISY_ITEM_LAUNCH(false, false); }
 #undef DAISY_ITEM_LAUNCH
             } else {
                 hipLaunchKernelGGL((k_staged_item<C, BLK, MODE, AP, AD, false>), g, b, 0, s, ctx->p_stage, ctx->coef, v, d, Qo,
@@ -1995,6 +2010,10 @@ static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_
         else if (mode == kModePlain) by_apply(std::integral_constant<int, kModePlain>{});
         else by_apply(std::integral_constant<int, kModePoint>{});
         return DAISY_OK;
+      };
+        // (the three-launch form is written for 256-thread workgroups)
+        if (merged) return with_block(std::integral_constant<int, kBlock>{});
+        return with_block(std::integral_constant<int, kStagedItemBlock>{});
     });
     if (rc) return rc;
     if (overflow) { set_error("staged step: the batch needs more edge records than the context holds"); return DAISY_ERR_STATE; }

@@ -162,7 +162,10 @@ class GeneralRecommender(AbstractRecommender):
         # under torch.distributed (one process per GPU): split the users over the ranks (default) or let every
         # rank train the whole model
         self.shard_users = bool(config.get("shard_users", True))
-        self.exchange_slices = int(config.get("exchange_slices", 1))     # > 1: pipeline the item exchange (sharding.py)
+        # 'auto' (default): sharding.auto_exchange_slices - the item exchange is pipelined under the item pass when it
+        # is worth cutting (RCCL, exchange bytes / assumed bus rate against the pass); an integer forces the count
+        xs = config.get("exchange_slices", "auto")
+        self.exchange_slices = "auto" if str(xs).lower() == "auto" else int(xs)
         # MF + Adam: the exact lazy row updates of ops.LazyAdam.  'auto': when a step references fewer rows than the
         # tables have (3B < U + I; measured: 1.55x at 10M x 1M with B = 2M, but 0.9x at 1M x 100K with B = 1M, where
         # every step touches most rows anyway and the dense streaming pass is cheaper than row-wise claims)
@@ -265,6 +268,7 @@ class GeneralRecommender(AbstractRecommender):
         index = plan = None
         trainer = UserShardedBprTrainer(ctx, P_loc, Q, lo, self.lr, self.reg_1, self.reg_2, loss_type=loss_id,
                                         item_mode=ops.ITEM_MODES["fused"], slices=self.exchange_slices,
+                                        auto_batch=max(1, B // world),     # (the context's batch is the GLOBAL one here)
                                         adam_steps=(self.epochs * ((n + B - 1) // B)) if (opt == "adam" and not dense) else 0,
                                         dense_opt=ops.DenseOptimizer(opt, self.lr) if dense else None)
         acc = torch.zeros(2, dtype=torch.float64, device=P.device)

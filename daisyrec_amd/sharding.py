@@ -31,7 +31,7 @@ reduce-scatter + all-gather pair a ring all-reduce is made of:
 Per step and rank at d=64: 2*(N-1)/N * I * 264 B on the wire (I=1M, N=8: 2 x 231 MB), against
 B_local interactions of compute; DESIGN.md section 5 has the budget.
 
-`slices=S` (> 1, opt-in): the item rows are cut into S ranges, the item pass runs range by range
+`slices=S` (> 1; 'auto' = `auto_exchange_slices`, the default of `MF.fit` and `bench.py` since round 5): the item rows are cut into S ranges, the item pass runs range by range
 (daisy_bpr_staged_item_slice; the entries are sorted by item) and the exchange of a finished range - reduce-scatter,
 owner update, all-gather - runs on a side stream while the next range is reduced.  Ownership then interleaves: rank
 r owns the r-th block of every range.  Every rank must use the same S.
@@ -62,6 +62,40 @@ def user_range(user_num: int, world_size: int, rank: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def auto_exchange_slices(item_num: int, d: int, world_size: int, batch_per_rank: int, backend: str = "nccl",
+                         bus_gbs: float | None = None) -> int:
+    """How many item ranges the item pass of a user-sharded step is cut into (`slices='auto'`).  A pure function of
+    numbers every rank holds identically (the GLOBAL batch / world size, not a rank's own share), so every rank arrives
+    at the same cuts - the replicas stay bit-identical only then.
+
+    The exchange of a step is fixed by the item table: reduce-scatter + all-gather of I x (d + 2) floats, 2 (N-1)/N of
+    them on the wire per rank, at the bus rate RCCL reaches on the node (assumed 300 GB/s on an 8-GPU xGMI node,
+    DESIGN.md section 5; `DAISY_XGMI_BUS_GBS` overrides).  The item pass it can hide under moves 2 B_local staged rows at
+    about 5 TB/s.  With S slices all but the last range's exchange run under the next range's reduction; a cut costs
+    about 0.15 % of the pass (4.77 -> 4.82 ms at S = 8).  One slice when the exchange is under a
+    tenth of the pass or the backend has no asynchronous collectives worth overlapping (gloo: the CPU tests); otherwise
+    the smallest power of two that leaves at most a tenth of the pass exposed - at most 16, no slice under ~100 us of item
+    pass (a slice is a launch and three collectives of its own), blocks of at least 1024 rows per owner and slice."""
+    import os
+    if world_size <= 1 or backend != "nccl":
+        return 1
+    if bus_gbs is None:
+        bus_gbs = float(os.environ.get("DAISY_XGMI_BUS_GBS", "300"))
+    t_exchange = 2.0 * (world_size - 1) / world_size * item_num * (d + 2) * 4.0 / (bus_gbs * 1e9)
+    t_item = 2.0 * batch_per_rank * 4.0 * d / 5.0e12
+    if t_exchange < 0.1 * t_item:
+        return 1
+    want = t_exchange / max(0.1 * t_item, 1e-9)
+    s_ = 2
+    while s_ < want and s_ < 16:
+        s_ *= 2
+    # a slice is a kernel launch and three collectives of its own: none shorter than ~100 us of item pass (a pass that
+    # short cannot hide much of the exchange anyway), no block under 1024 rows per owner and slice
+    while s_ > 1 and (t_item / s_ < 100e-6 or item_num // (world_size * s_) < 1024):
+        s_ //= 2
+    return s_
+
+
 def shard_triples(triples, user_num: int, world_size: int, rank: int):
     """Rows of an int32 [N,3] (user,pos,neg) array that belong to `rank`'s user range."""
     lo, hi = user_range(user_num, world_size, rank)
@@ -77,7 +111,7 @@ class UserShardedBprTrainer:
 
     def __init__(self, ctx, P_local, Q, user_lo, lr, reg_1, reg_2, loss_type=N.LOSS_BPR,
                  gamma=1e-10, item_mode=N.ITEM_FUSED, group=None, overlap=True, always_collective=False, slices=1,
-                 adam_steps=0, dense_opt=None):
+                 adam_steps=0, dense_opt=None, auto_batch=None):
         """adam_steps > 0: torch.optim.Adam instead of SGD (staged protocol only; the value sizes the table of per-step
         constants, it grows on demand): lazy on the rank's rows of P, dense on its own block(s) of Q (ops.ShardedAdam)"""
         self.ctx, self.P, self.Q = ctx, P_local, Q
@@ -111,6 +145,11 @@ class UserShardedBprTrainer:
         # collectives the backend lacks are emulated with the ones it has (gloo: no reduce_scatter);
         # "nccl" (= RCCL on ROCm) runs the real ones
         self._native_rs = self.collective and dist.get_backend(group) == "nccl"
+        if slices in ("auto", 0, None):      # decided from numbers all ranks share: see auto_exchange_slices
+            backend = dist.get_backend(group) if self.collective else "none"
+            # auto_batch: interactions per rank and step, the same number on every rank (default: the context's batch)
+            per_rank = int(auto_batch if auto_batch is not None else getattr(ctx, "max_batch", 0))
+            slices = auto_exchange_slices(Q.shape[0], Q.shape[1], self.world, per_rank, backend)
         self.slices = min(16, max(1, int(slices))) if self.staged and hasattr(ctx, "staged_item_slice") else 1
         self.side = None
         self.timeline = None         # enable_timing(): per-step (start, compute queued, end) events

@@ -318,3 +318,49 @@ def test_dense_optimiser_protocol_equals_single_process(tmp_path, kind, world):
     for o in outs[1:]:
         np.testing.assert_array_equal(outs[0]["Q"], o["Q"])
 
+
+
+def _auto_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from daisyrec_amd.sharding import UserShardedBprTrainer, auto_exchange_slices, user_range
+    from oracle_backend import OracleContext
+    # the rule itself, priced as if the job ran over RCCL, from numbers every rank holds - all-gathered and compared
+    cases = [(1_000_000, 64, 8, 1 << 21), (1_000_000, 64, 8, 1 << 24), (100_000, 64, 8, 1 << 21), (100_000, 64, 2, 1 << 16),
+             (3706, 64, 8, 65536), (1_000_000, 128, 4, 1 << 22), (5000, 16, world, 96)]
+    mine = [auto_exchange_slices(*c, backend="nccl") for c in cases]
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    # and through the trainer on this (gloo) job: 'auto' must resolve to ONE slice here and identically on every rank,
+    # whatever a rank's own share of the batch is (the context of rank 1 is larger on purpose)
+    lo, hi = user_range(U, world, rank)
+    ctx = OracleContext(B * (1 + rank), D, hi - lo, I)
+    P = torch.zeros(hi - lo, D)
+    Q = torch.zeros(I, D)
+    tr = UserShardedBprTrainer(ctx, P, Q, lo, LR, R1, R2, slices="auto", auto_batch=B // world)
+    got = [None] * world
+    dist.all_gather_object(got, tr.slices)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "auto.npz"), rule=np.array(everyone), trainer=np.array(got))
+    dist.destroy_process_group()
+
+
+def test_automatic_exchange_slices_are_the_same_on_every_rank(tmp_path):
+    """`slices='auto'` (sharding.auto_exchange_slices) is a function of the item table, the world size
+    and the per-rank share of the GLOBAL batch only - every rank of a 2-rank gloo job computes the same counts (a rank that
+    cut its item pass differently would exchange other rows: silent divergence of the replicas) - and follows the budget
+    of DESIGN.md section 5: one slice where the exchange is small against the item pass or the backend is gloo, more
+    where 2 x 231 MB per step stand against a 2 M-interaction pass."""
+    world = 2
+    mp.spawn(_auto_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    z = np.load(os.path.join(str(tmp_path), "auto.npz"))
+    rule, trainer = z["rule"], z["trainer"]
+    assert (rule == rule[0]).all() and (trainer == 1).all()
+    r = rule[0]
+    assert r[0] == 2 and r[1] == 16                       # configs[2] on 8 GPUs: a 2 M pass (0.2 ms) carries two slices, a 16 M one sixteen
+    assert r[2] == 2                                      # configs[1] tables on 8 GPUs at 2 M per rank
+    assert r[3] == 1                                      # a 65 536-interaction pass is too short to cut
+    assert r[4] == 1                                      # ml-1m's 3706 items: blocks under 1024 rows are not cut
+    assert r[6] == 1
+    from daisyrec_amd.sharding import auto_exchange_slices
+    assert auto_exchange_slices(1_000_000, 64, 1, 1 << 21) == 1 and auto_exchange_slices(1_000_000, 64, 8, 1 << 21, "gloo") == 1

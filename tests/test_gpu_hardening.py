@@ -367,8 +367,11 @@ def test_bare_step_with_a_non_finite_loss_is_the_same_in_both_launch_forms(ops, 
         assert not np.isfinite(float(sl.cpu()))
         out.append((P.cpu().numpy(), Q.cpu().numpy()))
         ctx.close()
-    # same rows written in both forms (NaN / inf patterns included: compare the bits)
-    assert np.array_equal(out[0][0].view(np.uint32), out[1][0].view(np.uint32))
-    assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+    # the same rows written in both forms, to summation order (the two forms cut the item pass into chunks of different
+    # sizes), NaN / inf patterns included
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(np.isnan(a), np.isnan(b)) and np.array_equal(np.isinf(a), np.isinf(b))
+        assert np.allclose(a, b, rtol=1e-5, atol=1e-7, equal_nan=True)
+    assert np.array_equal((out[0][1] != Q0).any(axis=1), (out[1][1] != Q0).any(axis=1))
     moved = (out[0][1][: I - 1] != Q0[: I - 1]).any(axis=1)
     assert moved.sum() > (I - 1) // 2                           # the step WAS applied (no halt word: nothing may stop it)

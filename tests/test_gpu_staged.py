@@ -649,14 +649,14 @@ def test_adam_fit_runs_the_epoch_call():
         if one_call:
             ops.LazyAdam.fit_epoch = lambda self, *a, **k: (calls.append(1), orig(self, *a, **k))[1]
         else:                                  # force the step-by-step loop of round 4
-            from daisyrec_amd.model import AbstractRecommender as AR
+            import importlib
+            AR = importlib.import_module("daisyrec_amd.model.AbstractRecommender")
             saved = AR._AdamState.staged_epoch
 
             def stepwise(self, ctx, plan, reg_1, reg_2, loss_id):
                 for k in range(plan.num_batches):
                     ctx.set_batch_from_plan(plan, k)
-                    self.step(ctx, self._P, self.lazy_staged.Q if self.lazy_staged else self._lazy_args[1], reg_1, reg_2,
-                              loss_id, ops.ITEM_MODES["fused"])
+                    self.step(ctx, self._lazy_args[0], self._lazy_args[1], reg_1, reg_2, loss_id, ops.ITEM_MODES["fused"])
                 self.flush()
             AR._AdamState.staged_epoch = stepwise
         try:

@@ -1,17 +1,8 @@
-# round-5 GPU call 1: what bounds k_staged_item.  Output under gpurun_out/r05.
+# counter passes of k_staged_item / k_staged_user at both shapes: wave-cycle split (the guide:
+# SQ_WAIT_ANY + SQ_WAIT_INST_ANY + SQ_ACTIVE_INST_ANY ~ SQ_WAVE_CYCLES), L2 hits / misses, fabric read requests, instruction
+# mix.  usage (on the GPU box): bash tools/pmc_item.sh > gpurun_out/r05/counters.txt     [DAISY_LIB_OVERRIDE=... for a dev build]
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-export ROUND=r05
-O=$R/gpurun_out/r05
-mkdir -p $O
-DEV=$R/daisyrec_amd/lib
-python $R/tools/mall_probe.py > $O/mall_probe.txt 2>&1
-for wl in c2 c3s; do
-  for v in dev dev_probe1 dev_probe3 dev_probe7; do
-    DAISY_LIB_OVERRIDE=$DEV/$v/libdaisyrec_hip.so bash $R/tools/probe_run.sh ${v}_$wl $wl
-  done
-done > $O/variants.txt 2>&1
-# counters of the two passes at both shapes (default build of the library)
 pmc() { n=$1; wl=$2; shift 2
   rm -rf /tmp/pmc_$n; timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_$n -o p -- python $R/tools/probe_step.py $wl 12 > /tmp/pmc_$n.log 2>&1
   python - <<PY
@@ -39,6 +30,4 @@ for wl in c2 c3s; do
   pmc b_$wl $wl TCC_HIT_sum TCC_MISS_sum
   pmc c_$wl $wl TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
   pmc d_$wl $wl SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_INSTS_LDS SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_INST_LEVEL_VMEM
-done > $O/counters.txt 2>&1
-tail -3 /tmp/pmc_b_c2.log >> $O/counters.txt
-cat $O/mall_probe.txt; cat $O/variants.txt; cat $O/counters.txt
+done
