@@ -723,6 +723,22 @@ def main():
         extra["mf_b65536"] = guarded("extra mf_b65536", extra_mf_epoch_loop, data, dev, 65536, a.reg, cpu_mid[0],
                                      collective=False)
         extra["mf_adam"] = guarded("extra mf_adam", extra_mf_adam, data, dev, 1 << 21, a.reg, collective=False)
+
+        def variant_leg(what, B_, reg_):
+            av = argparse.Namespace(**vars(a))
+            av.reg = reg_
+            rv = measure(av, data, rank, world, dev, B_, 1, a.steps, a.warmup)
+            achv, gpuv = roofline_of(rv, 1)
+            return {"workload": f"configs[1], {what}", "batch": rv["B"], "steps": rv["steps"],
+                    "value": rv["steps"] * rv["B"] / rv["dt"], "unit": "interactions/s",
+                    "ms_per_step": rv["dt"] / rv["steps"] * 1e3, "gpu_ms_per_step_events": gpuv,
+                    "roofline": {"bound": "hbm", "achieved": achv, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                 "frac": achv / HBM_PEAK_GBS, "traffic": None,
+                                 "algorithmic_bytes_per_interaction": ALGO_BYTES_PER_INTERACTION_SGD(64)}}
+        extra["mf_reg0"] = guarded("extra mf_reg0", variant_leg, "reg_1 = reg_2 = 0 (SURVEY 8d's variant), B = 2097152", 1 << 21,
+                                   0.0, collective=False)
+        extra["mf_b1m"] = guarded("extra mf_b1m", variant_leg, "B = 1048576 (SURVEY 8d's 1 M per GPU)", 1 << 20, a.reg,
+                                  collective=False)
     sweep = []
     if world > 1 and wl in ("c3", "tiny") and not a.no_sweep and a.item_mode == "fused" and (a.batch is None or wl == "tiny"):
         # the regimes of DESIGN.md section 5 in one launch: the exchange is a fixed 2 x 231 MB per step and rank, so

@@ -131,6 +131,8 @@ struct daisy_epoch_plan {
     uint2 *p_erec[2];                   // [2n]  entry records {item << 1 | slot, epoch position of the sample}
     uint32_t *p_counts, *p_offsets;     // [ndig * ntiles] per-tile digit counts / their exclusive scan
     uint32_t *p_inv;                    // [n]   inverse of an explicit permutation (DAISY_ORDER_PERM)
+    uint32_t *p_park;                   // [2n]  device shuffle: the epoch positions the entry records' counting kernel walked
+                                        //       to, parked for their scatter kernel
     void *ptemp;                        // rocPRIM scan scratch
     void *parena2;                      // second record set (plans with more than 256 batches: LSD passes ping-pong)
     int32_t p_cur;                      // record set holding the finished plan

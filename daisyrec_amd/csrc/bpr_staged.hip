@@ -103,6 +103,16 @@ static inline hipStream_t S(daisy_stream_t s) { return reinterpret_cast<hipStrea
 // =============================================================================
 // partitioned epoch plan
 // =============================================================================
+// DAISY_PLAN_PARK (round 5): the counting kernel of the ENTRY records parks the epoch positions its Feistel walks arrive
+// at (4 B per entry, through LDS so that they leave as whole-wave stores) and the entry scatter reads them instead of
+// walking again: 1.34 -> 1.22 ms per epoch at BASELINE configs[1], 2.63 -> 2.41 at 10 M x 1 M shapes.  (Not the sample
+// records: their scatter is not bound by the walk - parked, it ran 348 against 361 us while its count paid 131 against 119.)  Round 4 had taken this out ("a tie"): then the
+// scatter wrote 2.1 x its records in partial lines and was bound by that; with array-of-structures records every plan
+// kernel runs at 84-100 % of the VALU issue rate (profiles/r05_pmc_plan.txt: 651 M wave instructions x 4 cycles over
+// 1024 SIMDs = 1.06 of the 1.27 ms) while the build moves 3.3 GB in 1.27 ms - the memory system is the idle side now.
+#ifndef DAISY_PLAN_PARK
+#define DAISY_PLAN_PARK 1
+#endif
 constexpr int kPartThreads = 256;
 constexpr int kPartK = 8;                              // records per thread per sub-tile: samples (16-byte records)
 constexpr int kPartKE = 8;                             //   entries (8-byte records; 16 per thread measured 1.56 against
@@ -153,6 +163,7 @@ struct PartSrc {
     const uint32_t *ent_key;                            //                         item << 1 | slot
     const uint4 *srec;                                  // samples, record source (LSD pass >= 1)
     const uint2 *erec;                                  // entries, record source
+    uint32_t *park;                                     // the kind's parked epoch positions (device shuffle, first pass)
 };
 struct PartDst { uint4 *srec; uint2 *erec; };
 
@@ -177,6 +188,9 @@ __global__ __launch_bounds__(kPartThreads) void k_part_count(PartSrc src, PosFn 
                                                              int64_t ntiles, uint32_t *__restrict__ counts) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t lds_t[KIND == 1 ? kPartSub : 1];
+    // the positions of a sub-tile wait here for ONE coalesced store per thread and round: stored from inside the walk -
+    // a few lanes per trip - they made 440 us of count<entries>'s 262 (profiles/r05_notes.txt)
+    __shared__ uint32_t lds_p[(DAISY_PLAN_PARK && KIND == 1) ? kPartSub : 1];
     hist[threadIdx.x] = 0;
     __syncthreads();
     const int64_t lo = (int64_t)blockIdx.x * tile_elems;
@@ -211,10 +225,19 @@ __global__ __launch_bounds__(kPartThreads) void k_part_count(PartSrc src, PosFn 
                 x = feistel_once(x, pf.fk);
                 if (x < nn) {
                     atomicAdd(&hist[(batch_of(x, bd) >> shift) & 255u], 1u);
+                    if constexpr (DAISY_PLAN_PARK && KIND == 1) lds_p[j * kPartThreads + threadIdx.x] = x;
                     ++j;
                     e += kPartThreads;
                     active = (j < kPartK) && (e < hi);
                     if (active) x = first();
+                }
+            }
+            if constexpr (DAISY_PLAN_PARK && KIND == 1) {
+                // (each thread reads back what it wrote: no barrier; element sub + k * 256 + thread: coalesced)
+#pragma unroll
+                for (int k = 0; k < kPartK; ++k) {
+                    const int64_t ek = sub + k * kPartThreads + threadIdx.x;
+                    if (ek < hi) src.park[ek] = lds_p[k * kPartThreads + threadIdx.x];
                 }
             }
         }
@@ -301,7 +324,13 @@ __global__ __launch_bounds__(kPartThreads) void k_part_scatter(PartSrc src, PosF
         if constexpr (STATIC) {
             // slot of the record this thread holds in round r: wave*64*K + r*64 + wl
             const int xw = wave * (kWave * K) + wl;
-            if (pf.mode == DAISY_ORDER_FEISTEL) {
+            if (DAISY_PLAN_PARK && !SAMPLES && pf.mode == DAISY_ORDER_FEISTEL) {
+#pragma unroll
+                for (int r = 0; r < K; ++r) {              // parked by k_part_count: no second walk
+                    const int64_t e = wbase + r * kWave + wl;
+                    r_p[r] = src.park[(e < hi) ? e : hi - 1];
+                }
+            } else if (pf.mode == DAISY_ORDER_FEISTEL) {
                 const uint32_t nn = (uint32_t)pf.n;
 #pragma unroll
                 for (int r = 0; r < K; ++r) lp[xw + r * kWave] = pf.orig ? pf.orig[r_p[r]] : r_p[r];
@@ -501,7 +530,7 @@ static int plan_need_partitioned(daisy_epoch_plan *p, int set) {
     size_t off = 0;
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     const size_t o_s = take(n * 16), o_e = take(n * 16);
-    size_t o_cnt = 0, o_tmp = 0, o_inv = 0, cnt_elems = 0;
+    size_t o_cnt = 0, o_tmp = 0, o_inv = 0, o_park = 0, cnt_elems = 0;
     if (set == 0) {
         const int64_t max_tiles = (2 * (int64_t)n + kPartSub - 1) / kPartSub;
         const int64_t tiles = max_tiles < kPartMaxTiles ? max_tiles : kPartMaxTiles + 1;
@@ -510,6 +539,7 @@ static int plan_need_partitioned(daisy_epoch_plan *p, int set) {
         o_cnt = take(cnt_elems * 4 * 2);   // counts, then their exclusive scan
         o_tmp = take(p->ptemp_bytes);
         o_inv = take(n * 4);
+        o_park = DAISY_PLAN_PARK ? take(n * 8) : 0;
     }
     void *mem = nullptr;
     hipError_t e = hipMalloc(&mem, off);
@@ -527,6 +557,7 @@ static int plan_need_partitioned(daisy_epoch_plan *p, int set) {
         p->p_offsets = p->p_counts + cnt_elems;
         p->ptemp = b + o_tmp;
         p->p_inv = (uint32_t *)(b + o_inv);
+        p->p_park = DAISY_PLAN_PARK ? (uint32_t *)(b + o_park) : nullptr;
     }
     return DAISY_OK;
 }
@@ -612,6 +643,7 @@ static int plan_build_partitioned(daisy_epoch_plan *p, const daisy_train_index *
             src.triples = ix->triples; src.user_base = ix->user_base;
             src.ent_t = ix->ent_t; src.ent_key = ix->ent_key;
             src.srec = p->p_srec[sset]; src.erec = p->p_erec[sset];
+            src.park = entries ? p->p_park : nullptr;
             const PartDst dst{p->p_srec[dset], p->p_erec[dset]};
             const dim3 g((unsigned)ntiles), b(kPartThreads);
 #define DAISY_PART_COUNT(KIND)                                                                                      \
@@ -2037,11 +2069,13 @@ int staged_sgd_step(daisy_bpr_ctx *ctx, float *P, float *Q, int loss_type, float
     if (have_pre) n_pre = ctx->pre_n;        // > 0: partial sums wait behind the user pass's own; 0: stats[SQ_U_PRE] holds the sum
     else if ((rc = staged_prenorm(ctx, P, stats, false, &n_pre, s))) return rc;
     // THREE launches (MergedJob) for batches whose user pass leaves at most kMergeMaxPartials rows of partial sums (every
-    // item workgroup adds them itself): B <= 16384 at d = 64.  DAISY_STAGED_MERGE (read per call: the tests switch it):
+    // item workgroup adds them itself): B <= 32768 at d = 64.  DAISY_STAGED_MERGE (read per call: the tests switch it):
     // 0 never, 1 whenever the buffers allow it
     const char *env_merge = getenv("DAISY_STAGED_MERGE");
     const int tune_merge = env_merge ? atoi(env_merge) : -1;
-    constexpr int64_t kMergeMaxPartials = 512;
+    // (round 5, same box, four vs three launches: B = 32 768 - 1024 rows of partial sums - 36.9 -> 33.4 us per step; B =
+    // 65 536 - 2048 rows - 51.6 -> 58.6, and with the user pass capped at 1024 workgroups a tie: profiles/r05_mid_matrix.txt)
+    constexpr int64_t kMergeMaxPartials = 1024;
     const daisy_epoch_plan *pl = ctx->cur_plan;
     const bool ride_next = tune_ride && pl && pl->kind == 1 && ctx->cur_gen == pl->build_gen &&
                            ctx->cur_k + 1 < pl->num_batches && daisy_epoch_plan_batch_rows(pl, ctx->cur_k + 1) > 0;

@@ -650,3 +650,43 @@ def test_chunked_mode_is_bitwise_reproducible(ops):
     assert abs(outs[0][0] - loss) <= 1e-5 * abs(loss)
     np.testing.assert_allclose(outs[0][1], Pn, atol=2e-5)
     np.testing.assert_allclose(outs[0][2], Qn, atol=2e-5)
+
+
+def test_c2_scale_step_against_the_numpy_oracle(ops):
+    """BASELINE configs[1] at full size against the ORACLE itself (the test above compares with a torch
+    restatement on the GPU, the oracle link at this size was transitive): U = 1 M, I = 100 K, d = 64, one 2 097 152-sample
+    step - the bench's headline step: the first batch of a device-shuffled epoch of the partitioned plan through the
+    staged kernels - against oracle.mf_sgd_step (numpy, float64, the dense gradients of MFRecommender.py:70-97 + SGD) on
+    the same rows.  ~45 s of numpy on the host."""
+    U, I, d, B, n = 1_000_000, 100_000, 64, 1 << 21, 5_000_000
+    gen = torch.Generator(device=DEV)
+    gen.manual_seed(99)
+    P = torch.randn(U, d, device=DEV, generator=gen) * 0.01
+    Q = torch.randn(I, d, device=DEV, generator=gen) * 0.01
+    u = torch.sort(torch.randint(0, U, (n,), device=DEV, generator=gen)).values
+    tri = torch.stack([u, torch.randint(0, I, (n,), device=DEV, generator=gen),
+                       torch.randint(0, I, (n,), device=DEV, generator=gen)], 1).to(torch.int32).contiguous()
+    index = ops.TrainIndex(tri, U, I, user_sorted=True)
+    plan = ops.EpochPlan(n, U, I).build_indexed(index, B, order="feistel", seed=5, epoch=1)
+    rows = torch.stack(plan.read_batch(0, B)[:3], 1).cpu().numpy().astype(np.int64)
+    assert rows.shape == (B, 3)
+    P0, Q0 = P.cpu().numpy(), Q.cpu().numpy()
+    lr, r1, r2 = 0.01, 1e-3, 1e-3
+    ctx = ops.BprContext(B, d, U, I)
+    sl = torch.zeros(1, dtype=torch.float64, device=DEV)
+    ctx.set_batch_from_plan(plan, 0)
+    ctx.sgd_step(P, Q, lr, r1, r2, item_mode=ops.ITEM_MODES["fused"], step_loss=sl)
+    torch.cuda.synchronize()
+    want, Pn, Qn = O.mf_sgd_step(P0, Q0, rows[:, 0], rows[:, 1], rows[:, 2], lr, r1, r2)
+    got = float(sl.cpu())
+    assert abs(got - want) <= 1e-5 * abs(want), (got, want)          # (north_star's bar; measured ~1e-9)
+    assert abs(got - want) <= 1e-7 * abs(want), (got, want)
+    dP = np.abs(P.cpu().numpy() - Pn)
+    dQ = np.abs(Q.cpu().numpy() - Qn)
+    # fp32 sums of ~2 (users) / ~42 (items) terms of 1e-4 against the float64 result rounded once: a few ulps of 0.01
+    print(f"c2-scale step vs oracle: loss rel {abs(got - want) / abs(want):.2e}, max |dP| {dP.max():.2e}, max |dQ| {dQ.max():.2e}")
+    assert dP.max() < 3e-8 and dQ.max() < 1e-7, (dP.max(), dQ.max())
+    touched = np.zeros(U, bool)
+    touched[rows[:, 0]] = True
+    assert np.array_equal(P.cpu().numpy()[~touched], P0[~touched])
+    ctx.close(); plan.close(); index.close()
