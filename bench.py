@@ -727,7 +727,7 @@ def main():
         def variant_leg(what, B_, reg_):
             av = argparse.Namespace(**vars(a))
             av.reg = reg_
-            rv = measure(av, data, rank, world, dev, B_, 1, a.steps, a.warmup)
+            rv = measure(av, data, rank, world, dev, B_, 1, None, a.warmup)       # two whole epochs: one plan build per epoch
             achv, gpuv = roofline_of(rv, 1)
             return {"workload": f"configs[1], {what}", "batch": rv["B"], "steps": rv["steps"],
                     "value": rv["steps"] * rv["B"] / rv["dt"], "unit": "interactions/s",
@@ -789,7 +789,7 @@ def main():
             az.dist = "zipf"
             dz = build_data(az, rank, world, dev, "c2")
             try:
-                rz = measure(az, dz, rank, world, dev, 1 << 21, 1, a.steps, a.warmup)
+                rz = measure(az, dz, rank, world, dev, 1 << 21, 1, None, a.warmup)
             finally:
                 free_data(dz)
             achz, gpuz = roofline_of(rz, 1)

@@ -95,6 +95,8 @@ struct daisy_train_index {
     size_t bytes;
     int32_t pointwise;        // rows are (user, item, label): ONE entry per row (n_ent = n), else two (n_ent = 2n)
     int64_t n_ent;
+    int64_t max_item_entries; // entries of the most frequent item (the longest segment an item pass can meet, scaled by
+                              // the batch's share of the set: decides whether its edge chains are reduced in two levels)
 };
 
 // Epoch plan: the whole epoch laid out batch by batch (see the header comment of bpr_train.hip).
@@ -136,6 +138,7 @@ struct daisy_epoch_plan {
     void *ptemp;                        // rocPRIM scan scratch
     void *parena2;                      // second record set (plans with more than 256 batches: LSD passes ping-pong)
     int32_t p_cur;                      // record set holding the finished plan
+    double hot_item_share;              // max_item_entries / n_ent of the index the plan was built from
     uint64_t build_gen;                 // id of the build the plan currently holds, unique in the process (what a
                                         // batch index refers to: a context that computed something ahead for "batch k+1"
                                         // must not mistake a rebuilt - or another plan at the same address - for it)
@@ -147,6 +150,7 @@ struct daisy_epoch_plan {
 };
 
 constexpr int kMaxItemSlices = 16;  // daisy_bpr_staged_item_slices
+constexpr int kEdgeBlock = 32;      // chunks per block of the two-level edge chains
 constexpr int kPreBlocks = 256;   // workgroups (= partial sums) of the staged step's pre-norm pass
 constexpr int64_t kMergeMaxBatch = 131072;   // largest batch of the three-launch staged step (see staged_sgd_step)
 
@@ -176,6 +180,8 @@ struct daisy_bpr_ctx {
     float *edge2_vec; int32_t *edge2_item; float *edge2_cnt; int32_t *edge2_whole;
     int64_t edge2_chunks;
     float *edge_cnt;      // staged step, edge records of the item pass: [2*nchunks][2] (n_pos, n_neg)
+    // block sums of the item pass's edge chains (k_staged_item_edge_blocks): one record per kEdgeBlock chunks
+    float *eb_vec; int32_t *eb_item; float *eb_cnt; int32_t *eb_through; int64_t eb_blocks;
     int64_t *slice_rng;   // staged step in item slices (multi-GPU pipelining): entry range of slice s = [slice_rng[s], slice_rng[s+1])
     int32_t n_slices;     //   of the current batch (0: not prepared)
     int32_t pointwise;   // batches set through set_batch* hold (user, item, label) rows

@@ -463,6 +463,18 @@ __global__ void k_index_entries(const int32_t *__restrict__ triples, int64_t n, 
     }
 }
 
+// entries per item (once per fit): the longest segment an item pass can meet decides how its edge chains are reduced
+__global__ void k_item_hist(const uint32_t *__restrict__ ent_key, int64_t n_ent, uint32_t *__restrict__ hist) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n_ent; e += (int64_t)gridDim.x * blockDim.x)
+        atomicAdd(&hist[ent_key[e] >> 1], 1u);
+}
+__global__ void k_u32_max(const uint32_t *__restrict__ x, int64_t n, uint32_t *__restrict__ out) {
+    uint32_t m = 0;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+        m = x[e] > m ? x[e] : m;
+    atomicMax(out, m);
+}
+
 __global__ void k_gather_triples(const int32_t *__restrict__ triples, const uint32_t *__restrict__ order, int64_t n,
                                  int32_t *__restrict__ out) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
@@ -665,6 +677,7 @@ static int plan_build_partitioned(daisy_epoch_plan *p, const daisy_train_index *
         }
     }
     p->p_cur = 0;
+    p->hot_item_share = ix->n_ent > 0 ? (double)ix->max_item_entries / (double)ix->n_ent : 0.0;
     p->n = n; p->batch_size = batch_size; p->num_batches = nb;
     p->pointwise = ix->pointwise;
     p->kind = 1;
@@ -1638,6 +1651,53 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((ADAM || ME
     }
 }
 
+// Long edge chains in two levels (round 5).  A segment that runs through N chunks is a chain of N head edges which
+// its owner adds one after the other: ~42 entries per item at BASELINE configs[1] make chains of one or two links, but with
+// a Zipf(1.0) popularity the hottest item holds 7 % of a batch's entries - a chain of 2300 links walked by ONE lane group,
+// 198 us of a 0.83 ms step (profiles/r05_notes.txt).  Level 1 (this kernel, one lane group per block of kEdgeBlock
+// chunks): the sum of the head edges of the chain that ENTERS the block at its first chunk, as far as it runs inside the
+// block, and whether it leaves the block at the other end.  Level 2 (k_staged_item_edges): an owner walks to the next
+// block boundary link by link and from there block by block.  Fixed order, single writer: reproducible like the chains.
+struct EdgeBlocks { float *vec; int32_t *item; float *cnt; int32_t *through; };      // vec == NULL: chains link by link
+
+template <class C>
+__global__ __launch_bounds__(kBlock) void k_staged_item_edge_blocks(ItemEdges2 ed, int64_t nchunks, int d,
+                                                                    const int64_t *__restrict__ erange, int chunk_entries,
+                                                                    const double *__restrict__ halt, EdgeBlocks eb) {
+    if (halted(halt)) return;
+    if (erange) nchunks = (erange[1] - erange[0] + chunk_entries - 1) / chunk_entries;
+    const int lane = threadIdx.x % C::LPR;
+    const int group = threadIdx.x / C::LPR;
+    const int64_t nblocks = (nchunks + kEdgeBlock - 1) / kEdgeBlock;
+    const int64_t gstride = (int64_t)gridDim.x * C::GROUPS_PER_BLOCK;
+    for (int64_t b = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; b < nblocks; b += gstride) {
+        const int64_t k0 = b * kEdgeBlock;
+        const int64_t k1 = (k0 + kEdgeBlock < nchunks) ? k0 + kEdgeBlock : nchunks;
+        const int it = ed.item[2 * k0];
+        int through = 0;
+        if (it >= 0) {
+            Row<C> acc, t;
+            acc.load(ed.vec + (2 * k0) * d, lane, d);
+            float sp = ed.cnt[4 * (2 * k0)], sn = ed.cnt[4 * (2 * k0) + 1], sc = ed.cnt[4 * (2 * k0) + 2];
+            int64_t k = k0;
+            bool open = ed.whole[k0] != 0;                 // the chain also fills chunk k and runs on
+            while (open && ++k < k1 && ed.item[2 * k] == it) {
+                t.load(ed.vec + (2 * k) * d, lane, d);
+#pragma unroll
+                for (int q = 0; q < C::NE; ++q) acc.v[q] += t.v[q];
+                sp += ed.cnt[4 * (2 * k)];
+                sn += ed.cnt[4 * (2 * k) + 1];
+                sc += ed.cnt[4 * (2 * k) + 2];
+                open = ed.whole[k] != 0;
+            }
+            through = (open && k == k1) ? 1 : 0;           // every chunk of the block belongs to the chain, and it runs on
+            acc.store(eb.vec + b * d, lane, d);
+            if (lane == 0) { eb.cnt[4 * b] = sp; eb.cnt[4 * b + 1] = sn; eb.cnt[4 * b + 2] = sc; }
+        }
+        if (lane == 0) { eb.item[b] = it; eb.through[b] = through; }
+    }
+}
+
 // chains of edge records - the chunk whose TAIL edge starts a segment owns it and adds the head edges of
 // the chunks it runs through, in chunk order (single writer per row, fixed order)
 template <class C, bool APPLY, bool ADAM>
@@ -1647,7 +1707,7 @@ __global__ __launch_bounds__(kBlock) void k_staged_item_edges(ItemEdges2 ed, int
                                                               float reg_1, float reg_2,
                                                               const int64_t *__restrict__ erange, int chunk_entries,
                                                               const double *__restrict__ halt, StagedBias fm,
-                                                              RideReduce rr, RideUnorm ride) {
+                                                              RideReduce rr, RideUnorm ride, EdgeBlocks eb) {
     if (halted(halt)) return;
     if (ride.nblocks && (int)blockIdx.x >= ride.first_block) {     // three-launch form: the next batch's pre-norm rides HERE
         unorm_block(ride, (int)blockIdx.x - ride.first_block);     // (the user pass's edge chains ran in the item launch)
@@ -1685,14 +1745,30 @@ __global__ __launch_bounds__(kBlock) void k_staged_item_edges(ItemEdges2 ed, int
         Row<C> acc, t;
         acc.load(ed.vec + (2 * c + 1) * d, lane, d);
         float sp = ed.cnt[4 * (2 * c + 1)], sn = ed.cnt[4 * (2 * c + 1) + 1], sc = ed.cnt[4 * (2 * c + 1) + 2];
-        for (int64_t k = c + 1; k < nchunks && ed.item[2 * k] == it; ++k) {
+        int64_t k = c + 1;
+        bool open = true;
+        // link by link - to the end of the chain, or (two levels) to the next block boundary
+        for (; open && k < nchunks && (eb.vec == nullptr || k % kEdgeBlock != 0); ++k) {
+            if (ed.item[2 * k] != it) { open = false; break; }
             t.load(ed.vec + (2 * k) * d, lane, d);
 #pragma unroll
             for (int q = 0; q < C::NE; ++q) acc.v[q] += t.v[q];
             sp += ed.cnt[4 * (2 * k)];
             sn += ed.cnt[4 * (2 * k) + 1];
             sc += ed.cnt[4 * (2 * k) + 2];
-            if (!ed.whole[k]) break;
+            if (!ed.whole[k]) open = false;
+        }
+        // block by block: the block sum of the chain that enters block b is this chain's, if it bears its item
+        for (; eb.vec != nullptr && open && k < nchunks; k += kEdgeBlock) {
+            const int64_t b = k / kEdgeBlock;
+            if (eb.item[b] != it) break;
+            t.load(eb.vec + b * d, lane, d);
+#pragma unroll
+            for (int q = 0; q < C::NE; ++q) acc.v[q] += t.v[q];
+            sp += eb.cnt[4 * b];
+            sn += eb.cnt[4 * b + 1];
+            sc += eb.cnt[4 * b + 2];
+            if (!eb.through[b]) break;
         }
         item_commit<C, APPLY, ADAM>(Qo, cnt_out, it, acc, sp, sn, sc, lane, d, opt, reg_1, rI, rJ, fm);
     }
@@ -2003,6 +2079,17 @@ static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_
         const int64_t nchunks = (v.E + chunk_e - 1) / chunk_e;
         if (nchunks > edge_cap) { overflow = true; return DAISY_OK; }
         const int gi = grid_for(v.E, chunk_e, tune_ig > 0 ? tune_ig : 16384 * kBlock / BLK);
+        // Edge chains in two levels when the batch can hold a segment of 16 chunks or more: the hottest item's share of
+        // the set (the index counted it) x the batch's entries, with room for its fluctuation; unknown - a batch that did
+        // not come from a partitioned plan - means a large batch.  DAISY_EDGE_BLOCKS (read per call): 0 never, 1 always.
+        const daisy_epoch_plan *pl_ = (ctx->batch_kind == 1) ? ctx->cur_plan : nullptr;
+        const double hot = pl_ ? pl_->hot_item_share * (double)v.E : -1.0;
+        const char *env_eb = getenv("DAISY_EDGE_BLOCKS");
+        bool two_level = !merged && nchunks / kEdgeBlock + 2 <= ctx->eb_blocks &&
+                         (hot >= 0.0 ? (hot + 4.0 * sqrt(hot) >= 16.0 * chunk_e) : nchunks >= 64 * kEdgeBlock);
+        if (env_eb) two_level = atoi(env_eb) != 0 && !merged && nchunks / kEdgeBlock + 2 <= ctx->eb_blocks;
+        const EdgeBlocks eb = two_level ? EdgeBlocks{ctx->eb_vec, ctx->eb_item, ctx->eb_cnt, ctx->eb_through}
+                                        : EdgeBlocks{nullptr, nullptr, nullptr, nullptr};
         const int ge_own = grid_for(nchunks, C::GROUPS_PER_BLOCK) + (rr.n ? 1 : 0);
         RideUnorm ru = ride, ru_edge = RideUnorm{nullptr, nullptr, 0, nullptr, 0, 0};
         MergedJob mj{};
@@ -2030,8 +2117,12 @@ static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_
                 hipLaunchKernelGGL((k_staged_item<C, BLK, MODE, AP, AD, false>), g, b, 0, s, ctx->p_stage, ctx->coef, v, d, Qo,
                                    cnt_out, stats, opt, reg_1, reg_2, ed, erange, fm, ru, mj);
             }
+            if (two_level)
+                hipLaunchKernelGGL((k_staged_item_edge_blocks<C>),
+                                   dim3(grid_for((nchunks + kEdgeBlock - 1) / kEdgeBlock, C::GROUPS_PER_BLOCK)), dim3(kBlock), 0,
+                                   s, ed, nchunks, d, erange, chunk_e, v.halt, eb);
             hipLaunchKernelGGL((k_staged_item_edges<C, AP, AD>), ge, dim3(kBlock), 0, s, ed, nchunks, d, Qo, cnt_out, stats,
-                               opt, reg_1, reg_2, erange, chunk_e, v.halt, fm, rr, ru_edge);
+                               opt, reg_1, reg_2, erange, chunk_e, v.halt, fm, rr, ru_edge, eb);
         };
         auto by_apply = [&](auto mode_tag) {
             if (apply && adam) launch(mode_tag, std::true_type{}, std::true_type{});
@@ -2220,7 +2311,7 @@ int daisy_train_index_create(daisy_train_index **out, const int32_t *triples, in
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     const size_t o_k = take((size_t)n * 8), o_v = take((size_t)n * 8);
     const size_t o_uk = take((size_t)n * 4), o_uv = take((size_t)n * 4), o_uk2 = take((size_t)n * 4);
-    const size_t o_bad = take(256), o_tmp = take(t_sort);
+    const size_t o_bad = take(256), o_tmp = take(t_sort), o_hist = take((size_t)item_num * 4);
     char *scratch = nullptr;
     void *keep = nullptr;
     const size_t keep_bytes = align_up((size_t)n * 8) * 2 + (sorted ? 0 : align_up((size_t)n * 12) + align_up((size_t)n * 4));
@@ -2249,7 +2340,7 @@ int daisy_train_index_create(daisy_train_index **out, const int32_t *triples, in
         delete ix;
         return code;
     };
-    if (hipMemsetAsync(bad, 0, 4, s) != hipSuccess) return fail(DAISY_ERR_HIP);
+    if (hipMemsetAsync(bad, 0, 8, s) != hipSuccess) return fail(DAISY_ERR_HIP);
     const int32_t *src = triples;
     if (!sorted) {   // CSR order first: stable sort of the row indices by user, then one gather
         hipLaunchKernelGGL(k_index_entries, dim3(grid_for(n, kBlock)), dim3(kBlock), 0, s, triples, n, user_base,
@@ -2267,14 +2358,21 @@ int daisy_train_index_create(daisy_train_index **out, const int32_t *triples, in
     rc = sort_pairs_i32(scratch + o_tmp, t_sort, (const int32_t *)k, (int32_t *)ix->ent_key, (const int32_t *)v,
                         (int32_t *)ix->ent_t, ix->n_ent, bits_for(item_num) + 1, s);
     if (rc) return fail(rc);
-    int bad_host = 0;
-    if (hipMemcpyAsync(&bad_host, bad, 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+    // (bad[1]: entries of the most frequent item; out-of-range items were replaced by 0 and are reported below)
+    uint32_t *hist = (uint32_t *)(scratch + o_hist);
+    if (hipMemsetAsync(hist, 0, (size_t)item_num * 4, s) != hipSuccess) return fail(DAISY_ERR_HIP);
+    hipLaunchKernelGGL(k_item_hist, dim3(grid_for(ix->n_ent, kBlock * 4)), dim3(kBlock), 0, s, ix->ent_key, ix->n_ent, hist);
+    hipLaunchKernelGGL(k_u32_max, dim3(grid_for(item_num, kBlock * 4, 256)), dim3(kBlock), 0, s, hist, item_num,
+                       (uint32_t *)(bad + 1));
+    int bad_host[2] = {0, 0};
+    if (hipMemcpyAsync(bad_host, bad, 8, hipMemcpyDeviceToHost, s) != hipSuccess ||
         hipStreamSynchronize(s) != hipSuccess) {
         set_error("train_index_create: reading the validation flag failed");
         return fail(DAISY_ERR_HIP);
     }
+    ix->max_item_entries = (int64_t)(uint32_t)bad_host[1];
     (void)hipFree(scratch);
-    if (bad_host) {
+    if (bad_host[0]) {
         set_error("index out of range in the training triples: need %d <= user < %lld and 0 <= item < %lld "
                   "(the reference raises IndexError in nn.Embedding, MFRecommender.py:64-65)",
                   user_base, (long long)(user_base + user_num), (long long)item_num);

@@ -1571,6 +1571,8 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
     const size_t o_ev = take(n_edge * (size_t)d * 4), o_eu = take(n_edge * 4), o_en = take(n_edge * 8);
     const size_t o_ew = take(n_edge * 4);
     const size_t o_ec = take(n_edge * 16);        // staged item pass: (n_pos, n_neg, coefficient sum, -) per edge record
+    const size_t n_eb = max_chunks / kEdgeBlock + 2;      // block sums of long edge chains (k_staged_item_edge_blocks)
+    const size_t o_ebv = take(n_eb * (size_t)d * 4), o_ebi = take(n_eb * 4), o_ebc = take(n_eb * 16), o_ebt = take(n_eb * 4);
     // the item pass's own edge records in the three-launch form (its chunks are at least 2 entries x 16 lane groups)
     const size_t merge_b = (size_t)(max_batch < kMergeMaxBatch ? max_batch : kMergeMaxBatch);
     const size_t chunks2 = 2 * merge_b / 32 + 2, n_edge2 = 2 * chunks2;
@@ -1595,6 +1597,9 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
     c->edge_n = (float *)(base + o_en);
     c->edge_whole = (int32_t *)(base + o_ew);
     c->edge_cnt = (float *)(base + o_ec);
+    c->eb_vec = (float *)(base + o_ebv); c->eb_item = (int32_t *)(base + o_ebi);
+    c->eb_cnt = (float *)(base + o_ebc); c->eb_through = (int32_t *)(base + o_ebt);
+    c->eb_blocks = (int64_t)n_eb;
     c->edge2_vec = (float *)(base + o_e2v); c->edge2_item = (int32_t *)(base + o_e2i);
     c->edge2_cnt = (float *)(base + o_e2c); c->edge2_whole = (int32_t *)(base + o_e2w);
     c->edge2_chunks = (int64_t)chunks2;

@@ -671,3 +671,52 @@ def test_adam_fit_runs_the_epoch_call():
         out.append((list(m.epoch_losses), m.embed_user.weight.data.clone(), m.embed_item.weight.data.clone()))
     assert out[0][0] == out[1][0]
     assert torch.equal(out[0][1], out[1][1]) and torch.equal(out[0][2], out[1][2])
+
+
+@pytest.mark.parametrize("d,loss", [(64, "BPR"), (32, "TL"), (100, "CL")])
+@pytest.mark.parametrize("blocks", ["0", "1", None])
+def test_long_edge_chains_in_two_levels(d, loss, blocks, monkeypatch):
+    """Hot items (round 5): an item that holds a third of a batch's entries is one segment through hundreds of chunks of
+    the item pass - a chain of edge records.  Two levels (k_staged_item_edge_blocks: block sums of 32 chunks, then the
+    owner hops block by block) against link by link (DAISY_EDGE_BLOCKS=0) and the automatic choice (None: the index
+    counted the hottest item, the plan carries its share), each against the oracle; the two-level sums are bitwise
+    reproducible.  Chains that end inside a block, at a block boundary, run through several blocks, and several hot
+    items side by side."""
+    from daisyrec_amd import ops
+    if blocks is not None:
+        monkeypatch.setenv("DAISY_EDGE_BLOCKS", blocks)
+    monkeypatch.setenv("DAISY_STAGED_MERGE", "0")          # (the three-launch form keeps its chains link by link)
+    U, I, n, B = 3000, 400, 90_000, 40_000
+    rng = np.random.default_rng(d)
+    tri = _triples(n, U, I, d + 11)
+    hot = rng.random(n)
+    tri[hot < 0.45, 1] = 7                                  # ~45 % of the positives, ~22 % of the entries: ~140 chunks of 128
+    tri[(hot > 0.5) & (hot < 0.62), 2] = 7                  # ... and some negatives of the same item
+    tri[(hot > 0.7) & (hot < 0.80), 1] = 8                  # a second, shorter chain right behind it (~31 chunks)
+    tri[(hot > 0.85) & (hot < 0.95), 2] = 399               # and one at the very end of the entry list
+    point = loss in ("CL", "SL")
+    if point:
+        tri[:, 2] = rng.integers(0, 2, n)
+    P0, Q0 = _tables(U, I, d, d + 1, scale=0.05)
+    t_dev = torch.from_numpy(tri).to(DEV)
+    lid = ops.LOSS_IDS[loss]
+    runs = []
+    for rep in range(2):
+        index, plan = ops.TrainIndex(t_dev, U, I, pointwise=point), ops.EpochPlan(n, U, I)
+        plan.build_indexed(index, B, order="feistel", seed=5, epoch=1)
+        nb = plan.num_batches
+        P, Q = torch.from_numpy(P0).to(DEV), torch.from_numpy(Q0).to(DEV)
+        ctx = ops.BprContext(B, d, U, I)
+        sl = torch.zeros(nb, dtype=torch.float64, device=DEV)
+        ctx.fit_epoch_sgd(plan, P, Q, 0.002, 1e-3, 2e-3, loss_type=lid, item_mode=ops.ITEM_MODES["fused"], step_losses=sl)
+        torch.cuda.synchronize()
+        runs.append((P.clone(), Q.clone(), sl.clone()))
+        if rep == 0:
+            Pn, Qn = P0.astype(np.float64), Q0.astype(np.float64)
+            for k, (rows, _, _) in enumerate(_plan_batches(plan, nb, B)):
+                want, Pn, Qn = O.mf_sgd_step(Pn, Qn, rows[:, 0], rows[:, 1], rows[:, 2], 0.002, 1e-3, 2e-3, loss_type=lid)
+                assert abs(float(sl[k].cpu()) - want) <= 1e-5 * abs(want), (k, float(sl[k].cpu()), want)
+            # the hot row is a sum of ~10^4 fp32 terms: a few hundred ulps of its largest partial sum
+            assert np.abs(P.cpu().numpy() - Pn).max() < 5e-6 and np.abs(Q.cpu().numpy() - Qn).max() < 2e-5
+        ctx.close(); plan.close(); index.close()
+    assert all(torch.equal(a, b) for a, b in zip(runs[0], runs[1]))
