@@ -1660,6 +1660,52 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((ADAM || ME
 // block boundary link by link and from there block by block.  Fixed order, single writer: reproducible like the chains.
 struct EdgeBlocks { float *vec; int32_t *item; float *cnt; int32_t *through; };      // vec == NULL: chains link by link
 
+// How many of flag[first], flag[first + 1], ... (at most maxn) are non-zero before the first zero.  One lane group: its
+// lanes load C::LPR flags at a time, the wave ballot hands every group its own bits (a group that has left the loop
+// contributes none).  A chain's links used to be found one dependent load after the other - ~1 us per link.
+template <class C>
+__device__ __forceinline__ int64_t group_leading_ones(const int32_t *__restrict__ flag, int64_t first, int64_t maxn, int lane) {
+    constexpr int GPW = kWave / C::LPR;
+    const int gw = (threadIdx.x % kWave) / C::LPR;
+    int64_t total = 0;
+    for (int64_t base = 0; base < maxn; base += C::LPR) {
+        const int64_t idx = base + lane;
+        const bool f = idx < maxn && flag[first + idx] != 0;
+        const uint64_t m = __ballot(f);
+        int ones;
+        if constexpr (GPW == 1) ones = (m == ~0ull) ? 64 : __builtin_ctzll(~m);
+        else ones = __builtin_ctzll(~((m >> (C::LPR * gw)) & ((1ull << C::LPR) - 1)));
+        total += ones;
+        if (ones < C::LPR) break;
+    }
+    return total < maxn ? total : maxn;
+}
+
+// acc += the `count` records first, first + step, ... of (vec, cnt), in that order, four loads in flight
+template <class C>
+__device__ __forceinline__ void add_edge_records(Row<C> &acc, float &sp, float &sn, float &sc, const float *__restrict__ vec,
+                                                 const float *__restrict__ cnt, int64_t first, int64_t step, int64_t count,
+                                                 int lane, int d) {
+    for (int64_t j = 0; j < count; j += 4) {
+        Row<C> t[4];
+        float c0[4], c1[4], c2[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t r = first + ((j + q < count) ? (j + q) : (count - 1)) * step;      // (clamped: no load behind a branch)
+            t[q].load(vec + r * d, lane, d);
+            c0[q] = cnt[4 * r]; c1[q] = cnt[4 * r + 1]; c2[q] = cnt[4 * r + 2];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (j + q < count) {
+#pragma unroll
+                for (int e = 0; e < C::NE; ++e) acc.v[e] += t[q].v[e];
+                sp += c0[q]; sn += c1[q]; sc += c2[q];
+            }
+        }
+    }
+}
+
 template <class C>
 __global__ __launch_bounds__(kBlock) void k_staged_item_edge_blocks(ItemEdges2 ed, int64_t nchunks, int d,
                                                                     const int64_t *__restrict__ erange, int chunk_entries,
@@ -1676,21 +1722,14 @@ __global__ __launch_bounds__(kBlock) void k_staged_item_edge_blocks(ItemEdges2 e
         const int it = ed.item[2 * k0];
         int through = 0;
         if (it >= 0) {
-            Row<C> acc, t;
-            acc.load(ed.vec + (2 * k0) * d, lane, d);
-            float sp = ed.cnt[4 * (2 * k0)], sn = ed.cnt[4 * (2 * k0) + 1], sc = ed.cnt[4 * (2 * k0) + 2];
-            int64_t k = k0;
-            bool open = ed.whole[k0] != 0;                 // the chain also fills chunk k and runs on
-            while (open && ++k < k1 && ed.item[2 * k] == it) {
-                t.load(ed.vec + (2 * k) * d, lane, d);
-#pragma unroll
-                for (int q = 0; q < C::NE; ++q) acc.v[q] += t.v[q];
-                sp += ed.cnt[4 * (2 * k)];
-                sn += ed.cnt[4 * (2 * k) + 1];
-                sc += ed.cnt[4 * (2 * k) + 2];
-                open = ed.whole[k] != 0;
-            }
-            through = (open && k == k1) ? 1 : 0;           // every chunk of the block belongs to the chain, and it runs on
+            // chunk k0's head edge is the chain's; chunk k + 1's is too iff the chain also fills chunk k and runs on
+            const int64_t ones = group_leading_ones<C>(ed.whole, k0, k1 - k0, lane);
+            const int64_t links = (ones + 1 < k1 - k0) ? ones + 1 : k1 - k0;
+            through = (ones == k1 - k0) ? 1 : 0;           // every chunk of the block belongs to the chain, and it runs on
+            Row<C> acc;
+            acc.zero();
+            float sp = 0.f, sn = 0.f, sc = 0.f;
+            add_edge_records<C>(acc, sp, sn, sc, ed.vec, ed.cnt, 2 * k0, 2, links, lane, d);
             acc.store(eb.vec + b * d, lane, d);
             if (lane == 0) { eb.cnt[4 * b] = sp; eb.cnt[4 * b + 1] = sn; eb.cnt[4 * b + 2] = sc; }
         }
@@ -1742,33 +1781,32 @@ __global__ __launch_bounds__(kBlock) void k_staged_item_edges(ItemEdges2 ed, int
     for (int64_t c = (int64_t)blockIdx.x * C::GROUPS_PER_BLOCK + group; c < nchunks; c += gstride) {
         const int it = ed.item[2 * c + 1];
         if (it < 0) continue;
-        Row<C> acc, t;
+        Row<C> acc;
         acc.load(ed.vec + (2 * c + 1) * d, lane, d);
         float sp = ed.cnt[4 * (2 * c + 1)], sn = ed.cnt[4 * (2 * c + 1) + 1], sc = ed.cnt[4 * (2 * c + 1) + 2];
-        int64_t k = c + 1;
-        bool open = true;
-        // link by link - to the end of the chain, or (two levels) to the next block boundary
-        for (; open && k < nchunks && (eb.vec == nullptr || k % kEdgeBlock != 0); ++k) {
-            if (ed.item[2 * k] != it) { open = false; break; }
-            t.load(ed.vec + (2 * k) * d, lane, d);
-#pragma unroll
-            for (int q = 0; q < C::NE; ++q) acc.v[q] += t.v[q];
-            sp += ed.cnt[4 * (2 * k)];
-            sn += ed.cnt[4 * (2 * k) + 1];
-            sc += ed.cnt[4 * (2 * k) + 2];
-            if (!ed.whole[k]) open = false;
+        // link by link - to the end of the chain, or (two levels) to the next block boundary: chunk c + 1's head edge is
+        // the chain's (this tail edge runs on into it); chunk k + 1's is iff the chain also fills chunk k
+        const int64_t k = c + 1;
+        int64_t reach = nchunks;
+        if (eb.vec != nullptr) {
+            const int64_t bnd = (k + kEdgeBlock - 1) / kEdgeBlock * kEdgeBlock;
+            reach = bnd < nchunks ? bnd : nchunks;
         }
-        // block by block: the block sum of the chain that enters block b is this chain's, if it bears its item
-        for (; eb.vec != nullptr && open && k < nchunks; k += kEdgeBlock) {
-            const int64_t b = k / kEdgeBlock;
-            if (eb.item[b] != it) break;
-            t.load(eb.vec + b * d, lane, d);
-#pragma unroll
-            for (int q = 0; q < C::NE; ++q) acc.v[q] += t.v[q];
-            sp += eb.cnt[4 * b];
-            sn += eb.cnt[4 * b + 1];
-            sc += eb.cnt[4 * b + 2];
-            if (!eb.through[b]) break;
+        bool open = k < nchunks && ed.item[2 * k] == it;
+        if (open && reach > k) {
+            const int64_t ones = group_leading_ones<C>(ed.whole, k, reach - k, lane);
+            const int64_t links = (ones + 1 < reach - k) ? ones + 1 : reach - k;
+            add_edge_records<C>(acc, sp, sn, sc, ed.vec, ed.cnt, 2 * k, 2, links, lane, d);
+            open = ones == reach - k;
+        }
+        // block by block: the block sum of the chain that enters block b is this chain's; it runs on while `through`
+        if (eb.vec != nullptr && open && reach < nchunks) {
+            const int64_t b0 = reach / kEdgeBlock, nb = (nchunks + kEdgeBlock - 1) / kEdgeBlock;
+            if (eb.item[b0] == it) {
+                const int64_t ones = group_leading_ones<C>(eb.through, b0, nb - b0, lane);
+                const int64_t blocks = (ones + 1 < nb - b0) ? ones + 1 : nb - b0;
+                add_edge_records<C>(acc, sp, sn, sc, eb.vec, eb.cnt, b0, 1, blocks, lane, d);
+            }
         }
         item_commit<C, APPLY, ADAM>(Qo, cnt_out, it, acc, sp, sn, sc, lane, d, opt, reg_1, rI, rJ, fm);
     }
