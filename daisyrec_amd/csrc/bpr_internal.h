@@ -334,12 +334,19 @@ struct RowOpt {
 // bias gradients go to g_bu / g_bi (and stats[DAISY_ST_SUM_COEF] for bias_) for a dense optimiser; else SGD in place.
 struct StagedBias { float *bu, *bi, *b0; float *g_bu, *g_bi; int32_t grad_out; };
 
+// m_pre / v_pre (Adam): the row's moments, loaded by the caller together with the row itself - a commit then issues no
+// load at all.  (Loaded here, they sit behind every store the wave has issued: the vector-memory counter counts stores,
+// and s_waitcnt vmcnt(0) in front of the first use waits for all of them - profiles/r05_item_pass_counters.txt.)
 template <class C, bool ADAM>
-__device__ __forceinline__ void row_apply(Row<C> &w, const Row<C> &g, const RowOpt &o, int64_t row, int lane, int d) {
+__device__ __forceinline__ void row_apply(Row<C> &w, const Row<C> &g, const RowOpt &o, int64_t row, int lane, int d,
+                                          const Row<C> *m_pre = nullptr, const Row<C> *v_pre = nullptr) {
     if constexpr (ADAM) {
         Row<C> m, v;
-        m.load(o.m + row * d, lane, d);
-        v.load(o.v + row * d, lane, d);
+        if (m_pre) { m = *m_pre; v = *v_pre; }             // (compile-time at every call site)
+        else {
+            m.load(o.m + row * d, lane, d);
+            v.load(o.v + row * d, lane, d);
+        }
         adam_row<C>(w, m, v, g, o.step_size, o.bc2_sqrt, o.beta1, o.beta2, o.eps);
         m.store(o.m + row * d, lane, d);
         v.store(o.v + row * d, lane, d);

@@ -834,12 +834,13 @@ __device__ __forceinline__ double prenorm_sum(const double *__restrict__ stats, 
 template <class C, bool ADAM>
 __device__ __forceinline__ void user_commit(float *__restrict__ P, float *__restrict__ p_sqnorm, int64_t user, Row<C> &p,
                                             const Row<C> &acc, float n, float reg_1, float rU, const RowOpt &opt, int lane,
-                                            int d, bool stream_row = false) {
+                                            int d, bool stream_row = false, const Row<C> *m_pre = nullptr,
+                                            const Row<C> *v_pre = nullptr) {
     const float w1 = reg_1 * n, w2 = rU * n;
     Row<C> g;
 #pragma unroll
     for (int k = 0; k < C::NE; ++k) g.v[k] = acc.v[k] + fmaf(w2, p.v[k], w1 * sgn(p.v[k]));
-    row_apply<C, ADAM>(p, g, opt, user, lane, d);
+    row_apply<C, ADAM>(p, g, opt, user, lane, d, m_pre, v_pre);
     if (stream_row) p.store_nt(P + user * d, lane, d);      // (a table far beyond the caches: see StreamView::p_stream)
     else p.store(P + user * d, lane, d);
     const float sq = row_dot<C>(p, p);
@@ -897,6 +898,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((C::NE <= 4
     // round 5 the finisher loaded the row again - a dependent trip to memory behind this chunk's row and stage STORES, which
     // the vector-memory counter also counts: s_waitcnt vmcnt(0) in front of the commit waited for all of them.)
     __shared__ float part_p[G * ROWF];
+    __shared__ float part_m[ADAM ? G * ROWF : 4], part_v[ADAM ? G * ROWF : 4];      // ... and (Adam) its moments
     __shared__ int slot_user[G + 1], slot_next[G + 1];
     __shared__ int run_first[G], run_last[G];
 
@@ -957,6 +959,16 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((C::NE <= 4
 
         // ---- hop 2: the rows of every sample of the run
         Row<C> qi[RUN], qj[PAIR ? RUN : 1], pr[RUN];
+        // Adam: the moments of every sample's user row travel with the row (round 5): the run's owner then commits from
+        // registers.  (Round 4 had measured exactly this as "no change" - with its first use still behind a vmcnt(0) wait
+        // for the run's stage stores; see the touch below.)
+        Row<C> pm[ADAM ? RUN : 1], pv[ADAM ? RUN : 1];
+        auto moments = [&](int x, int64_t urow) {
+            if constexpr (ADAM) {
+                pm[x].load(opt.m + urow * d, lane, d);
+                pv[x].load(opt.v + urow * d, lane, d);
+            }
+        };
         if (__all(cnt == RUN) && v.p_stream) {     // (wave-uniform: no branch between the gathers)
             // a user table far beyond the Infinity Cache: its rows come back once every few steps, so they are read and
             // written past the caches and leave them to Q (10 M x 1 M shapes: 449 -> 420 us per pass with BOTH the loads
@@ -967,6 +979,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((C::NE <= 4
                 qi[x].load(Q + (int64_t)group_bcast<C>(my_ij.x, x) * d, lane, d);
                 if constexpr (PAIR) qj[x].load(Q + (int64_t)group_bcast<C>(my_ij.y, x) * d, lane, d);
                 pr[x].load_nt(P + (int64_t)group_bcast<C>(my_user, x) * d, lane, d);
+                moments(x, (int64_t)group_bcast<C>(my_user, x));
             }
         } else if (__all(cnt == RUN)) {
 #pragma unroll
@@ -974,6 +987,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((C::NE <= 4
                 qi[x].load(Q + (int64_t)group_bcast<C>(my_ij.x, x) * d, lane, d);
                 if constexpr (PAIR) qj[x].load(Q + (int64_t)group_bcast<C>(my_ij.y, x) * d, lane, d);
                 pr[x].load(P + (int64_t)group_bcast<C>(my_user, x) * d, lane, d);
+                moments(x, (int64_t)group_bcast<C>(my_user, x));
             }
         } else {
 #pragma unroll
@@ -985,9 +999,11 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((C::NE <= 4
                     qi[x].load(Q + (int64_t)ix * d, lane, d);
                     if constexpr (PAIR) qj[x].load(Q + (int64_t)jx * d, lane, d);
                     pr[x].load(P + (int64_t)ux * d, lane, d);
+                    moments(x, (int64_t)ux);
                 } else {
                     qi[x].zero(); pr[x].zero();
                     if constexpr (PAIR) qj[x].zero();
+                    if constexpr (ADAM) { pm[x].zero(); pv[x].zero(); }
                 }
             }
         }
@@ -1043,13 +1059,23 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((C::NE <= 4
             // ---- user gradient over the runs of equal users; the staged rows leave on the way
             int32_t cur_user = user_first;
             Row<C> pcur = pr[0];                     // pre-step P row of the current run's user
+            Row<C> mcur = pm[0], vcur = pv[0];       // (Adam) and its moments
+            if constexpr (ADAM) {
+                // the moment registers are "used" here, in front of the first store of this chunk: the compiler's wait
+                // for their gathers happens now, and the commits below wait for nothing
+#pragma unroll
+                for (int x = 0; x < RUN; ++x)
+#pragma unroll
+                    for (int k = 0; k < C::NE; ++k) { asm volatile("" : "+v"(pm[x].v[k])); asm volatile("" : "+v"(pv[x].v[k])); }
+            }
             Row<C> acc;
             acc.zero();
             float cn_ = 0.f, sb_ = 0.f;
             auto finish = [&](bool ends_here, bool to_next_chunk, const Row<C> &prow) {
                 if (cur_slot < 0 && ends_here) {     // this group owns P[cur_user]
                     Row<C> pn = prow;
-                    user_commit<C, ADAM>(P, p_sqnorm, cur_user, pn, acc, cn_, reg_1, rU, opt, lane, d, v.p_stream != 0);
+                    user_commit<C, ADAM>(P, p_sqnorm, cur_user, pn, acc, cn_, reg_1, rU, opt, lane, d, v.p_stream != 0,
+                                         ADAM ? &mcur : nullptr, ADAM ? &vcur : nullptr);
                     if constexpr (BIAS) user_bias_commit(fm, cur_user, sb_, opt.lr, lane);
                 } else {
                     const int s = (cur_slot >= 0) ? cur_slot : group + 1;
@@ -1061,6 +1087,11 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((C::NE <= 4
                         float *pd = part_p + group * ROWF;
 #pragma unroll
                         for (int k = 0; k < C::NE; ++k) pd[k * C::LPR + lane] = prow.v[k];
+                        if constexpr (ADAM) {
+                            float *md = part_m + group * ROWF, *vd = part_v + group * ROWF;
+#pragma unroll
+                            for (int k = 0; k < C::NE; ++k) { md[k * C::LPR + lane] = mcur.v[k]; vd[k * C::LPR + lane] = vcur.v[k]; }
+                        }
                     }
                     if (lane == 0) {
                         part_slot[q] = s;
@@ -1083,6 +1114,7 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((C::NE <= 4
                         cur_user = ux;
                         cur_slot = -1;
                         pcur = pr[x];
+                        if constexpr (ADAM) { mcur = pm[x]; vcur = pv[x]; }
                         acc.zero();
                         cn_ = 0.f; sb_ = 0.f;
                     }
@@ -1134,7 +1166,14 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((C::NE <= 4
                 const float *ps = part_p + (s - 1) * ROWF;
 #pragma unroll
                 for (int k = 0; k < C::NE; ++k) p.v[k] = ps[k * C::LPR + lane];
-                user_commit<C, ADAM>(P, p_sqnorm, uu, p, g, ns, reg_1, rU, opt, lane, d);
+                Row<C> mrow, vrow;
+                if constexpr (ADAM) {
+                    const float *ms = part_m + (s - 1) * ROWF, *vs = part_v + (s - 1) * ROWF;
+#pragma unroll
+                    for (int k = 0; k < C::NE; ++k) { mrow.v[k] = ms[k * C::LPR + lane]; vrow.v[k] = vs[k * C::LPR + lane]; }
+                }
+                user_commit<C, ADAM>(P, p_sqnorm, uu, p, g, ns, reg_1, rU, opt, lane, d, false, ADAM ? &mrow : nullptr,
+                                     ADAM ? &vrow : nullptr);
                 if constexpr (BIAS) user_bias_commit(fm, uu, sb, opt.lr, lane);
             } else {
                 const int64_t e = 2 * chunk + (from_prev ? 0 : 1);
