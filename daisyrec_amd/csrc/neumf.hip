@@ -732,12 +732,26 @@ struct L16 { static constexpr int LPR = 16; };
 
 // x0[r] = [uM[user] | iM[item]] (* dropout), g[r] = uG[user]*iG[item]; TRAIN: the ten regulariser sums.
 // H: the activations live as bf16 in HBM (precision level 2)
-template <bool TRAIN, bool H = false>
+// FACT (round 5, "the first layer through the tables"): the MLP's first layer is linear in the concatenated embedding
+// rows, z1[r] = W1[:, :dm] uM[user] + W1[:, dm:] iM[item] + b1, and a step of R rows meets only U + I DISTINCT table rows
+// (ml-1m: 9746 against 524 288).  So T_u = uM W1[:, :dm]^T and T_i = iM W1[:, dm:]^T are two small GEMMs over the tables
+// (Fact::tu, Fact::ti: fp32 [rows][n1]) and x1[r] = relu(T_u[user] + T_i[item] + b1) is a gather: x0 - 1 KB per row in bf16 -
+// is never formed, the largest GEMM of the tower and its 2 x 512-column operand stream are gone.  The backward pass
+// mirrors it (neumf_scatter_owner).  Needs dropout = 0 (a mask on x0's elements would not factor).
+struct Fact { const uint16_t *tu, *ti; const float *b1; uint16_t *x1; int n1; const float2 *nu, *ni; };    // nu / ni: k_nmf_row_norms
+// (the products are handed to the gather as bf16: it is bound by reading them - 2 x 1 KB per row in fp32 from beyond L2 -
+// and the plain path rounds x0 and W1 to bf16 BEFORE the product)
+__global__ void k_f32_to_bf16(const float *__restrict__ x, int64_t n, uint16_t *__restrict__ y) {
+    for (int64_t e = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) * 2; e < n; e += (int64_t)gridDim.x * blockDim.x * 2)
+        *reinterpret_cast<uint32_t *>(y + e) = bf16_pack2(x[e], x[e + 1]);
+}
+
+template <bool TRAIN, bool H = false, bool FACT = false>
 __global__ __launch_bounds__(kBlock) void k_nmf_gather(daisy_neumf_params p, PairSrc src, int64_t R, int d,
                                                        int dm, int pointwise, float *__restrict__ X0,
                                                        float *__restrict__ G, uint32_t thresh,
                                                        float scale, uint64_t seed,
-                                                       double *__restrict__ stats) {
+                                                       double *__restrict__ stats, Fact fact = Fact{}) {
     const int lane = threadIdx.x % 16, group = threadIdx.x / 16;
     const int64_t gstride = (int64_t)gridDim.x * (kBlock / 16);
     float s1[5] = {0, 0, 0, 0, 0}, s2[5] = {0, 0, 0, 0, 0};
@@ -750,7 +764,30 @@ __global__ __launch_bounds__(kBlock) void k_nmf_gather(daisy_neumf_params p, Pai
         const float *um = p.uM + user * dm, *im = p.iM + item * dm;
         float *x = X0 + r * (int64_t)(2 * dm);
         uint16_t *xh = reinterpret_cast<uint16_t *>(X0) + r * (int64_t)(2 * dm);
-        for (int c = 4 * lane; c < dm; c += 64) {
+        if constexpr (FACT) {
+            // x1 from the two table products; the embedding rows themselves are read only where the regulariser counts
+            // them (the positive half of the rows: NeuMFRecommender.py:149-167)
+            const uint16_t *tu = fact.tu + user * fact.n1, *ti = fact.ti + item * fact.n1;
+            uint16_t *x1 = fact.x1 + r * (int64_t)fact.n1;
+            for (int c = 4 * lane; c < fact.n1; c += 64) {
+                const uint2 ah = *reinterpret_cast<const uint2 *>(tu + c), bh = *reinterpret_cast<const uint2 *>(ti + c);
+                const float4 a4 = make_float4(__uint_as_float(ah.x << 16), __uint_as_float(ah.x & 0xFFFF0000u),
+                                              __uint_as_float(ah.y << 16), __uint_as_float(ah.y & 0xFFFF0000u));
+                const float4 b4 = make_float4(__uint_as_float(bh.x << 16), __uint_as_float(bh.x & 0xFFFF0000u),
+                                              __uint_as_float(bh.y << 16), __uint_as_float(bh.y & 0xFFFF0000u));
+                const float4 c4 = *reinterpret_cast<const float4 *>(fact.b1 + c);
+                const float z0 = fmaxf((a4.x + b4.x) + c4.x, 0.f), z1 = fmaxf((a4.y + b4.y) + c4.y, 0.f);
+                const float z2 = fmaxf((a4.z + b4.z) + c4.z, 0.f), z3 = fmaxf((a4.w + b4.w) + c4.w, 0.f);
+                *reinterpret_cast<uint2 *>(x1 + c) = make_uint2(bf16_pack2(z0, z1), bf16_pack2(z2, z3));
+            }
+        }
+        if constexpr (FACT && TRAIN) {
+            if (first && lane == 0) {              // the MLP rows' share of the regulariser sums, from the per-row table
+                const float2 a = fact.nu[user], b = fact.ni[item];
+                s1[1] += a.x; s2[1] += a.y; s1[3] += b.x; s2[3] += b.y;
+            }
+        }
+        for (int c = 4 * lane; c < dm && !FACT; c += 64) {
             const float4 a4 = *reinterpret_cast<const float4 *>(um + c), b4 = *reinterpret_cast<const float4 *>(im + c);
             float a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
             if (TRAIN) {
@@ -766,7 +803,9 @@ __global__ __launch_bounds__(kBlock) void k_nmf_gather(daisy_neumf_params p, Pai
                     }
                 }
             }
-            if constexpr (H) {
+            if constexpr (FACT) {
+                // (no x0)
+            } else if constexpr (H) {
                 *reinterpret_cast<uint2 *>(xh + c) =
                     make_uint2(bf16_pack2(a[0], a[1]), bf16_pack2(a[2], a[3]));
                 *reinterpret_cast<uint2 *>(xh + dm + c) =
@@ -894,6 +933,43 @@ __global__ __launch_bounds__(kBlock) void k_reduce_slices(const float *__restric
         }
         for (; sidx < nslices; ++sidx) t0 += ws[(int64_t)sidx * len + c];
         out[c] += (t0 + t1) + (t2 + t3);
+    }
+}
+
+// the same into a [rows][cols] block of a wider matrix (leading dimension ldo): slices are contiguous [rows][cols]
+__global__ __launch_bounds__(kBlock) void k_reduce_slices_2d(const float *__restrict__ ws, int nslices, int rows, int cols,
+                                                             float *__restrict__ out, int64_t ldo) {
+    const int64_t len = (int64_t)rows * cols;
+    for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < len; c += (int64_t)gridDim.x * blockDim.x) {
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+        int sidx = 0;
+        for (; sidx + 3 < nslices; sidx += 4) {
+            t0 += ws[(int64_t)sidx * len + c];
+            t1 += ws[(int64_t)(sidx + 1) * len + c];
+            t2 += ws[(int64_t)(sidx + 2) * len + c];
+            t3 += ws[(int64_t)(sidx + 3) * len + c];
+        }
+        for (; sidx < nslices; ++sidx) t0 += ws[(int64_t)sidx * len + c];
+        out[(c / cols) * ldo + (c % cols)] += (t0 + t1) + (t2 + t3);
+    }
+}
+
+// per table row: (sum |x|, sum x^2) - what the regulariser sums of a step need from an MLP embedding row
+// (k_nmf_gather<FACT>, which does not read the rows themselves)
+__global__ __launch_bounds__(kBlock) void k_nmf_row_norms(const float *__restrict__ T, int64_t rows, int width,
+                                                          float2 *__restrict__ out) {
+    const int lane = threadIdx.x % 16, group = threadIdx.x / 16;
+    const int64_t gstride = (int64_t)gridDim.x * (kBlock / 16);
+    for (int64_t r = (int64_t)blockIdx.x * (kBlock / 16) + group; r < rows; r += gstride) {
+        float a = 0.f, b = 0.f;
+        for (int c = 4 * lane; c < width; c += 64) {
+            const float4 v = *reinterpret_cast<const float4 *>(T + r * (int64_t)width + c);
+            a += (fabsf(v.x) + fabsf(v.y)) + (fabsf(v.z) + fabsf(v.w));
+            b = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, b))));
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) { a += __shfl_xor(a, o, 16); b += __shfl_xor(b, o, 16); }
+        if (lane == 0) out[r] = make_float2(a, b);
     }
 }
 
@@ -1240,6 +1316,7 @@ struct daisy_neumf_ctx {
     // row tiles of the column sums ...), added in a fixed order by k_reduce_slices; allocated at the first training step
     float *det_ws;
     size_t det_ws_floats;
+    float *fact_t;                           // T_u [U][n1] then T_i [I][n1]: the first layer through the tables (k_nmf_gather<FACT>)
 };
 
 constexpr int kWgradChunkDefault = 2048;
@@ -1269,8 +1346,48 @@ static int neumf_need_det_ws(daisy_neumf_ctx *ctx) {
     return DAISY_OK;
 }
 
+// Many slices (the split-K weight gradients: 256 slices of up to 131 072 elements; the column sums: 1024 slices of 64-256):
+// one thread per element walking all slices left most of the chip idle with four loads in flight per thread - 33.5 MB in
+// 66 us, and ONE workgroup for the column sums.  Here a workgroup takes C elements and its 256 / C thread groups every
+// (256 / C)-th slice each; the partial sums meet in LDS in group order: still one fixed association per element.
+template <int C>
+__global__ __launch_bounds__(kBlock) void k_reduce_slices_wide(const float *__restrict__ ws, int nslices, int64_t len,
+                                                               float *__restrict__ out) {
+    constexpr int G = kBlock / C;
+    __shared__ float sm[G][C];
+    const int c = threadIdx.x % C, g = threadIdx.x / C;
+    for (int64_t c0 = (int64_t)blockIdx.x * C; c0 < len; c0 += (int64_t)gridDim.x * C) {
+        const int64_t col = c0 + c;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+        if (col < len) {
+            int sidx = g;
+            for (; sidx + 3 * G < nslices; sidx += 4 * G) {
+                t0 += ws[(int64_t)sidx * len + col];
+                t1 += ws[(int64_t)(sidx + G) * len + col];
+                t2 += ws[(int64_t)(sidx + 2 * G) * len + col];
+                t3 += ws[(int64_t)(sidx + 3 * G) * len + col];
+            }
+            for (; sidx < nslices; sidx += G) t0 += ws[(int64_t)sidx * len + col];
+        }
+        sm[g][c] = (t0 + t1) + (t2 + t3);
+        __syncthreads();
+        if (g == 0 && col < len) {
+            float t = sm[0][c];
+#pragma unroll
+            for (int k = 1; k < G; ++k) t += sm[k][c];
+            out[col] += t;
+        }
+        __syncthreads();
+    }
+}
+
 static void reduce_slices(const float *ws, int nslices, int64_t len, float *out, hipStream_t s) {
-    hipLaunchKernelGGL(k_reduce_slices, dim3(grid_for(len, kBlock, 2048)), dim3(kBlock), 0, s, ws, nslices, len, out);
+    if (nslices >= 32 && len >= 4096)
+        hipLaunchKernelGGL((k_reduce_slices_wide<64>), dim3(grid_for(len, 64, 4096)), dim3(kBlock), 0, s, ws, nslices, len, out);
+    else if (nslices >= 64)
+        hipLaunchKernelGGL((k_reduce_slices_wide<16>), dim3(grid_for(len, 16, 4096)), dim3(kBlock), 0, s, ws, nslices, len, out);
+    else
+        hipLaunchKernelGGL(k_reduce_slices, dim3(grid_for(len, kBlock, 2048)), dim3(kBlock), 0, s, ws, nslices, len, out);
 }
 
 static inline hipStream_t NS(daisy_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
@@ -1289,6 +1406,26 @@ static bool neumf_use_h(const daisy_neumf_ctx *ctx, int64_t R) {
     return true;
 }
 
+// the first layer through the tables: bf16 storage (the throughput mode), training, no dropout, a first layer of the
+// standard halving tower, and fewer distinct table rows than rows in the step.  DAISY_NMF_FACT=0 switches it off (A/B).
+static bool neumf_use_fact(const daisy_neumf_ctx *ctx, int64_t R, bool train, uint32_t thresh) {
+    const char *env = getenv("DAISY_NMF_FACT");              // (read per call: the tests switch it)
+    const int tune = env ? atoi(env) : 1;
+    return tune != 0 && train && thresh == 0 && neumf_use_h(ctx, R) && ctx->L >= 1 && ctx->width[1] == ctx->dm &&
+           ctx->dm % 64 == 0 && ctx->U + ctx->I <= R;
+}
+static int neumf_need_fact(daisy_neumf_ctx *ctx) {
+    if (ctx->fact_t) return DAISY_OK;
+    // the products in fp32, the row norms (2 floats per row), the products again as bf16 (half a float per element)
+    const size_t n = (size_t)(ctx->U + ctx->I) * ((size_t)ctx->width[1] + 2 + (size_t)ctx->width[1] / 2);
+    if (hipMalloc((void **)&ctx->fact_t, n * sizeof(float)) != hipSuccess) {
+        set_error("neumf: hipMalloc(%zu) of the first-layer table products failed", n * sizeof(float));
+        ctx->fact_t = nullptr;
+        return DAISY_ERR_HIP;
+    }
+    return DAISY_OK;
+}
+
 // x_L and pred for R pairs starting at src.base (eval: thresh == 0)
 static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p, const PairSrc &src, int64_t R,
                               bool train, int pointwise, uint32_t thresh, float scale, uint64_t seed,
@@ -1303,7 +1440,32 @@ static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p,
                                ctx->width[l - 1], ctx->W16[l - 1], ctx->W16T[l - 1]);
         }
     }
-    if (train) {
+    const bool fact = neumf_use_fact(ctx, R, train, thresh);
+    if (fact) {
+        int rc = neumf_need_fact(ctx);
+        if (rc) return rc;
+        const int n1 = ctx->width[1];
+        float *tu = ctx->fact_t, *ti = ctx->fact_t + (size_t)ctx->U * n1;
+        for (int side = 0; side < 2; ++side) {          // T = table x W1[:, half]^T  (fp32: the tables are fp32)
+            GemmOp op{};
+            op.A = side ? p->iM : p->uM; op.sam = dm; op.sak = 1;
+            op.B = p->W[0] + (side ? dm : 0); op.sbn = ctx->width[0]; op.sbk = 1;
+            op.C = side ? ti : tu; op.ldc = n1;
+            op.M = side ? ctx->I : ctx->U; op.N = n1; op.K = dm;
+            op.k_chunk = op.K;
+            op.bf16 = 1;
+            launch_gemm<EPI_STORE>(op, s);
+        }
+        float2 *nu = reinterpret_cast<float2 *>(ctx->fact_t + (size_t)(ctx->U + ctx->I) * n1), *ni = nu + ctx->U;
+        hipLaunchKernelGGL(k_nmf_row_norms, dim3(grid_for(ctx->U, kBlock / 16)), dim3(kBlock), 0, s, p->uM, ctx->U, dm, nu);
+        hipLaunchKernelGGL(k_nmf_row_norms, dim3(grid_for(ctx->I, kBlock / 16)), dim3(kBlock), 0, s, p->iM, ctx->I, dm, ni);
+        uint16_t *t16 = reinterpret_cast<uint16_t *>(ni + ctx->I);
+        const int64_t nt = (int64_t)(ctx->U + ctx->I) * n1;
+        hipLaunchKernelGGL(k_f32_to_bf16, dim3(grid_for(nt, kBlock * 2)), dim3(kBlock), 0, s, tu, nt, t16);
+        const Fact f{t16, t16 + (size_t)ctx->U * n1, p->b[0], reinterpret_cast<uint16_t *>(ctx->X[1]), n1, nu, ni};
+        hipLaunchKernelGGL((k_nmf_gather<true, true, true>), dim3(grid), dim3(kBlock), 0, s, *p, src, R, d, dm, pointwise,
+                           ctx->X[0], ctx->G, thresh, scale, seed, stats, f);
+    } else if (train) {
         if (H) hipLaunchKernelGGL((k_nmf_gather<true, true>), dim3(grid), dim3(kBlock), 0, s, *p, src, R, d, dm, pointwise,
                                   ctx->X[0], ctx->G, thresh, scale, seed, stats);
         else hipLaunchKernelGGL((k_nmf_gather<true, false>), dim3(grid), dim3(kBlock), 0, s, *p, src, R, d, dm, pointwise,
@@ -1316,7 +1478,7 @@ static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p,
     }
     DAISY_LAUNCH_CHECK();
     if (ctx->model != DAISY_NEUMF_GMF) {
-        for (int l = 1; l <= L; ++l) {
+        for (int l = fact ? 2 : 1; l <= L; ++l) {        // (fact: x1 came out of the gather)
             GemmOp op{};
             op.A = ctx->X[l - 1]; op.sam = ctx->width[l - 1]; op.sak = 1;
             op.B = p->W[l - 1]; op.sbn = ctx->width[l - 1]; op.sbk = 1;
@@ -1390,9 +1552,12 @@ static int neumf_scatter_scratch(daisy_neumf_ctx *c) {
 }
 
 // g.{uG,iG,uM,iM} += the embedding gradients of the step (DX0: fp32 [R, 2*dm] input gradient of the MLP tower)
+// fact (the first layer through the tables): DX0 is dZ_1 (bf16 [R, n1]) instead; S = its segmented sums by table row
+// (fp32 [rows, n1], in the row-sum table), then  g.table += S W1[:, half]  and  gW_1[:, half] += S^T table  - two GEMMs over
+// the TABLE's rows where the plain path runs one over the step's R rows and a [R, 2 dm] input gradient
 static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, const daisy_neumf_params &g,
                                const PairSrc &src, int64_t R, int pointwise, const float *DX0, bool dx0_bf16,
-                               const double *stats, float reg_1, float reg_2, hipStream_t s) {
+                               const double *stats, float reg_1, float reg_2, hipStream_t s, bool fact = false) {
     int rc = neumf_scatter_scratch(c);
     if (rc) return rc;
     const int d = c->d, dm = c->dm, model = c->model;
@@ -1411,14 +1576,41 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
         const int ge = grid_for(n_pad, kBlock * 2), gt = grid_for(rows, kBlock / 16 * 2);
         // MLP table: source row = half `side` of DX0[r]
         if (model != DAISY_NEUMF_GMF) {
-            hipLaunchKernelGGL(k_nmf_entries, dim3(ge), dim3(kBlock), 0, s, c->sc_ks, c->sc_vs, R, n_pad, 2, side, c->sc_ekey,
-                               c->sc_esu, c->sc_w);
+            hipLaunchKernelGGL(k_nmf_entries, dim3(ge), dim3(kBlock), 0, s, c->sc_ks, c->sc_vs, R, n_pad, fact ? 1 : 2,
+                               fact ? 0 : side, c->sc_ekey, c->sc_esu, c->sc_w);
             rc = segsum_rows(DX0, c->sc_w, c->sc_ekey, c->sc_esu, n_pad, dm, c->sc_sum, c->sc_edge_vec, c->sc_edge_item,
                              c->sc_edge_b, c->sc_edge_whole, s, dx0_bf16);
             if (rc) return rc;
         }
+        if (fact) {
+            const int n1 = dm, w0 = 2 * dm;
+            GemmOp a{};                        // g.table[rows, dm] += S[rows, n1] W1[:, half]      (k = n1)
+            a.A = c->sc_sum; a.sam = n1; a.sak = 1;
+            a.B = p.W[0] + (side ? dm : 0); a.sbn = 1; a.sbk = w0;
+            a.C = side ? g.iM : g.uM; a.ldc = dm;
+            a.M = rows; a.N = dm; a.K = n1; a.k_chunk = a.K;
+            launch_gemm<EPI_ATOMIC>(a, s);     // (one workgroup per output tile, k in one piece: a single add per element)
+            GemmOp b{};                        // gW_1[n1, half] += S^T[n1, rows] table[rows, dm]    (k = the table's rows)
+            b.A = c->sc_sum; b.sam = 1; b.sak = n1;
+            b.B = side ? p.iM : p.uM; b.sbn = 1; b.sbk = dm;
+            // (k in slices of 128 table rows, side by side in the workspace, added in slice order: enough workgroups, no
+            // fp32 atomics on shared elements)
+            b.M = n1; b.N = dm; b.K = rows; b.k_chunk = 128;
+            const int bsplits = (int)((rows + 127) / 128);
+            rc = neumf_need_det_ws(c);
+            if (rc) return rc;
+            if ((size_t)bsplits * (size_t)n1 * (size_t)dm > c->det_ws_floats) {
+                set_error("neumf: the reduction workspace is too small for the first layer's table products");
+                return DAISY_ERR_STATE;
+            }
+            b.C = c->det_ws; b.ldc = dm; b.slice_stride = (int64_t)n1 * dm;
+            launch_gemm<EPI_ATOMIC>(b, s);
+            hipLaunchKernelGGL(k_reduce_slices_2d, dim3(grid_for((int64_t)n1 * dm, kBlock, 2048)), dim3(kBlock), 0, s, c->det_ws,
+                               bsplits, n1, dm, g.W[0] + (side ? dm : 0), (int64_t)w0);
+            DAISY_HIP(hipMemsetAsync(c->sc_sum, 0, (size_t)rows * (size_t)n1 * sizeof(float), s));   // (kept all-zero between uses)
+        }
         hipLaunchKernelGGL(k_nmf_table_commit, dim3(gt), dim3(kBlock), 0, s, side ? g.iM : g.uM,
-                           (model != DAISY_NEUMF_GMF) ? c->sc_sum : (float *)nullptr, side ? p.iM : p.uM, rows, dm,
+                           (model != DAISY_NEUMF_GMF && !fact) ? c->sc_sum : (float *)nullptr, side ? p.iM : p.uM, rows, dm,
                            side ? c->sc_ci : c->sc_cu, side ? 3 : 1, (int32_t *)nullptr, 0, 0.f, stats, reg_1, reg_2, 0);
         // GMF table: source row = the materialised per-row gradient
         if (model != DAISY_NEUMF_MLP) {
@@ -1491,6 +1683,7 @@ int daisy_neumf_ctx_destroy(daisy_neumf_ctx *ctx) {
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->sc_arena) (void)hipFree(ctx->sc_arena);
     if (ctx->det_ws) (void)hipFree(ctx->det_ws);
+    if (ctx->fact_t) (void)hipFree(ctx->fact_t);
     delete ctx;
     return DAISY_OK;
 }
@@ -1570,9 +1763,27 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
                             ctx->G, dg, ctx->X[L], nl, p.Wp, R, dz, ws);
     reduce_slices(ws, pb_grid, dg + nl, g.Wp, s);       // gWp += the workgroups' column sums, in workgroup order
     DAISY_LAUNCH_CHECK();
+    const bool fact = neumf_use_fact(ctx, R, true, thresh);          // (the forward pass took the same decision)
     if (model != DAISY_NEUMF_GMF) {
         for (int l = L; l >= 1; --l) {
             const int n_out = ctx->width[l], n_in = ctx->width[l - 1];
+            if (fact && l == 1) {
+                // the first layer through the tables: gb_1 here; gW_1 and the MLP tables' gradients come out of the
+                // scatter (segmented sums of dZ_1 by user and by item, then two small GEMMs each) - no [R, 2 dm] input
+                // gradient, no weight-gradient GEMM over the R rows
+                if (n_out % 8 == 0 && kBlock % (n_out / 8) == 0) {
+                    const int tiles = (int)((R + kColsumRowsH - 1) / kColsumRowsH);
+                    hipLaunchKernelGGL(k_colsum_h, dim3((unsigned)tiles), dim3(kBlock), 0, s,
+                                       reinterpret_cast<const uint16_t *>(dz), R, n_out, ws);
+                    reduce_slices(ws, tiles, n_out, g.b[0], s);
+                } else {
+                    const dim3 cs((unsigned)((n_out + 63) / 64), (unsigned)((R + kColsumRows - 1) / kColsumRows));
+                    hipLaunchKernelGGL((k_colsum<true>), cs, dim3(kBlock), 0, s, dz, R, n_out, (int64_t)n_out, ws);
+                    reduce_slices(ws, (int)cs.y, n_out, g.b[0], s);
+                }
+                DAISY_LAUNCH_CHECK();
+                break;
+            }
             GemmOp w{};                                   // gW_l[n_out, n_in] += dZ^T x_{l-1}
             if (n_out % kGemmBM == 0) {
                 w.A = dz; w.sam = 1; w.sak = n_out;
@@ -1642,8 +1853,8 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
             float *t = dz; dz = dz_next; dz_next = t;
         }
     }
-    if (owner_scatter) {
-        rc = neumf_scatter_owner(ctx, p, g, src, R, pointwise, dz, H, stats, reg_1, reg_2, s);
+    if (owner_scatter || fact) {
+        rc = neumf_scatter_owner(ctx, p, g, src, R, pointwise, dz, H, stats, reg_1, reg_2, s, fact);
         if (rc) return rc;
     } else if (H) {
         hipLaunchKernelGGL((k_nmf_scatter<true>), dim3(grid_for(R, kBlock / 16 * 2)), dim3(kBlock), 0, s, p, g, src, R, d, dm,

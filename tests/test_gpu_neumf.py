@@ -393,3 +393,55 @@ def test_neumf_step_is_bitwise_reproducible(level):
         assert np.array_equal(outs[0][k], outs[1][k]), k
         if k != "bp":                              # (the predict bias has an exactly zero gradient under BPR, like autograd)
             assert np.abs(outs[0][k]).max() > 0, k
+
+
+@pytest.mark.parametrize("loss,B", [(0, 256), (3, 512)])
+def test_neumf_first_layer_through_the_tables(loss, B, monkeypatch):
+    """Round 5 (precision level 2, dropout 0, fewer distinct table rows than rows in the step): the MLP's first layer
+    factored through the embedding tables - x1 = relu(T_u[user] + T_i[item] + b1) with T = table x W1[:, half]^T, and in the
+    backward pass gW1 / the MLP tables' gradients from the segmented sums of dZ1 - against the plain bf16-storage path
+    (DAISY_NMF_FACT=0) and the fp32 parity mode: the same step up to bf16 rounding (the factored path rounds LESS: its
+    first layer runs on the fp32 tables), every parameter's gradient, the loss, bitwise repeatable."""
+    from daisyrec_amd import ops
+    rng = np.random.default_rng(15)
+    U, I, d, L = 100, 80, 64, 3
+    dm = d << (L - 1)
+    shapes = {"uG": (U, d), "iG": (I, d), "uM": (U, dm), "iM": (I, dm), "Wp": (1, 2 * d), "bp": (1,)}
+    w = 2 * dm
+    for l in range(1, L + 1):
+        shapes[f"W{l}"], shapes[f"b{l}"] = (w // 2, w), (w // 2,)
+        w //= 2
+    p_np = {k: (rng.standard_normal(s) * 0.05).astype(np.float32) for k, s in shapes.items()}
+    u, i = (torch.as_tensor(rng.integers(0, n, B).astype(np.int32)).to(DEV) for n in (U, I))
+    j = torch.as_tensor((rng.integers(0, I, B) if loss == 0 else rng.integers(0, 2, B)).astype(np.int32)).to(DEV)
+    R = B if loss >= 3 else 2 * B
+    assert U + I <= R
+
+    def run(level, fact):
+        monkeypatch.setenv("DAISY_NMF_FACT", fact)
+        p = _dev(p_np)
+        grads = {k: torch.zeros_like(v) for k, v in p.items()}
+        ctx = ops.NeumfContext(R, d, L, U, I)
+        ctx.set_precision(level)
+        ctx.step_grads(p, grads, u, i, j, loss, 1e-3, 1e-3)
+        out = float(ctx.stats[11].cpu()), {k: v.cpu().numpy() for k, v in grads.items()}
+        ctx.close()
+        return out
+
+    l32, g32 = run(0, "1")
+    lf, gf = run(2, "1")
+    lp, gp = run(2, "0")
+    lf2, gf2 = run(2, "1")
+    assert lf == lf2 and all(np.array_equal(gf[k], gf2[k]) for k in shapes)          # reproducible
+    assert lf != lp                                                                 # the factored path really ran
+    assert abs(lf - l32) <= 2e-3 * abs(l32) and abs(lp - l32) <= 2e-3 * abs(l32)
+    for k in shapes:
+        n32 = np.linalg.norm(g32[k])
+        if n32 == 0:
+            continue
+        ef = np.linalg.norm(gf[k] - g32[k]) / n32
+        ep = np.linalg.norm(gp[k] - g32[k]) / n32
+        cos = float((gf[k] * g32[k]).sum() / (np.linalg.norm(gf[k]) * n32 + 1e-30))
+        assert ef < 0.25 and cos > 0.97, (k, ef, ep, cos)
+        assert ef < 2.5 * ep + 0.03, (k, ef, ep)             # and of the same size as the plain bf16 path's (ReLU gates
+                                                              # within rounding of 0 flip differently in the two)
