@@ -129,3 +129,31 @@ def test_sharded_adam_table_matches_the_dense_optimisers_constants():
     lr, b1, b2 = (float(np.float32(x)) for x in (0.01, 0.9, 0.999))        # the C entry takes floats
     for s in range(1, n + 1):
         assert t[s, 0] == np.float32(lr / (1.0 - b1 ** s)) and t[s, 1] == np.float32(np.sqrt(1.0 - b2 ** s)), s
+
+
+def test_state_dict_of_a_table_on_a_row_pitch_is_contiguous(tmp_path):
+    """a table homed on a row pitch is an [n, d] VIEW of a padded [n, d'] buffer; torch.save(state_dict())
+    would write the whole padded storage (a third more bytes at d = 50, and not comparable with the reference's
+    checkpoint).  The state dict carries contiguous [n, d] copies; loading one back gives the same weights."""
+    import torch
+    from daisyrec_amd.model.MFRecommender import MF
+    cfg = {"gpu": "0", "logger": None, "lr": 0.01, "reg_1": 0.0, "reg_2": 0.0, "epochs": 1, "topk": 5, "user_num": 40,
+           "item_num": 30, "factors": 50, "loss_type": "BPR", "optimizer": "sgd", "init_method": "default",
+           "early_stop": False}
+    m = MF(cfg)
+    want = {k: v.clone() for k, v in m.state_dict().items()}
+    for name in ("embed_user", "embed_item"):                   # what `_tables()` does on the device: re-home on 64 columns
+        w = getattr(m, name).weight
+        buf = torch.zeros(w.shape[0], 64)
+        buf[:, :50].copy_(w.data)
+        w.data = buf[:, :50]
+        assert not w.data.is_contiguous()
+    sd = m.state_dict()
+    for k, v in sd.items():
+        assert v.is_contiguous() and tuple(v.shape) == tuple(want[k].shape) and torch.equal(v, want[k])
+    path = tmp_path / "mf.pt"
+    torch.save(sd, path)
+    assert path.stat().st_size < 1.15 * (40 + 30) * 50 * 4 + 4096          # the bare tables, not the padded storage
+    m2 = MF(cfg)
+    m2.load_state_dict(torch.load(path))
+    assert torch.equal(m2.embed_user.weight.data, want["embed_user.weight"])
