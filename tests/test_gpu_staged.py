@@ -454,12 +454,16 @@ def test_staged_phases_equal_single_call():
     assert np.abs(res[0][0] - Pn).max() < 3e-6 and np.abs(res[0][1] - Qn).max() < 3e-6
 
 
+@pytest.mark.parametrize("blocks", [None, "1"])
 @pytest.mark.parametrize("loss", ["BPR", "TL"])
-def test_item_pass_in_slices_equals_the_whole_pass(loss):
+def test_item_pass_in_slices_equals_the_whole_pass(loss, blocks, monkeypatch):
     """daisy_bpr_staged_item_slices / _slice: the item pass cut at item boundaries (what a multi-GPU step pipelines
     its exchange under) writes the same counts and the same gQ up to the order in which a long segment's partial sums
-    meet (the cuts move the workgroup boundaries) - even cuts, cuts at popular items, empty slices."""
+    meet (the cuts move the workgroup boundaries) - even cuts, cuts at popular items, empty slices.  blocks = "1": the
+    edge chains of every slice in two levels (round 5) - the gradient form, slice-relative block numbering."""
     from daisyrec_amd import ops
+    if blocks:
+        monkeypatch.setenv("DAISY_EDGE_BLOCKS", blocks)
     U, I, d, B = 400, 257, 64, 20000
     rng = np.random.default_rng(3)
     tri = np.stack([rng.integers(0, U, B), (rng.zipf(1.3, B) % I), rng.integers(0, I, B)], 1).astype(np.int32)

@@ -123,3 +123,21 @@ def test_bench_byte_model_and_roofline_arithmetic():
     ach8, _ = bench.roofline_of(dict(r, dt=0.0090), 8)                                      # N > 1: per-GPU event time
     assert abs(ach8 - 1548 * B / 0.60e-3 / 1e9) < 1e-6 * ach8
     assert 0.0 < ach / bench.HBM_PEAK_GBS < 1.0
+
+
+def test_bench_cpu_leg_runs_and_reports_its_three_samples():
+    """bench.py's cpu_baseline (the only place outside tests/ and smoke() that may touch oracle/): the reference's op
+    composition on the host at the headline batch, the >= 30 steps of SURVEY 8(d) at a smaller batch of the same epoch,
+    and the reference's default batch - on a miniature here: the keys the driver's line carries, positive rates, the
+    step counts clamped to what the batch holds."""
+    import torch
+    import bench
+    g = torch.Generator().manual_seed(3)
+    U, I, d, B = 500, 300, 16, 8192
+    batches = [tuple(torch.randint(0, hi, (B,), generator=g) for hi in (U, I, I)) for _ in range(2)]
+    out = bench.cpu_baseline(U, I, d, B, batches, 1e-3)
+    assert out["kind"] == "port" and out["unit"] == "interactions/s" and out["value"] > 0 and out["cores"] >= 1
+    assert "2 SGD steps at B=8192" in out["sample"]
+    mid, small = out["steps30_b65536"], out["reference_default_batch"]
+    assert mid["batch"] == 8192 and mid["steps"] == 1 and mid["value"] > 0          # (a batch of 8192 rows holds one slice of its size)
+    assert small["batch"] == 256 and small["steps"] == 10 and small["value"] > 0
