@@ -1237,24 +1237,22 @@ __global__ void k_nmf_entries(const int32_t *__restrict__ key_sorted, const int3
     }
 }
 
-// GMF branch: per-row gradients  d/d uG[user] = dpred * Wp * iG[item],  d/d iG[item] = dpred * Wp * uG[user]
-__global__ __launch_bounds__(kBlock) void k_nmf_gmf_rows(daisy_neumf_params p, PairSrc src, int64_t R, int d,
-                                                         const float *__restrict__ dpred, float *__restrict__ gu,
-                                                         float *__restrict__ gi) {
-    const int lane = threadIdx.x % 16, group = threadIdx.x / 16;
-    const int64_t gstride = (int64_t)gridDim.x * (kBlock / 16);
-    for (int64_t r = (int64_t)blockIdx.x * (kBlock / 16) + group; r < R; r += gstride) {
+// GMF branch: d/d uG[user] = Wp * sum over the user's rows of dpred[r] * iG[item_r]  (and the mirror image for iG).  The
+// sum is a segmented reduction over the rows sorted by user whose SOURCE rows are the other table's - cache-resident - rows
+// and whose weights are dpred[r]: entry e -> (key = table row << 1, source row = the other id of row r, weight dpred[r]);
+// Wp multiplies the finished sum (k_nmf_table_commit).  Until round 5 the per-row products were materialised first (two
+// [R, d] fp32 arrays written by a kernel of their own and read back by the reductions: 0.4 GB per step at R = 524 288).
+__global__ void k_nmf_entries_gmf(const int32_t *__restrict__ key_sorted, const int32_t *__restrict__ val_sorted, int64_t R,
+                                  int64_t n_pad, PairSrc src, int side, const float *__restrict__ dpred,
+                                  uint32_t *__restrict__ ekey, uint2 *__restrict__ esu, float2 *__restrict__ w) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n_pad; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t q = e < R ? e : R - 1;               // an odd count is padded with a weightless copy of the last entry
+        const int64_t r = val_sorted[q];
         int64_t user, item;
         pair_ids(src, r, user, item);
-        const float dp = dpred[r];
-        for (int c = 4 * lane; c < d; c += 64) {              // 4 consecutive columns per lane (d % 4 == 0)
-            const float4 wp = *reinterpret_cast<const float4 *>(p.Wp + c);
-            const float4 ig = *reinterpret_cast<const float4 *>(p.iG + item * d + c);
-            const float4 ug = *reinterpret_cast<const float4 *>(p.uG + user * d + c);
-            const float w0 = dp * wp.x, w1 = dp * wp.y, w2 = dp * wp.z, w3 = dp * wp.w;
-            *reinterpret_cast<float4 *>(gu + r * (int64_t)d + c) = make_float4(w0 * ig.x, w1 * ig.y, w2 * ig.z, w3 * ig.w);
-            *reinterpret_cast<float4 *>(gi + r * (int64_t)d + c) = make_float4(w0 * ug.x, w1 * ug.y, w2 * ug.z, w3 * ug.w);
-        }
+        ekey[e] = (uint32_t)key_sorted[q] << 1;
+        esu[e] = make_uint2((uint32_t)e, (uint32_t)(side ? user : item));
+        w[e] = make_float2(e < R ? dpred[r] : 0.f, 0.f);
     }
 }
 
@@ -1263,7 +1261,8 @@ __global__ __launch_bounds__(kBlock) void k_nmf_table_commit(float *__restrict__
                                                              const float *__restrict__ w, int64_t rows, int width,
                                                              int32_t *__restrict__ ca, int ka, int32_t *__restrict__ cb,
                                                              int kb, float scale_b, const double *__restrict__ stats,
-                                                             float reg_1, float reg_2, int clear_counts) {
+                                                             float reg_1, float reg_2, int clear_counts,
+                                                             const float *__restrict__ colscale = nullptr) {
     const int lane = threadIdx.x % 16, group = threadIdx.x / 16;
     const int64_t gstride = (int64_t)gridDim.x * (kBlock / 16);
     auto inv = [&](int k) { const double n = stats[DAISY_NST_NORM + k]; return (n > 0.0) ? (float)((double)reg_2 / n) : 0.f; };
@@ -1274,7 +1273,7 @@ __global__ __launch_bounds__(kBlock) void k_nmf_table_commit(float *__restrict__
         for (int c = lane; c < width; c += 16) {
             const int64_t x = row * (int64_t)width + c;
             float v = 0.f;
-            if (sum) { v = sum[x]; sum[x] = 0.f; }
+            if (sum) { v = colscale ? sum[x] * colscale[c] : sum[x]; sum[x] = 0.f; }      // (GMF tables: Wp x the summed rows)
             if (na + nb > 0.f) { const float e = w[x]; v += fmaf(r2, e, r1 * sgn(e)); }
             if (v != 0.f) g[x] += v;
         }
@@ -1308,7 +1307,7 @@ struct daisy_neumf_ctx {
     void *sc_arena;
     int32_t *sc_ku, *sc_ki, *sc_val, *sc_ks, *sc_vs, *sc_cu, *sc_ci, *sc_cj;
     uint32_t *sc_ekey; uint2 *sc_esu; float2 *sc_w;
-    float *sc_gu, *sc_gi, *sc_sum, *sc_edge_vec, *sc_edge_b;
+    float *sc_sum, *sc_edge_vec, *sc_edge_b;
     int32_t *sc_edge_item, *sc_edge_whole;
     void *sc_tmp; size_t sc_tmp_bytes;
     int bf16;                                // daisy_neumf_ctx_set_precision: 0 fp32, 1 bf16 MFMA inputs, 2 bf16 storage
@@ -1514,7 +1513,7 @@ static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p,
 
 static int neumf_scatter_scratch(daisy_neumf_ctx *c) {
     if (c->sc_arena) return DAISY_OK;
-    const size_t R = (size_t)c->max_rows + 1, dm = (size_t)c->dm, d = (size_t)c->d;
+    const size_t R = (size_t)c->max_rows + 1, dm = (size_t)c->dm;
     const size_t rows_max = (size_t)(c->U > c->I ? c->U : c->I);
     size_t chunks = (size_t)segsum_chunks((int64_t)R + 1, c->dm);
     const size_t ch2 = (size_t)segsum_chunks((int64_t)R + 1, c->d);
@@ -1526,7 +1525,7 @@ static int neumf_scatter_scratch(daisy_neumf_ctx *c) {
     const size_t o_ku = take(R * 4), o_ki = take(R * 4), o_val = take(R * 4), o_ks = take(R * 4), o_vs = take(R * 4);
     const size_t o_cu = take((size_t)c->U * 4), o_ci = take((size_t)c->I * 4), o_cj = take((size_t)c->I * 4);
     const size_t o_ek = take((R + 1) * 4), o_es = take((R + 1) * 8), o_w = take((R + 1) * 8);
-    const size_t o_gu = take(R * d * 4), o_gi = take(R * d * 4), o_sum = take(rows_max * dm * 4);
+    const size_t o_sum = take(rows_max * dm * 4);
     const size_t o_ev = take(2 * chunks * dm * 4), o_ei = take(2 * chunks * 4), o_eb = take(2 * chunks * 4), o_ew = take(chunks * 4);
     const size_t o_tmp = take(c->sc_tmp_bytes);
     hipError_t e = hipMalloc(&c->sc_arena, off);
@@ -1540,7 +1539,7 @@ static int neumf_scatter_scratch(daisy_neumf_ctx *c) {
     c->sc_ks = (int32_t *)(b + o_ks); c->sc_vs = (int32_t *)(b + o_vs);
     c->sc_cu = (int32_t *)(b + o_cu); c->sc_ci = (int32_t *)(b + o_ci); c->sc_cj = (int32_t *)(b + o_cj);
     c->sc_ekey = (uint32_t *)(b + o_ek); c->sc_esu = (uint2 *)(b + o_es); c->sc_w = (float2 *)(b + o_w);
-    c->sc_gu = (float *)(b + o_gu); c->sc_gi = (float *)(b + o_gi); c->sc_sum = (float *)(b + o_sum);
+    c->sc_sum = (float *)(b + o_sum);
     c->sc_edge_vec = (float *)(b + o_ev); c->sc_edge_item = (int32_t *)(b + o_ei); c->sc_edge_b = (float *)(b + o_eb);
     c->sc_edge_whole = (int32_t *)(b + o_ew);
     c->sc_tmp = b + o_tmp;
@@ -1564,9 +1563,6 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
     const int64_t n_pad = R + (R & 1);
     hipLaunchKernelGGL(k_nmf_sort_keys, dim3(grid_for(R, kBlock * 2)), dim3(kBlock), 0, s, src, R, c->sc_ku, c->sc_ki,
                        c->sc_val, pointwise, c->sc_cu, c->sc_ci, c->sc_cj);
-    if (model != DAISY_NEUMF_MLP)
-        hipLaunchKernelGGL(k_nmf_gmf_rows, dim3(grid_for(R, kBlock / 16 * 2)), dim3(kBlock), 0, s, p, src, R, d, c->dpred,
-                           c->sc_gu, c->sc_gi);
     DAISY_LAUNCH_CHECK();
     for (int side = 0; side < 2; ++side) {            // 0: the user tables, 1: the item tables
         const int64_t rows = side ? c->I : c->U;
@@ -1613,10 +1609,10 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
                            (model != DAISY_NEUMF_GMF && !fact) ? c->sc_sum : (float *)nullptr, side ? p.iM : p.uM, rows, dm,
                            side ? c->sc_ci : c->sc_cu, side ? 3 : 1, (int32_t *)nullptr, 0, 0.f, stats, reg_1, reg_2, 0);
         // GMF table: source row = the materialised per-row gradient
-        if (model != DAISY_NEUMF_MLP) {
-            hipLaunchKernelGGL(k_nmf_entries, dim3(ge), dim3(kBlock), 0, s, c->sc_ks, c->sc_vs, R, n_pad, 1, 0, c->sc_ekey,
-                               c->sc_esu, c->sc_w);
-            rc = segsum_rows(side ? c->sc_gi : c->sc_gu, c->sc_w, c->sc_ekey, c->sc_esu, n_pad, d, c->sc_sum, c->sc_edge_vec,
+        if (model != DAISY_NEUMF_MLP) {          // source rows: the OTHER table's, weights dpred (k_nmf_entries_gmf)
+            hipLaunchKernelGGL(k_nmf_entries_gmf, dim3(ge), dim3(kBlock), 0, s, c->sc_ks, c->sc_vs, R, n_pad, src, side, c->dpred,
+                               c->sc_ekey, c->sc_esu, c->sc_w);
+            rc = segsum_rows(side ? p.uG : p.iG, c->sc_w, c->sc_ekey, c->sc_esu, n_pad, d, c->sc_sum, c->sc_edge_vec,
                              c->sc_edge_item, c->sc_edge_b, c->sc_edge_whole, s);
             if (rc) return rc;
         }
@@ -1624,7 +1620,7 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
         hipLaunchKernelGGL(k_nmf_table_commit, dim3(gt), dim3(kBlock), 0, s, side ? g.iG : g.uG,
                            (model != DAISY_NEUMF_MLP) ? c->sc_sum : (float *)nullptr, side ? p.iG : p.uG, rows, d,
                            side ? c->sc_ci : c->sc_cu, side ? 2 : 0, side ? c->sc_cj : (int32_t *)nullptr, 4, 2.f, stats,
-                           reg_1, reg_2, 1);
+                           reg_1, reg_2, 1, (model != DAISY_NEUMF_MLP) ? p.Wp : (const float *)nullptr);
         DAISY_LAUNCH_CHECK();
     }
     return DAISY_OK;
