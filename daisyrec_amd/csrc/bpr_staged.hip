@@ -1734,6 +1734,14 @@ template <class C>
 __device__ __forceinline__ void add_edge_records(Row<C> &acc, float &sp, float &sn, float &sc, const float *__restrict__ vec,
                                                  const float *__restrict__ cnt, int64_t first, int64_t step, int64_t count,
                                                  int lane, int d) {
+    if (count == 1) {                       // (the common chain at uniform ids: one link - one load, not four clamped ones)
+        Row<C> t;
+        t.load(vec + first * d, lane, d);
+#pragma unroll
+        for (int e = 0; e < C::NE; ++e) acc.v[e] += t.v[e];
+        sp += cnt[4 * first]; sn += cnt[4 * first + 1]; sc += cnt[4 * first + 2];
+        return;
+    }
     for (int64_t j = 0; j < count; j += 4) {
         Row<C> t[4];
         float c0[4], c1[4], c2[4];
