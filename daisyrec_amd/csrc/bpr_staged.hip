@@ -1068,8 +1068,9 @@ __global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((C::NE <= 4
             // ---- user gradient over the runs of equal users; the staged rows leave on the way
             int32_t cur_user = user_first;
             Row<C> pcur = pr[0];                     // pre-step P row of the current run's user
-            Row<C> mcur = pm[0], vcur = pv[0];       // (Adam) and its moments
+            Row<C> mcur, vcur;                       // (Adam) and its moments
             if constexpr (ADAM) {
+                mcur = pm[0]; vcur = pv[0];
                 // the moment registers are "used" here, in front of the first store of this chunk: the compiler's wait
                 // for their gathers happens now, and the commits below wait for nothing
 #pragma unroll
@@ -1366,11 +1367,13 @@ __device__ __forceinline__ void item_commit(float *__restrict__ Qo, float *__res
 // MODE (see k_staged_user): premul - entry weight +/-1; plain - the sample's (dL/dpos, dL/dneg) gathered from coef;
 // point - weight 1 (a negative slot, which only the sorted layout's point-wise batches have, is inert: weight 0, not
 // counted).
+// (Occupancy floor: four waves per SIMD; two for the Adam and three-launch forms; three for the sparse flavour of rows of
+// 16 floats per lane - d > 128 -, whose two Q rows per run do not fit 128 registers.)
 // MERGED (three-launch form, see MergedJob; SGD in place only): the launch also carries the user pass's edge chains and
 // the reduction of its sums, as workgroups behind the item pass's own, and every item workgroup derives the norms (and
 // whether this step's loss is finite) from the user pass's per-workgroup sums itself.
 template <class C, int BLK, int MODE, bool APPLY, bool ADAM, bool SPARSE, bool MERGED = false>
-__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((ADAM || MERGED) ? 2 : DAISY_ITEM_WAVES, 8))) void k_staged_item(const float *__restrict__ stage,
+__global__ __launch_bounds__(BLK) __attribute__((amdgpu_waves_per_eu((ADAM || MERGED) ? 2 : ((SPARSE && C::NE > 8) ? 3 : DAISY_ITEM_WAVES), 8))) void k_staged_item(const float *__restrict__ stage,
                                                         const float2 *__restrict__ coef, StreamView v, int d,
                                                         float *__restrict__ Qo, float *__restrict__ cnt_out,
                                                         const double *__restrict__ stats, RowOpt opt,
