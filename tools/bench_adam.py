@@ -18,7 +18,7 @@ ADAM_BYTES = 72 * 64 + 12
 SHAPES = (("configs[1] shapes (1M x 100K)", 1_000_000, 100_000, 50_000_000, 1 << 21),
           ("configs[2] shapes (10M x 1M)", 10_000_000, 1_000_000, 50_000_000, 1 << 21))
 MODES = tuple(os.environ.get("ADAM_MODES", "dense,lazy,staged").split(","))          # e.g. ADAM_MODES=staged
-for name, U, I, nnz, B in SHAPES[:int(os.environ.get("ADAM_SHAPES", "2"))]:
+for name, U, I, nnz, B in SHAPES[int(os.environ.get("ADAM_FIRST", "0")):int(os.environ.get("ADAM_SHAPES", "2"))]:
     d = 64
     triples = bench.synth_triples(U, I, nnz, 2022, dev)
     n = triples.shape[0]
