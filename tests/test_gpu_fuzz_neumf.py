@@ -1,0 +1,135 @@
+"""Randomised differential test of the NeuMF step (csrc/neumf.hip: daisy_neumf_step_grads): random table sizes, factor
+counts, tower depths, batch sizes, the three model types, the five losses - loss and EVERY parameter's gradient of the fp32
+parity mode against the numpy oracle (NeuMFRecommender.py:118-169), and the bf16-storage mode with the first layer
+through the embedding tables (round 5) against the fp32 mode where it applies (fewer distinct table rows than rows in
+the step).  Case k is a pure function of (DAISY_FUZZ_SEED, k); DAISY_FUZZ_CASES widens the campaign
+(profiles/r05_fuzz.txt)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bpr_mf_numpy as O
+from oracle import neumf_numpy as NO
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+CASES = int(os.environ.get("DAISY_FUZZ_CASES", "36"))
+SEED = int(os.environ.get("DAISY_FUZZ_SEED", "2022"))
+
+
+def _log_uniform(rng, lo, hi):
+    return int(round(float(np.exp(rng.uniform(np.log(lo), np.log(hi))))))
+
+
+def draw_case(k):
+    rng = np.random.default_rng([SEED, k, 15])
+    d = int(rng.choice([4, 8, 16, 32, 64]))
+    L = int(rng.choice([1, 2, 3, 3, 4]))
+    model = str(rng.choice(["NeuMF", "NeuMF", "NeuMF", "MLP", "GMF"]))
+    dm = d << (L - 1)
+    U, I = _log_uniform(rng, 1, 7000), _log_uniform(rng, 1, 5000)
+    B = max(1, min(_log_uniform(rng, 1, 20000), 3_000_000 // dm))
+    loss = str(rng.choice(["BPR", "BPR", "HL", "TL", "CL", "SL"]))
+    reg = [(0.0, 0.0), (1e-3, 1e-3), (0.01, 0.0), (0.0, 5e-3)][int(rng.integers(0, 4))]
+    scale = float(rng.choice([0.05, 0.1]))
+    return dict(k=k, d=d, L=L, model=model, U=U, I=I, B=B, loss=loss, reg=reg, scale=scale, rng=rng)
+
+
+def _shapes(U, I, d, L, model):
+    dm = d << (L - 1)
+    shapes = {"uG": (U, d), "iG": (I, d), "uM": (U, dm), "iM": (I, dm), "Wp": (1, 2 * d if model == "NeuMF" else d), "bp": (1,)}
+    w = 2 * dm
+    for l in range(1, L + 1):
+        shapes[f"W{l}"], shapes[f"b{l}"] = (w // 2, w), (w // 2,)
+        w //= 2
+    return shapes
+
+
+def _used(model, L):
+    """the parameters a model type's step moves: the regularisers of NeuMFRecommender.py:149-167 name all four tables
+    whatever the model type; the tower's weights only where there is a tower (the others keep a zero gradient: checked)"""
+    names = ["uG", "iG", "uM", "iM"]
+    if model != "GMF":
+        names += [f"{t}{l}" for l in range(1, L + 1) for t in ("W", "b")]
+    return names + ["Wp", "bp"]
+
+
+@pytest.mark.parametrize("k", range(CASES))
+def test_random_neumf_step_matches_the_oracle(k, monkeypatch):
+    from daisyrec_amd import ops
+    c = draw_case(k)
+    rng, d, L, model, U, I, B = c["rng"], c["d"], c["L"], c["model"], c["U"], c["I"], c["B"]
+    tag = {key: v for key, v in c.items() if key != "rng"}
+    shapes = _shapes(U, I, d, L, model)
+    p_np = {key: (rng.standard_normal(s) * c["scale"]).astype(np.float32) for key, s in shapes.items()}
+    lt = O.LOSS_IDS[c["loss"]]
+    point = c["loss"] in ("CL", "SL")
+    u, i = rng.integers(0, U, B).astype(np.int32), rng.integers(0, I, B).astype(np.int32)
+    j = (rng.integers(0, 2, B) if point else rng.integers(0, I, B)).astype(np.int32)
+    reg_1, reg_2 = c["reg"]
+    R = B if point else 2 * B
+    want_loss, want = NO.neumf_grad(p_np, u, i, j, reg_1, reg_2, L, lt, model)
+    idx = [torch.as_tensor(x).to(DEV) for x in (u, i, j)]
+
+    def run(level, fact=None):
+        if fact is not None:
+            monkeypatch.setenv("DAISY_NMF_FACT", fact)
+        p = {key: torch.as_tensor(v).to(DEV) for key, v in p_np.items()}
+        grads = {key: torch.zeros_like(v) for key, v in p.items()}
+        ctx = ops.NeumfContext(R, d, L, U, I, model=model)
+        ctx.set_precision(level)
+        ctx.step_grads(p, grads, *idx, lt, reg_1, reg_2)
+        out = float(ctx.stats[11].cpu()), {key: v.cpu().numpy() for key, v in grads.items()}
+        ctx.close()
+        return out
+
+    got_loss, got = run(0)
+    assert abs(got_loss - want_loss) <= 1e-5 * abs(want_loss) + 1e-6, (tag, got_loss, want_loss)
+    # Kinks.  A ReLU whose pre-activation is within fp32 round-off of 0 (or a hinge within round-off of its kink) is open in
+    # one precision and shut in the other - ~1e-7 of a step's units, i.e. 0.1 ... 1 per large case.  ONE sample's term then
+    # differs: first-hand in one row (unit) of that layer's W and b and in the sample's rows of the tables - up to a few
+    # per cent of those elements -, second-hand (through that sample's dx) thinly in everything below.  So a case is held
+    # to the strict tolerance unless some element leaves it; then at most three rows per parameter may be further than ten
+    # times the tolerance (recorded with their indices - profiles/r05_fuzz.txt: one unit, one user, one item per case,
+    # interior rows: not what a fault of the kernels would pick) and everything else stays within ten times
+    worst, kinks, errs = 0.0, [], {}
+    for key in shapes:
+        w64 = want[key]
+        if key not in _used(model, L):
+            assert not got[key].any() and not w64.any(), (tag, key)
+            continue
+        # fp32 products of chains of GEMMs against fp64: errors relative to the gradient's own size, element by element
+        # up to the sums' round-off (a BPR bias gradient cancels pairwise to exactly zero in fp64 and to round-off here)
+        tol = 3e-4 * np.abs(w64).max() + 3e-6 * (1 + np.sqrt(R))
+        err = np.abs(got[key] - w64)
+        err = err.reshape(err.shape[0], -1) if err.ndim == 2 and err.shape[0] > 1 else err.reshape(-1, 1)
+        errs[key] = (err, tol, float(np.abs(w64).max()))
+    strict = all(float(e.max()) <= tol for e, tol, _ in errs.values())
+    for key, (err, tol, top) in errs.items():
+        if strict:
+            worst = max(worst, float(err.max()) / tol)
+            continue
+        rows = np.flatnonzero(err.max(1) > tol)
+        far = np.flatnonzero(err.max(1) > 10.0 * tol)
+        assert len(far) <= 3 and err.max() <= 0.1 * top + 10.0 * tol, (tag, key, far[:8].tolist(), float(err.max()), tol)
+        if len(rows):
+            kinks.append((key, rows[:4].tolist(), len(rows), err.shape[0], round(float(err.max() / top), 5)))
+    if kinks:
+        assert model != "GMF" or c["loss"] == "HL", (tag, kinks)            # (no ReLU, no hinge: nothing has a kink)
+
+    # the throughput mode: bf16 storage, and - where the step has more rows than the tables have distinct ones - the first
+    # layer through the tables; against the fp32 mode of the same library (bf16 keeps 8 bits: a loose, whole-tensor check)
+    if model != "GMF" and d >= 8:
+        lb, gb = run(2, "1")
+        assert abs(lb - got_loss) <= 5e-3 * abs(got_loss) + 1e-3, (tag, lb, got_loss)
+        for key in _used(model, L):
+            n32 = np.linalg.norm(got[key])
+            if n32 < 1e-6 * max(1.0, np.sqrt(got[key].size)) * R:       # (all but cancelled: nothing to compare a direction with)
+                continue
+            e = np.linalg.norm(gb[key] - got[key]) / n32
+            assert e < 0.3, (tag, key, float(e))
+    if os.environ.get("DAISY_FUZZ_LOG"):
+        with open(os.environ["DAISY_FUZZ_LOG"], "a") as f:
+            f.write(f"{tag} R={R} worst err/tol={worst:.3f} kinks={kinks}\n")
