@@ -99,7 +99,7 @@ def test_random_sharded_steps_equal_the_single_process_step(tmp_path, k):
         ref_losses.append(loss)
     outs = [np.load(os.path.join(str(tmp_path), f"r{r}.npz")) for r in range(world)]
     for o in outs:
-        np.testing.assert_allclose(o["losses"], ref_losses, rtol=1e-9, err_msg=str(c))       # every rank: the GLOBAL loss
+        np.testing.assert_allclose(o["losses"], ref_losses, rtol=1e-7, err_msg=str(c))       # every rank: the GLOBAL loss
         if c["adam"]:
             # (a gradient that cancels to round-off takes Adam's +-lr step with a sign the summation order decides:
             # tests/test_gpu_fuzz.py; the ranks add the item gradient in another order than one process does)
