@@ -141,3 +141,25 @@ def test_bench_cpu_leg_runs_and_reports_its_three_samples():
     mid, small = out["steps30_b65536"], out["reference_default_batch"]
     assert mid["batch"] == 8192 and mid["steps"] == 1 and mid["value"] > 0          # (a batch of 8192 rows holds one slice of its size)
     assert small["batch"] == 256 and small["steps"] == 10 and small["value"] > 0
+
+
+def test_auto_exchange_slices_properties():
+    """sharding.auto_exchange_slices (`slices='auto'`): a power of two up to 16, one without RCCL or without peers, never
+    a block under 1024 rows per owner and slice nor a slice under ~100 us of item pass, one slice where the exchange is
+    under a tenth of the pass, and a slower bus never asks for fewer"""
+    from daisyrec_amd.sharding import auto_exchange_slices as f
+    rng = np.random.default_rng(4)
+    for _ in range(400):
+        I = int(np.exp(rng.uniform(np.log(10), np.log(5e6))))
+        d = int(rng.choice([8, 32, 64, 128, 256]))
+        world = int(rng.integers(1, 17))
+        B = int(np.exp(rng.uniform(np.log(1), np.log(3e7))))
+        s = f(I, d, world, B)
+        assert s in (1, 2, 4, 8, 16)
+        assert f(I, d, world, B, backend="gloo") == 1 and f(I, d, 1, B) == 1
+        if s > 1:
+            assert I // (world * s) >= 1024 and 2.0 * B * 4.0 * d / 5.0e12 / s >= 100e-6
+        t_ex = 2.0 * (world - 1) / world * I * (d + 2) * 4.0 / 300e9
+        if t_ex < 0.1 * (2.0 * B * 4.0 * d / 5.0e12):
+            assert s == 1
+        assert f(I, d, world, B, bus_gbs=50.0) >= f(I, d, world, B, bus_gbs=2000.0)      # a slower bus never asks for fewer
