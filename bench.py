@@ -48,6 +48,81 @@ HBM_PEAK_GBS = 8000.0                                        # MI355X_MICROARCH.
 SECONDARY_NNZ = 100_000_000                                  # interactions of the N=1 `secondary` leg (configs[2] tables)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# The printed line.  The driver keeps an 8 KB tail of stdout: the line carries numbers and short keys only (the prose that
+# explains each leg lives in DESIGN.md section 6 under the same names) and prints the `extra` legs BEFORE `secondary` and
+# `cpu_baseline`; the verbose record of the same run goes to gpurun_out/bench_full.json (scratch, not tracked).
+# ------------------------------------------------------------------------------------------------------------------
+_KEEP_STR = {"metric", "unit", "dtype", "data", "scaling", "bound", "kind", "optimizer", "loss", "item_mode", "parallelism",
+             "id_distribution", "plan_layout", "error", "precision", "exchange", "rccl", "workload", "sample"}
+
+
+def _sig(x, n=6):
+    return float(f"{x:.{n}g}") if isinstance(x, float) and x == x and abs(x) != float("inf") else x
+
+
+def _shrink(x, key=""):
+    """numbers rounded to 6 significant digits; strings over 72 characters are dropped unless their key is a name the
+    contract asks for, in which case they are cut to 120 (`error` strings to 300)"""
+    if isinstance(x, dict):
+        out = {}
+        for k, v in x.items():
+            if isinstance(v, str) and len(v) > 72:
+                if k not in _KEEP_STR:
+                    continue
+                v = v[:300 if k == "error" else 120]
+            if k in ("traceback", "repeats_note", "speedup_note", "six_x_budget"):
+                continue
+            out[k] = _shrink(v, k)
+        return out
+    if isinstance(x, (list, tuple)):
+        return [_shrink(v, key) for v in x]
+    return _sig(x)
+
+
+def _leg(e):
+    """one `extra` leg -> {"v": value, "ms": ms per step, "frac": roofline.frac, "B": batch, ...}"""
+    if not isinstance(e, dict) or "error" in e:
+        return _shrink(e)
+    ms = e.get("ms_per_step", e.get("us_per_step", 0.0) / 1e3 if "us_per_step" in e else None)
+    out = {"v": e.get("value"), "unit": e.get("unit"), "B": e.get("batch"), "steps": e.get("steps"), "ms": ms}
+    rf = e.get("roofline")
+    if isinstance(rf, dict):
+        out.update(bound=rf.get("bound"), frac=rf.get("frac"), achieved=rf.get("achieved"), peak=rf.get("peak"))
+    if "points" in e:           # per point: [batch, precision / tag, value, ms per step, bound, frac, dispatches per step, MB per step]
+        out["points"] = [[q.get("batch"), q.get("precision", q.get("tag")), q.get("value"), q.get("ms_per_step"),
+                          (q.get("roofline") or {}).get("bound"), (q.get("roofline") or {}).get("frac"),
+                          q.get("dispatches_per_step"), q.get("algorithmic_MB_per_step")] for q in e["points"]]
+    for k in ("spmm", "wire_bytes_per_step", "small_batch"):
+        if k in e:
+            out[k] = e[k]
+    cb = e.get("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu"] = {k: cb.get(k) for k in ("value", "unit", "cores", "kind", "batch", "steps") if k in cb}
+    return _shrink({k: v for k, v in out.items() if v is not None})
+
+
+def emit(out):
+    """print the ONE JSON line (compact); keep the verbose record beside it"""
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_full.json"), "w") as f:
+            f.write(json.dumps(out) + "\n")
+    except OSError:
+        pass
+    special = ("extra", "secondary", "cpu_baseline", "repeats")
+    line = _shrink({k: v for k, v in out.items() if k not in special})
+    if "repeats" in out and isinstance(line.get("roofline"), dict):
+        line["roofline"]["repeats"] = _shrink(out["repeats"])
+    if "extra" in out:           # the legs before the two objects the contract asks for (a cut tail loses the least)
+        line["extra"] = {n: _leg(e) for n, e in out["extra"].items()}
+    tail = {k: _shrink(out[k]) for k in ("secondary", "cpu_baseline") if k in out}
+    line.update(tail)
+    txt = json.dumps(line, separators=(",", ":"))
+    line["line_bytes"] = len(txt)
+    print(json.dumps(line, separators=(",", ":")), flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -199,7 +274,7 @@ def free_data(data):
     torch.cuda.empty_cache()
 
 
-def measure(a, data, rank, world, dev, B, slices, steps, warmup, want_cpu_batches=0, repeats=1):
+def measure(a, data, rank, world, dev, B, slices, steps, warmup, want_cpu_batches=0, repeats=1, exchange="dense"):
     """warmup + `steps` timed steps of batch size B (per rank) over `data`; max over ranks of the wall time.
     repeats > 1: that many timed regions of `steps` steps, each bracketed like the first; the result is the region
     with the MEDIAN wall time, the others are listed in `repeats`."""
@@ -211,7 +286,8 @@ def measure(a, data, rank, world, dev, B, slices, steps, warmup, want_cpu_batche
     lr, reg = 0.01, a.reg
     ctx = ops.BprContext(B, d, U_loc, I, device=dev)
     item_mode = ops.ITEM_MODES[a.item_mode]
-    trainer = UserShardedBprTrainer(ctx, P, Q, 0, lr, reg, reg, item_mode=item_mode, slices=slices or "auto") if world > 1 else None
+    trainer = (UserShardedBprTrainer(ctx, P, Q, 0, lr, reg, reg, item_mode=item_mode, slices=slices or "auto", exchange=exchange)
+               if world > 1 else None)
     if trainer is not None:
         slices = trainer.slices                # (0 / 'auto' resolved: the same on every rank by construction)
     if trainer is not None:
@@ -307,7 +383,8 @@ def measure(a, data, rank, world, dev, B, slices, steps, warmup, want_cpu_batche
            "dt": dt, "lr": lr, "reg": reg, "step_ms": step_ms, "plan_kind": data["plan_kind"], "cpu_batches": cpu_batches,
            "plan_bytes": sum(p.nbytes for p in plans), "index_bytes": index.nbytes if index is not None else 0,
            "staged": trainer.staged if trainer is not None else (a.item_mode == "fused"), "slices": slices,
-           "split_ms": split, "loss_sum": loss_sum, "all_dt": all_dt}
+           "split_ms": split, "loss_sum": loss_sum, "all_dt": all_dt,
+           "wire_bytes": dict(trainer.wire_bytes) if trainer is not None else None}
     ctx.close()
     for p in plans:
         p.close()
@@ -773,6 +850,22 @@ def main():
                 fb = max(1, data["n"] // min(Bl, data["n"]))
                 sweep.append(guarded(f"sweep point B_local={Bl} slices={sl}", measure, a, data, rank, world, dev, Bl, sl,
                                      min(fb, 16), 2))
+    xchg = []
+    if world > 1 and wl in ("c3", "tiny") and not a.no_sweep and a.item_mode == "fused" and (a.batch is None or wl == "tiny"):
+        # the reference's batch sizes under the sharded step (basic.yaml:23: B = 256 ... 65 536): the dense exchange moves
+        # the whole item table for a few thousand touched rows, the touched-rows exchange (sharding.py, round 6) only their
+        # union - wire bytes per step and rank of both forms, and the measured step of each (no speed-up claim is made
+        # for either: this is the first time they meet more than one rank)
+        for Bl in ((4096, 32768) if wl == "c3" else (256, 2048)):
+            for mode in ("dense", "sparse"):
+                fb = max(1, data["n"] // min(Bl, data["n"]))
+                rr = guarded(f"exchange point B_local={Bl} {mode}", measure, a, data, rank, world, dev, Bl, 1, min(fb, 16), 2,
+                             0, 1, mode)
+                xchg.append(rr if "error" in rr else
+                            {"batch_per_gpu": rr["B"], "exchange": mode, "ms_per_step": rr["dt"] / rr["steps"] * 1e3,
+                             "value": rr["steps"] * rr["B"] * world / rr["dt"], "wire_bytes_per_step_and_rank": rr["wire_bytes"][mode],
+                             "auto_would_pick": __import__("daisyrec_amd.sharding", fromlist=["x"]).auto_item_exchange(
+                                 data["I"], data["d"], world, rr["B"])})
     free_data(data)
 
     secondary = None
@@ -914,6 +1007,7 @@ def main():
             out["pipelined_exchange_failed"] = main_note
         if world > 1:
             out["distributed"] = diag
+            out["item_exchange"] = {"main_point_wire_bytes_per_step_and_rank": r.get("wire_bytes"), "small_batch_points": xchg}
             if r["split_ms"] is not None:
                 out["step_split_ms"] = {"compute": r["split_ms"][0], "exposed_exchange": r["split_ms"][1],
                                         "note": "HIP events on the step's stream around the item exchange (rank 0): "
@@ -968,7 +1062,7 @@ def main():
             out["cpu_baseline"] = r["cpu_result"]
         elif r["cpu_batches"]:
             out["cpu_baseline"] = cpu_baseline(r["U"], r["I"], d, B, r["cpu_batches"], r["reg"])
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -2171,7 +2171,13 @@ static int staged_item(daisy_bpr_ctx *ctx, int loss_type, float *Qo, float *cnt_
         constexpr int win_rows = (kItemWinFloats * BLK / kBlock) / (C::NE * C::LPR);
         bool sparse = apply && !adam && (double)v.E * win_rows < (double)E_dense * (double)ctx->I;
         if (tune_sparse >= 0) sparse = apply && !adam && tune_sparse != 0;
-        if (sparse && (v.E + E_sparse - 1) / E_sparse > edge_cap) sparse = false;
+        if (sparse && (v.E + E_sparse - 1) / E_sparse > edge_cap) {
+            // (cannot happen with the context's own sizing, which counts StagedItemCfg<C, 128, true>::E; a build with
+            // another DAISY_ITEM_BLK / run length says so once instead of silently running the slower flavour)
+            static bool warned = false;
+            if (!warned) { warned = true; fprintf(stderr, "daisyrec: staged item pass: %lld sparse chunks exceed the %lld edge records of the context - dense flavour\n", (long long)((v.E + E_sparse - 1) / E_sparse), (long long)edge_cap); }
+            sparse = false;
+        }
         const int chunk_e = sparse ? E_sparse : E_dense;
         const int64_t nchunks = (v.E + chunk_e - 1) / chunk_e;
         if (nchunks > edge_cap) { overflow = true; return DAISY_OK; }

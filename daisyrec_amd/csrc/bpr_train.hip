@@ -1560,7 +1560,11 @@ int daisy_bpr_ctx_create(daisy_bpr_ctx **out, int64_t max_batch, int32_t d, int6
         using C = decltype(cfg);
         const size_t cu = ((size_t)max_batch + UserRunCfg<C>::E - 1) / UserRunCfg<C>::E;
         const size_t ci = (2 * (size_t)max_batch + RunCfg<C>::E - 1) / RunCfg<C>::E;
-        const size_t cs = ((size_t)max_batch + C::GROUPS_PER_BLOCK - 1) / C::GROUPS_PER_BLOCK;   // staged passes: >= 128 threads, RUN >= 2
+        // staged passes: the item pass runs 128-thread workgroups (kStagedItemBlock) over 2 B entries, and its sparse
+        // flavour keeps 4 (rows of <= 8 floats per lane) or 2 (wider rows) entries per lane group in flight: that is
+        // its smallest chunk (StagedItemCfg<C, 128, true>::E)
+        const size_t e_min = (size_t)(128 / C::LPR) * (C::NE <= 8 ? 4 : 2);
+        const size_t cs = (2 * (size_t)max_batch + e_min - 1) / e_min;
         max_chunks = (cu > ci ? cu : ci);
         if (cs > max_chunks) max_chunks = cs;
         max_chunks += 2;

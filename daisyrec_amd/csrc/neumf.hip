@@ -1591,14 +1591,15 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
             b.B = side ? p.iM : p.uM; b.sbn = 1; b.sbk = dm;
             // (k in slices of 128 table rows, side by side in the workspace, added in slice order: enough workgroups, no
             // fp32 atomics on shared elements)
-            b.M = n1; b.N = dm; b.K = rows; b.k_chunk = 128;
-            const int bsplits = (int)((rows + 127) / 128);
+            // slices of 128 table rows while the workspace holds them; a table with more rows than that (the workspace is
+            // sized by the step's rows, not by the tables') takes proportionally longer slices - never an error mid-step
             rc = neumf_need_det_ws(c);
             if (rc) return rc;
-            if ((size_t)bsplits * (size_t)n1 * (size_t)dm > c->det_ws_floats) {
-                set_error("neumf: the reduction workspace is too small for the first layer's table products");
-                return DAISY_ERR_STATE;
-            }
+            const int64_t cap = (int64_t)(c->det_ws_floats / ((size_t)n1 * (size_t)dm));      // >= 2: the workspace holds a [width1][width0] slice
+            int64_t kc = 128;
+            if ((rows + kc - 1) / kc > cap) kc = (((rows + cap - 1) / cap) + 127) / 128 * 128;
+            b.M = n1; b.N = dm; b.K = rows; b.k_chunk = kc;
+            const int bsplits = (int)((rows + kc - 1) / kc);
             b.C = c->det_ws; b.ldc = dm; b.slice_stride = (int64_t)n1 * dm;
             launch_gemm<EPI_ATOMIC>(b, s);
             hipLaunchKernelGGL(k_reduce_slices_2d, dim3(grid_for((int64_t)n1 * dm, kBlock, 2048)), dim3(kBlock), 0, s, c->det_ws,

@@ -166,6 +166,11 @@ class GeneralRecommender(AbstractRecommender):
         # is worth cutting (RCCL, exchange bytes / assumed bus rate against the pass); an integer forces the count
         xs = config.get("exchange_slices", "auto")
         self.exchange_slices = "auto" if str(xs).lower() == "auto" else int(xs)
+        # config['item_exchange'] (sharded SGD fits): 'auto' (default; sharding.auto_item_exchange), 'dense' (the whole item
+        # table per step) or 'sparse' (the union of the ranks' touched rows - what pays at the reference's batch sizes)
+        self.item_exchange = str(config.get("item_exchange", "auto")).lower()
+        if self.item_exchange not in ("auto", "dense", "sparse"):
+            raise ValueError(f"config['item_exchange']={self.item_exchange!r}: expected 'auto', 'dense' or 'sparse'")
         # MF + Adam: the exact lazy row updates of ops.LazyAdam.  'auto': when a step references fewer rows than the
         # tables have (3B < U + I; measured: 1.55x at 10M x 1M with B = 2M, but 0.9x at 1M x 100K with B = 1M, where
         # every step touches most rows anyway and the dense streaming pass is cheaper than row-wise claims)
@@ -269,8 +274,16 @@ class GeneralRecommender(AbstractRecommender):
         trainer = UserShardedBprTrainer(ctx, P_loc, Q, lo, self.lr, self.reg_1, self.reg_2, loss_type=loss_id,
                                         item_mode=ops.ITEM_MODES["fused"], slices=self.exchange_slices,
                                         auto_batch=max(1, B // world),     # (the context's batch is the GLOBAL one here)
+                                        # SGD on the staged protocol: only the item rows a step touched travel when
+                                        # 2 B << I (sharding.auto_item_exchange: a pure function of I, d, world, B)
+                                        exchange=self.item_exchange if (opt == "sgd" and not dense) else "dense", global_batch=B,
                                         adam_steps=(self.epochs * ((n + B - 1) // B)) if (opt == "adam" and not dense) else 0,
                                         dense_opt=ops.DenseOptimizer(opt, self.lr) if dense else None)
+        self.logger.info("sharded HIP fit over %d ranks: item exchange %s (%d bytes per step and rank on the wire; the other "
+                         "form would move %d), %d slice(s)", world, trainer.wire_bytes["used"],
+                         trainer.wire_bytes[trainer.wire_bytes["used"]],
+                         trainer.wire_bytes["dense" if trainer.wire_bytes["used"] == "sparse" else "sparse"], trainer.slices)
+        self.last_exchange = dict(trainer.wire_bytes, slices=trainer.slices)
         acc = torch.zeros(2, dtype=torch.float64, device=P.device)
         nb = (n + B - 1) // B
         last_loss = 0.0
@@ -332,6 +345,14 @@ class GeneralRecommender(AbstractRecommender):
     def fit(self, train_loader):
         """AbstractRecommender.py:103-137, natively: one enqueue per epoch, one host
         sync per epoch (for the loss the early-stop rule needs)."""
+        pitch = getattr(self, "row_pitch", None)
+        try:
+            return self._fit(train_loader)
+        finally:
+            if pitch is not None:
+                self.row_pitch = pitch          # (a sharded fit trains without the automatic pitch: not a lasting change)
+
+    def _fit(self, train_loader):
         self._require_device()
         self.to(self.device)
         opt = self._resolve_optimizer()

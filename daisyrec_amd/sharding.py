@@ -36,6 +36,19 @@ B_local interactions of compute; DESIGN.md section 5 has the budget.
 owner update, all-gather - runs on a side stream while the next range is reduced.  Ownership then interleaves: rank
 r owns the r-th block of every range.  Every rank must use the same S.
 
+TOUCHED-ROWS exchange (`exchange='sparse'`; 'auto' = `auto_item_exchange`; SURVEY.md section 8e "send only touched rows
+(index-union + values) when 2B << I", north_star "only where users overlap items").  A step of B_local samples per rank
+touches at most 2 B_local item rows per rank; when world x 2 B_local << I the dense exchange above moves I x 264 B for a
+few thousand rows that changed.  Instead, with static shapes and no host synchronisation:
+
+    ids_r        = the rank's touched item ids (ascending, padded with I)        | all_gather (world x cap_local x 4 B)
+    union        = sorted distinct ids of all ranks - the SAME list on every rank (bit-identical replicas need that)
+    buf[k]       = [gQ[union_k] | cnt[union_k]]   (zero rows for the padding)    | reduce_scatter (cap_union x (d+2) floats)
+    owner apply  rank r: SGD on union rows [r*rows, (r+1)*rows) of Q            | all_gather (cap_union x d floats)
+    Q[union_k]   = the gathered rows; the rank's touched rows of gQ / cnt are re-zeroed
+
+SGD only: under torch's dense Adam every row of Q moves in every step (no row is untouched), so Adam keeps the dense exchange.
+
 PHASE protocol (item modes 'chunked' / 'sorted', or a backend without the staged phases):
 forward -> all_reduce(stats) -> item_grad -> all_reduce(gQ) overlapped with user_sgd -> dense
 item_sgd_apply.  Kept for the modes the staged step does not cover.
@@ -96,6 +109,45 @@ def auto_exchange_slices(item_num: int, d: int, world_size: int, batch_per_rank:
     return s_
 
 
+def sparse_exchange_caps(item_num: int, world_size: int, max_local_batch: int, global_batch: int | None = None):
+    """(cap_local, cap_union, rows_per_owner) of the touched-rows exchange: a rank whose share of a step is at most
+    `max_local_batch` samples touches at most twice that many distinct items (positives and negatives); the union over
+    the ranks at most 2 x `global_batch` (default: world x max_local_batch), never more than I; the union is cut into
+    `world` equal owner blocks (padded)."""
+    W = int(world_size)
+    cap_local = max(1, min(int(item_num), 2 * int(max_local_batch)))
+    gb = int(global_batch) if global_batch else W * int(max_local_batch)
+    cap_union = max(1, min(int(item_num), 2 * gb, W * cap_local))
+    rows = (cap_union + W - 1) // W
+    return cap_local, rows * W, rows
+
+
+def item_exchange_bytes(item_num: int, d: int, world_size: int, max_local_batch: int, global_batch: int | None = None,
+                        slices: int = 1):
+    """bytes a rank puts on the wire per step for the item exchange: {'dense': ..., 'sparse': ...} (ring collectives:
+    (N-1)/N of the payload per rank for an all-gather or a reduce-scatter)"""
+    W = int(world_size)
+    if W <= 1:
+        return {"dense": 0, "sparse": 0}
+    f = (W - 1) / W
+    rows = (int(item_num) + W * slices - 1) // (W * slices) * W * slices
+    dense = f * rows * (d + 2) * 4 + f * rows * d * 4               # reduce-scatter of [gQ | cnt], all-gather of the Q rows
+    cap_local, cap_union, _ = sparse_exchange_caps(item_num, W, max_local_batch, global_batch)
+    sparse = f * W * cap_local * 4 + f * cap_union * (d + 2) * 4 + f * cap_union * d * 4
+    return {"dense": int(dense), "sparse": int(sparse)}
+
+
+def auto_item_exchange(item_num: int, d: int, world_size: int, max_local_batch: int, global_batch: int | None = None) -> str:
+    """'sparse' (touched rows only) or 'dense' (the whole item table) for a user-sharded SGD step - like
+    `auto_exchange_slices` a pure function of numbers every rank holds identically.  Sparse when it puts at most half of
+    the dense exchange's bytes on the wire (its pack / unpack passes and the O(I) mask are not free): at d = 64, 8 ranks,
+    I = 1 M that is B_local <= ~30 000; configs[2] at B_local >= 2 M touches nearly every item and stays dense."""
+    if world_size <= 1:
+        return "dense"
+    b = item_exchange_bytes(item_num, d, world_size, max_local_batch, global_batch)
+    return "sparse" if 2 * b["sparse"] <= b["dense"] else "dense"
+
+
 def shard_triples(triples, user_num: int, world_size: int, rank: int):
     """Rows of an int32 [N,3] (user,pos,neg) array that belong to `rank`'s user range."""
     lo, hi = user_range(user_num, world_size, rank)
@@ -111,9 +163,13 @@ class UserShardedBprTrainer:
 
     def __init__(self, ctx, P_local, Q, user_lo, lr, reg_1, reg_2, loss_type=N.LOSS_BPR,
                  gamma=1e-10, item_mode=N.ITEM_FUSED, group=None, overlap=True, always_collective=False, slices=1,
-                 adam_steps=0, dense_opt=None, auto_batch=None):
+                 adam_steps=0, dense_opt=None, auto_batch=None, exchange="dense", global_batch=None):
         """adam_steps > 0: torch.optim.Adam instead of SGD (staged protocol only; the value sizes the table of per-step
-        constants, it grows on demand): lazy on the rank's rows of P, dense on its own block(s) of Q (ops.ShardedAdam)"""
+        constants, it grows on demand): lazy on the rank's rows of P, dense on its own block(s) of Q (ops.ShardedAdam)
+        exchange: 'dense' (the whole item table per step), 'sparse' (the union of the ranks' touched rows: module docstring)
+        or 'auto' (`auto_item_exchange`); its buffers are sized by the LARGEST share of a step a rank can hold (the
+        context's batch) and by `global_batch` (samples of a step over all ranks; default world x the context's batch);
+        sparse needs the staged protocol with SGD and runs unsliced"""
         self.ctx, self.P, self.Q = ctx, P_local, Q
         self.user_lo = int(user_lo)
         self.lr, self.reg_1, self.reg_2 = float(lr), float(reg_1), float(reg_2)
@@ -145,12 +201,37 @@ class UserShardedBprTrainer:
         # collectives the backend lacks are emulated with the ones it has (gloo: no reduce_scatter);
         # "nccl" (= RCCL on ROCm) runs the real ones
         self._native_rs = self.collective and dist.get_backend(group) == "nccl"
+        # auto_batch: interactions per rank and step, the same number on every rank (default: the context's batch)
+        per_rank = int(auto_batch if auto_batch is not None else getattr(ctx, "max_batch", 0))
+        max_local = int(getattr(ctx, "max_batch", 0) or per_rank)
+        gbatch = int(global_batch) if global_batch else None
+        can_sparse = self.staged and not adam_steps and self.world > 1 and max_local > 0
+        if exchange == "auto":
+            exchange = auto_item_exchange(Q.shape[0], Q.shape[1], self.world, max_local, gbatch) if can_sparse else "dense"
+        if exchange not in ("dense", "sparse"):
+            raise ValueError(f"UserShardedBprTrainer: exchange={exchange!r} (expected 'dense', 'sparse' or 'auto')")
+        if exchange == "sparse" and not (self.staged and not adam_steps):
+            raise NotImplementedError("UserShardedBprTrainer: the touched-rows exchange needs the staged protocol with SGD "
+                                      "(under dense Adam every item row moves in every step)")
+        self.sparse = exchange == "sparse" and self.collective and max_local > 0
         if slices in ("auto", 0, None):      # decided from numbers all ranks share: see auto_exchange_slices
             backend = dist.get_backend(group) if self.collective else "none"
-            # auto_batch: interactions per rank and step, the same number on every rank (default: the context's batch)
-            per_rank = int(auto_batch if auto_batch is not None else getattr(ctx, "max_batch", 0))
             slices = auto_exchange_slices(Q.shape[0], Q.shape[1], self.world, per_rank, backend)
         self.slices = min(16, max(1, int(slices))) if self.staged and hasattr(ctx, "staged_item_slice") else 1
+        if self.sparse:
+            self.slices = 1
+        if self.collective and self.world > 1:
+            # every rank must cut and own the same blocks: a rank whose environment (DAISY_XGMI_BUS_GBS) or arguments
+            # resolved differently would diverge silently - compare instead of trusting
+            kb = (max_local, gbatch or 0)
+            mine = torch.tensor([self.slices, -self.slices, int(self.sparse), -int(self.sparse), kb[0], -kb[0], kb[1], -kb[1]],
+                                dtype=torch.int64, device=Q.device)
+            dist.all_reduce(mine, op=dist.ReduceOp.MAX, group=group)
+            lo_hi = [int(x) for x in mine.cpu()]
+            if lo_hi[0] != -lo_hi[1] or lo_hi[2] != -lo_hi[3] or (self.sparse and (lo_hi[4] != -lo_hi[5] or lo_hi[6] != -lo_hi[7])):
+                raise RuntimeError(f"UserShardedBprTrainer: the ranks disagree on the exchange (slices {-lo_hi[1]}..{lo_hi[0]}, "
+                                   f"sparse {-lo_hi[3]}..{lo_hi[2]}, largest local batch {-lo_hi[5]}..{lo_hi[4]}, global batch "
+                                   f"{-lo_hi[7]}..{lo_hi[6]}): pass the same slices / exchange / batch sizes on every rank")
         self.side = None
         self.timeline = None         # enable_timing(): per-step (start, compute queued, end) events
         if self.staged:
@@ -168,6 +249,21 @@ class UserShardedBprTrainer:
             self.Q_gather = Q if Ipad == I else torch.zeros(Ipad, d, dtype=torch.float32, device=Q.device)
             self.own_lo = self.rank * self.rows                     # (of slice 0; slice s: + s*world*rows)
             self.own_hi = min(self.own_lo + self.rows, I)
+            if self.sparse:
+                # gQ / cnt get one row more: row I stays zero and is what the padding of the id lists points at
+                self.cap_local, self.cap_union, self.rows_s = sparse_exchange_caps(I, self.world, max_local, gbatch)
+                dev = Q.device
+                self.gQ = torch.zeros(I + 1, d, dtype=torch.float32, device=dev)
+                self.cnt = torch.zeros(I + 1, 2, dtype=torch.float32, device=dev)
+                self.ids_all = torch.empty(self.world * self.cap_local, dtype=torch.int32, device=dev)
+                self.mask = torch.zeros(I + 1, dtype=torch.bool, device=dev)
+                self.xbuf = torch.zeros(self.cap_union, d + 2, dtype=torch.float32, device=dev)
+                self.x_own = torch.zeros(self.rows_s, d + 2, dtype=torch.float32, device=dev)
+                self.q_all = torch.zeros(self.cap_union, d, dtype=torch.float32, device=dev)
+                self.k_arange = torch.arange(self.cap_union, device=dev)
+        # bytes this rank puts on the wire per step for the item exchange (ring collectives; bench.py reports both forms)
+        self.wire_bytes = item_exchange_bytes(Q.shape[0], Q.shape[1], self.world, max(max_local, 1), gbatch, self.slices)
+        self.wire_bytes["used"] = "sparse" if getattr(self, "sparse", False) else "dense"
         self.adam = None
         if adam_steps:
             if not self.staged:
@@ -390,7 +486,58 @@ class UserShardedBprTrainer:
                     if top > a:
                         self.Q[a:top].copy_(self.Q_gather[a:top])
 
+    def _exchange_items_sparse(self):
+        """the touched-rows exchange (module docstring): static shapes, no host synchronisation, the same union - hence
+        the same owners and the same arithmetic - on every rank"""
+        c, Q = self.ctx, self.Q
+        I, d, W = Q.shape[0], Q.shape[1], self.world
+        touched = (self.cnt[:I, 0] + self.cnt[:I, 1]) > 0
+        ids = torch.nonzero_static(touched, size=self.cap_local, fill_value=I).view(-1)       # ascending, padded with I
+        mine32 = ids.to(torch.int32)
+        if self._native_rs:
+            dist.all_gather_into_tensor(self.ids_all, mine32, group=self.group)
+        else:
+            parts = [torch.empty_like(mine32) for _ in range(W)]
+            dist.all_gather(parts, mine32, group=self.group)
+            torch.cat(parts, out=self.ids_all)
+        self.mask.zero_()
+        self.mask[self.ids_all.long()] = True
+        uid = torch.nonzero_static(self.mask[:I], size=self.cap_union, fill_value=I).view(-1)   # the union, ascending
+        self.xbuf[:, :d] = self.gQ.index_select(0, uid)                # (row I of gQ / cnt is the zero row)
+        self.xbuf[:, d:] = self.cnt.index_select(0, uid)
+        r0 = self.rank * self.rows_s
+        if self._native_rs:
+            dist.reduce_scatter_tensor(self.x_own, self.xbuf, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.all_reduce(self.xbuf, op=dist.ReduceOp.SUM, group=self.group)
+            self.x_own.copy_(self.xbuf[r0:r0 + self.rows_s])
+        self.gQ.index_fill_(0, ids, 0.0)                                # the rank's touched rows (and row I) back to zero
+        self.cnt.index_fill_(0, ids, 0.0)
+        my = uid[r0:r0 + self.rows_s]
+        q_rows = Q.index_select(0, my.clamp(max=I - 1))                 # (padding: some row, left as it is, never written back)
+        g_own, c_own = self.x_own[:, :d].contiguous(), self.x_own[:, d:].contiguous()
+        c.item_apply_counts(q_rows, g_own, c_own, self.lr, self.reg_1, self.reg_2)
+        if self._native_rs:
+            dist.all_gather_into_tensor(self.q_all, q_rows, group=self.group)
+        else:
+            parts = [torch.empty_like(q_rows) for _ in range(W)]
+            dist.all_gather(parts, q_rows, group=self.group)
+            torch.cat(parts, out=self.q_all)
+        # unpack without a data-dependent shape: the padding aliases entry 0 (same target, same row: duplicate writes of
+        # one value); a step nobody contributed a sample to (uid[0] == I) rewrites row I-1 with itself
+        valid = uid < I
+        src = torch.where(valid, self.k_arange, torch.zeros_like(self.k_arange))
+        tgt = uid.index_select(0, src)
+        rows = self.q_all.index_select(0, src)
+        none = tgt >= I
+        tgt = tgt.clamp(max=I - 1)
+        rows = torch.where(none[:, None], Q.index_select(0, tgt), rows)
+        Q.index_copy_(0, tgt, rows)
+        return c.stats
+
     def _exchange_items(self):
+        if self.sparse:
+            return self._exchange_items_sparse()
         for s_ in range(self.slices):
             self._exchange_slice(s_)
         self._join_side()

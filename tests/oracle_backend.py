@@ -9,6 +9,7 @@ from oracle import bpr_mf_numpy as O
 class OracleContext:
     def __init__(self, max_batch, d, user_num, item_num):
         self.d, self.user_num, self.item_num = d, user_num, item_num
+        self.max_batch = int(max_batch)
         self.stats = torch.zeros(16, dtype=torch.float64)
         self.epoch_acc = torch.zeros(2, dtype=torch.float64)
         self.gQ = torch.zeros(item_num, d, dtype=torch.float32)

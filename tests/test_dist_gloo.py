@@ -26,7 +26,7 @@ def _data(lopsided=False):
     return P0, Q0, batches
 
 
-def _worker(rank, world, port, out_dir, mode, lopsided=False, slices=1, adam=False):
+def _worker(rank, world, port, out_dir, mode, lopsided=False, slices=1, adam=False, exchange="dense"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from daisyrec_amd.sharding import UserShardedBprTrainer, shard_triples, user_range
@@ -39,8 +39,10 @@ def _worker(rank, world, port, out_dir, mode, lopsided=False, slices=1, adam=Fal
     ctx = OracleContext(B, D, hi - lo, I)
     tr = UserShardedBprTrainer(ctx, P, Q, lo, LR, R1, R2, overlap=(rank % 2 == 0),
                                item_mode={"fused": N.ITEM_FUSED, "chunked": N.ITEM_CHUNKED}[mode], slices=slices,
-                               adam_steps=2 if adam else 0)       # (the table of step constants grows on demand)
-    assert tr.staged == (mode == "fused") and tr.slices == (slices if mode == "fused" else 1)
+                               adam_steps=2 if adam else 0,       # (the table of step constants grows on demand)
+                               exchange=exchange, global_batch=B)
+    assert tr.staged == (mode == "fused") and tr.slices == (slices if mode == "fused" and not tr.sparse else 1)
+    assert tr.sparse == (exchange == "sparse")
     losses = []
     for b in batches:
         mine = shard_triples(b, U, world, rank)
@@ -105,6 +107,113 @@ def test_ranks_without_samples_in_a_step_only_join_the_exchanges(tmp_path):
         np.testing.assert_allclose(o["losses"], ref_losses, rtol=1e-9)
         np.testing.assert_allclose(o["Q"], Q, atol=2e-6)
         np.testing.assert_allclose(o["P"], P[int(o["lo"]):int(o["hi"])], atol=2e-6)
+
+
+# ---- the touched-rows item exchange (sharding.py: exchange='sparse'; SURVEY 8e, north_star "only where users overlap items")
+SP_U, SP_I, SP_B = 60, 500, 12            # 2 B << I: at most 24 of 500 item rows move per step
+
+
+def _sparse_data(kind):
+    """kind 'few': 2 B << I, step 1 leaves every rank but the first without samples and step 2 repeats one item in
+    every sample (a union of 1 + B rows, hit by every rank); 'all': the union is the whole table (I = 30 <= 2 B)"""
+    if kind == "all":
+        return (U, I, B) + _data(True)
+    rng = np.random.default_rng(17)
+    P0 = (rng.standard_normal((SP_U, D)) * 0.2).astype(np.float32)
+    Q0 = (rng.standard_normal((SP_I, D)) * 0.2).astype(np.float32)
+    batches = [np.stack([rng.integers(0, SP_U, SP_B), rng.integers(0, SP_I, SP_B), rng.integers(0, SP_I, SP_B)], 1)
+               .astype(np.int32) for _ in range(4)]
+    batches[1][:, 0] = rng.integers(0, SP_U // 8, SP_B)
+    batches[2][:, 1] = 7
+    batches[3] = batches[3][:5]                         # the epoch's partial last batch
+    return SP_U, SP_I, SP_B, P0, Q0, batches
+
+
+def _sparse_worker(rank, world, port, out_dir, kind, exchange):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from daisyrec_amd.sharding import UserShardedBprTrainer, shard_triples, user_range
+    from daisyrec_amd import _native as N
+    from oracle_backend import OracleContext
+    U_, I_, B_, P0, Q0, batches = _sparse_data(kind)
+    lo, hi = user_range(U_, world, rank)
+    P, Q = torch.from_numpy(P0[lo:hi].copy()), torch.from_numpy(Q0.copy())
+    ctx = OracleContext(B_, D, hi - lo, I_)             # (a rank may hold the whole global batch of a step)
+    tr = UserShardedBprTrainer(ctx, P, Q, lo, LR, R1, R2, item_mode=N.ITEM_FUSED, overlap=(rank % 2 == 0), slices=3,
+                               exchange=exchange, global_batch=B_)
+    losses, moved = [], []
+    for b in batches:
+        mine = shard_triples(b, U_, world, rank)
+        q_before = Q.clone()
+        stats = tr.step_from_plan(None, 0) if len(mine) == 0 else tr.step_from_triples(torch.from_numpy(mine))
+        losses.append(float(stats[7]))
+        moved.append(int((Q != q_before).any(1).sum()))
+    assert float(tr.gQ.abs().sum()) == 0.0 and float(tr.cnt.abs().sum()) == 0.0     # re-zeroed behind every exchange
+    np.savez(os.path.join(out_dir, f"r{rank}.npz"), P=P.numpy(), Q=Q.numpy(), lo=lo, hi=hi, losses=np.array(losses),
+             moved=np.array(moved), sparse=int(tr.sparse), slices=tr.slices, wire=tr.wire_bytes[tr.wire_bytes["used"]],
+             caps=np.array([tr.cap_local, tr.cap_union, tr.rows_s]) if tr.sparse else np.zeros(3))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,world,exchange", [("few", 2, "sparse"), ("few", 4, "sparse"), ("all", 4, "sparse"),
+                                                 ("few", 3, "auto"), ("all", 2, "auto")])
+def test_touched_rows_exchange_equals_single_process(tmp_path, kind, world, exchange):
+    """only the union of the ranks' touched item rows travels (index lists all-gathered, the union merged identically on
+    every rank, reduce-scatter / owner apply / all-gather over |union| rows): against the oracle step on the union batch,
+    with a rank that holds no sample of a step, items only one rank touches, an item every rank touches, and a union that
+    is the whole table; 'auto' picks sparse for 2 B << I and dense when the table is smaller than the batch"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    mp.spawn(_sparse_worker, args=(world, _free_port(), str(tmp_path), kind, exchange), nprocs=world, join=True)
+    U_, I_, B_, P, Q, batches = _sparse_data(kind)
+    ref_losses, touched = [], []
+    for b in batches:
+        loss, P, Q = O.mf_sgd_step(P, Q, b[:, 0], b[:, 1], b[:, 2], LR, R1, R2)
+        ref_losses.append(loss)
+        touched.append(len(set(b[:, 1]) | set(b[:, 2])))
+    outs = [np.load(os.path.join(str(tmp_path), f"r{r}.npz")) for r in range(world)]
+    want_sparse = exchange == "sparse" or kind == "few"
+    for o in outs:
+        assert bool(o["sparse"]) == want_sparse and int(o["slices"]) == (1 if want_sparse else 3)
+        np.testing.assert_allclose(o["losses"], ref_losses, rtol=1e-9)
+        np.testing.assert_allclose(o["Q"], Q, atol=2e-6)
+        np.testing.assert_allclose(o["P"], P[int(o["lo"]):int(o["hi"])], atol=2e-6)
+        assert list(o["moved"]) == touched              # exactly the touched rows of Q changed in every step
+        if want_sparse:
+            cap_local, cap_union, rows = (int(x) for x in o["caps"])
+            assert cap_local == min(I_, 2 * B_) and cap_union == rows * world and cap_union >= min(I_, 2 * B_)
+    for o in outs[1:]:
+        np.testing.assert_array_equal(outs[0]["Q"], o["Q"])                  # replicas stay bit-identical
+    if kind == "few":                                   # the point of it: a fraction of the dense exchange's bytes
+        from daisyrec_amd.sharding import item_exchange_bytes
+        b = item_exchange_bytes(I_, D, world, B_, B_)
+        assert int(outs[0]["wire"]) == b["sparse"] and b["sparse"] * 5 < b["dense"]
+
+
+def _disagree_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from daisyrec_amd.sharding import UserShardedBprTrainer, user_range
+    from daisyrec_amd import _native as N
+    from oracle_backend import OracleContext
+    lo, hi = user_range(U, world, rank)
+    P, Q = torch.zeros(hi - lo, D), torch.zeros(I, D)
+    try:
+        UserShardedBprTrainer(OracleContext(B, D, hi - lo, I), P, Q, lo, LR, R1, R2, item_mode=N.ITEM_FUSED, slices=2 + rank)
+        msg = "no error"
+    except RuntimeError as e:
+        msg = str(e)
+    open(os.path.join(out_dir, f"r{rank}.txt"), "w").write(msg)
+    dist.destroy_process_group()
+
+
+def test_ranks_that_disagree_on_the_slices_are_told_so(tmp_path):
+    """a slice count resolved per rank (environment, arguments) is compared across the ranks instead of trusted"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    mp.spawn(_disagree_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert "disagree on the exchange" in open(os.path.join(str(tmp_path), f"r{r}.txt")).read()
 
 
 @pytest.mark.parametrize("world,slices", [(2, 3), (4, 5)])

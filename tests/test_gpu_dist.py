@@ -18,16 +18,17 @@ U, I, D, B, STEPS = 400, 300, 64, 4096, 3
 LR, R1, R2 = 0.05, 0.01, 0.02
 
 
-def _data():
+def _data(items=None):
     rng = np.random.default_rng(11)
+    I_ = items or I
     P0 = (rng.standard_normal((U, D)) * 0.2).astype(np.float32)
-    Q0 = (rng.standard_normal((I, D)) * 0.2).astype(np.float32)
-    batches = [np.stack([rng.integers(0, U, B), rng.integers(0, I, B), rng.integers(0, I, B)], 1).astype(np.int32)
+    Q0 = (rng.standard_normal((I_, D)) * 0.2).astype(np.float32)
+    batches = [np.stack([rng.integers(0, U, B), rng.integers(0, I_, B), rng.integers(0, I_, B)], 1).astype(np.int32)
                for _ in range(STEPS)]
     return P0, Q0, batches
 
 
-def _worker(rank, world, port, out_dir, use_plan, mode, backend="gloo", slices=1):
+def _worker(rank, world, port, out_dir, use_plan, mode, backend="gloo", slices=1, exchange="dense", items=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from daisyrec_amd import ops
@@ -38,14 +39,16 @@ def _worker(rank, world, port, out_dir, use_plan, mode, backend="gloo", slices=1
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    P0, Q0, batches = _data()
+    P0, Q0, batches = _data(items)
+    I = Q0.shape[0]
     lo, hi = user_range(U, world, rank)
     P = torch.from_numpy(P0[lo:hi].copy()).to(dev)
     Q = torch.from_numpy(Q0.copy()).to(dev)
     ctx = ops.BprContext(B, D, hi - lo, I, device=dev)
-    tr = UserShardedBprTrainer(ctx, P, Q, lo, LR, R1, R2, item_mode=ops.ITEM_MODES[mode], slices=slices)
-    assert tr.slices == (slices if mode == "fused" else 1)
-    assert tr.staged == (mode == "fused")
+    tr = UserShardedBprTrainer(ctx, P, Q, lo, LR, R1, R2, item_mode=ops.ITEM_MODES[mode], slices=slices, exchange=exchange,
+                               global_batch=B)
+    assert tr.slices == (slices if mode == "fused" and not tr.sparse else 1)
+    assert tr.staged == (mode == "fused") and tr.sparse == (exchange == "sparse")
     losses = []
     for b in batches:
         mine = torch.from_numpy(shard_triples(b, U, world, rank)).to(dev)
@@ -82,8 +85,8 @@ def _free_port():
     return p
 
 
-def _check(tmp_path, world):
-    P, Q, batches = _data()
+def _check(tmp_path, world, items=None):
+    P, Q, batches = _data(items)
     ref = []
     for b in batches:
         loss, P, Q = O.mf_sgd_step(P, Q, b[:, 0], b[:, 1], b[:, 2], LR, R1, R2)
@@ -113,6 +116,17 @@ def test_item_pass_in_slices_with_the_exchange_on_a_side_stream(tmp_path, world,
     _check(tmp_path, world)
 
 
+@pytest.mark.parametrize("world,use_plan", [(2, True), (3, False)])
+def test_touched_rows_exchange_with_the_real_kernels(tmp_path, world, use_plan):
+    """exchange='sparse' (round 6): 2 B = 8192 of 100 003 item rows per step - id lists all-gathered, the union merged on
+    every rank, reduce-scatter / k_item_apply_counts on the union's owner blocks / all-gather; the staged item pass writes
+    gQ / cnt with the zero row behind them"""
+    items = 100003
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), use_plan, "fused", "gloo", 1, "sparse", items), nprocs=world,
+             join=True)
+    _check(tmp_path, world, items)
+
+
 def test_item_rows_not_divisible_by_the_world_size(tmp_path):
     """the staged protocol's padded path: a world size that does not divide the item count"""
     world = 4 if I % 4 else 7
@@ -121,13 +135,14 @@ def test_item_rows_not_divisible_by_the_world_size(tmp_path):
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="RCCL needs one GPU per rank (this box has one)")
-@pytest.mark.parametrize("mode", ["fused", "chunked"])
-def test_rccl_ranks_equal_the_single_process_step(tmp_path, mode):
+@pytest.mark.parametrize("mode,exchange", [("fused", "dense"), ("chunked", "dense"), ("fused", "sparse")])
+def test_rccl_ranks_equal_the_single_process_step(tmp_path, mode, exchange):
     """The same check over the real collectives (reduce_scatter_tensor / all_gather_into_tensor / all_reduce
     on RCCL), one rank per GPU: runs on the first box that has more than one GPU."""
     world = min(torch.cuda.device_count(), 8)
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True, mode, "nccl"), nprocs=world, join=True)
-    _check(tmp_path, world)
+    items = 100003 if exchange == "sparse" else None
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), True, mode, "nccl", 1, exchange, items), nprocs=world, join=True)
+    _check(tmp_path, world, items)
 
 
 def test_bench_refuses_more_gpus_than_the_box_has():

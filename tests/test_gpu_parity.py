@@ -488,6 +488,33 @@ def test_sharded_trainer_on_rccl_world1(ops):
             if tr.staged:
                 assert float(tr.gQ.abs().max().cpu()) == 0.0 and float(tr.cnt.abs().max().cpu()) == 0.0
             ctx.close()
+        # the touched-rows exchange (round 6) over the same backend: 2 B << I, two steps (the second re-uses the re-zeroed
+        # gQ / cnt), against the oracle; only rows the batches touched may move
+        I2, B2 = 20000, 256
+        Q0b = (rng.standard_normal((I2, d)) * 0.1).astype(np.float32)
+        tris = [np.stack([rng.integers(0, U, n_), rng.integers(0, I2, n_), rng.integers(0, I2, n_)], 1).astype(np.int32)
+                for n_ in (B2, 100)]
+        Pn, Qn = P0, Q0b
+        P, Q = _t(P0), _t(Q0b)
+        ctx = ops.BprContext(B2, d, U, I2)
+        tr = UserShardedBprTrainer(ctx, P, Q, 0, 0.01, 1e-3, 1e-3, item_mode=ops.ITEM_MODES["fused"], always_collective=True,
+                                   slices=4, exchange="sparse")
+        assert tr.sparse and tr.slices == 1 and tr.cap_local == 2 * B2 and tr.wire_bytes["used"] == "sparse"
+        for tri2 in tris:
+            loss, Pn, Qn = O.mf_sgd_step(Pn, Qn, tri2[:, 0], tri2[:, 1], tri2[:, 2], 0.01, 1e-3, 1e-3)
+            stats = tr.step_from_triples(_t(tri2))
+            torch.cuda.synchronize()
+            assert abs(float(stats[7].cpu()) - loss) <= 1e-5 * abs(loss)
+            assert float(tr.gQ.abs().max().cpu()) == 0.0 and float(tr.cnt.abs().max().cpu()) == 0.0
+        np.testing.assert_allclose(P.cpu().numpy(), Pn, atol=3e-6)
+        np.testing.assert_allclose(Q.cpu().numpy(), Qn, atol=3e-6)
+        moved = (Q.cpu().numpy() != Q0b).any(1)
+        hit = np.zeros(I2, bool)
+        for tri2 in tris:
+            hit[tri2[:, 1]] = True
+            hit[tri2[:, 2]] = True
+        assert np.array_equal(moved, hit)
+        ctx.close()
     finally:
         if created:
             dist.destroy_process_group()
