@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "neumf_internal.h"
 
 #include <type_traits>
 
@@ -26,7 +27,6 @@
 
 namespace daisy {
 
-typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int kBK = 16;        // k depth of an LDS tile
 constexpr int kGemmBM = 128;   // block tile rows (2 x 2 waves, each 64 rows)
@@ -255,23 +255,8 @@ __global__ __launch_bounds__(kBlock) void k_gemm(GemmOp op) {
 // fragment is 8 consecutive k = one 16-byte read - at an 80-byte row pitch (odd multiple of 16 B:
 // conflict free).  Interior, aligned tiles only (launch_gemm falls back to the fp32 kernel otherwise).
 // ---------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int kBK16 = 32, kLdk16 = kBK16 + 8;
 
-__device__ __forceinline__ uint32_t bf16_rne(float f) {
-    uint32_t u = __float_as_uint(f);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
-// two floats -> two bf16 (round to nearest even) in one dword, lo in bits 0..15: gfx950's v_cvt_pk_bf16_f32 - one
-// instruction where the integer form above takes five per value (the epilogue of a 128x128 tile converts 64 values
-// per lane: that was more VALU work than the tile's MFMAs at K = 128)
-__device__ __forceinline__ uint32_t bf16_pack2(float lo, float hi) {
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-    const f32x2 v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-}
 
 template <int WN, int EPI, bool DROP>
 __global__ __launch_bounds__(kBlock) void k_gemm_bf16(GemmOp op) {
@@ -385,7 +370,6 @@ __global__ __launch_bounds__(kBlock) void k_gemm_bf16(GemmOp op) {
 // kernels above, which is what bounded them).  Operands that are contiguous along their rows instead of k (the
 // weight-gradient GEMM) keep that layout in LDS and are transposed by the fragment read (lds_frag_tr below).
 // Epilogues: bias + ReLU (+dropout) or gate with bf16 output (round to nearest even), or fp32 atomics (split-K).
-__device__ __forceinline__ bool bf16_positive(uint16_t h) { return (h & 0x8000u) == 0 && (h & 0x7FFFu) != 0; }
 
 // Which tile a workgroup computes.  Workgroups go to the 8 XCDs round-robin by their linear id (observed, used for
 // speed only), and each XCD has its own L2: tiles that read the same operand panel are given to workgroups that
@@ -408,7 +392,6 @@ __device__ __forceinline__ TileId tile_of_block() {
     return t;
 }
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kBKH = DAISY_BKH, kLdkH = kBKH;          // k depth of a tile (64: 587 vs 610 TFLOP/s on the forward shape, step equal -
                                                 // 64 KB of LDS per workgroup halve the resident workgroups).  k-contiguous tiles
                                                 // are unpadded (64-byte rows); the four 16-byte chunks of row r sit at
@@ -428,15 +411,6 @@ __device__ __forceinline__ int swz_chunk(int row, int chunk) { return chunk ^ sw
 // gradients against 430-600 on the k-contiguous GEMMs.  Pitch rows + 32 halfwords: the 8 k rows one instruction
 // touches fall on 4 distinct 16-bank offsets, twice - the two LDS cycles its 512 bytes need anyway.
 constexpr int kPadT = 32;
-typedef short short4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bf16x8 lds_frag_tr(const uint16_t *p, int pitch) {
-    typedef __attribute__((address_space(3))) short4v *lds_v4;
-    const short4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)p);
-    const short4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4)(p + 4 * pitch));
-    typedef short short8v __attribute__((ext_vector_type(8)));
-    const short8v v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(bf16x8, v);
-}
 
 template <int WN, int EPI, bool DROP, bool AK, bool BK>      // AK / BK: operand A / B is contiguous along k (else along its rows)
 __global__ __launch_bounds__(kBlock) void k_gemm_h(GemmOp op) {
@@ -708,25 +682,6 @@ static void launch_gemm(GemmOp op, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------
 // the three pair layouts of daisy_neumf_scores plus the training batch
 // ---------------------------------------------------------------------------------------------
-struct PairSrc {
-    const int32_t *u, *i, *j;     // training: row r < B -> (u[r], i[r]); r >= B -> (u[r-B], j[r-B])
-    int64_t B;
-    const int64_t *users, *items; // scoring
-    int64_t C;                    // > 0: user of pair e = users[e / C];  0 with items == NULL: (users[0], e)
-    int64_t base;                 // first pair of this chunk
-};
-__device__ __forceinline__ void pair_ids(const PairSrc &s, int64_t r, int64_t &user, int64_t &item) {
-    if (s.u) {
-        const int64_t b = (r < s.B) ? r : r - s.B;
-        user = s.u[b];
-        item = (r < s.B) ? s.i[b] : s.j[b];
-    } else {
-        const int64_t e = s.base + r;
-        if (!s.items) { user = s.users[0]; item = e; }
-        else if (s.C > 0) { user = s.users[e / s.C]; item = s.items[e]; }
-        else { user = s.users[e]; item = s.items[e]; }
-    }
-}
 
 struct L16 { static constexpr int LPR = 16; };
 
@@ -1316,6 +1271,7 @@ struct daisy_neumf_ctx {
     float *det_ws;
     size_t det_ws_floats;
     float *fact_t;                           // T_u [U][n1] then T_i [I][n1]: the first layer through the tables (k_nmf_gather<FACT>)
+    Fact fact_cur;                           // ... as the forward pass of the current step set them up (the fused tower reads them)
 };
 
 constexpr int kWgradChunkDefault = 2048;
@@ -1335,6 +1291,9 @@ static int neumf_need_det_ws(daisy_neumf_ctx *ctx) {
     size_t n = splits * layer;
     const size_t pred = (size_t)1024 * 512;
     if (pred > n) n = pred;
+    // the fused tower (csrc/neumf_tower.hip): one slab of partial sums per workgroup
+    const size_t tower = (neumf_tower_ws_bytes(ctx->d, neumf_tower_blocks((ctx->max_rows + 63) / 64)) + 3) / 4;
+    if (tower > n) n = tower;
     hipError_t e = hipMalloc((void **)&ctx->det_ws, n * sizeof(float));
     if (e != hipSuccess) {
         ctx->det_ws = nullptr;
@@ -1413,10 +1372,20 @@ static bool neumf_use_fact(const daisy_neumf_ctx *ctx, int64_t R, bool train, ui
     return tune != 0 && train && thresh == 0 && neumf_use_h(ctx, R) && ctx->L >= 1 && ctx->width[1] == ctx->dm &&
            ctx->dm % 64 == 0 && ctx->U + ctx->I <= R;
 }
+// layers 2..3, the predict layer, the criterion and their backward pass in one persistent kernel (csrc/neumf_tower.hip):
+// the first layer through the tables, the 4d -> 2d -> d tower at d = 64, the full model.  DAISY_NMF_TOWER=0: the
+// layer-by-layer kernels (A/B, and the reference the fused kernel is tested against).
+static bool neumf_use_tower(const daisy_neumf_ctx *ctx, int64_t R, bool train, uint32_t thresh) {
+    const char *env = getenv("DAISY_NMF_TOWER");              // (read per call: the tests switch it)
+    const int tune = env ? atoi(env) : 1;
+    return tune != 0 && neumf_use_fact(ctx, R, train, thresh) && ctx->L == 3 && ctx->d == 64 && ctx->model == DAISY_NEUMF_FULL &&
+           R % 64 == 0;
+}
 static int neumf_need_fact(daisy_neumf_ctx *ctx) {
     if (ctx->fact_t) return DAISY_OK;
     // the products in fp32, the row norms (2 floats per row), the products again as bf16 (half a float per element)
-    const size_t n = (size_t)(ctx->U + ctx->I) * ((size_t)ctx->width[1] + 2 + (size_t)ctx->width[1] / 2);
+    // (+ 32 floats: the bf16 copy starts on a 128-byte boundary - its rows are whole cache lines for the tower's gather)
+    const size_t n = (size_t)(ctx->U + ctx->I) * ((size_t)ctx->width[1] + 2 + (size_t)ctx->width[1] / 2) + 32;
     if (hipMalloc((void **)&ctx->fact_t, n * sizeof(float)) != hipSuccess) {
         set_error("neumf: hipMalloc(%zu) of the first-layer table products failed", n * sizeof(float));
         ctx->fact_t = nullptr;
@@ -1452,16 +1421,23 @@ static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p,
             op.C = side ? ti : tu; op.ldc = n1;
             op.M = side ? ctx->I : ctx->U; op.N = n1; op.K = dm;
             op.k_chunk = op.K;
-            op.bf16 = 1;
+            // fp32 products of the fp32 tables and weights, rounded to bf16 once (k_f32_to_bf16): the rounding points do not
+            // depend on whether the table's row count happens to tile (oracle/neumf_numpy.py: neumf_grad_bf16 'fact')
+            op.bf16 = 0;
             launch_gemm<EPI_STORE>(op, s);
         }
         float2 *nu = reinterpret_cast<float2 *>(ctx->fact_t + (size_t)(ctx->U + ctx->I) * n1), *ni = nu + ctx->U;
         hipLaunchKernelGGL(k_nmf_row_norms, dim3(grid_for(ctx->U, kBlock / 16)), dim3(kBlock), 0, s, p->uM, ctx->U, dm, nu);
         hipLaunchKernelGGL(k_nmf_row_norms, dim3(grid_for(ctx->I, kBlock / 16)), dim3(kBlock), 0, s, p->iM, ctx->I, dm, ni);
-        uint16_t *t16 = reinterpret_cast<uint16_t *>(ni + ctx->I);
+        uint16_t *t16 = reinterpret_cast<uint16_t *>(ctx->fact_t + (((size_t)(ctx->U + ctx->I) * ((size_t)n1 + 2) + 31) / 32) * 32);
         const int64_t nt = (int64_t)(ctx->U + ctx->I) * n1;
         hipLaunchKernelGGL(k_f32_to_bf16, dim3(grid_for(nt, kBlock * 2)), dim3(kBlock), 0, s, tu, nt, t16);
         const Fact f{t16, t16 + (size_t)ctx->U * n1, p->b[0], reinterpret_cast<uint16_t *>(ctx->X[1]), n1, nu, ni};
+        ctx->fact_cur = f;
+        if (neumf_use_tower(ctx, R, train, thresh)) {        // the gather, the layers and the predict layer happen in the tower kernel
+            DAISY_LAUNCH_CHECK();
+            return DAISY_OK;
+        }
         hipLaunchKernelGGL((k_nmf_gather<true, true, true>), dim3(grid), dim3(kBlock), 0, s, *p, src, R, d, dm, pointwise,
                            ctx->X[0], ctx->G, thresh, scale, seed, stats, f);
     } else if (train) {
@@ -1734,13 +1710,7 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
     if (rc) return rc;
     if ((rc = neumf_need_det_ws(ctx))) return rc;
     float *ws = ctx->det_ws;
-    const int loss_grid = grid_for(B, kBlock * 2);
-    hipLaunchKernelGGL(k_nmf_loss, dim3(loss_grid), dim3(kBlock), 0, s, ctx->pred, j, B,
-                       (int)loss_type, gamma, pointwise, ctx->dpred, stats, ws);
-    reduce_slices(ws, loss_grid, 1, g.bp, s);
-    hipLaunchKernelGGL(k_nmf_finalize, dim3(1), dim3(64), 0, s, stats, reg_1, reg_2, pointwise);
-    DAISY_LAUNCH_CHECK();
-    // ---- backward
+    const bool tower = neumf_use_tower(ctx, R, true, thresh);        // (the forward pass took the same decision)
     const int dg = (model == DAISY_NEUMF_MLP) ? 0 : d;
     const int nl = (model == DAISY_NEUMF_GMF) ? 0 : ctx->width[L];
     float *dz = ctx->DZ[0], *dz_next = ctx->DZ[1];
@@ -1748,6 +1718,28 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
     // 1 (default): owner-based, reproducible embedding scatter; 0: the fp32-atomics kernel (kept for A/B measurements)
     static const int tune_scatter = getenv("DAISY_NMF_SCATTER_OWNER") ? atoi(getenv("DAISY_NMF_SCATTER_OWNER")) : 1;
     const bool owner_scatter = tune_scatter != 0;
+    if (tower) {
+        // x1 gathered from the table products, layers 2..3, predict, criterion, dZ3 .. dZ1, gW3, gW2, gb3, gb2, gWp, gbp and
+        // the step's statistics: one persistent kernel + the fixed-order sum of its workgroups' slabs
+        TowerArgs ta{};
+        ta.tu = ctx->fact_cur.tu; ta.ti = ctx->fact_cur.ti; ta.nu = ctx->fact_cur.nu; ta.ni = ctx->fact_cur.ni;
+        ta.b1 = p.b[0];
+        ta.W2 = ctx->W16[1]; ta.W3 = ctx->W16[2];
+        ta.b2 = p.b[1]; ta.b3 = p.b[2]; ta.Wp = p.Wp; ta.bp = p.bp;
+        ta.uG = p.uG; ta.iG = p.iG;
+        ta.u = u; ta.i = i; ta.j = j; ta.B = B;
+        ta.pointwise = pointwise; ta.loss_type = (int)loss_type; ta.gamma = gamma;
+        ta.dZ1 = reinterpret_cast<uint16_t *>(dz); ta.dpred = ctx->dpred; ta.ws = ws;
+        rc = neumf_tower_step(ta, d, R, g.W[1], g.W[2], g.b[1], g.b[2], g.Wp, g.bp, stats, reg_1, reg_2, s);
+        if (rc) return rc;
+    } else {
+    const int loss_grid = grid_for(B, kBlock * 2);
+    hipLaunchKernelGGL(k_nmf_loss, dim3(loss_grid), dim3(kBlock), 0, s, ctx->pred, j, B,
+                       (int)loss_type, gamma, pointwise, ctx->dpred, stats, ws);
+    reduce_slices(ws, loss_grid, 1, g.bp, s);
+    hipLaunchKernelGGL(k_nmf_finalize, dim3(1), dim3(64), 0, s, stats, reg_1, reg_2, pointwise);
+    DAISY_LAUNCH_CHECK();
+    // ---- backward
     const bool vec_pred = dg == nl && dg > 0 && dg <= 64 && dg % 4 == 0;          // NeuMF proper (not the GMF / MLP ablations)
     const int pb_grid = vec_pred ? grid_for(R, kBlock / 16 * 8, 512) : grid_for(R, kBlock / 16 * 16, 1024);
     if (vec_pred && H) hipLaunchKernelGGL((k_nmf_pred_bwd_v<true>), dim3(pb_grid), dim3(kBlock), 0, s, ctx->dpred, ctx->G, dg,
@@ -1760,9 +1752,10 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
                             ctx->G, dg, ctx->X[L], nl, p.Wp, R, dz, ws);
     reduce_slices(ws, pb_grid, dg + nl, g.Wp, s);       // gWp += the workgroups' column sums, in workgroup order
     DAISY_LAUNCH_CHECK();
+    }
     const bool fact = neumf_use_fact(ctx, R, true, thresh);          // (the forward pass took the same decision)
     if (model != DAISY_NEUMF_GMF) {
-        for (int l = L; l >= 1; --l) {
+        for (int l = tower ? 1 : L; l >= 1; --l) {          // (tower: dz already holds dZ_1)
             const int n_out = ctx->width[l], n_in = ctx->width[l - 1];
             if (fact && l == 1) {
                 // the first layer through the tables: gb_1 here; gW_1 and the MLP tables' gradients come out of the
