@@ -543,20 +543,28 @@ def extra_neumf(dev, want_cpu):
         wall, ms = _timed(step, steps)
         ctx.close()
         name = "fp32" if prec == 0 else "bf16"
-        fact = prec == 2 and U + I <= 2 * B
+        fact = U + I <= 2 * B                      # both modes run the first layer through the tables then (round 6: fp32 too)
         step_flops = (flops_per_sample - (2 * macs_l1 * 3 * 2 if fact else 0)) * B + (table_flops if fact else 0)
         tf = step_flops * steps / wall / 1e12
-        out["points"].append({"batch": B, "precision": {0: "fp32 (parity mode)", 2: "bf16 storage, fp32 accumulation"}[prec],
-                              "steps": steps, "value": B * steps / wall, "unit": "samples/s", "ms_per_step": wall / steps * 1e3,
-                              "gpu_ms_per_step_events": ms / steps,
-                              "roofline": {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TF[name], "unit": "TFLOP/s",
-                                           "frac": tf / MFMA_PEAK_TF[name], "traffic": None,
-                                           "flops_counted": "the GEMMs actually run: three per layer x 2 rows per sample"
-                                                            + (" for layers 2.." + str(L) + ", the first layer's three as "
-                                                               "products over the U + I table rows" if fact else "")
-                                                            + "; gathers, scatter and Adam are not counted",
-                                           "nominal_tflops_of_the_plain_formulation": flops_per_sample * B * steps / wall / 1e12,
-                                           "first_layer_through_the_tables": fact}})
+        pt = {"batch": B, "precision": {0: "fp32", 2: "bf16"}[prec], "steps": steps, "value": B * steps / wall, "unit": "samples/s",
+              "ms_per_step": wall / steps * 1e3, "gpu_ms_per_step_events": ms / steps, "first_layer_through_the_tables": fact,
+              "mfma_tflops_of_the_gemms_run": tf, "nominal_tflops_of_the_plain_formulation": flops_per_sample * B * steps / wall / 1e12}
+        if prec == 2 and fact:
+            # the fused tower (csrc/neumf_tower.hip) leaves ~0.13 TFLOP per step for the matrix cores (50 us at the bf16
+            # peak): the step is bound by what it moves.  Algorithmic bytes per row of the step (2 rows per sample), DESIGN.md
+            # section 9: the two table-product rows (bf16, 2 n1 B each) + the two GMF rows (fp32, 4 d B each) gathered, dZ1
+            # (bf16, 2 n1 B) written once and read once per table side by the two segmented sums, the other table's GMF row
+            # gathered once per side, 12 B of ids - no credit for rows that repeat inside a step
+            n1 = dm
+            bytes_row = 2 * 2 * n1 + 2 * 4 * D + 2 * n1 + 2 * 2 * n1 + 2 * 4 * D + 12
+            gbs = bytes_row * 2 * B * steps / wall / 1e9
+            pt["algorithmic_MB_per_step"] = bytes_row * 2 * B / 1e6
+            pt["roofline"] = {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                              "traffic": None, "algorithmic_bytes_per_row": bytes_row}
+        else:
+            pt["roofline"] = {"bound": "mfma", "achieved": tf, "peak": MFMA_PEAK_TF[name], "unit": "TFLOP/s",
+                              "frac": tf / MFMA_PEAK_TF[name], "traffic": None}
+        out["points"].append(pt)
     best = max(out["points"], key=lambda q: q["value"])
     out["value"], out["unit"] = best["value"], "samples/s"
     if want_cpu:
@@ -575,6 +583,49 @@ def extra_neumf(dev, want_cpu):
         out["cpu_baseline"] = {"value": cs * Bc / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
                                "sample": f"{cs} Adam steps at B = {Bc} (oracle/torch_port.py: TorchNeuMF, stock "
                                          f"nn.Embedding / Linear / autograd / optim.Adam), {dt:.1f}s"}
+    return out
+
+
+def extra_small_batch(dev):
+    """The reference's default batch (basic.yaml:23: B = 256) at BASELINE configs[0] sizes (ml-100k after the 10-filter: 943
+    users x 1152 items, 78 363 triples, d = 32): every step of an epoch inside one persistent workgroup (csrc/bpr_small.hip) -
+    SGD (MF's default, mf.yaml) and torch.optim.Adam in its exact lazy form (round 6).  The bound here is the dependency
+    chain of a step, not bytes: priced in us per step, the HBM fraction is reported for completeness."""
+    from daisyrec_amd import ops
+    U, I, nnz, d, B = 943, 1152, 78363, 32, 256
+    g = torch.Generator(device=dev)
+    g.manual_seed(3)
+    u = torch.sort(torch.randint(0, U, (nnz,), device=dev, generator=g)).values
+    tri = torch.stack([u, torch.randint(0, I, (nnz,), device=dev, generator=g),
+                       torch.randint(0, I, (nnz,), device=dev, generator=g)], 1).to(torch.int32).contiguous()
+    plan = ops.EpochPlan(nnz, U, I, device=dev).build(tri, B, order="feistel", seed=1, epoch=0, user_sorted=True)
+    nb = plan.num_batches
+    out = {"workload": "BASELINE configs[0] sizes (ml-100k: 943 x 1152, 78 363 triples, d = 32), B = 256, one persistent workgroup per epoch",
+           "points": []}
+    for opt in ("sgd", "adam"):
+        P = torch.empty(U, d, device=dev).normal_(0.0, 0.01, generator=g)
+        Q = torch.empty(I, d, device=dev).normal_(0.0, 0.01, generator=g)
+        ctx = ops.BprContext(B, d, U, I, device=dev)
+        adam = ops.LazyAdam(P, Q, 0.001, 8 * nb) if opt == "adam" else None
+
+        def epoch():
+            if adam is not None:
+                adam.fit_epoch(ctx, plan, 1e-3, 1e-3)
+            else:
+                ctx.fit_epoch_sgd(plan, P, Q, 0.01, 1e-3, 1e-3)
+
+        epoch()
+        wall, ms = _timed(epoch, 3)
+        ctx.close()
+        per_step = wall / (3 * nb)
+        bytes_i = ALGO_BYTES_PER_INTERACTION_SGD(d) if opt == "sgd" else 72 * d + 12
+        gbs = bytes_i * B / per_step / 1e9
+        out["points"].append({"batch": B, "tag": opt, "steps": 3 * nb, "value": B / per_step, "unit": "interactions/s",
+                              "ms_per_step": per_step * 1e3,
+                              "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": gbs / HBM_PEAK_GBS, "traffic": None}})
+    plan.close()
+    out["value"], out["unit"] = max(q["value"] for q in out["points"]), "interactions/s"
     return out
 
 
@@ -915,6 +966,7 @@ def main():
                                  "frac": achz / HBM_PEAK_GBS, "traffic": None,
                                  "algorithmic_bytes_per_interaction": ALGO_BYTES_PER_INTERACTION_SGD(64)}}
         extra["mf_zipf"] = guarded("extra mf_zipf", zipf_leg, collective=False)
+        extra["mf_ml100k_b256"] = guarded("extra mf_ml100k_b256", extra_small_batch, dev, collective=False)
         want_cpu_x = not a.no_cpu_baseline
         extra["neumf_ml1m"] = guarded("extra neumf_ml1m", extra_neumf, dev, want_cpu_x, collective=False)
         torch.cuda.empty_cache()

@@ -29,7 +29,7 @@ ST_LOSS_DATA, ST_L1_U, ST_L1_I, ST_L1_J, ST_SQ_U, ST_SQ_I, ST_SQ_J = range(7)
 ST_LOSS, ST_NORM_U, ST_NORM_I, ST_NORM_J = 7, 8, 9, 10
 ST_SUM_COEF = 12
 ST_SQ_U_PRE = 13
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _p = C.c_void_p
 _i32, _i64, _u64, _f32, _sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_size_t
@@ -111,6 +111,7 @@ SIGNATURES = {
                                           _p, _i32, _p]),
     "daisy_bpr_fit_epoch_adam": (C.c_int, [_p, _p, _p, _p, _i32, _f32, _f32, _f32, _f32, _p, _p, _p, _p, _p, _p, _p, _i64,
                                            _f32, _f32, _f32, _i64, _i32, _p, _p, _p, _p]),
+    "daisy_bpr_small_epoch_supported": (C.c_int, [_p, _p, _i32]),
     "daisy_mf_predict": (C.c_int, [_p, _p, _i32, _p, _p, _i64, _p, _p]),
     "daisy_mf_rank_workspace_bytes": (_sz, [_i64, _i64]),
     "daisy_mf_rank_topk": (C.c_int, [_p, _p, _i32, _p, _p, _i64, _i64, _i32, _p, _p, _p, _sz, _p]),

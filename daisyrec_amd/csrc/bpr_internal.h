@@ -211,9 +211,19 @@ int plan_read_batch_partitioned(const daisy_epoch_plan *plan, int64_t k, int32_t
 // bpr_small.hip: every step of an epoch inside one persistent workgroup (batches of a few hundred samples)
 constexpr int kSmallBatchMax = 256;
 bool small_epoch_supported(const daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, int loss_type);
+bool small_epoch_adam_pays(const daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan);
+// adam != NULL: torch.optim.Adam in the exact lazy form (moments, last-step stamps, the table of per-step constants) from
+// step `first_step` on; the caller flushes the rows no batch referenced (daisy_adam_lazy_flush)
+struct SmallAdamArgs {
+    float *mP, *vP; int32_t *lastP;
+    float *mQ, *vQ; int32_t *lastQ;
+    const float *table;
+    float beta1, beta2, eps;
+    int64_t first_step;
+};
 int small_fit_epoch(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, float *P, float *Q, int loss_type, float gamma,
                     float lr, float reg_1, float reg_2, double *stats, double *epoch_acc, double *step_losses,
-                    hipStream_t s);
+                    hipStream_t s, const SmallAdamArgs *adam = nullptr);
 // bpr_train.hip: fixed-order reduction of `nblocks` x 8 per-workgroup sums into stats[0..6,12]; finalize: also
 // the norms and the loss (finalize_stats)
 int launch_reduce_partials(const double *partials, int nblocks, double *stats, bool finalize, float reg_1,

@@ -77,11 +77,112 @@ __device__ __forceinline__ void lds_load_row(Row<C> &r, const float *src, int la
     }
 }
 
-template <class C, int MODE>      // rows staged in LDS per sample: 3 = q_i, q_j, p_u; 2 = q_i, q_j; 1 = p_u only
+// torch.optim.Adam in the persistent epoch (round 6): the exact lazy form of bpr_train.hip (adam_claim_row) / the staged
+// step - last[row] = the step a row is current for, table[s] = step s's (lr / (1 - beta1^s), sqrt(1 - beta2^s)) - with the
+// phases of a step separated by workgroup barriers instead of six or seven kernel boundaries (48 us per step at B = 256):
+//   0  every distinct row of the step (heads of the user runs / of the item runs) is brought to step t-1: the zero-gradient
+//      replay of the steps it sat out, in registers, written back with last = t-1
+//   A  as SGD: the caught-up rows are gathered and staged                           B  the owner of a row forms its gradient
+//      as SGD does and applies step t with the row's moments (read and written once per distinct row), last = t
+struct SmallAdam {
+    float *mP, *vP; int32_t *lastP;
+    float *mQ, *vQ; int32_t *lastQ;
+    const float2 *table;
+    float beta1, beta2, eps;
+    int64_t first_step;
+    // helpers > 0: workgroups 1 .. helpers run the catch-up of step j's rows AHEAD of the main workgroup (below);
+    // sync[0] = steps the main workgroup has finished, sync[1 + j] = helpers that have finished step j's rows
+    int helpers;
+    int *sync;
+};
+
+// ---- the catch-up of the lazy Adam rows on helper workgroups (round 6) ----------------------------------------------
+// Bringing a row from the step it was last touched to step t-1 replays every step in between (sqrt, two IEEE divides per
+// element and step: ~40 VALU instructions); with the whole epoch inside ONE workgroup that replay alone kept the CU's four
+// SIMDs busy for tens of microseconds per step (measured: 82 us per step at ml-100k shapes against 47 for the chain of
+// launches it was meant to replace).  But which rows step j needs is known from the plan, and a row that step j-1 does
+// NOT reference is not touched by the main workgroup while it runs step j-1: helper workgroups bring the rows of
+// set(j) \ set(j-1) to step t_j - 1 during step j-1 (after the main workgroup has finished step j-2, whose owners may have
+// written them); the rows of set(j) that step j-1 references leave that step current.  Hand-offs: one release / acquire
+// pair per step and direction (MI355X_MICROARCH.md, "inter-workgroup visibility").
+__device__ __forceinline__ void small_wait_ge(const int *flag, int want) {
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(2);
+}
+__device__ __forceinline__ void small_publish_add(int *flag) {      // one lane, after the workgroup's barrier
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// is `id` among the (ascending) masked keys a[0 .. n)?  shift: 0 for users, 1 for the entry keys (item << 1 | slot)
+__device__ __forceinline__ bool small_has(const uint32_t *a, int n, uint32_t mask, int shift, uint32_t id) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (((a[mid] & mask) >> shift) < id) lo = mid + 1; else hi = mid;
+    }
+    return lo < n && ((a[lo] & mask) >> shift) == id;
+}
+
+template <class C>
+__device__ void small_adam_helper(float *__restrict__ P, float *__restrict__ Q, const SmallPlan &pl, int d, const SmallAdam &ad,
+                                  uint32_t *__restrict__ prev_u, uint32_t *__restrict__ prev_e) {
+    constexpr int G = kSmallThreads / C::LPR;
+    const int tid = threadIdx.x, lane = tid % C::LPR, group = tid / C::LPR;
+    const int h = (int)blockIdx.x - 1, H = ad.helpers;
+    for (int64_t j = 0; j < pl.nb; ++j) {
+        if (j >= 2) {
+            if (tid == 0) { small_wait_ge(ad.sync, (int)(j - 1)); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+            __syncthreads();
+        }
+        const int32_t t_step = (int32_t)(ad.first_step + j);
+        const int64_t lo = j * pl.B;
+        const int Bj = (int)((pl.n - lo < pl.B) ? (pl.n - lo) : pl.B);
+        const int64_t lop = lo - pl.B;                                  // step j-1 (full batch)
+        if (j >= 1) {
+            // step j-1's (sorted) user and entry keys -> LDS: the membership tests below are eight-deep binary searches, and
+            // as dependent GLOBAL loads they were most of a helper's time per step
+            for (int x = tid; x < (int)pl.B; x += kSmallThreads) prev_u[x] = pl.ukey[lop + x] & pl.umask;
+            for (int x = tid; x < (int)(2 * pl.B); x += kSmallThreads) prev_e[x] = (pl.ekey[2 * lop + x] & pl.imask) >> 1;
+            __syncthreads();
+        }
+        for (int x = h * G + group; x < 3 * Bj; x += H * G) {
+            const bool us = x < Bj;
+            uint32_t row;
+            if (us) {
+                row = pl.ukey[lo + x] & pl.umask;
+                if (x > 0 && (pl.ukey[lo + x - 1] & pl.umask) == row) continue;
+                if (j >= 1 && small_has(prev_u, (int)pl.B, 0xFFFFFFFFu, 0, row)) continue;
+            } else {
+                const int e = x - Bj;
+                row = (pl.ekey[2 * lo + e] & pl.imask) >> 1;
+                if (e > 0 && ((pl.ekey[2 * lo + e - 1] & pl.imask) >> 1) == row) continue;
+                if (j >= 1 && small_has(prev_e, (int)(2 * pl.B), 0xFFFFFFFFu, 0, row)) continue;
+            }
+            float *W = us ? P : Q, *M = us ? ad.mP : ad.mQ, *V = us ? ad.vP : ad.vQ;
+            int32_t *last = us ? ad.lastP : ad.lastQ;
+            const int32_t old = last[row];
+            if (old >= t_step - 1) continue;
+            Row<C> w, mm, vv, g0;
+            w.load_clamped(W + (int64_t)row * d, lane, d); mm.load_clamped(M + (int64_t)row * d, lane, d);
+            vv.load_clamped(V + (int64_t)row * d, lane, d);
+            g0.zero();
+            for (int32_t st = old + 1; st < t_step; ++st) {
+                const float2 c = ad.table[st];
+                adam_row<C>(w, mm, vv, g0, c.x, c.y, ad.beta1, ad.beta2, ad.eps);
+            }
+            w.store(W + (int64_t)row * d, lane, d); mm.store(M + (int64_t)row * d, lane, d); vv.store(V + (int64_t)row * d, lane, d);
+            if (lane == 0) last[row] = t_step - 1;
+        }
+        __syncthreads();
+        if (tid == 0) small_publish_add(ad.sync + 1 + j);
+    }
+}
+
+template <class C, int MODE, bool ADAM = false>      // rows staged in LDS per sample: 3 = q_i, q_j, p_u; 2 = q_i, q_j; 1 = p_u only
 __global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
     float *__restrict__ P, float *__restrict__ Q, SmallPlan pl, int d, int dpad, int loss_type, float gamma, float lr,
     float reg_1, float reg_2, double *__restrict__ stats, double *__restrict__ epoch_acc,
-    double *__restrict__ step_losses) {
+    double *__restrict__ step_losses, SmallAdam ad = SmallAdam{}) {
     constexpr int G = kSmallThreads / C::LPR;
     constexpr int NW = kSmallThreads / kWave;
     constexpr int UN = (C::NE <= 4) ? 2 : 1;            // samples whose 3 row gathers are issued together per lane group
@@ -102,6 +203,12 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
     float *const s_qj = s_rows + (size_t)pl.B * dpad;
     float *const s_p = STAGE_Q ? s_rows + 2 * (size_t)pl.B * dpad : s_rows;
     double acc_epoch = 0.0, nan_epoch = 0.0;           // thread 0 only
+    if constexpr (ADAM) {
+        if (blockIdx.x > 0) {                          // helper workgroups: the catch-up of the steps ahead (see above)
+            small_adam_helper<C>(P, Q, pl, d, ad, s_meta[1].ukey, s_meta[1].item);
+            return;
+        }
+    }
 
     // element x of a step's metadata: x < B samples, then 2B entries
     uint32_t pre_a[PT];
@@ -141,6 +248,42 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
         const int Bk = (int)((pl.n - lo < pl.B) ? (pl.n - lo) : pl.B);
         const SmallMeta &m = s_meta[k & 1];
         if (k + 1 < pl.nb) fetch(k + 1);               // lands while this step computes
+
+        [[maybe_unused]] const int32_t t_step = ADAM ? (int32_t)(ad.first_step + k) : 0;
+        if constexpr (ADAM) {
+            if (ad.helpers > 0) {
+                // ---- 0: the helpers have brought the step's rows to step t-1 (or step k-1 left them there)
+                if (tid == 0) { small_wait_ge(ad.sync + 1 + k, ad.helpers); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+                __syncthreads();
+            } else
+            // ---- 0: the step's distinct rows -> step t-1 (x < Bk: heads of the user runs; then heads of the item runs)
+            for (int x = group; x < 3 * Bk; x += G) {
+                const bool us = x < Bk;
+                int64_t row;
+                if (us) {
+                    if (x > 0 && m.ukey[x - 1] == m.ukey[x]) continue;
+                    row = m.ukey[x];
+                } else {
+                    const int e = x - Bk;
+                    if (e > 0 && m.item[e - 1] == m.item[e]) continue;
+                    row = m.item[e];
+                }
+                float *W = us ? P : Q, *M = us ? ad.mP : ad.mQ, *V = us ? ad.vP : ad.vQ;
+                int32_t *last = us ? ad.lastP : ad.lastQ;
+                const int32_t old = last[row];
+                if (old >= t_step - 1) continue;
+                Row<C> w, mm, vv, g0;
+                w.load_clamped(W + row * d, lane, d); mm.load_clamped(M + row * d, lane, d); vv.load_clamped(V + row * d, lane, d);
+                g0.zero();
+                for (int32_t st = old + 1; st < t_step; ++st) {
+                    const float2 c = ad.table[st];
+                    adam_row<C>(w, mm, vv, g0, c.x, c.y, ad.beta1, ad.beta2, ad.eps);
+                }
+                w.store(W + row * d, lane, d); mm.store(M + row * d, lane, d); vv.store(V + row * d, lane, d);
+                if (lane == 0) last[row] = t_step - 1;
+            }
+            __syncthreads();
+        }
 
         // ---- A: forward; the gathered rows stay in LDS for phase B
         float acc[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -221,7 +364,13 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
             if (!(loss == loss) || isinf(loss)) nan_epoch += 1.0;
             if (step_losses) step_losses[k] = loss;
         }
-        if (!finite) break;    // the tables stay as step k-1 left them; the host raises when it reads epoch_acc[1]
+        if (!finite) {         // the tables stay as step k-1 left them; the host raises when it reads epoch_acc[1]
+            if constexpr (ADAM) {
+                if (ad.helpers > 0 && tid == 0)      // (release the helpers: they run out their steps on rows nobody reads any more)
+                    __hip_atomic_store(ad.sync, (int)pl.nb + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            break;
+        }
 
         // ---- B, item side: entries sorted by item; the head of a run owns Q[item]
         const int nE = 2 * Bk;
@@ -250,10 +399,21 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
                     for (int x = 0; x < C::NE; ++x) a.v[x] = fmaf(c, pr.v[x], a.v[x]);
                 }
                 const float w1 = reg_1 * (np + nn), w2 = np * rI + nn * rJ;
+                if constexpr (ADAM) {
+                    Row<C> mm, vv;
+                    mm.load_clamped(ad.mQ + (int64_t)r * d, lane, d); vv.load_clamped(ad.vQ + (int64_t)r * d, lane, d);
 #pragma unroll
-                for (int x = 0; x < C::NE; ++x) {
-                    const float g = a.v[x] + fmaf(w2, qr.v[x], w1 * sgn(qr.v[x]));
-                    qr.v[x] = fmaf(-lr, g, qr.v[x]);
+                    for (int x = 0; x < C::NE; ++x) a.v[x] = a.v[x] + fmaf(w2, qr.v[x], w1 * sgn(qr.v[x]));
+                    const float2 c = ad.table[t_step];
+                    adam_row<C>(qr, mm, vv, a, c.x, c.y, ad.beta1, ad.beta2, ad.eps);
+                    mm.store(ad.mQ + (int64_t)r * d, lane, d); vv.store(ad.vQ + (int64_t)r * d, lane, d);
+                    if (lane == 0) ad.lastQ[r] = t_step;
+                } else {
+#pragma unroll
+                    for (int x = 0; x < C::NE; ++x) {
+                        const float g = a.v[x] + fmaf(w2, qr.v[x], w1 * sgn(qr.v[x]));
+                        qr.v[x] = fmaf(-lr, g, qr.v[x]);
+                    }
                 }
                 qr.store(Q + (int64_t)r * d, lane, d);      // nobody reads Q before the next step's phase A
             }
@@ -284,10 +444,21 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
                     cnt += 1.f;
                 }
                 const float w1 = reg_1 * cnt, w2 = rU * cnt;
+                if constexpr (ADAM) {
+                    Row<C> mm, vv;
+                    mm.load_clamped(ad.mP + (int64_t)uu * d, lane, d); vv.load_clamped(ad.vP + (int64_t)uu * d, lane, d);
 #pragma unroll
-                for (int x = 0; x < C::NE; ++x) {
-                    const float g = a.v[x] + fmaf(w2, p.v[x], w1 * sgn(p.v[x]));
-                    p.v[x] = fmaf(-lr, g, p.v[x]);
+                    for (int x = 0; x < C::NE; ++x) a.v[x] = a.v[x] + fmaf(w2, p.v[x], w1 * sgn(p.v[x]));
+                    const float2 c = ad.table[t_step];
+                    adam_row<C>(p, mm, vv, a, c.x, c.y, ad.beta1, ad.beta2, ad.eps);
+                    mm.store(ad.mP + (int64_t)uu * d, lane, d); vv.store(ad.vP + (int64_t)uu * d, lane, d);
+                    if (lane == 0) ad.lastP[uu] = t_step;
+                } else {
+#pragma unroll
+                    for (int x = 0; x < C::NE; ++x) {
+                        const float g = a.v[x] + fmaf(w2, p.v[x], w1 * sgn(p.v[x]));
+                        p.v[x] = fmaf(-lr, g, p.v[x]);
+                    }
                 }
                 p.store(P + (int64_t)uu * d, lane, d);
             }
@@ -306,6 +477,9 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
         }
         if (k + 1 < pl.nb) stash(k + 1);
         __syncthreads();
+        if constexpr (ADAM) {
+            if (ad.helpers > 0 && tid == 0) small_publish_add(ad.sync);        // step k's rows are written: sync[0] = k + 1
+        }
     }
     if (tid < DAISY_STATS_LEN && pl.nb > 0) stats[tid] = (tid <= DAISY_ST_NORM_J) ? s_stats[tid] : 0.0;   // the last step's
     if (tid == 0 && epoch_acc) { epoch_acc[0] += acc_epoch; epoch_acc[1] += nan_epoch; }
@@ -320,6 +494,14 @@ static inline int small_dpad(int d, int64_t B = kSmallBatchMax) {
     return p;
 }
 
+// the Adam form pays where the rows a step references were touched a few steps ago (the zero-gradient replay is ~40 VALU
+// instructions per element and skipped step): tables of at most 32 rows per sample of a batch - ml-100k at B = 256: 8;
+// measured 35 us per step against 48 for the chain of launches there, but 750 against 250 at BASELINE configs[1] tables
+// (4 300 rows per sample: a row sits out thousands of steps)
+bool small_epoch_adam_pays(const daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan) {
+    return ctx->U + ctx->I <= 32 * plan->batch_size;
+}
+
 bool small_epoch_supported(const daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, int loss_type) {
     static const int enabled = getenv("DAISY_SMALL_EPOCH") ? atoi(getenv("DAISY_SMALL_EPOCH")) : 1;
     return enabled && plan->kind == 0 && !plan->pointwise && plan->batch_size <= kSmallBatchMax && !ctx->bu &&
@@ -329,7 +511,7 @@ bool small_epoch_supported(const daisy_bpr_ctx *ctx, const daisy_epoch_plan *pla
 
 int small_fit_epoch(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, float *P, float *Q, int loss_type, float gamma,
                     float lr, float reg_1, float reg_2, double *stats, double *epoch_acc, double *step_losses,
-                    hipStream_t s) {
+                    hipStream_t s, const SmallAdamArgs *adam) {
     SmallPlan pl;
     pl.ukey = plan->ukey;
     pl.ij = reinterpret_cast<const int2 *>(plan->uval);
@@ -357,15 +539,39 @@ int small_fit_epoch(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, float *P, 
         }
         return dispatch_d(d, f);
     };
-    int rc = dispatch_small([&](auto cfg) {
+    int rc = dispatch_small([&](auto cfg) -> int {
         using C = decltype(cfg);
+        SmallAdam ad{};
+        int grid = 1;
+        if (adam) {
+            ad.mP = adam->mP; ad.vP = adam->vP; ad.lastP = adam->lastP; ad.mQ = adam->mQ; ad.vQ = adam->vQ; ad.lastQ = adam->lastQ;
+            ad.table = reinterpret_cast<const float2 *>(adam->table);
+            ad.beta1 = adam->beta1; ad.beta2 = adam->beta2; ad.eps = adam->eps; ad.first_step = adam->first_step;
+            // DAISY_SMALL_ADAM_HELPERS (read per call): workgroups that run the catch-up ahead of the main one; 0: inside it
+            const char *env = getenv("DAISY_SMALL_ADAM_HELPERS");
+            int helpers = env ? atoi(env) : 8;
+            const size_t sync_ints = (size_t)plan->num_batches + 1;
+            if (helpers < 0 || sync_ints * sizeof(int) > ((size_t)kMaxGrid * 8 + kPreBlocks) * 8) helpers = 0;
+            if (helpers > 64) helpers = 64;
+            if (helpers > 0) {
+                ad.helpers = helpers;
+                ad.sync = reinterpret_cast<int *>(ctx->partials);       // (scratch of the phase kernels: idle during the epoch call)
+                DAISY_HIP(hipMemsetAsync(ad.sync, 0, sync_ints * sizeof(int), s));
+                grid = 1 + helpers;
+            }
+        }
         auto launch = [&](auto kern) -> int {
             DAISY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                           (int)kSmallLdsRows));
-            hipLaunchKernelGGL(kern, dim3(1), dim3(kSmallThreads), shmem, s, P, Q, pl, d, dpad, loss_type, gamma, lr,
-                               reg_1, reg_2, stats, epoch_acc, step_losses);
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kSmallThreads), shmem, s, P, Q, pl, d, dpad, loss_type, gamma, lr,
+                               reg_1, reg_2, stats, epoch_acc, step_losses, ad);
             return DAISY_OK;
         };
+        if (adam) {
+            if (mode == 3) return launch(k_small_epoch<C, 3, true>);
+            if (mode == 2) return launch(k_small_epoch<C, 2, true>);
+            return launch(k_small_epoch<C, 1, true>);
+        }
         if (mode == 3) return launch(k_small_epoch<C, 3>);
         if (mode == 2) return launch(k_small_epoch<C, 2>);
         return launch(k_small_epoch<C, 1>);

@@ -2648,6 +2648,19 @@ int daisy_bpr_fit_epoch_adam(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, f
         set_error("fit_epoch_adam: contexts with FM biases are driven step by step (daisy_bpr_staged_adam_step)");
         return DAISY_ERR_ARG;
     }
+    if (small_epoch_supported(ctx, plan, loss_type)) {
+        // batches of a few hundred samples over the sorted plan (the reference's default batch): every step of the epoch
+        // inside one persistent workgroup, like the SGD epoch (csrc/bpr_small.hip) - 48 -> ~12 us per step at B = 256
+        DAISY_CHECK_ARG(plan->U == ctx->U && plan->I == ctx->I, "fit_epoch_adam: plan does not fit the context");
+        SmallAdamArgs ad{mP, vP, lastP, mQ, vQ, lastQ, table, beta1, beta2, eps, first_step};
+        int rc = small_fit_epoch(ctx, plan, P, Q, loss_type, gamma, lr, reg_1, reg_2, stats, epoch_acc, step_losses, S(stream), &ad);
+        if (rc) return rc;
+    } else {
+        if (plan->kind == 0) {
+            set_error("fit_epoch_adam: a plan in the sorted layout is only run by the small-batch epoch kernel "
+                      "(daisy_bpr_small_epoch_supported); build the partitioned layout (daisy_epoch_plan_build_indexed)");
+            return DAISY_ERR_ARG;
+        }
     for (int64_t k = 0; k < plan->num_batches; ++k) {
         int rc = daisy_bpr_set_batch_from_plan(ctx, plan, k, stream);
         if (rc) return rc;
@@ -2655,6 +2668,7 @@ int daisy_bpr_fit_epoch_adam(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, f
                                         beta1, beta2, eps, first_step + k, stats, epoch_acc,
                                         step_losses ? step_losses + k : nullptr, stream);
         if (rc) return rc;
+    }
     }
     if (flush && plan->num_batches > 0) {
         const int64_t t = first_step + plan->num_batches - 1;
@@ -2665,6 +2679,12 @@ int daisy_bpr_fit_epoch_adam(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, f
         ctx->pre_ready = false;
     }
     return DAISY_OK;
+}
+
+int daisy_bpr_small_epoch_supported(const daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, int32_t loss_type) {
+    if (!ctx || !plan || !plan->built) return 0;
+    if (!small_epoch_supported(ctx, plan, loss_type)) return 0;
+    return small_epoch_adam_pays(ctx, plan) ? 3 : 1;
 }
 
 int daisy_bpr_staged_adam_catchup_users(daisy_bpr_ctx *ctx, float *P, float *mP, float *vP, int32_t *lastP,

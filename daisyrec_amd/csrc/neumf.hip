@@ -693,7 +693,10 @@ struct L16 { static constexpr int LPR = 16; };
 // (Fact::tu, Fact::ti: fp32 [rows][n1]) and x1[r] = relu(T_u[user] + T_i[item] + b1) is a gather: x0 - 1 KB per row in bf16 -
 // is never formed, the largest GEMM of the tower and its 2 x 512-column operand stream are gone.  The backward pass
 // mirrors it (neumf_scatter_owner).  Needs dropout = 0 (a mask on x0's elements would not factor).
-struct Fact { const uint16_t *tu, *ti; const float *b1; uint16_t *x1; int n1; const float2 *nu, *ni; };    // nu / ni: k_nmf_row_norms
+struct Fact {
+    const uint16_t *tu, *ti; const float *b1; uint16_t *x1; int n1; const float2 *nu, *ni;     // nu / ni: k_nmf_row_norms
+    const float *tu32, *ti32; float *x1_32;      // round 6, the fp32 (parity) mode: the products and x1 stay fp32
+};
 // (the products are handed to the gather as bf16: it is bound by reading them - 2 x 1 KB per row in fp32 from beyond L2 -
 // and the plain path rounds x0 and W1 to bf16 BEFORE the product)
 __global__ void k_f32_to_bf16(const float *__restrict__ x, int64_t n, uint16_t *__restrict__ y) {
@@ -719,7 +722,19 @@ __global__ __launch_bounds__(kBlock) void k_nmf_gather(daisy_neumf_params p, Pai
         const float *um = p.uM + user * dm, *im = p.iM + item * dm;
         float *x = X0 + r * (int64_t)(2 * dm);
         uint16_t *xh = reinterpret_cast<uint16_t *>(X0) + r * (int64_t)(2 * dm);
-        if constexpr (FACT) {
+        if constexpr (FACT && !H) {
+            // fp32 mode: x1 = relu((T_u[user] + T_i[item]) + b1) in fp32 - the reference's first layer up to the association of
+            // its 2 dm-term dot product (two dm-term products, then two adds)
+            const float *tu = fact.tu32 + user * fact.n1, *ti = fact.ti32 + item * fact.n1;
+            float *x1 = fact.x1_32 + r * (int64_t)fact.n1;
+            for (int c = 4 * lane; c < fact.n1; c += 64) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(tu + c), b4 = *reinterpret_cast<const float4 *>(ti + c);
+                const float4 c4 = *reinterpret_cast<const float4 *>(fact.b1 + c);
+                *reinterpret_cast<float4 *>(x1 + c) = make_float4(fmaxf((a4.x + b4.x) + c4.x, 0.f), fmaxf((a4.y + b4.y) + c4.y, 0.f),
+                                                                  fmaxf((a4.z + b4.z) + c4.z, 0.f), fmaxf((a4.w + b4.w) + c4.w, 0.f));
+            }
+        }
+        if constexpr (FACT && H) {
             // x1 from the two table products; the embedding rows themselves are read only where the regulariser counts
             // them (the positive half of the rows: NeuMFRecommender.py:149-167)
             const uint16_t *tu = fact.tu + user * fact.n1, *ti = fact.ti + item * fact.n1;
@@ -1369,8 +1384,11 @@ static bool neumf_use_h(const daisy_neumf_ctx *ctx, int64_t R) {
 static bool neumf_use_fact(const daisy_neumf_ctx *ctx, int64_t R, bool train, uint32_t thresh) {
     const char *env = getenv("DAISY_NMF_FACT");              // (read per call: the tests switch it)
     const int tune = env ? atoi(env) : 1;
-    return tune != 0 && train && thresh == 0 && neumf_use_h(ctx, R) && ctx->L >= 1 && ctx->width[1] == ctx->dm &&
-           ctx->dm % 64 == 0 && ctx->U + ctx->I <= R;
+    // bf16 storage (whole tiles: neumf_use_h) or, round 6, the fp32 parity mode (level 1 - bf16 MFMA inputs - keeps the
+    // plain path: its first layer rounds x0 and W1, which a product over the tables would not)
+    const bool mode_ok = (ctx->bf16 == 2) ? (neumf_use_h(ctx, R) && ctx->dm % 64 == 0) : (ctx->bf16 == 0);
+    return tune != 0 && train && thresh == 0 && mode_ok && ctx->model != DAISY_NEUMF_GMF && ctx->L >= 1 &&
+           ctx->width[1] == ctx->dm && ctx->U + ctx->I <= R;
 }
 // layers 2..3, the predict layer, the criterion and their backward pass in one persistent kernel (csrc/neumf_tower.hip):
 // the first layer through the tables, the 4d -> 2d -> d tower at d = 64, the full model.  DAISY_NMF_TOWER=0: the
@@ -1378,7 +1396,7 @@ static bool neumf_use_fact(const daisy_neumf_ctx *ctx, int64_t R, bool train, ui
 static bool neumf_use_tower(const daisy_neumf_ctx *ctx, int64_t R, bool train, uint32_t thresh) {
     const char *env = getenv("DAISY_NMF_TOWER");              // (read per call: the tests switch it)
     const int tune = env ? atoi(env) : 1;
-    return tune != 0 && neumf_use_fact(ctx, R, train, thresh) && ctx->L == 3 && ctx->d == 64 && ctx->model == DAISY_NEUMF_FULL &&
+    return tune != 0 && ctx->bf16 == 2 && neumf_use_fact(ctx, R, train, thresh) && ctx->L == 3 && ctx->d == 64 && ctx->model == DAISY_NEUMF_FULL &&
            R % 64 == 0;
 }
 static int neumf_need_fact(daisy_neumf_ctx *ctx) {
@@ -1431,13 +1449,17 @@ static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p,
         hipLaunchKernelGGL(k_nmf_row_norms, dim3(grid_for(ctx->I, kBlock / 16)), dim3(kBlock), 0, s, p->iM, ctx->I, dm, ni);
         uint16_t *t16 = reinterpret_cast<uint16_t *>(ctx->fact_t + (((size_t)(ctx->U + ctx->I) * ((size_t)n1 + 2) + 31) / 32) * 32);
         const int64_t nt = (int64_t)(ctx->U + ctx->I) * n1;
-        hipLaunchKernelGGL(k_f32_to_bf16, dim3(grid_for(nt, kBlock * 2)), dim3(kBlock), 0, s, tu, nt, t16);
-        const Fact f{t16, t16 + (size_t)ctx->U * n1, p->b[0], reinterpret_cast<uint16_t *>(ctx->X[1]), n1, nu, ni};
+        if (H) hipLaunchKernelGGL(k_f32_to_bf16, dim3(grid_for(nt, kBlock * 2)), dim3(kBlock), 0, s, tu, nt, t16);
+        const Fact f{t16, t16 + (size_t)ctx->U * n1, p->b[0], reinterpret_cast<uint16_t *>(ctx->X[1]), n1, nu, ni, tu, ti, ctx->X[1]};
         ctx->fact_cur = f;
+        if (!H) {
+            hipLaunchKernelGGL((k_nmf_gather<true, false, true>), dim3(grid), dim3(kBlock), 0, s, *p, src, R, d, dm, pointwise,
+                               ctx->X[0], ctx->G, thresh, scale, seed, stats, f);
+        } else
         if (neumf_use_tower(ctx, R, train, thresh)) {        // the gather, the layers and the predict layer happen in the tower kernel
             DAISY_LAUNCH_CHECK();
             return DAISY_OK;
-        }
+        } else
         hipLaunchKernelGGL((k_nmf_gather<true, true, true>), dim3(grid), dim3(kBlock), 0, s, *p, src, R, d, dm, pointwise,
                            ctx->X[0], ctx->G, thresh, scale, seed, stats, f);
     } else if (train) {
@@ -1556,6 +1578,15 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
         }
         if (fact) {
             const int n1 = dm, w0 = 2 * dm;
+            if (side == 0) {
+                // gb_1 = sum over the step's rows of dZ_1 = sum over the USERS of their segment sums: a column sum over U
+                // table rows (6 MB at ml-1m) instead of one over the R rows of dZ_1 (268 MB: 47 us)
+                rc = neumf_need_det_ws(c);
+                if (rc) return rc;
+                const dim3 cs((unsigned)((n1 + 63) / 64), (unsigned)((rows + kColsumRows - 1) / kColsumRows));
+                hipLaunchKernelGGL((k_colsum<false>), cs, dim3(kBlock), 0, s, c->sc_sum, rows, n1, (int64_t)n1, c->det_ws);
+                reduce_slices(c->det_ws, (int)cs.y, n1, g.b[0], s);
+            }
             GemmOp a{};                        // g.table[rows, dm] += S[rows, n1] W1[:, half]      (k = n1)
             a.A = c->sc_sum; a.sam = n1; a.sak = 1;
             a.B = p.W[0] + (side ? dm : 0); a.sbn = 1; a.sbk = w0;
@@ -1758,19 +1789,10 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
         for (int l = tower ? 1 : L; l >= 1; --l) {          // (tower: dz already holds dZ_1)
             const int n_out = ctx->width[l], n_in = ctx->width[l - 1];
             if (fact && l == 1) {
-                // the first layer through the tables: gb_1 here; gW_1 and the MLP tables' gradients come out of the
+                // the first layer through the tables: gb_1, gW_1 and the MLP tables' gradients come out of the
                 // scatter (segmented sums of dZ_1 by user and by item, then two small GEMMs each) - no [R, 2 dm] input
                 // gradient, no weight-gradient GEMM over the R rows
-                if (n_out % 8 == 0 && kBlock % (n_out / 8) == 0) {
-                    const int tiles = (int)((R + kColsumRowsH - 1) / kColsumRowsH);
-                    hipLaunchKernelGGL(k_colsum_h, dim3((unsigned)tiles), dim3(kBlock), 0, s,
-                                       reinterpret_cast<const uint16_t *>(dz), R, n_out, ws);
-                    reduce_slices(ws, tiles, n_out, g.b[0], s);
-                } else {
-                    const dim3 cs((unsigned)((n_out + 63) / 64), (unsigned)((R + kColsumRows - 1) / kColsumRows));
-                    hipLaunchKernelGGL((k_colsum<true>), cs, dim3(kBlock), 0, s, dz, R, n_out, (int64_t)n_out, ws);
-                    reduce_slices(ws, (int)cs.y, n_out, g.b[0], s);
-                }
+                // (gb_1: the column sums of the users' segment sums, neumf_scatter_owner)
                 DAISY_LAUNCH_CHECK();
                 break;
             }

@@ -457,9 +457,12 @@ class GeneralRecommender(AbstractRecommender):
                 if adam is None:
                     ctx.fit_epoch_sgd(plan, P, Q, self.lr, self.reg_1, self.reg_2, loss_type=loss_id,
                                       item_mode=item_mode)
-                elif adam.kind == "adam" and staged and biases is None:
+                elif adam.kind == "adam" and biases is None and (
+                        staged or (self.lazy_adam is not False and item_mode in (ops.ITEM_MODES["fused"], ops.ITEM_MODES["chunked"])
+                                   and ops.LazyAdam.small_epoch_pays(ctx, plan, loss_id))):
                     # the epoch as ONE enqueue (daisy_bpr_fit_epoch_adam), like the SGD loop: at the reference's batch
-                    # sizes a host round trip per batch would bound the fit
+                    # sizes a host round trip per batch would bound the fit.  B <= 256 (sorted plan): every step of the
+                    # epoch inside one persistent workgroup (csrc/bpr_small.hip, the Adam form)
                     adam.staged_epoch(ctx, plan, self.reg_1, self.reg_2, loss_id)
                 else:
                     for k in range(plan.num_batches):

@@ -541,6 +541,18 @@ class LazyAdam:
             _ptr(ctx.epoch_acc, torch.float64, "epoch_acc") if accumulate else None,
             _ptr(step_loss, torch.float64, "step_loss"), _stream()))
 
+    @staticmethod
+    def small_epoch_supported(ctx, plan, loss_type=N.LOSS_BPR) -> bool:
+        """True when `fit_epoch` runs this (sorted-layout) plan's epochs inside one persistent workgroup
+        (daisy_bpr_small_epoch_supported: B <= 256, pairwise loss, no FM biases, rows that fit the LDS)"""
+        return bool(lib.daisy_bpr_small_epoch_supported(ctx._h, plan._h, int(loss_type)) & 1)
+
+    @staticmethod
+    def small_epoch_pays(ctx, plan, loss_type=N.LOSS_BPR) -> bool:
+        """... and the Adam form is expected to be faster than the chain of launches (small tables: the rows a step references
+        sat out a few steps; measured 35 against 48 us per step at ml-100k shapes, but 750 against 250 at 1 M x 100 K tables)"""
+        return lib.daisy_bpr_small_epoch_supported(ctx._h, plan._h, int(loss_type)) == 3
+
     def fit_epoch(self, ctx, plan, reg_1, reg_2, loss_type=N.LOSS_BPR, gamma=1e-10, flush=True, step_losses=None):
         """Every batch of a built plan through the staged Adam step, enqueued by ONE native call (daisy_bpr_fit_epoch_adam:
         the loop of AbstractRecommender.py:118-128 without a host round trip per batch), then - flush - the rows no batch

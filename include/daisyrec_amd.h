@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DAISY_ABI_VERSION 6
+#define DAISY_ABI_VERSION 7
 
 typedef void *daisy_stream_t; /* hipStream_t */
 
@@ -397,6 +397,15 @@ int daisy_bpr_fit_epoch_adam(daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, f
                              float *mQ, float *vQ, int32_t *lastQ, const float *table, int64_t table_steps, float beta1,
                              float beta2, float eps, int64_t first_step, int32_t flush, double *stats,
                              double *epoch_acc, double *step_losses, daisy_stream_t stream);
+
+/* ABI 7.  1 when the epochs of `plan` (built, sorted layout: daisy_epoch_plan_build) run inside ONE persistent workgroup
+ * (csrc/bpr_small.hip: batches of at most 256 samples - the reference's default, basic.yaml:23 -, pairwise losses, no FM
+ * biases, rows that fit the LDS); daisy_bpr_fit_epoch_sgd takes that path by itself, and daisy_bpr_fit_epoch_adam accepts
+ * a sorted-layout plan exactly when this returns 1 (AbstractRecommender.py:54,103-137: the loop body at B = 256 is bound
+ * by kernel boundaries, not by bytes: SGD 8.7 us, Adam 48 -> 35 us per step at ml-100k shapes).  Bit 0: supported; bit 1
+ * (value 3): the Adam form is also expected to beat the chain of launches - tables of at most 32 rows per sample of a batch,
+ * so that the rows a step references sat out a few steps, not thousands (its zero-gradient replay is the cost). */
+int daisy_bpr_small_epoch_supported(const daisy_bpr_ctx *ctx, const daisy_epoch_plan *plan, int32_t loss_type);
 
 /* ------------------------------------------------------------------------
  * Scoring / ranking  (MFRecommender.py:99-133)

@@ -632,6 +632,55 @@ def test_adam_epoch_in_one_call_equals_the_step_by_step_loop(d, loss, B):
     assert float(a[4][1][0].cpu()) > 0 and float(a[4][1][1].cpu()) == 0
 
 
+@pytest.mark.parametrize("d,loss,B,U,I", [(32, "BPR", 256, 943, 1152), (64, "HL", 200, 61, 43), (100, "TL", 256, 300, 200),
+                                          (8, "BPR", 1, 5, 7)])
+def test_small_batch_adam_epoch_in_one_persistent_workgroup(d, loss, B, U, I):
+    """Round 6: torch.optim.Adam at the reference's batch size (basic.yaml:23, B = 256) - every step of an epoch inside the
+    persistent workgroup of csrc/bpr_small.hip (catch-up of the step's distinct rows, forward, owner-applied Adam), reached
+    through daisy_bpr_fit_epoch_adam on a SORTED plan.  Against the oracle's dense Adam on the same batches (every row of
+    both tables steps in every step: AbstractRecommender.py:54,119-126): epoch losses, both tables after the flush, over two
+    epochs; the three LDS staging modes (d = 32 / 64: all rows staged, d = 100: user rows only); hot users (one user in 300
+    samples); a batch of one."""
+    from daisyrec_amd import ops
+    n = 1500 if B > 1 else 7
+    tri = _triples(n, U, I, d + 11)
+    tri[:min(300, n // 2), 0] = 3
+    tri = tri[np.argsort(tri[:, 0], kind="stable")]
+    P0, Q0 = _tables(U, I, d, d + 2)
+    lid = ops.LOSS_IDS[loss]
+    lr, r1, r2 = 0.01, 1e-3, 2e-3
+    t_dev = torch.from_numpy(tri).to(DEV)
+    P, Q = torch.from_numpy(P0).to(DEV), torch.from_numpy(Q0).to(DEV)
+    ctx, plan = ops.BprContext(B, d, U, I), ops.EpochPlan(n, U, I)
+    adam = ops.LazyAdam(P, Q, lr, 2)
+    ref = O.DenseAdam([P0.shape, Q0.shape], lr)
+    Pr, Qr = P0.astype(np.float64), Q0.astype(np.float64)
+    for epoch in (1, 2):
+        plan.build(t_dev, B, order="feistel", seed=9, epoch=epoch, user_sorted=True)
+        assert ops.LazyAdam.small_epoch_supported(ctx, plan, lid)
+        nb = plan.num_batches
+        sl = torch.zeros(nb, dtype=torch.float64, device=DEV)
+        ctx.epoch_acc.zero_()
+        adam.fit_epoch(ctx, plan, r1, r2, lid, step_losses=sl)
+        torch.cuda.synchronize()
+        want = []
+        for k in range(nb):
+            u, i, j = (x.cpu().numpy().astype(np.int64) for x in plan.read_batch(k, B)[:3])
+            loss_k, gP, gQ = O.mf_pair_grad(Pr, Qr, u, i, j, r1, r2, loss_type=lid)
+            Pr, Qr = ref.step([Pr, Qr], [gP, gQ])
+            want.append(loss_k)
+        np.testing.assert_allclose(sl.cpu().numpy(), want, rtol=2e-5)
+        assert abs(float(ctx.epoch_acc[0].cpu()) - sum(want)) <= 2e-5 * abs(sum(want)) and float(ctx.epoch_acc[1].cpu()) == 0
+        # (a gradient that cancels to round-off takes Adam's +-lr step with a sign the summation order decides: rare
+        # elements up to 2 lr per step apart, tests/test_gpu_fuzz.py; everything else at fp32 round-off of the updates)
+        for got, ref_t in ((P, Pr), (Q, Qr)):
+            diff = np.abs(got.cpu().numpy() - ref_t)
+            assert (diff > 5e-5).mean() < 0.01 and diff.max() <= 2.5 * lr * nb * epoch, (epoch, float(diff.max()))
+    assert adam.t == 2 * nb
+    assert int(adam.last[0].min().cpu()) == adam.t and int(adam.last[1].min().cpu()) == adam.t      # flushed
+    ctx.close(); plan.close()
+
+
 def test_adam_fit_runs_the_epoch_call():
     """MF.fit with Adam takes the one-enqueue epoch (daisy_bpr_fit_epoch_adam) and equals the fit driven step by step:
     the same epoch losses, the same tables."""

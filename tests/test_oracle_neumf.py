@@ -134,3 +134,72 @@ def test_neumf_ml100k_adam_end_to_end(kat_neumf):
     pred, _ = N.neumf_rank(p, g["ml/test_u"], g["ml/cands"], int(g["ml/topk"]), L)
     same = (pred == g["ml/preds"]).all(axis=1).mean()
     assert same > 0.9, f"top-N lists identical for {same:.3f} of the users"
+
+
+def _replay_d64(bf16_points=None):
+    """tests/golden/kat_neumf_d64.npz (make_golden_neumf_d64.py: the REFERENCE's fit at the configs[3] tower shape) replayed
+    with the numpy oracle: the model's init from the seed (checked against the reference's checksums), the DataLoader's
+    order from the stored RNG state, 12 SGD steps"""
+    import logging
+    from daisyrec_amd.model.NeuMFRecommender import NeuMF
+    g = np.load(os.path.join(HERE, "golden", "kat_neumf_d64.npz"))
+    U, I, d, L = (int(x) for x in g["meta"])
+    lr, r1, r2 = (float(x) for x in g["hyper"])
+    cfg = {"gpu": "0", "logger": logging.getLogger("t"), "lr": lr, "reg_1": r1, "reg_2": r2, "epochs": 1, "topk": 50,
+           "user_num": U, "item_num": I, "factors": d, "num_layers": L, "dropout": 0.0, "loss_type": "BPR",
+           "optimizer": "sgd", "init_method": "default", "early_stop": False, "model_name": "NeuMF", "GMF_model": None,
+           "MLP_model": None, "algo_name": "neumf", "progress": False}
+    torch.manual_seed(int(g["seed"]))
+    model = NeuMF(cfg)
+    names = N.param_names(L)
+    p = {k: v.detach().cpu().numpy().copy() for k, v in model._named().items()}
+    for k in names:
+        np.testing.assert_allclose([p[k].astype(np.float64).sum(), np.abs(p[k].astype(np.float64)).sum()], g[f"{k}0_sum"], rtol=1e-12)
+    init = {k: v.copy() for k, v in p.items()}
+    samples, B = g["samples"], int(g["batch_size"])
+    n = len(samples)
+    torch.set_rng_state(torch.from_numpy(g["rng_state_before_fit"]))
+    torch.empty((), dtype=torch.int64).random_()
+    gen = torch.Generator()
+    gen.manual_seed(int(torch.empty((), dtype=torch.int64).random_().item()))
+    perm = torch.randperm(n, generator=gen).numpy()
+    tot = 0.0
+    for s in range(0, n, B):
+        idx = perm[s:s + B]
+        loss, grads = N.neumf_grad(p, samples[idx, 0], samples[idx, 1], samples[idx, 2], r1, r2, L, bf16_points=bf16_points)
+        p = {k: (np.asarray(p[k], np.float64) - lr * grads[k]).astype(np.float32) for k in names}
+        tot += loss
+    return g, p, init, tot
+
+
+def test_neumf_d64_golden_fp64_oracle():
+    """the oracle against the reference's fit at factors 64 / 3 layers: epoch loss within 1e-5, the 12-step change of every
+    parameter at round-off"""
+    g, p, init, tot = _replay_d64()
+    ref = float(g["epoch_losses"][0])
+    assert abs(tot - ref) <= 1e-5 * abs(ref), (tot, ref)
+    for k in p:
+        rows = g[f"{k}_delta"].shape[0]
+        want = g[f"{k}_delta"]
+        got = (p[k] - init[k])[:rows]
+        assert np.linalg.norm(got - want) <= 2e-3 * np.linalg.norm(want) + 1e-9, k
+        np.testing.assert_allclose(p[k][:rows], g[f"{k}1"], atol=2e-6, err_msg=k)
+
+
+def test_neumf_d64_golden_bf16_oracle_states_the_distance_of_bf16_arithmetic():
+    """the SAME fit with the roundings of the HIP path's bf16-storage mode (neumf_grad_bf16 'fact'): how far bf16 arithmetic
+    ITSELF is from the reference over twelve steps.  Measured here: the epoch loss 2.8e-6 away, the GMF tables' change 7e-5
+    (that branch never leaves fp32), the MLP parameters' change 2.3 ... 3.7 % - a BPR step's MLP gradient is the DIFFERENCE of the
+    positive and the negative row's nearly equal contributions, so a 2^-9 rounding of either side is a few per cent of what
+    is left.  The GPU test holds the bf16 fit to the reference with these distances plus a margin, and to THIS replay tightly
+    (tests/test_gpu_neumf.py::test_neumf_ml100k_d64_fit_against_the_reference)."""
+    g, p, init, tot = _replay_d64("fact")
+    ref = float(g["epoch_losses"][0])
+    assert 1e-7 < abs(tot - ref) / abs(ref) <= 5e-5, (tot, ref)
+    err = {}
+    for k in p:
+        rows = g[f"{k}_delta"].shape[0]
+        want = g[f"{k}_delta"]
+        err[k] = float(np.linalg.norm((p[k] - init[k])[:rows] - want) / max(np.linalg.norm(want), 1e-30))
+    assert err["uG"] <= 1e-3 and err["iG"] <= 1e-3, err
+    assert all(e <= 0.06 for e in err.values()) and max(err.values()) > 0.01, err

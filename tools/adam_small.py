@@ -26,6 +26,30 @@ for name, U, I, nnz, d in (("ml-100k shapes", 943, 1152, 78_363, 32), ("configs[
         plan = ops.EpochPlan(n, U, I, device=dev).build_indexed(index, B, order="feistel", seed=1, epoch=0)
         nb = plan.num_batches
         res = {}
+        if B <= ops.SMALL_BATCH_MAX:
+            # round 6: the sorted plan -> every step of the epoch inside one persistent workgroup (csrc/bpr_small.hip), SGD and Adam
+            splan = ops.EpochPlan(n, U, I, device=dev).build(tr, B, order="feistel", seed=1, epoch=0, user_sorted=True)
+            for opt in ("sgd", "adam"):
+                P = torch.empty(U, d, device=dev).normal_(0.0, 0.01, generator=g)
+                Q = torch.empty(I, d, device=dev).normal_(0.0, 0.01, generator=g)
+                ctx = ops.BprContext(B, d, U, I, device=dev)
+                adam = ops.LazyAdam(P, Q, 0.001, 4 * nb) if opt == "adam" else None
+                assert ops.LazyAdam.small_epoch_supported(ctx, splan)
+
+                def epoch():
+                    if adam is not None:
+                        adam.fit_epoch(ctx, splan, 1e-3, 1e-3)
+                    else:
+                        ctx.fit_epoch_sgd(splan, P, Q, 0.01, 1e-3, 1e-3)
+
+                epoch()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                epoch()
+                torch.cuda.synchronize()
+                res[f"persistent workgroup, {opt}"] = (time.perf_counter() - t0) / nb * 1e6
+                ctx.close()
+            splan.close()
         for how in ("python loop", "one enqueue"):
             P = torch.empty(U, d, device=dev).normal_(0.0, 0.01, generator=g)
             Q = torch.empty(I, d, device=dev).normal_(0.0, 0.01, generator=g)
@@ -48,6 +72,5 @@ for name, U, I, nnz, d in (("ml-100k shapes", 943, 1152, 78_363, 32), ("configs[
             torch.cuda.synchronize()
             res[how] = (time.perf_counter() - t0) / nb * 1e6
             ctx.close()
-        print(f"{name}, d={d}, B={B:5d}, {nb} steps per epoch: python loop {res['python loop']:7.1f} us/step, "
-              f"one enqueue {res['one enqueue']:7.1f} us/step", flush=True)
+        print(f"{name}, d={d}, B={B:5d}, {nb} steps per epoch: " + ", ".join(f"{k} {v:7.1f} us/step" for k, v in res.items()), flush=True)
         plan.close(); index.close()
