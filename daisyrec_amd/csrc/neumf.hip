@@ -679,6 +679,7 @@ static void launch_gemm(GemmOp op, hipStream_t s) {
     }
 }
 
+
 // ---------------------------------------------------------------------------------------------
 // the three pair layouts of daisy_neumf_scores plus the training batch
 // ---------------------------------------------------------------------------------------------
@@ -1181,6 +1182,144 @@ __global__ __launch_bounds__(kBlock) void k_nmf_scatter(daisy_neumf_params p, da
 // With ml-1m's 6040 users a batch of 524 288 rows hits every user row ~87 times: the atomic kernel serialises
 // on those addresses.  The regulariser terms are count * f(row) per table row (integer counts).
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Round 6: the step's rows grouped by user and by item with ONE stable counting pass per side instead of two radix sorts
+// (rocprim: two digit passes + histogram + ~5 memsets per sort - 88 us per side at 524 288 rows, a launch chain, not
+// bandwidth).  The table has a few thousand rows (ml-1m: 6040 / 3706), so a whole histogram fits a wave's share of LDS:
+//   k_cs_count    each wave counts the keys of ITS contiguous range of rows (LDS atomics: counts do not depend on order)
+//   k_cs_prefix   per key: exclusive prefix over the waves' counts, in wave order (= row order); the pos / neg halves' totals
+//                 are the regulariser's occurrence counts (what k_nmf_sort_keys counted with global atomics)
+//   k_cs_base     exclusive scan of the keys' totals
+//   k_cs_scatter  each wave walks its rows in order, 64 at a time: a row's slot = base[key] + the waves before + the rows of
+//                 this wave before it with the same key (ballot match inside the 64, a running LDS counter across them)
+// Stable by construction - rows of one key stay in ascending row order - hence the same bits as the radix sorts' output.
+// Both sides (users, items) ride in the same four launches (blockIdx.y).
+// ---------------------------------------------------------------------------------------------
+constexpr int kCsBlocks = 128, kCsWaves = kBlock / kWave, kCsNW = kCsBlocks * kCsWaves;      // 512 wave ranges per side
+constexpr int kCsMaxKeys = 9600;                                                             // 4 waves x keys x 4 B <= 150 KB of LDS
+
+struct CsRange { int64_t lo, hi; };
+// wave range gw of a step of R rows: the pos half [0, B) and the neg half [B, R) are cut separately (so that a half's counts
+// are whole waves); point-wise steps have one half
+__device__ __forceinline__ CsRange cs_range(int gw, int64_t R, int64_t B, int halves) {
+    const int wph = kCsNW / halves, hf = gw / wph, within = gw % wph;
+    const int64_t len = (halves == 2) ? ((hf == 0) ? B : R - B) : R, base = (halves == 2 && hf == 1) ? B : 0;
+    const int64_t chunk = ((len + wph - 1) / wph + kWave - 1) / kWave * kWave;
+    int64_t lo = base + within * chunk, hi = lo + chunk;
+    if (lo > base + len) lo = base + len;
+    if (hi > base + len) hi = base + len;
+    return CsRange{lo, hi};
+}
+__device__ __forceinline__ int32_t cs_key(const PairSrc &src, int64_t r, int side) {
+    int64_t user, item;
+    pair_ids(src, r, user, item);
+    return (int32_t)(side ? item : user);
+}
+
+__global__ __launch_bounds__(kBlock) void k_cs_count(PairSrc src, int64_t R, int halves, int Ku, int Ki, int kstride,
+                                                     int32_t *__restrict__ hist) {
+    extern __shared__ int32_t cs_lds[];
+    const int side = blockIdx.y, K = side ? Ki : Ku;
+    const int lane = threadIdx.x % kWave, w = threadIdx.x / kWave, gw = blockIdx.x * kCsWaves + w;
+    int32_t *h = cs_lds + w * kstride;
+    for (int k = lane; k < K; k += kWave) h[k] = 0;
+    const CsRange rg = cs_range(gw, R, src.B, halves);
+    for (int64_t r0 = rg.lo + lane; r0 < rg.hi; r0 += 4 * kWave) {          // four rows' ids in flight per lane
+        int32_t key[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) key[x] = (r0 + x * kWave < rg.hi) ? cs_key(src, r0 + x * kWave, side) : -1;
+#pragma unroll
+        for (int x = 0; x < 4; ++x) if (key[x] >= 0) atomicAdd(&h[key[x]], 1);
+    }
+    // (a wave's LDS operations complete in order: no barrier between its own adds and reads)
+    int32_t *out = hist + ((int64_t)side * kCsNW + gw) * kstride;
+    for (int k = lane; k < K; k += kWave) out[k] = h[k];
+}
+
+__global__ __launch_bounds__(kBlock) void k_cs_prefix(int halves, int Ku, int Ki, int kstride, int32_t *__restrict__ hist,
+                                                      int32_t *__restrict__ total, int32_t *__restrict__ cnt_u,
+                                                      int32_t *__restrict__ cnt_i, int32_t *__restrict__ cnt_j) {
+    const int side = blockIdx.y, K = side ? Ki : Ku;
+    const int key = blockIdx.x * kBlock + threadIdx.x;
+    if (key >= K) return;
+    int32_t *col = hist + (int64_t)side * kCsNW * kstride + key;
+    const int wph = kCsNW / halves;
+    int32_t run = 0, first_half = 0;
+    static_assert(kCsNW % 16 == 0, "the prefix walks the wave ranges 8 at a time, and a half is a whole number of such groups");
+    for (int g0 = 0; g0 < kCsNW; g0 += 8) {                     // 8 independent loads in flight, then the running sum
+        int32_t cnt[8];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) cnt[x] = col[(int64_t)(g0 + x) * kstride];
+#pragma unroll
+        for (int x = 0; x < 8; ++x) { col[(int64_t)(g0 + x) * kstride] = run; run += cnt[x]; }
+        if (g0 + 8 == wph) first_half = run;
+    }
+    if (halves == 1) first_half = run;
+    total[side * kstride + key] = run;
+    // the regulariser's occurrence counts (NeuMFRecommender.py:149-167): users / items of the positive rows, items of the negatives
+    if (side == 0) cnt_u[key] = first_half;
+    else { cnt_i[key] = first_half; cnt_j[key] = run - first_half; }
+}
+
+// exclusive scan of total[side][0 .. K) in place (one workgroup per side; K <= kCsMaxKeys)
+__global__ __launch_bounds__(1024) void k_cs_base(int Ku, int Ki, int kstride, int32_t *__restrict__ total) {
+    __shared__ int32_t part[1024];
+    const int side = blockIdx.x, K = side ? Ki : Ku, tid = threadIdx.x;
+    int32_t *t = total + side * kstride;
+    const int per = (K + 1023) / 1024, lo = tid * per, hi = (lo + per < K) ? lo + per : K;
+    int32_t sum = 0;
+    for (int k = lo; k < hi; ++k) sum += t[k];
+    part[tid] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {                 // Hillis-Steele over the 1024 partial sums
+        const int32_t v = (tid >= off) ? part[tid - off] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int32_t run = part[tid] - sum;                             // exclusive
+    for (int k = lo; k < hi; ++k) { const int32_t c = t[k]; t[k] = run; run += c; }
+}
+
+__global__ __launch_bounds__(kBlock) void k_cs_scatter(PairSrc src, int64_t R, int halves, int Ku, int Ki, int kstride,
+                                                       const int32_t *__restrict__ hist, const int32_t *__restrict__ total,
+                                                       int32_t *__restrict__ ks_u, int32_t *__restrict__ vs_u,
+                                                       int32_t *__restrict__ ks_i, int32_t *__restrict__ vs_i) {
+    extern __shared__ int32_t cs_lds[];
+    const int side = blockIdx.y, K = side ? Ki : Ku;
+    const int lane = threadIdx.x % kWave, w = threadIdx.x / kWave, gw = blockIdx.x * kCsWaves + w;
+    int32_t *off = cs_lds + w * kstride;
+    const int32_t *mine = hist + ((int64_t)side * kCsNW + gw) * kstride, *base = total + side * kstride;
+    for (int k = lane; k < K; k += kWave) off[k] = base[k] + mine[k];
+    int32_t *ks = side ? ks_i : ks_u, *vs = side ? vs_i : vs_u;
+    const CsRange rg = cs_range(gw, R, src.B, halves);
+    const uint64_t lt = ((uint64_t)1 << lane) - 1;
+    for (int64_t rb = rg.lo; rb < rg.hi; rb += 4 * kWave) {
+      int32_t keys[4];                                         // the ids of four 64-row groups in flight
+#pragma unroll
+      for (int x = 0; x < 4; ++x) keys[x] = (rb + x * kWave + lane < rg.hi) ? cs_key(src, rb + x * kWave + lane, side) : -1;
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        const int64_t r = rb + x * kWave + lane;
+        const bool valid = r < rg.hi;
+        const int32_t key = keys[x];
+        if (rb + x * kWave >= rg.hi) break;
+        uint64_t peers = __ballot(valid);                      // lanes of this 64 with the same key
+#pragma unroll
+        for (int b = 0; b < 14; ++b) {
+            const uint64_t m = __ballot((key >> b) & 1);
+            peers &= ((key >> b) & 1) ? m : ~m;
+        }
+        if (valid) {
+            const int32_t slot = off[key] + (int32_t)__popcll(peers & lt);
+            ks[slot] = key;
+            vs[slot] = (int32_t)r;
+            if ((peers & lt) == 0) off[key] += (int32_t)__popcll(peers);      // one lane per key moves the running counter
+        }
+      }
+    }
+}
+
 __global__ void k_nmf_sort_keys(PairSrc src, int64_t R, int32_t *__restrict__ ku, int32_t *__restrict__ ki,
                                 int32_t *__restrict__ val, int pointwise, int32_t *__restrict__ cnt_u,
                                 int32_t *__restrict__ cnt_i, int32_t *__restrict__ cnt_j) {
@@ -1280,6 +1419,7 @@ struct daisy_neumf_ctx {
     float *sc_sum, *sc_edge_vec, *sc_edge_b;
     int32_t *sc_edge_item, *sc_edge_whole;
     void *sc_tmp; size_t sc_tmp_bytes;
+    int32_t *cs_hist;                        // counting pass: [2 sides][kCsNW waves][key stride] counts -> prefixes, then [2][stride] totals
     int bf16;                                // daisy_neumf_ctx_set_precision: 0 fp32, 1 bf16 MFMA inputs, 2 bf16 storage
     // per-workgroup partial sums of the reductions over the batch rows (split-K slices of the weight-gradient GEMMs,
     // row tiles of the column sums ...), added in a fixed order by k_reduce_slices; allocated at the first training step
@@ -1530,6 +1670,7 @@ static int neumf_scatter_scratch(daisy_neumf_ctx *c) {
     if (e != hipSuccess) {
         set_error("neumf: hipMalloc(%zu) of the scatter scratch failed: %s", off, hipGetErrorString(e));
         c->sc_arena = nullptr;
+    c->cs_hist = nullptr;
         return DAISY_ERR_HIP;
     }
     char *b = (char *)c->sc_arena;
@@ -1559,18 +1700,51 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
     if (rc) return rc;
     const int d = c->d, dm = c->dm, model = c->model;
     const int64_t n_pad = R + (R & 1);
-    hipLaunchKernelGGL(k_nmf_sort_keys, dim3(grid_for(R, kBlock * 2)), dim3(kBlock), 0, s, src, R, c->sc_ku, c->sc_ki,
-                       c->sc_val, pointwise, c->sc_cu, c->sc_ci, c->sc_cj);
+    // rows grouped by table row: the counting pass (tables of at most kCsMaxKeys rows - a histogram per wave fits the LDS),
+    // else two radix sorts.  DAISY_NMF_COUNTING=0 (read per call): always the sorts (A/B, and the tests' cross-check)
+    const char *env_cs = getenv("DAISY_NMF_COUNTING");
+    const int Kmax = (int)(c->U > c->I ? c->U : c->I);
+    const bool counting = (!env_cs || atoi(env_cs) != 0) && Kmax <= kCsMaxKeys && Kmax < (1 << 14) && R >= 4096;
+    const int kstride = (Kmax + 63) / 64 * 64;
+    if (counting) {
+        if (!c->cs_hist) {
+            const size_t n = (size_t)2 * (kCsNW + 1) * (size_t)((kCsMaxKeys + 63) / 64 * 64);
+            if (hipMalloc((void **)&c->cs_hist, n * sizeof(int32_t)) != hipSuccess) {
+                c->cs_hist = nullptr;
+                set_error("neumf: hipMalloc(%zu) of the counting pass's histograms failed", n * sizeof(int32_t));
+                return DAISY_ERR_HIP;
+            }
+            DAISY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cs_count), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+            DAISY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cs_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
+        }
+        const int halves = pointwise ? 1 : 2;
+        int32_t *total = c->cs_hist + (size_t)2 * kCsNW * kstride;
+        const size_t lds = (size_t)kCsWaves * kstride * sizeof(int32_t);
+        hipLaunchKernelGGL(k_cs_count, dim3(kCsBlocks, 2), dim3(kBlock), lds, s, src, R, halves, (int)c->U, (int)c->I, kstride, c->cs_hist);
+        hipLaunchKernelGGL(k_cs_prefix, dim3((Kmax + kBlock - 1) / kBlock, 2), dim3(kBlock), 0, s, halves, (int)c->U, (int)c->I, kstride,
+                           c->cs_hist, total, c->sc_cu, c->sc_ci, c->sc_cj);
+        hipLaunchKernelGGL(k_cs_base, dim3(2), dim3(1024), 0, s, (int)c->U, (int)c->I, kstride, total);
+        hipLaunchKernelGGL(k_cs_scatter, dim3(kCsBlocks, 2), dim3(kBlock), lds, s, src, R, halves, (int)c->U, (int)c->I, kstride,
+                           c->cs_hist, total, c->sc_ks, c->sc_vs, c->sc_ku, c->sc_val);
+    } else {
+        hipLaunchKernelGGL(k_nmf_sort_keys, dim3(grid_for(R, kBlock * 2)), dim3(kBlock), 0, s, src, R, c->sc_ku, c->sc_ki,
+                           c->sc_val, pointwise, c->sc_cu, c->sc_ci, c->sc_cj);
+    }
     DAISY_LAUNCH_CHECK();
     for (int side = 0; side < 2; ++side) {            // 0: the user tables, 1: the item tables
         const int64_t rows = side ? c->I : c->U;
-        rc = sort_pairs_i32(c->sc_tmp, c->sc_tmp_bytes, side ? c->sc_ki : c->sc_ku, c->sc_ks, c->sc_val, c->sc_vs, R,
-                            bits_for(rows), s);
-        if (rc) return rc;
+        // the side's grouped rows: (keys, row ids) in table-row order, rows ascending inside a key
+        const int32_t *g_ks = c->sc_ks, *g_vs = c->sc_vs;
+        if (counting) { if (side) { g_ks = c->sc_ku; g_vs = c->sc_val; } }
+        else {
+            rc = sort_pairs_i32(c->sc_tmp, c->sc_tmp_bytes, side ? c->sc_ki : c->sc_ku, c->sc_ks, c->sc_val, c->sc_vs, R,
+                                bits_for(rows), s);
+            if (rc) return rc;
+        }
         const int ge = grid_for(n_pad, kBlock * 2), gt = grid_for(rows, kBlock / 16 * 2);
         // MLP table: source row = half `side` of DX0[r]
         if (model != DAISY_NEUMF_GMF) {
-            hipLaunchKernelGGL(k_nmf_entries, dim3(ge), dim3(kBlock), 0, s, c->sc_ks, c->sc_vs, R, n_pad, fact ? 1 : 2,
+            hipLaunchKernelGGL(k_nmf_entries, dim3(ge), dim3(kBlock), 0, s, g_ks, g_vs, R, n_pad, fact ? 1 : 2,
                                fact ? 0 : side, c->sc_ekey, c->sc_esu, c->sc_w);
             rc = segsum_rows(DX0, c->sc_w, c->sc_ekey, c->sc_esu, n_pad, dm, c->sc_sum, c->sc_edge_vec, c->sc_edge_item,
                              c->sc_edge_b, c->sc_edge_whole, s, dx0_bf16);
@@ -1592,6 +1766,9 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
             a.B = p.W[0] + (side ? dm : 0); a.sbn = 1; a.sbk = w0;
             a.C = side ? g.iM : g.uM; a.ldc = dm;
             a.M = rows; a.N = dm; a.K = n1; a.k_chunk = a.K;
+            // (measured and rejected, round 6: whole 128-row tiles through the branch-free kernel + the ragged remainder through
+            // the guarded one - the six table products of a step are latency-bound per TILE (94 workgroups, 16 dependent k
+            // steps each: 22-27 us with either loader), so two launches per product cost more: 1.09 -> 1.22 ms per step)
             launch_gemm<EPI_ATOMIC>(a, s);     // (one workgroup per output tile, k in one piece: a single add per element)
             GemmOp b{};                        // gW_1[n1, half] += S^T[n1, rows] table[rows, dm]    (k = the table's rows)
             b.A = c->sc_sum; b.sam = 1; b.sak = n1;
@@ -1618,7 +1795,7 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
                            side ? c->sc_ci : c->sc_cu, side ? 3 : 1, (int32_t *)nullptr, 0, 0.f, stats, reg_1, reg_2, 0);
         // GMF table: source row = the materialised per-row gradient
         if (model != DAISY_NEUMF_MLP) {          // source rows: the OTHER table's, weights dpred (k_nmf_entries_gmf)
-            hipLaunchKernelGGL(k_nmf_entries_gmf, dim3(ge), dim3(kBlock), 0, s, c->sc_ks, c->sc_vs, R, n_pad, src, side, c->dpred,
+            hipLaunchKernelGGL(k_nmf_entries_gmf, dim3(ge), dim3(kBlock), 0, s, g_ks, g_vs, R, n_pad, src, side, c->dpred,
                                c->sc_ekey, c->sc_esu, c->sc_w);
             rc = segsum_rows(side ? p.uG : p.iG, c->sc_w, c->sc_ekey, c->sc_esu, n_pad, d, c->sc_sum, c->sc_edge_vec,
                              c->sc_edge_item, c->sc_edge_b, c->sc_edge_whole, s);
@@ -1686,6 +1863,7 @@ int daisy_neumf_ctx_destroy(daisy_neumf_ctx *ctx) {
     if (!ctx) return DAISY_OK;
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->sc_arena) (void)hipFree(ctx->sc_arena);
+    if (ctx->cs_hist) (void)hipFree(ctx->cs_hist);
     if (ctx->det_ws) (void)hipFree(ctx->det_ws);
     if (ctx->fact_t) (void)hipFree(ctx->fact_t);
     delete ctx;
