@@ -67,13 +67,17 @@ struct GemmOp {
 
 template <int WN, int EPI, bool FAST, bool DROP>
 __device__ __forceinline__ void gemm_epilogue(const GemmOp &op, floatx16 (&acc)[2][WN], int64_t m0, int n0, int wm,
-                                              int wn, int lane) {
+                                              int wn, int lane, unsigned zslice) {
     // lane holds column (lane % 32), rows (i/4)*8 + (lane/32)*4 + i%4 of each 32x32 block (all MFMA
     // 32x32 shapes share this C/D map on gfx950).  epilogue: lane holds column (lane % 32), rows (i/4)*8 + (lane/32)*4 + i%4 of each 32x32 block.
     // 32-bit offsets from the tile origin (a tile spans < 2^31 elements of C: 128 rows x ldc)
     const int scn = op.scn ? (int)op.scn : 1;
     float *__restrict__ Ct = op.C + m0 * op.ldc + (int64_t)n0 * scn;
-    if constexpr (EPI == EPI_ATOMIC) Ct += (int64_t)blockIdx.z * op.slice_stride;
+    // (the k slice this workgroup computed - k_gemm_h remaps workgroups to tiles, so that is NOT blockIdx.z there: until round 6
+    // the slices of the bf16-storage weight gradients landed in the slot of blockIdx.z, two workgroups per slot whenever the
+    // slice count was a multiple of 8 and an output had fewer than 8 tiles - partial products lost, unseen by tests that
+    // allowed 25 %; found by the bf16 oracle at 2 %)
+    if constexpr (EPI == EPI_ATOMIC) Ct += (int64_t)zslice * op.slice_stride;
     const float *__restrict__ Gt = (EPI == EPI_GATE && op.gate) ? op.gate + m0 * op.ldg + n0 : nullptr;
     const int ldc = (int)op.ldc, ldg = (int)op.ldg;
 #pragma unroll
@@ -245,7 +249,7 @@ __global__ __launch_bounds__(kBlock) void k_gemm(GemmOp op) {
         }
     }
 
-    gemm_epilogue<WN, EPI, FAST, DROP>(op, acc, m0, n0, wm, wn, lane);
+    gemm_epilogue<WN, EPI, FAST, DROP>(op, acc, m0, n0, wm, wn, lane, blockIdx.z);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(kBlock) void k_gemm_bf16(GemmOp op) {
             cur ^= 1;
         }
     }
-    gemm_epilogue<WN, EPI, true, DROP>(op, acc, m0, n0, wm, wn, lane);
+    gemm_epilogue<WN, EPI, true, DROP>(op, acc, m0, n0, wm, wn, lane, blockIdx.z);
 }
 
 // bf16-STORAGE variant (precision level 2): both operands are bf16 in HBM, so a tile row of 32 k is 64 bytes -
@@ -527,7 +531,7 @@ __global__ __launch_bounds__(kBlock) void k_gemm_h(GemmOp op) {
         }
     }
     if (EPI == EPI_ATOMIC || op.C16 == nullptr) {      // fp32 result: split-K atomics, or the tower's input gradient
-        gemm_epilogue<WN, EPI, true, DROP>(op, acc, m0, n0, wm, wn, lane);
+        gemm_epilogue<WN, EPI, true, DROP>(op, acc, m0, n0, wm, wn, lane, tile.z);
     } else {        // bf16 output (interior tiles only: launch_gemm_h checks)
         // The MFMA result layout gives a lane ONE column and 32 scattered rows: written directly that is 64 two-byte
         // stores per lane.  So the tile takes a detour through LDS (the operand stages are dead by now) and
@@ -1988,6 +1992,17 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
             }
             w.K = R;
             w.k_chunk = wgrad_chunk();
+            {
+                // few rows (the reference's own batch: 256 samples = 512 rows) and a small layer: ONE workgroup would walk all
+                // rows of the step with guarded loads - 50 us per weight gradient at factors 24, a third of that step.  Slices
+                // of at least 64 rows, as many as give the chip ~256 workgroups and as the reduction workspace holds.
+                const int64_t tiles = ((w.M + kGemmBM - 1) / kGemmBM) * ((w.N + ((w.N > 64) ? 128 : 64) - 1) / ((w.N > 64) ? 128 : 64));
+                int64_t kc = (R * tiles / 256 + 63) / 64 * 64;
+                if (kc < 64) kc = 64;
+                const int64_t cap = (int64_t)(ctx->det_ws_floats / (size_t)((int64_t)n_out * n_in));
+                if (cap > 0 && (R + kc - 1) / kc > cap) kc = ((R + cap - 1) / cap + 63) / 64 * 64;
+                if (kc < w.k_chunk) w.k_chunk = kc;
+            }
             w.bf16 = ctx->bf16 ? 1 : 0;
             // split-K slices land side by side in the workspace and are added in slice order (no fp32 atomics)
             const int64_t wlen = (int64_t)n_out * n_in;

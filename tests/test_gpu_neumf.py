@@ -332,14 +332,16 @@ BF16_PATHS = {"tower": (2, {"DAISY_NMF_FACT": "1", "DAISY_NMF_TOWER": "1"}, "fac
 
 
 @pytest.mark.parametrize("path", ["tower", "fact", "plain", "inputs"])
-@pytest.mark.parametrize("loss,B,scale", [(0, 256, 0.05), (0, 1024, 0.2), (3, 512, 0.1), (2, 128, 0.1)])
+@pytest.mark.parametrize("loss,B,scale", [(0, 256, 0.05), (0, 1024, 0.2), (3, 512, 0.1), (2, 128, 0.1), (0, 8192, 0.1)])
 def test_neumf_bf16_step_against_the_bf16_oracle(path, loss, B, scale, monkeypatch):
     """Round 6: the bf16 modes pinned to an oracle that rounds to bf16 at the same points (oracle/neumf_numpy.py:
     neumf_grad_bf16 - the table products, every stored activation and back-propagated gradient, the MFMA inputs), instead of
     'within 25 % of the fp32 mode'.  What is left between the two is fp32-vs-fp64 accumulation and the rare element whose
     bf16 rounding (or ReLU gate) sits on a tie: the loss to 1e-4, every gradient to 2 % of its norm - a dropped bias term, a
     wrong scale on one layer or a missing rounding point is ten times that.  Paths: the fused tower kernel (csrc/neumf_tower.hip),
-    the layer-by-layer kernels behind the table products, the plain bf16-storage step, and precision level 1."""
+    the layer-by-layer kernels behind the table products, the plain bf16-storage step, and precision level 1.  B = 8192: 16 384
+    rows = 8 split-K slices of the weight gradients - the count at which the bf16-storage GEMM remaps workgroups to tiles (until
+    round 6 its slices then landed in the wrong workspace slots: partial products lost, inside the old 25 % tolerance)."""
     from daisyrec_amd import ops
     level, env, mode = BF16_PATHS[path]
     rng = np.random.default_rng(5 + B)
