@@ -1187,6 +1187,86 @@ __global__ __launch_bounds__(kBlock) void k_nmf_scatter(daisy_neumf_params p, da
 // on those addresses.  The regulariser terms are count * f(row) per table row (integer counts).
 // ---------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------
+// Round 6: the embedding gradients of a SMALL step (at most 1024 rows: the reference's own batch of 256 samples is 512) in
+// two workgroups - one per side - instead of the ~22 launches of the owner-based scatter below (keys, two sorts, entry
+// lists, four segmented reductions with their edge launches, four commits): at that size every one of them is a few
+// microseconds of launch latency around almost no work, and together they were a third of the 300 us step.
+// Per side: the rows' (table row, row) pairs are sorted in LDS (bitonic, one element per thread); a lane group owns each
+// table row that occurs and adds its rows' contributions in ascending row order (deterministic), then the regulariser terms
+// of NeuMFRecommender.py:149-167 from the run's own counts, and writes the four gradient rows.
+// ---------------------------------------------------------------------------------------------
+constexpr int kScatterSmallRows = 1024;
+__global__ __launch_bounds__(kScatterSmallRows) void k_nmf_scatter_small(daisy_neumf_params p, daisy_neumf_params g, PairSrc src,
+                                                                        int R, int d, int dm, int model, int pointwise,
+                                                                        const float *__restrict__ dpred,
+                                                                        const float *__restrict__ DX0,
+                                                                        const double *__restrict__ stats, float reg_1,
+                                                                        float reg_2) {
+    __shared__ uint32_t comp[kScatterSmallRows];          // table row << 10 | step row; padding sorts last
+    const int side = blockIdx.x, tid = threadIdx.x;
+    {
+        uint32_t c = 0xFFFFFFFFu;
+        if (tid < R) {
+            int64_t user, item;
+            pair_ids(src, tid, user, item);
+            c = ((uint32_t)(side ? item : user) << 10) | (uint32_t)tid;
+        }
+        comp[tid] = c;
+    }
+    __syncthreads();
+    for (int k = 2; k <= kScatterSmallRows; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int other = tid ^ j;
+            if (other > tid) {
+                const uint32_t a = comp[tid], b = comp[other];
+                const bool up = (tid & k) == 0;
+                if ((a > b) == up) { comp[tid] = b; comp[other] = a; }
+            }
+            __syncthreads();
+        }
+    auto inv = [&](int k) { const double n = stats[DAISY_NST_NORM + k]; return (n > 0.0) ? (float)((double)reg_2 / n) : 0.f; };
+    const float i_m = inv(side ? 3 : 1), i_g = inv(side ? 2 : 0), i_neg = 2.f * inv(4);
+    const int lane = tid % 16, group = tid / 16;
+    const float *tabM = side ? p.iM : p.uM, *tabG = side ? p.iG : p.uG, *otherG = side ? p.uG : p.iG;
+    float *gM = side ? g.iM : g.uM, *gG = side ? g.iG : g.uG;
+    for (int e = group; e < R; e += kScatterSmallRows / 16) {
+        const uint32_t row = comp[e] >> 10;
+        if (e > 0 && (comp[e - 1] >> 10) == row) continue;            // the head of a run owns the table row
+        int run = 1;
+        while (e + run < R && (comp[e + run] >> 10) == row) ++run;
+        float npos = 0.f, nneg = 0.f;
+        for (int q = 0; q < run; ++q) { if ((int64_t)(comp[e + q] & 1023u) < src.B) npos += 1.f; else nneg += 1.f; }
+        // MLP table: the rows' input gradients (this side's half of dX0), the regulariser on the positive rows' occurrences
+        for (int c = lane; c < dm; c += 16) {
+            float v = 0.f;
+            if (model != DAISY_NEUMF_GMF)
+                for (int q = 0; q < run; ++q) v += DX0[(int64_t)(comp[e + q] & 1023u) * (2 * dm) + side * dm + c];
+            if (npos > 0.f) { const float w = tabM[(int64_t)row * dm + c]; v += fmaf(npos * i_m, w, reg_1 * npos * sgn(w)); }
+            if (v != 0.f) gM[(int64_t)row * dm + c] += v;
+        }
+        // GMF table: Wp[c] x sum of dpred[r] x the OTHER table's row; the negative item's rows count twice in the regulariser
+        for (int c = lane; c < d; c += 16) {
+            float v = 0.f;
+            if (model != DAISY_NEUMF_MLP) {
+                for (int q = 0; q < run; ++q) {
+                    const int64_t r = comp[e + q] & 1023u;
+                    int64_t user, item;
+                    pair_ids(src, r, user, item);
+                    v = fmaf(dpred[r], otherG[(side ? user : item) * d + c], v);
+                }
+                v *= p.Wp[c];
+            }
+            const float na = npos, nb = (side && !pointwise) ? nneg : 0.f;
+            if (na + nb > 0.f) {
+                const float w = tabG[(int64_t)row * d + c];
+                v += fmaf(na * i_g + nb * i_neg, w, reg_1 * (na + 2.f * nb) * sgn(w));
+            }
+            if (v != 0.f) gG[(int64_t)row * d + c] += v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Round 6: the step's rows grouped by user and by item with ONE stable counting pass per side instead of two radix sorts
 // (rocprim: two digit passes + histogram + ~5 memsets per sort - 88 us per side at 524 288 rows, a launch chain, not
 // bandwidth).  The table has a few thousand rows (ml-1m: 6040 / 3706), so a whole histogram fits a wave's share of LDS:
@@ -1700,6 +1780,16 @@ static int neumf_scatter_scratch(daisy_neumf_ctx *c) {
 static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, const daisy_neumf_params &g,
                                const PairSrc &src, int64_t R, int pointwise, const float *DX0, bool dx0_bf16,
                                const double *stats, float reg_1, float reg_2, hipStream_t s, bool fact = false) {
+    {
+        // small steps: the whole scatter in two workgroups (k_nmf_scatter_small).  DAISY_NMF_SCATTER_SMALL=0 (read per call): off
+        const char *env_sm = getenv("DAISY_NMF_SCATTER_SMALL");
+        if (R <= kScatterSmallRows && !dx0_bf16 && !fact && (!env_sm || atoi(env_sm) != 0) && c->U < (1 << 22) && c->I < (1 << 22)) {
+            hipLaunchKernelGGL(k_nmf_scatter_small, dim3(2), dim3(kScatterSmallRows), 0, s, p, g, src, (int)R, c->d, c->dm, c->model,
+                               pointwise, c->dpred, DX0, stats, reg_1, reg_2);
+            DAISY_LAUNCH_CHECK();
+            return DAISY_OK;
+        }
+    }
     int rc = neumf_scatter_scratch(c);
     if (rc) return rc;
     const int d = c->d, dm = c->dm, model = c->model;

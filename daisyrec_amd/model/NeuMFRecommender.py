@@ -195,14 +195,17 @@ class NeuMF(GeneralRecommender):
                 self.train()
                 perm = self._epoch_order(train_loader, triples.shape[0])
                 order = triples[:n] if perm is None else triples[perm[:n].to(self.device)]
+                # the epoch's ids column by column, once: a batch is then three views (at B = 256 the three per-batch copies
+                # were 3 of the step's ~46 launches, each a few microseconds of latency)
+                cols = [order[:, k].contiguous() for k in range(3)]
+                loss_of_step = ctx.stats[N.NST_LOSS:N.NST_LOSS + 1]
                 acc.zero_()
                 for s in range(0, n, B):
-                    rows = order[s:s + B]
-                    u, i, j = (rows[:, k].contiguous() for k in range(3))
+                    u, i, j = (col[s:s + B] for col in cols)
                     step += 1
                     ctx.step_grads(p, grads, u, i, j, loss_id, self.reg_1, self.reg_2, dropout=self.dropout,
                                    seed=(self.seed << 32) | step)
-                    acc[0] += ctx.stats[N.NST_LOSS]
+                    acc[0:1].add_(loss_of_step)
                     optim.next_step()
                     optim.step(self._flat, gflat)          # also clears the gradient
                 current_loss = float(acc[0].cpu())

@@ -449,6 +449,49 @@ def test_neumf_rows_grouped_by_a_counting_pass_equal_the_radix_sorts(loss, B, le
     assert abs(la - want_loss) <= (1e-4 if level == 2 else 1e-5) * abs(want_loss)
 
 
+@pytest.mark.parametrize("model,loss,B,L,d", [("NeuMF", 0, 256, 2, 24), ("NeuMF", 3, 1000, 3, 16), ("GMF", 0, 100, 2, 8), ("MLP", 2, 37, 1, 12)])
+def test_neumf_small_steps_scatter_in_one_launch(model, loss, B, L, d, monkeypatch):
+    """Round 6: at most 1024 rows per step (the reference's batch of 256 samples is 512) - the embedding gradients come from
+    two workgroups (k_nmf_scatter_small: LDS sort + one owner per table row) instead of ~22 launches.  Against the
+    owner-based scatter it replaces (DAISY_NMF_SCATTER_SMALL=0; other association of the same sums: fp32 round-off) and the
+    fp64 oracle; hot rows (7 users), every model variant, point-wise rows, a row count that is no power of two; repeatable."""
+    from daisyrec_amd import ops
+    rng = np.random.default_rng(B + d)
+    U, I = 7, 300
+    dm = d << (L - 1)
+    shapes = {"uG": (U, d), "iG": (I, d), "uM": (U, dm), "iM": (I, dm), "Wp": (1, d if model != "NeuMF" else 2 * d), "bp": (1,)}
+    w = 2 * dm
+    for l in range(1, L + 1):
+        shapes[f"W{l}"], shapes[f"b{l}"] = (w // 2, w), (w // 2,)
+        w //= 2
+    p_np = {k: (rng.standard_normal(s) * 0.2).astype(np.float32) for k, s in shapes.items()}
+    u, i = (rng.integers(0, n, B).astype(np.int32) for n in (U, I))
+    j = (rng.integers(0, I, B) if loss < 3 else rng.integers(0, 2, B)).astype(np.int32)
+    R = B if loss >= 3 else 2 * B
+    idx = [torch.as_tensor(x).to(DEV) for x in (u, i, j)]
+
+    def run(env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        p = _dev(p_np)
+        grads = {k: torch.zeros_like(v) for k, v in p.items()}
+        ctx = ops.NeumfContext(R, d, L, U, I, model=model)
+        ctx.step_grads(p, grads, *idx, loss, 1e-3, 2e-3)
+        out = float(ctx.stats[11].cpu()), {k: v.cpu().numpy() for k, v in grads.items()}
+        ctx.close()
+        return out
+
+    la, ga = run({"DAISY_NMF_SCATTER_SMALL": "1"})
+    la2, ga2 = run({"DAISY_NMF_SCATTER_SMALL": "1"})
+    lb, gb = run({"DAISY_NMF_SCATTER_SMALL": "0"})
+    want_loss, want = NO.neumf_grad(p_np, u, i, j, 1e-3, 2e-3, L, loss, model)
+    assert la == la2 == lb and abs(la - want_loss) <= 1e-5 * abs(want_loss)
+    for k in ("uG", "iG", "uM", "iM"):
+        assert np.array_equal(ga[k], ga2[k]), k
+        tol = 3e-4 * np.abs(want[k]).max() + 3e-6 * (1 + np.sqrt(R))
+        assert np.abs(ga[k] - want[k]).max() <= tol and np.abs(ga[k] - gb[k]).max() <= tol, (k, float(np.abs(ga[k] - want[k]).max()), tol)
+
+
 @pytest.mark.parametrize("M,N,K,chunk", [(256, 512, 4096, 2048), (128, 64, 96, 32), (512, 256, 16384, 2048),
                                           (128, 128, 640, 64), (256, 64, 1024, 1024)])
 def test_mfma_gemm_tn_bf16_weight_gradient_layout(M, N, K, chunk):
