@@ -1051,9 +1051,12 @@ __global__ __launch_bounds__(kBlock) void k_nmf_pred_bwd_v(const float *__restri
 // ws[row tile][n] = sum over the tile's rows of X[r*ld + n]: a block takes 64 columns x kColsumRows rows (grid = column
 // tiles x row tiles); k_reduce_slices adds the row tiles in order
 constexpr int kColsumRows = 512;
+// rows per workgroup: 512, or 64 for matrices of a few thousand rows (a step of 512 rows was ONE workgroup per 64 columns
+// walking all of them: 15 us for 100 KB)
+static inline int colsum_rows(int64_t R) { return R <= 8192 ? 64 : kColsumRows; }
 template <bool H = false>
 __global__ __launch_bounds__(kBlock) void k_colsum(const float *__restrict__ X, int64_t R, int N, int64_t ld,
-                                                   float *__restrict__ out) {
+                                                   float *__restrict__ out, int rows_per_block = kColsumRows) {
     auto at = [&](int64_t idx) -> float {
         if constexpr (H) return bf16_to_f32(reinterpret_cast<const uint16_t *>(X)[idx]);
         else return X[idx];
@@ -1061,8 +1064,8 @@ __global__ __launch_bounds__(kBlock) void k_colsum(const float *__restrict__ X, 
     __shared__ float sm[4][64];
     const int c = threadIdx.x % 64, rr = threadIdx.x / 64;
     const int n = blockIdx.x * 64 + c;
-    const int64_t r0 = (int64_t)blockIdx.y * kColsumRows;
-    const int64_t r1 = (r0 + kColsumRows < R) ? r0 + kColsumRows : R;
+    const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+    const int64_t r1 = (r0 + rows_per_block < R) ? r0 + rows_per_block : R;
     float s0 = 0.f, s1 = 0.f;
     if (n < N) {
         int64_t r = r0 + rr;
@@ -1188,7 +1191,7 @@ __global__ __launch_bounds__(kBlock) void k_nmf_scatter(daisy_neumf_params p, da
 // ---------------------------------------------------------------------------------------------
 // ---------------------------------------------------------------------------------------------
 // Round 6: the embedding gradients of a SMALL step (at most 1024 rows: the reference's own batch of 256 samples is 512) in
-// two workgroups - one per side - instead of the ~22 launches of the owner-based scatter below (keys, two sorts, entry
+// one launch - sixteen workgroups per side - instead of the ~22 launches of the owner-based scatter below (keys, two sorts, entry
 // lists, four segmented reductions with their edge launches, four commits): at that size every one of them is a few
 // microseconds of launch latency around almost no work, and together they were a third of the 300 us step.
 // Per side: the rows' (table row, row) pairs are sorted in LDS (bitonic, one element per thread); a lane group owns each
@@ -1203,6 +1206,8 @@ __global__ __launch_bounds__(kScatterSmallRows) void k_nmf_scatter_small(daisy_n
                                                                         const double *__restrict__ stats, float reg_1,
                                                                         float reg_2) {
     __shared__ uint32_t comp[kScatterSmallRows];          // table row << 10 | step row; padding sorts last
+    // (16 workgroups per side: every one sorts the whole list - microseconds - and owns the runs whose heads fall on its
+    // share of the positions; two workgroups walked ~250 runs each through dependent loads: 90 us)
     const int side = blockIdx.x, tid = threadIdx.x;
     {
         uint32_t c = 0xFFFFFFFFu;
@@ -1229,7 +1234,7 @@ __global__ __launch_bounds__(kScatterSmallRows) void k_nmf_scatter_small(daisy_n
     const int lane = tid % 16, group = tid / 16;
     const float *tabM = side ? p.iM : p.uM, *tabG = side ? p.iG : p.uG, *otherG = side ? p.uG : p.iG;
     float *gM = side ? g.iM : g.uM, *gG = side ? g.iG : g.uG;
-    for (int e = group; e < R; e += kScatterSmallRows / 16) {
+    for (int e = (int)blockIdx.y * (kScatterSmallRows / 16) + group; e < R; e += (int)gridDim.y * (kScatterSmallRows / 16)) {
         const uint32_t row = comp[e] >> 10;
         if (e > 0 && (comp[e - 1] >> 10) == row) continue;            // the head of a run owns the table row
         int run = 1;
@@ -1784,7 +1789,7 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
         // small steps: the whole scatter in two workgroups (k_nmf_scatter_small).  DAISY_NMF_SCATTER_SMALL=0 (read per call): off
         const char *env_sm = getenv("DAISY_NMF_SCATTER_SMALL");
         if (R <= kScatterSmallRows && !dx0_bf16 && !fact && (!env_sm || atoi(env_sm) != 0) && c->U < (1 << 22) && c->I < (1 << 22)) {
-            hipLaunchKernelGGL(k_nmf_scatter_small, dim3(2), dim3(kScatterSmallRows), 0, s, p, g, src, (int)R, c->d, c->dm, c->model,
+            hipLaunchKernelGGL(k_nmf_scatter_small, dim3(2, 16), dim3(kScatterSmallRows), 0, s, p, g, src, (int)R, c->d, c->dm, c->model,
                                pointwise, c->dpred, DX0, stats, reg_1, reg_2);
             DAISY_LAUNCH_CHECK();
             return DAISY_OK;
@@ -1851,8 +1856,9 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
                 // table rows (6 MB at ml-1m) instead of one over the R rows of dZ_1 (268 MB: 47 us)
                 rc = neumf_need_det_ws(c);
                 if (rc) return rc;
-                const dim3 cs((unsigned)((n1 + 63) / 64), (unsigned)((rows + kColsumRows - 1) / kColsumRows));
-                hipLaunchKernelGGL((k_colsum<false>), cs, dim3(kBlock), 0, s, c->sc_sum, rows, n1, (int64_t)n1, c->det_ws);
+                const int cr = colsum_rows(rows);
+                const dim3 cs((unsigned)((n1 + 63) / 64), (unsigned)((rows + cr - 1) / cr));
+                hipLaunchKernelGGL((k_colsum<false>), cs, dim3(kBlock), 0, s, c->sc_sum, rows, n1, (int64_t)n1, c->det_ws, cr);
                 reduce_slices(c->det_ws, (int)cs.y, n1, g.b[0], s);
             }
             GemmOp a{};                        // g.table[rows, dm] += S[rows, n1] W1[:, half]      (k = n1)
@@ -2100,7 +2106,8 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
             float *wdst = w.C;
             w.C = ws;
             w.slice_stride = wlen;
-            const dim3 cs_grid((unsigned)((n_out + 63) / 64), (unsigned)((R + kColsumRows - 1) / kColsumRows));
+            const int cr = colsum_rows(R);
+            const dim3 cs_grid((unsigned)((n_out + 63) / 64), (unsigned)((R + cr - 1) / cr));
             if (H) {
                 w.A16 = reinterpret_cast<const uint16_t *>(w.A);
                 w.B16 = reinterpret_cast<const uint16_t *>(w.B);
@@ -2113,13 +2120,13 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
                                        reinterpret_cast<const uint16_t *>(dz), R, n_out, ws);
                     reduce_slices(ws, tiles, n_out, g.b[l - 1], s);
                 } else {
-                    hipLaunchKernelGGL((k_colsum<true>), cs_grid, dim3(kBlock), 0, s, dz, R, n_out, (int64_t)n_out, ws);
+                    hipLaunchKernelGGL((k_colsum<true>), cs_grid, dim3(kBlock), 0, s, dz, R, n_out, (int64_t)n_out, ws, cr);
                     reduce_slices(ws, (int)cs_grid.y, n_out, g.b[l - 1], s);
                 }
             } else {
                 launch_gemm<EPI_ATOMIC>(w, s);
                 reduce_slices(ws, wsplits, wlen, wdst, s);
-                hipLaunchKernelGGL((k_colsum<false>), cs_grid, dim3(kBlock), 0, s, dz, R, n_out, (int64_t)n_out, ws);
+                hipLaunchKernelGGL((k_colsum<false>), cs_grid, dim3(kBlock), 0, s, dz, R, n_out, (int64_t)n_out, ws, cr);
                 reduce_slices(ws, (int)cs_grid.y, n_out, g.b[l - 1], s);
             }
             GemmOp x{};                                   // dZ_{l-1}[R, n_in] = (dZ W_l) gated
