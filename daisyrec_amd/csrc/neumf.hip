@@ -118,7 +118,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmOp &op, floatx16 (&acc)[
 // of kBK (checked by launch_gemm) - the guarded loader and its address registers are compiled out, which
 // is what lets four waves per SIMD share the MFMA pipe.
 template <int WN, int EPI, bool FAST, bool DROP>
-__global__ __launch_bounds__(kBlock) void k_gemm(GemmOp op) {
+__device__ __forceinline__ void gemm_f32_tile(const GemmOp &op, unsigned bx, unsigned by, unsigned bz) {
     constexpr int BM = kGemmBM, BN = 64 * WN;
     constexpr int EA = BM * kBK / kBlock, EB = BN * kBK / kBlock;     // elements per thread per tile
     constexpr int LA = BM + kLdsPad, LB = BN + kLdsPad;
@@ -126,9 +126,9 @@ __global__ __launch_bounds__(kBlock) void k_gemm(GemmOp op) {
     __shared__ __attribute__((aligned(16))) float Bs[2][kBK * LB];
     const int tid = threadIdx.x, lane = tid % kWave, wave = tid / kWave;
     const int wm = wave / 2, wn = wave % 2;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
-    const int64_t k_lo = (int64_t)blockIdx.z * op.k_chunk;
+    const int64_t m0 = (int64_t)bx * BM;
+    const int n0 = by * BN;
+    const int64_t k_lo = (int64_t)bz * op.k_chunk;
     const int64_t k_hi = (k_lo + op.k_chunk < op.K) ? (k_lo + op.k_chunk) : op.K;
     const bool a_kfast = (op.sak == 1), b_kfast = (op.sbk == 1);
     const bool a_vec = FAST || (op.vec_a && (m0 + BM <= op.M)), b_vec = FAST || (op.vec_b && (n0 + BN <= op.N));
@@ -249,7 +249,20 @@ __global__ __launch_bounds__(kBlock) void k_gemm(GemmOp op) {
         }
     }
 
-    gemm_epilogue<WN, EPI, FAST, DROP>(op, acc, m0, n0, wm, wn, lane, blockIdx.z);
+    gemm_epilogue<WN, EPI, FAST, DROP>(op, acc, m0, n0, wm, wn, lane, bz);
+}
+
+template <int WN, int EPI, bool FAST, bool DROP>
+__global__ __launch_bounds__(kBlock) void k_gemm(GemmOp op) {
+    gemm_f32_tile<WN, EPI, FAST, DROP>(op, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+// Two independent products in ONE launch (round 6): the user side's and the item side's table products of a NeuMF step are
+// each ~100 workgroups of 16 dependent k steps - latency-bound, 29-34 us per launch whatever the loader.  Side by side
+// (workgroups [0, ax) take `a`, the rest `b`; k slices beyond a product's own count leave at once) the pair costs what one did.
+template <int WN, int EPI>
+__global__ __launch_bounds__(kBlock) void k_gemm_pair(GemmOp a, GemmOp b, unsigned ax, unsigned az, unsigned bz_n) {
+    if (blockIdx.x < ax) { if (blockIdx.z < az) gemm_f32_tile<WN, EPI, false, false>(a, blockIdx.x, blockIdx.y, blockIdx.z); }
+    else if (blockIdx.z < bz_n) gemm_f32_tile<WN, EPI, false, false>(b, blockIdx.x - ax, blockIdx.y, blockIdx.z);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -683,6 +696,24 @@ static void launch_gemm(GemmOp op, hipStream_t s) {
     }
 }
 
+
+// two products of the same (N, tile width) in one launch (k_gemm_pair): guarded-loader kernels, fp32
+template <int EPI>
+static void launch_gemm_pair(GemmOp a, GemmOp b, hipStream_t s) {
+    auto prep = [](GemmOp &op) -> unsigned {
+        const int64_t splits = (op.k_chunk < op.K) ? (op.K + op.k_chunk - 1) / op.k_chunk : 1;
+        if (op.k_chunk >= op.K) op.k_chunk = op.K;
+        op.vec_a = vec_ok(op.A, op.sam, op.sak, splits > 1 ? op.k_chunk : 4);
+        op.vec_b = vec_ok(op.B, op.sbn, op.sbk, splits > 1 ? op.k_chunk : 4);
+        return (unsigned)splits;
+    };
+    const unsigned az = prep(a), bz = prep(b);
+    const int bn = (a.N > 64) ? 128 : 64;
+    const unsigned ax = (unsigned)((a.M + kGemmBM - 1) / kGemmBM), bx = (unsigned)((b.M + kGemmBM - 1) / kGemmBM);
+    const dim3 grid(ax + bx, (unsigned)((a.N + bn - 1) / bn), az > bz ? az : bz);
+    if (a.N > 64) hipLaunchKernelGGL((k_gemm_pair<2, EPI>), grid, dim3(kBlock), 0, s, a, b, ax, az, bz);
+    else hipLaunchKernelGGL((k_gemm_pair<1, EPI>), grid, dim3(kBlock), 0, s, a, b, ax, az, bz);
+}
 
 // ---------------------------------------------------------------------------------------------
 // the three pair layouts of daisy_neumf_scores plus the training batch
@@ -1479,6 +1510,61 @@ __global__ __launch_bounds__(kBlock) void k_nmf_table_commit(float *__restrict__
     }
 }
 
+// the same with 16-byte accesses (width % 4 == 0, 16-byte aligned tables): a lane takes 4 consecutive columns - the scalar form
+// above walks a 256-column row in 16 dependent trips per lane and cost 15-19 us per table for 6 MB
+__global__ __launch_bounds__(kBlock) void k_nmf_table_commit_v(float *__restrict__ g, float *__restrict__ sum,
+                                                               const float *__restrict__ w, int64_t rows, int width,
+                                                               int32_t *__restrict__ ca, int ka, int32_t *__restrict__ cb,
+                                                               int kb, float scale_b, const double *__restrict__ stats,
+                                                               float reg_1, float reg_2, int clear_counts,
+                                                               const float *__restrict__ colscale) {
+    const int lane = threadIdx.x % 16, group = threadIdx.x / 16;
+    const int64_t gstride = (int64_t)gridDim.x * (kBlock / 16);
+    auto inv = [&](int k) { const double n = stats[DAISY_NST_NORM + k]; return (n > 0.0) ? (float)((double)reg_2 / n) : 0.f; };
+    const float ia = inv(ka), ib = cb ? scale_b * inv(kb) : 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * (kBlock / 16) + group; row < rows; row += gstride) {
+        const float na = (float)ca[row], nb = cb ? (float)cb[row] : 0.f;
+        const float r2 = na * ia + nb * ib, r1 = reg_1 * (na + scale_b * nb);
+        const bool reg = na + nb > 0.f;
+        if (!sum && !reg) continue;
+        for (int c = 4 * lane; c < width; c += 64) {
+            const int64_t x = row * (int64_t)width + c;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (sum) {
+                const float4 sv = *reinterpret_cast<const float4 *>(sum + x);
+                v[0] = sv.x; v[1] = sv.y; v[2] = sv.z; v[3] = sv.w;
+                if (colscale) {
+                    const float4 cs = *reinterpret_cast<const float4 *>(colscale + c);
+                    v[0] *= cs.x; v[1] *= cs.y; v[2] *= cs.z; v[3] *= cs.w;
+                }
+                *reinterpret_cast<float4 *>(sum + x) = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            if (reg) {
+                const float4 ev = *reinterpret_cast<const float4 *>(w + x);
+                const float e[4] = {ev.x, ev.y, ev.z, ev.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] += fmaf(r2, e[k], r1 * sgn(e[k]));
+            }
+            float4 gv = *reinterpret_cast<float4 *>(g + x);
+            gv.x += v[0]; gv.y += v[1]; gv.z += v[2]; gv.w += v[3];      // (+ 0 where nothing arrived: the bits of g stay)
+            *reinterpret_cast<float4 *>(g + x) = gv;
+        }
+        if (clear_counts && lane == 0) { ca[row] = 0; if (cb) cb[row] = 0; }
+    }
+}
+
+static void launch_table_commit(float *g, float *sum, const float *w, int64_t rows, int width, int32_t *ca, int ka, int32_t *cb,
+                                int kb, float scale_b, const double *stats, float reg_1, float reg_2, int clear_counts,
+                                const float *colscale, hipStream_t s) {
+    auto al = [](const void *p) { return p == nullptr || ((uintptr_t)p & 15) == 0; };
+    if (width % 4 == 0 && al(g) && al(sum) && al(w) && al(colscale))
+        hipLaunchKernelGGL(k_nmf_table_commit_v, dim3(grid_for(rows, kBlock / 16)), dim3(kBlock), 0, s, g, sum, w, rows, width, ca, ka,
+                           cb, kb, scale_b, stats, reg_1, reg_2, clear_counts, colscale);
+    else
+        hipLaunchKernelGGL(k_nmf_table_commit, dim3(grid_for(rows, kBlock / 16 * 2)), dim3(kBlock), 0, s, g, sum, w, rows, width, ca,
+                           ka, cb, kb, scale_b, stats, reg_1, reg_2, clear_counts, colscale);
+}
+
 __global__ __launch_bounds__(kBlock) void k_sgd_dense(float *__restrict__ W, float *__restrict__ g, int64_t n,
                                                       float lr) {
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
@@ -1505,7 +1591,7 @@ struct daisy_neumf_ctx {
     void *sc_arena;
     int32_t *sc_ku, *sc_ki, *sc_val, *sc_ks, *sc_vs, *sc_cu, *sc_ci, *sc_cj;
     uint32_t *sc_ekey; uint2 *sc_esu; float2 *sc_w;
-    float *sc_sum, *sc_edge_vec, *sc_edge_b;
+    float *sc_sum, *sc_sum2, *sc_sumg, *sc_edge_vec, *sc_edge_b;      // row sums: MLP (users / plain), MLP items (first layer through the tables), GMF
     int32_t *sc_edge_item, *sc_edge_whole;
     void *sc_tmp; size_t sc_tmp_bytes;
     int32_t *cs_hist;                        // counting pass: [2 sides][kCsNW waves][key stride] counts -> prefixes, then [2][stride] totals
@@ -1649,7 +1735,8 @@ static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p,
     const int grid = grid_for(R, kBlock / 16 * 2);
     const bool H = neumf_use_h(ctx, R);
     if (H) {          // bf16 copies of the MLP weights (a few hundred KB)
-        for (int l = 1; l <= L; ++l) {
+        // (the first layer's copy - the largest - has no reader when that layer runs through the tables)
+        for (int l = neumf_use_fact(ctx, R, train, thresh) ? 2 : 1; l <= L; ++l) {
             const int64_t nw = (int64_t)ctx->width[l] * ctx->width[l - 1];
             hipLaunchKernelGGL(k_to_bf16, dim3(grid_for(nw, kBlock * 4)), dim3(kBlock), 0, s, p->W[l - 1], nw,
                                ctx->width[l - 1], ctx->W16[l - 1], ctx->W16T[l - 1]);
@@ -1661,6 +1748,7 @@ static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p,
         if (rc) return rc;
         const int n1 = ctx->width[1];
         float *tu = ctx->fact_t, *ti = ctx->fact_t + (size_t)ctx->U * n1;
+        GemmOp top[2];
         for (int side = 0; side < 2; ++side) {          // T = table x W1[:, half]^T  (fp32: the tables are fp32)
             GemmOp op{};
             op.A = side ? p->iM : p->uM; op.sam = dm; op.sak = 1;
@@ -1671,8 +1759,9 @@ static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p,
             // fp32 products of the fp32 tables and weights, rounded to bf16 once (k_f32_to_bf16): the rounding points do not
             // depend on whether the table's row count happens to tile (oracle/neumf_numpy.py: neumf_grad_bf16 'fact')
             op.bf16 = 0;
-            launch_gemm<EPI_STORE>(op, s);
+            top[side] = op;
         }
+        launch_gemm_pair<EPI_STORE>(top[0], top[1], s);      // (both sides in one launch: k_gemm_pair)
         float2 *nu = reinterpret_cast<float2 *>(ctx->fact_t + (size_t)(ctx->U + ctx->I) * n1), *ni = nu + ctx->U;
         hipLaunchKernelGGL(k_nmf_row_norms, dim3(grid_for(ctx->U, kBlock / 16)), dim3(kBlock), 0, s, p->uM, ctx->U, dm, nu);
         hipLaunchKernelGGL(k_nmf_row_norms, dim3(grid_for(ctx->I, kBlock / 16)), dim3(kBlock), 0, s, p->iM, ctx->I, dm, ni);
@@ -1752,7 +1841,7 @@ static int neumf_scatter_scratch(daisy_neumf_ctx *c) {
     const size_t o_ku = take(R * 4), o_ki = take(R * 4), o_val = take(R * 4), o_ks = take(R * 4), o_vs = take(R * 4);
     const size_t o_cu = take((size_t)c->U * 4), o_ci = take((size_t)c->I * 4), o_cj = take((size_t)c->I * 4);
     const size_t o_ek = take((R + 1) * 4), o_es = take((R + 1) * 8), o_w = take((R + 1) * 8);
-    const size_t o_sum = take(rows_max * dm * 4);
+    const size_t o_sum = take(rows_max * dm * 4), o_sum2 = take(rows_max * dm * 4), o_sumg = take(rows_max * (size_t)c->d * 4);
     const size_t o_ev = take(2 * chunks * dm * 4), o_ei = take(2 * chunks * 4), o_eb = take(2 * chunks * 4), o_ew = take(chunks * 4);
     const size_t o_tmp = take(c->sc_tmp_bytes);
     hipError_t e = hipMalloc(&c->sc_arena, off);
@@ -1767,13 +1856,13 @@ static int neumf_scatter_scratch(daisy_neumf_ctx *c) {
     c->sc_ks = (int32_t *)(b + o_ks); c->sc_vs = (int32_t *)(b + o_vs);
     c->sc_cu = (int32_t *)(b + o_cu); c->sc_ci = (int32_t *)(b + o_ci); c->sc_cj = (int32_t *)(b + o_cj);
     c->sc_ekey = (uint32_t *)(b + o_ek); c->sc_esu = (uint2 *)(b + o_es); c->sc_w = (float2 *)(b + o_w);
-    c->sc_sum = (float *)(b + o_sum);
+    c->sc_sum = (float *)(b + o_sum); c->sc_sum2 = (float *)(b + o_sum2); c->sc_sumg = (float *)(b + o_sumg);
     c->sc_edge_vec = (float *)(b + o_ev); c->sc_edge_item = (int32_t *)(b + o_ei); c->sc_edge_b = (float *)(b + o_eb);
     c->sc_edge_whole = (int32_t *)(b + o_ew);
     c->sc_tmp = b + o_tmp;
     // the counts and the row-sum table are kept all-zero between calls by the kernels that consume them
     e = hipMemset(b + o_cu, 0, o_ek - o_cu);
-    if (e == hipSuccess) e = hipMemset(b + o_sum, 0, rows_max * dm * 4);
+    if (e == hipSuccess) e = hipMemset(b + o_sum, 0, (o_sumg - o_sum) + rows_max * (size_t)c->d * 4);      // (the three sum tables: contiguous)
     if (e != hipSuccess) { set_error("neumf: hipMemset of the scatter scratch failed"); return DAISY_ERR_HIP; }
     return DAISY_OK;
 }
@@ -1840,72 +1929,74 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
                                 bits_for(rows), s);
             if (rc) return rc;
         }
-        const int ge = grid_for(n_pad, kBlock * 2), gt = grid_for(rows, kBlock / 16 * 2);
+        const int ge = grid_for(n_pad, kBlock * 2);
         // MLP table: source row = half `side` of DX0[r]
         if (model != DAISY_NEUMF_GMF) {
             hipLaunchKernelGGL(k_nmf_entries, dim3(ge), dim3(kBlock), 0, s, g_ks, g_vs, R, n_pad, fact ? 1 : 2,
                                fact ? 0 : side, c->sc_ekey, c->sc_esu, c->sc_w);
-            rc = segsum_rows(DX0, c->sc_w, c->sc_ekey, c->sc_esu, n_pad, dm, c->sc_sum, c->sc_edge_vec, c->sc_edge_item,
-                             c->sc_edge_b, c->sc_edge_whole, s, dx0_bf16);
+            rc = segsum_rows(DX0, c->sc_w, c->sc_ekey, c->sc_esu, n_pad, dm, (fact && side) ? c->sc_sum2 : c->sc_sum, c->sc_edge_vec,
+                             c->sc_edge_item, c->sc_edge_b, c->sc_edge_whole, s, dx0_bf16);
             if (rc) return rc;
         }
-        if (fact) {
-            const int n1 = dm, w0 = 2 * dm;
-            if (side == 0) {
-                // gb_1 = sum over the step's rows of dZ_1 = sum over the USERS of their segment sums: a column sum over U
-                // table rows (6 MB at ml-1m) instead of one over the R rows of dZ_1 (268 MB: 47 us)
-                rc = neumf_need_det_ws(c);
-                if (rc) return rc;
-                const int cr = colsum_rows(rows);
-                const dim3 cs((unsigned)((n1 + 63) / 64), (unsigned)((rows + cr - 1) / cr));
-                hipLaunchKernelGGL((k_colsum<false>), cs, dim3(kBlock), 0, s, c->sc_sum, rows, n1, (int64_t)n1, c->det_ws, cr);
-                reduce_slices(c->det_ws, (int)cs.y, n1, g.b[0], s);
-            }
-            GemmOp a{};                        // g.table[rows, dm] += S[rows, n1] W1[:, half]      (k = n1)
-            a.A = c->sc_sum; a.sam = n1; a.sak = 1;
-            a.B = p.W[0] + (side ? dm : 0); a.sbn = 1; a.sbk = w0;
-            a.C = side ? g.iM : g.uM; a.ldc = dm;
-            a.M = rows; a.N = dm; a.K = n1; a.k_chunk = a.K;
-            // (measured and rejected, round 6: whole 128-row tiles through the branch-free kernel + the ragged remainder through
-            // the guarded one - the six table products of a step are latency-bound per TILE (94 workgroups, 16 dependent k
-            // steps each: 22-27 us with either loader), so two launches per product cost more: 1.09 -> 1.22 ms per step)
-            launch_gemm<EPI_ATOMIC>(a, s);     // (one workgroup per output tile, k in one piece: a single add per element)
-            GemmOp b{};                        // gW_1[n1, half] += S^T[n1, rows] table[rows, dm]    (k = the table's rows)
-            b.A = c->sc_sum; b.sam = 1; b.sak = n1;
-            b.B = side ? p.iM : p.uM; b.sbn = 1; b.sbk = dm;
-            // (k in slices of 128 table rows, side by side in the workspace, added in slice order: enough workgroups, no
-            // fp32 atomics on shared elements)
-            // slices of 128 table rows while the workspace holds them; a table with more rows than that (the workspace is
-            // sized by the step's rows, not by the tables') takes proportionally longer slices - never an error mid-step
-            rc = neumf_need_det_ws(c);
-            if (rc) return rc;
-            const int64_t cap = (int64_t)(c->det_ws_floats / ((size_t)n1 * (size_t)dm));      // >= 2: the workspace holds a [width1][width0] slice
-            int64_t kc = 128;
-            if ((rows + kc - 1) / kc > cap) kc = (((rows + cap - 1) / cap) + 127) / 128 * 128;
-            b.M = n1; b.N = dm; b.K = rows; b.k_chunk = kc;
-            const int bsplits = (int)((rows + kc - 1) / kc);
-            b.C = c->det_ws; b.ldc = dm; b.slice_stride = (int64_t)n1 * dm;
-            launch_gemm<EPI_ATOMIC>(b, s);
-            hipLaunchKernelGGL(k_reduce_slices_2d, dim3(grid_for((int64_t)n1 * dm, kBlock, 2048)), dim3(kBlock), 0, s, c->det_ws,
-                               bsplits, n1, dm, g.W[0] + (side ? dm : 0), (int64_t)w0);
-            DAISY_HIP(hipMemsetAsync(c->sc_sum, 0, (size_t)rows * (size_t)n1 * sizeof(float), s));   // (kept all-zero between uses)
-        }
-        hipLaunchKernelGGL(k_nmf_table_commit, dim3(gt), dim3(kBlock), 0, s, side ? g.iM : g.uM,
-                           (model != DAISY_NEUMF_GMF && !fact) ? c->sc_sum : (float *)nullptr, side ? p.iM : p.uM, rows, dm,
-                           side ? c->sc_ci : c->sc_cu, side ? 3 : 1, (int32_t *)nullptr, 0, 0.f, stats, reg_1, reg_2, 0);
+        launch_table_commit(side ? g.iM : g.uM, (model != DAISY_NEUMF_GMF && !fact) ? c->sc_sum : (float *)nullptr,
+                            side ? p.iM : p.uM, rows, dm, side ? c->sc_ci : c->sc_cu, side ? 3 : 1, (int32_t *)nullptr, 0, 0.f,
+                            stats, reg_1, reg_2, 0, nullptr, s);
         // GMF table: source row = the materialised per-row gradient
         if (model != DAISY_NEUMF_MLP) {          // source rows: the OTHER table's, weights dpred (k_nmf_entries_gmf)
             hipLaunchKernelGGL(k_nmf_entries_gmf, dim3(ge), dim3(kBlock), 0, s, g_ks, g_vs, R, n_pad, src, side, c->dpred,
                                c->sc_ekey, c->sc_esu, c->sc_w);
-            rc = segsum_rows(side ? p.uG : p.iG, c->sc_w, c->sc_ekey, c->sc_esu, n_pad, d, c->sc_sum, c->sc_edge_vec,
+            rc = segsum_rows(side ? p.uG : p.iG, c->sc_w, c->sc_ekey, c->sc_esu, n_pad, d, c->sc_sumg, c->sc_edge_vec,
                              c->sc_edge_item, c->sc_edge_b, c->sc_edge_whole, s);
             if (rc) return rc;
         }
         // (the negative item's GMF rows enter the regulariser twice, NeuMFRecommender.py:158-161)
-        hipLaunchKernelGGL(k_nmf_table_commit, dim3(gt), dim3(kBlock), 0, s, side ? g.iG : g.uG,
-                           (model != DAISY_NEUMF_MLP) ? c->sc_sum : (float *)nullptr, side ? p.iG : p.uG, rows, d,
-                           side ? c->sc_ci : c->sc_cu, side ? 2 : 0, side ? c->sc_cj : (int32_t *)nullptr, 4, 2.f, stats,
-                           reg_1, reg_2, 1, (model != DAISY_NEUMF_MLP) ? p.Wp : (const float *)nullptr);
+        launch_table_commit(side ? g.iG : g.uG, (model != DAISY_NEUMF_MLP) ? c->sc_sumg : (float *)nullptr, side ? p.iG : p.uG,
+                            rows, d, side ? c->sc_ci : c->sc_cu, side ? 2 : 0, side ? c->sc_cj : (int32_t *)nullptr, 4, 2.f, stats,
+                            reg_1, reg_2, 1, (model != DAISY_NEUMF_MLP) ? p.Wp : (const float *)nullptr, s);
+        DAISY_LAUNCH_CHECK();
+    }
+    if (fact && model != DAISY_NEUMF_GMF) {
+        // the first layer through the tables, backward: S_u / S_i (the segment sums of dZ_1 by user / by item) are both in place;
+        // every product runs for both sides in ONE launch (k_gemm_pair: each side alone is a latency-bound ~100 workgroups)
+        const int n1 = dm, w0 = 2 * dm;
+        rc = neumf_need_det_ws(c);
+        if (rc) return rc;
+        {   // gb_1 = sum over the step's rows of dZ_1 = sum over the USERS of their segment sums: a column sum over U table rows
+            // (6 MB at ml-1m) instead of one over the R rows of dZ_1 (268 MB: 47 us)
+            const int cr = colsum_rows(c->U);
+            const dim3 cs((unsigned)((n1 + 63) / 64), (unsigned)((c->U + cr - 1) / cr));
+            hipLaunchKernelGGL((k_colsum<false>), cs, dim3(kBlock), 0, s, c->sc_sum, c->U, n1, (int64_t)n1, c->det_ws, cr);
+            reduce_slices(c->det_ws, (int)cs.y, n1, g.b[0], s);
+        }
+        GemmOp a[2], b[2];
+        // slices of 128 table rows while the workspace holds both sides' slices; tables with more rows than that (the
+        // workspace is sized by the step's rows) take proportionally longer slices - never an error mid-step
+        const int64_t cap = (int64_t)(c->det_ws_floats / ((size_t)n1 * (size_t)dm));      // >= 2
+        int64_t kc = 128;
+        while ((c->U + kc - 1) / kc + (c->I + kc - 1) / kc > cap) kc += 128;
+        int bsplits[2];
+        for (int side = 0; side < 2; ++side) {
+            const int64_t rows = side ? c->I : c->U;
+            float *S = side ? c->sc_sum2 : c->sc_sum;
+            a[side] = GemmOp{};                // g.table[rows, dm] += S[rows, n1] W1[:, half]      (k = n1)
+            a[side].A = S; a[side].sam = n1; a[side].sak = 1;
+            a[side].B = p.W[0] + (side ? dm : 0); a[side].sbn = 1; a[side].sbk = w0;
+            a[side].C = side ? g.iM : g.uM; a[side].ldc = dm;
+            a[side].M = rows; a[side].N = dm; a[side].K = n1; a[side].k_chunk = n1;
+            b[side] = GemmOp{};                // gW_1[n1, half] += S^T[n1, rows] table[rows, dm]    (k = the table's rows, in slices)
+            b[side].A = S; b[side].sam = 1; b[side].sak = n1;
+            b[side].B = side ? p.iM : p.uM; b[side].sbn = 1; b[side].sbk = dm;
+            b[side].M = n1; b[side].N = dm; b[side].K = rows; b[side].k_chunk = kc;
+            bsplits[side] = (int)((rows + kc - 1) / kc);
+            b[side].C = c->det_ws + (side ? (size_t)bsplits[0] * n1 * dm : 0); b[side].ldc = dm; b[side].slice_stride = (int64_t)n1 * dm;
+        }
+        launch_gemm_pair<EPI_ATOMIC>(a[0], a[1], s);       // (one workgroup per output tile, k in one piece: a single add per element)
+        launch_gemm_pair<EPI_ATOMIC>(b[0], b[1], s);
+        for (int side = 0; side < 2; ++side)
+            hipLaunchKernelGGL(k_reduce_slices_2d, dim3(grid_for((int64_t)n1 * dm, kBlock, 2048)), dim3(kBlock), 0, s, b[side].C,
+                               bsplits[side], n1, dm, g.W[0] + (side ? dm : 0), (int64_t)w0);
+        // (both sum tables back to all-zero: they are contiguous)
+        DAISY_HIP(hipMemsetAsync(c->sc_sum, 0, (size_t)((char *)c->sc_sumg - (char *)c->sc_sum), s));
         DAISY_LAUNCH_CHECK();
     }
     return DAISY_OK;
