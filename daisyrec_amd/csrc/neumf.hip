@@ -1401,17 +1401,22 @@ __global__ __launch_bounds__(1024) void k_cs_base(int Ku, int Ki, int kstride, i
     for (int k = lo; k < hi; ++k) { const int32_t c = t[k]; t[k] = run; run += c; }
 }
 
+// The grouped rows leave as the segmented reduction's entry lists (what k_nmf_entries / k_nmf_entries_gmf wrote in four launches
+// of their own): per side, entry e -> key = table row << 1; MLP list: source row = mlp_rows_per * r + half, weight 1; GMF list:
+// source row = the OTHER id of row r, weight dpred[r].  An odd count is padded with a weightless copy of the last entry.
+struct CsEntries { uint32_t *ekey; uint2 *esu_m; float2 *w_m; uint2 *esu_g; float2 *w_g; };
 __global__ __launch_bounds__(kBlock) void k_cs_scatter(PairSrc src, int64_t R, int halves, int Ku, int Ki, int kstride,
                                                        const int32_t *__restrict__ hist, const int32_t *__restrict__ total,
-                                                       int32_t *__restrict__ ks_u, int32_t *__restrict__ vs_u,
-                                                       int32_t *__restrict__ ks_i, int32_t *__restrict__ vs_i) {
+                                                       CsEntries eu, CsEntries ei, int mlp_rows_per, int mlp_half_by_side,
+                                                       const float *__restrict__ dpred) {
     extern __shared__ int32_t cs_lds[];
     const int side = blockIdx.y, K = side ? Ki : Ku;
     const int lane = threadIdx.x % kWave, w = threadIdx.x / kWave, gw = blockIdx.x * kCsWaves + w;
     int32_t *off = cs_lds + w * kstride;
     const int32_t *mine = hist + ((int64_t)side * kCsNW + gw) * kstride, *base = total + side * kstride;
     for (int k = lane; k < K; k += kWave) off[k] = base[k] + mine[k];
-    int32_t *ks = side ? ks_i : ks_u, *vs = side ? vs_i : vs_u;
+    const CsEntries en = side ? ei : eu;
+    const int half = mlp_half_by_side ? side : 0;
     const CsRange rg = cs_range(gw, R, src.B, halves);
     const uint64_t lt = ((uint64_t)1 << lane) - 1;
     for (int64_t rb = rg.lo; rb < rg.hi; rb += 4 * kWave) {
@@ -1432,8 +1437,18 @@ __global__ __launch_bounds__(kBlock) void k_cs_scatter(PairSrc src, int64_t R, i
         }
         if (valid) {
             const int32_t slot = off[key] + (int32_t)__popcll(peers & lt);
-            ks[slot] = key;
-            vs[slot] = (int32_t)r;
+            int64_t user, item;
+            pair_ids(src, r, user, item);
+            const uint32_t ek = (uint32_t)key << 1, sm = (uint32_t)(mlp_rows_per * (int32_t)r + half), sg = (uint32_t)(side ? user : item);
+            const float dp = dpred ? dpred[r] : 0.f;
+            en.ekey[slot] = ek;
+            en.esu_m[slot] = make_uint2((uint32_t)slot, sm); en.w_m[slot] = make_float2(1.f, 0.f);
+            en.esu_g[slot] = make_uint2((uint32_t)slot, sg); en.w_g[slot] = make_float2(dp, 0.f);
+            if ((R & 1) && slot == R - 1) {                    // the weightless copy that makes the count even
+                en.ekey[R] = ek;
+                en.esu_m[R] = make_uint2((uint32_t)R, sm); en.w_m[R] = make_float2(0.f, 0.f);
+                en.esu_g[R] = make_uint2((uint32_t)R, sg); en.w_g[R] = make_float2(0.f, 0.f);
+            }
             if ((peers & lt) == 0) off[key] += (int32_t)__popcll(peers);      // one lane per key moves the running counter
         }
       }
@@ -1594,6 +1609,7 @@ struct daisy_neumf_ctx {
     float *sc_sum, *sc_sum2, *sc_sumg, *sc_edge_vec, *sc_edge_b;      // row sums: MLP (users / plain), MLP items (first layer through the tables), GMF
     int32_t *sc_edge_item, *sc_edge_whole;
     void *sc_tmp; size_t sc_tmp_bytes;
+    void *cs_ent;                            // counting pass: the two sides' entry lists (CsEntries)
     int32_t *cs_hist;                        // counting pass: [2 sides][kCsNW waves][key stride] counts -> prefixes, then [2][stride] totals
     int bf16;                                // daisy_neumf_ctx_set_precision: 0 fp32, 1 bf16 MFMA inputs, 2 bf16 storage
     // per-workgroup partial sums of the reductions over the batch rows (split-K slices of the weight-gradient GEMMs,
@@ -1601,6 +1617,7 @@ struct daisy_neumf_ctx {
     float *det_ws;
     size_t det_ws_floats;
     float *fact_t;                           // T_u [U][n1] then T_i [I][n1]: the first layer through the tables (k_nmf_gather<FACT>)
+    bool tower_aligned;                      // W2 / W3 of the current call are 16-byte aligned (the tower reads them as float4)
     Fact fact_cur;                           // ... as the forward pass of the current step set them up (the fused tower reads them)
 };
 
@@ -1712,7 +1729,7 @@ static bool neumf_use_tower(const daisy_neumf_ctx *ctx, int64_t R, bool train, u
     const char *env = getenv("DAISY_NMF_TOWER");              // (read per call: the tests switch it)
     const int tune = env ? atoi(env) : 1;
     return tune != 0 && ctx->bf16 == 2 && neumf_use_fact(ctx, R, train, thresh) && ctx->L == 3 && ctx->d == 64 && ctx->model == DAISY_NEUMF_FULL &&
-           R % 64 == 0;
+           R % 64 == 0 && ctx->tower_aligned;
 }
 static int neumf_need_fact(daisy_neumf_ctx *ctx) {
     if (ctx->fact_t) return DAISY_OK;
@@ -1736,7 +1753,9 @@ static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p,
     const bool H = neumf_use_h(ctx, R);
     if (H) {          // bf16 copies of the MLP weights (a few hundred KB)
         // (the first layer's copy - the largest - has no reader when that layer runs through the tables)
-        for (int l = neumf_use_fact(ctx, R, train, thresh) ? 2 : 1; l <= L; ++l) {
+        ctx->tower_aligned = L >= 3 && (((uintptr_t)p->W[1] | (uintptr_t)p->W[2]) & 15) == 0;
+        // (... and none at all under the fused tower, which rounds W2 / W3 as it loads them into LDS)
+        for (int l = neumf_use_tower(ctx, R, train, thresh) ? L + 1 : (neumf_use_fact(ctx, R, train, thresh) ? 2 : 1); l <= L; ++l) {
             const int64_t nw = (int64_t)ctx->width[l] * ctx->width[l - 1];
             hipLaunchKernelGGL(k_to_bf16, dim3(grid_for(nw, kBlock * 4)), dim3(kBlock), 0, s, p->W[l - 1], nw,
                                ctx->width[l - 1], ctx->W16[l - 1], ctx->W16T[l - 1]);
@@ -1849,6 +1868,7 @@ static int neumf_scatter_scratch(daisy_neumf_ctx *c) {
         set_error("neumf: hipMalloc(%zu) of the scatter scratch failed: %s", off, hipGetErrorString(e));
         c->sc_arena = nullptr;
     c->cs_hist = nullptr;
+    c->cs_ent = nullptr;
         return DAISY_ERR_HIP;
     }
     char *b = (char *)c->sc_arena;
@@ -1871,6 +1891,12 @@ static int neumf_scatter_scratch(daisy_neumf_ctx *c) {
 // fact (the first layer through the tables): DX0 is dZ_1 (bf16 [R, n1]) instead; S = its segmented sums by table row
 // (fp32 [rows, n1], in the row-sum table), then  g.table += S W1[:, half]  and  gW_1[:, half] += S^T table  - two GEMMs over
 // the TABLE's rows where the plain path runs one over the step's R rows and a [R, 2 dm] input gradient
+static CsEntries cs_entries(const daisy_neumf_ctx *c, int side) {
+    const size_t per = align_up(((size_t)c->max_rows + 2) * 8);
+    char *b = (char *)c->cs_ent + (size_t)side * 5 * per;
+    return CsEntries{(uint32_t *)b, (uint2 *)(b + per), (float2 *)(b + 2 * per), (uint2 *)(b + 3 * per), (float2 *)(b + 4 * per)};
+}
+
 static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, const daisy_neumf_params &g,
                                const PairSrc &src, int64_t R, int pointwise, const float *DX0, bool dx0_bf16,
                                const double *stats, float reg_1, float reg_2, hipStream_t s, bool fact = false) {
@@ -1902,6 +1928,12 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
                 set_error("neumf: hipMalloc(%zu) of the counting pass's histograms failed", n * sizeof(int32_t));
                 return DAISY_ERR_HIP;
             }
+            const size_t per = align_up(((size_t)c->max_rows + 2) * 8);       // one array of (rows + pad) x 8 bytes
+            if (hipMalloc(&c->cs_ent, 2 * 5 * per) != hipSuccess) {
+                c->cs_ent = nullptr;
+                set_error("neumf: hipMalloc(%zu) of the counting pass's entry lists failed", 2 * 5 * per);
+                return DAISY_ERR_HIP;
+            }
             DAISY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cs_count), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
             DAISY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_cs_scatter), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 4096));
         }
@@ -1913,7 +1945,8 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
                            c->cs_hist, total, c->sc_cu, c->sc_ci, c->sc_cj);
         hipLaunchKernelGGL(k_cs_base, dim3(2), dim3(1024), 0, s, (int)c->U, (int)c->I, kstride, total);
         hipLaunchKernelGGL(k_cs_scatter, dim3(kCsBlocks, 2), dim3(kBlock), lds, s, src, R, halves, (int)c->U, (int)c->I, kstride,
-                           c->cs_hist, total, c->sc_ks, c->sc_vs, c->sc_ku, c->sc_val);
+                           c->cs_hist, total, cs_entries(c, 0), cs_entries(c, 1), fact ? 1 : 2, fact ? 0 : 1,
+                           (const float *)c->dpred);
     } else {
         hipLaunchKernelGGL(k_nmf_sort_keys, dim3(grid_for(R, kBlock * 2)), dim3(kBlock), 0, s, src, R, c->sc_ku, c->sc_ki,
                            c->sc_val, pointwise, c->sc_cu, c->sc_ci, c->sc_cj);
@@ -1923,8 +1956,8 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
         const int64_t rows = side ? c->I : c->U;
         // the side's grouped rows: (keys, row ids) in table-row order, rows ascending inside a key
         const int32_t *g_ks = c->sc_ks, *g_vs = c->sc_vs;
-        if (counting) { if (side) { g_ks = c->sc_ku; g_vs = c->sc_val; } }
-        else {
+        const CsEntries en = counting ? cs_entries(c, side) : CsEntries{c->sc_ekey, c->sc_esu, c->sc_w, c->sc_esu, c->sc_w};
+        if (!counting) {
             rc = sort_pairs_i32(c->sc_tmp, c->sc_tmp_bytes, side ? c->sc_ki : c->sc_ku, c->sc_ks, c->sc_val, c->sc_vs, R,
                                 bits_for(rows), s);
             if (rc) return rc;
@@ -1932,9 +1965,10 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
         const int ge = grid_for(n_pad, kBlock * 2);
         // MLP table: source row = half `side` of DX0[r]
         if (model != DAISY_NEUMF_GMF) {
-            hipLaunchKernelGGL(k_nmf_entries, dim3(ge), dim3(kBlock), 0, s, g_ks, g_vs, R, n_pad, fact ? 1 : 2,
-                               fact ? 0 : side, c->sc_ekey, c->sc_esu, c->sc_w);
-            rc = segsum_rows(DX0, c->sc_w, c->sc_ekey, c->sc_esu, n_pad, dm, (fact && side) ? c->sc_sum2 : c->sc_sum, c->sc_edge_vec,
+            if (!counting)
+                hipLaunchKernelGGL(k_nmf_entries, dim3(ge), dim3(kBlock), 0, s, g_ks, g_vs, R, n_pad, fact ? 1 : 2,
+                                   fact ? 0 : side, c->sc_ekey, c->sc_esu, c->sc_w);
+            rc = segsum_rows(DX0, en.w_m, en.ekey, en.esu_m, n_pad, dm, (fact && side) ? c->sc_sum2 : c->sc_sum, c->sc_edge_vec,
                              c->sc_edge_item, c->sc_edge_b, c->sc_edge_whole, s, dx0_bf16);
             if (rc) return rc;
         }
@@ -1943,9 +1977,10 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
                             stats, reg_1, reg_2, 0, nullptr, s);
         // GMF table: source row = the materialised per-row gradient
         if (model != DAISY_NEUMF_MLP) {          // source rows: the OTHER table's, weights dpred (k_nmf_entries_gmf)
-            hipLaunchKernelGGL(k_nmf_entries_gmf, dim3(ge), dim3(kBlock), 0, s, g_ks, g_vs, R, n_pad, src, side, c->dpred,
-                               c->sc_ekey, c->sc_esu, c->sc_w);
-            rc = segsum_rows(side ? p.uG : p.iG, c->sc_w, c->sc_ekey, c->sc_esu, n_pad, d, c->sc_sumg, c->sc_edge_vec,
+            if (!counting)
+                hipLaunchKernelGGL(k_nmf_entries_gmf, dim3(ge), dim3(kBlock), 0, s, g_ks, g_vs, R, n_pad, src, side, c->dpred,
+                                   c->sc_ekey, c->sc_esu, c->sc_w);
+            rc = segsum_rows(side ? p.uG : p.iG, en.w_g, en.ekey, en.esu_g, n_pad, d, c->sc_sumg, c->sc_edge_vec,
                              c->sc_edge_item, c->sc_edge_b, c->sc_edge_whole, s);
             if (rc) return rc;
         }
@@ -2055,6 +2090,7 @@ int daisy_neumf_ctx_destroy(daisy_neumf_ctx *ctx) {
     if (ctx->arena) (void)hipFree(ctx->arena);
     if (ctx->sc_arena) (void)hipFree(ctx->sc_arena);
     if (ctx->cs_hist) (void)hipFree(ctx->cs_hist);
+    if (ctx->cs_ent) (void)hipFree(ctx->cs_ent);
     if (ctx->det_ws) (void)hipFree(ctx->det_ws);
     if (ctx->fact_t) (void)hipFree(ctx->fact_t);
     delete ctx;
@@ -2124,7 +2160,7 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
         TowerArgs ta{};
         ta.tu = ctx->fact_cur.tu; ta.ti = ctx->fact_cur.ti; ta.nu = ctx->fact_cur.nu; ta.ni = ctx->fact_cur.ni;
         ta.b1 = p.b[0];
-        ta.W2 = ctx->W16[1]; ta.W3 = ctx->W16[2];
+        ta.W2 = p.W[1]; ta.W3 = p.W[2];
         ta.b2 = p.b[1]; ta.b3 = p.b[2]; ta.Wp = p.Wp; ta.bp = p.bp;
         ta.uG = p.uG; ta.iG = p.iG;
         ta.u = u; ta.i = i; ta.j = j; ta.B = B;

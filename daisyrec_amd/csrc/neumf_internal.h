@@ -77,7 +77,7 @@ struct TowerArgs {
     const uint16_t *tu, *ti;          // bf16 [U][4d], [I][4d]: the first layer's table products (FACT)
     const float2 *nu, *ni;            // per table row (sum |x|, sum x^2) of uM / iM
     const float *b1;                  // [4d]
-    const uint16_t *W2, *W3;          // bf16 [2d][4d], [d][2d]
+    const float *W2, *W3;             // fp32 [2d][4d], [d][2d] (16-byte aligned): rounded to bf16 as the kernel loads them
     const float *b2, *b3, *Wp, *bp;   // fp32 [2d], [d], [2d], [1]
     const float *uG, *iG;             // fp32 [U][d], [I][d]
     const int32_t *u, *i, *j;         // the batch (j: negatives, or the labels of a point-wise loss)

@@ -104,13 +104,18 @@ __global__ __launch_bounds__(kTwBlock, 1) void k_nmf_tower(TowerArgs a, int64_t 
     const int sc = tw_swz(c);                 // (rows c, 32 + c, 64 + c ... share it: it reads bits 0..3 of the row)
 
     // ---- the tower's weights: HBM -> LDS once per workgroup
+    // (the fp32 master weights are rounded to bf16 - nearest even, as k_to_bf16 did in launches of its own - on their way in)
+    auto w_chunk = [](const float *src) {
+        const float4 lo = *reinterpret_cast<const float4 *>(src), hi = *reinterpret_cast<const float4 *>(src + 4);
+        return u32x4{bf16_pack2(lo.x, lo.y), bf16_pack2(lo.z, lo.w), bf16_pack2(hi.x, hi.y), bf16_pack2(hi.z, hi.w)};
+    };
     for (int e = tid; e < N2 * N1 / 8; e += kTwBlock) {
         const int row = e / (N1 / 8), ch = e % (N1 / 8);
-        *reinterpret_cast<u32x4 *>(W2s + tw_off<N1>(row, ch)) = reinterpret_cast<const u32x4 *>(a.W2)[e];
+        *reinterpret_cast<u32x4 *>(W2s + tw_off<N1>(row, ch)) = w_chunk(a.W2 + (int64_t)e * 8);
     }
     for (int e = tid; e < N3 * N2 / 8; e += kTwBlock) {
         const int row = e / (N2 / 8), ch = e % (N2 / 8);
-        *reinterpret_cast<u32x4 *>(W3s + tw_off<N2>(row, ch)) = reinterpret_cast<const u32x4 *>(a.W3)[e];
+        *reinterpret_cast<u32x4 *>(W3s + tw_off<N2>(row, ch)) = w_chunk(a.W3 + (int64_t)e * 8);
     }
     for (int e = tid; e < N1; e += kTwBlock) b1s[e] = a.b1[e];
     for (int e = tid; e < N2; e += kTwBlock) b2s[e] = a.b2[e];
