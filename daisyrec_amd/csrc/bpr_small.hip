@@ -253,7 +253,9 @@ __global__ __launch_bounds__(kSmallThreads) void k_small_epoch(
         if constexpr (ADAM) {
             if (ad.helpers > 0) {
                 // ---- 0: the helpers have brought the step's rows to step t-1 (or step k-1 left them there)
+#ifndef DAISY_SMALL_NOWAIT          // (timing experiments only: the main workgroup's own step time, results meaningless)
                 if (tid == 0) { small_wait_ge(ad.sync + 1 + k, ad.helpers); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+#endif
                 __syncthreads();
             } else
             // ---- 0: the step's distinct rows -> step t-1 (x < Bk: heads of the user runs; then heads of the item runs)
