@@ -34,14 +34,6 @@ constexpr int kLdsPad = 4;
 
 enum { EPI_STORE = 0, EPI_BIAS_RELU = 1, EPI_GATE = 2, EPI_ATOMIC = 3 };
 
-// keep mask of element `idx` of dropout stream `stream` (one stream per MLP layer input)
-__host__ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint32_t stream, uint64_t idx,
-                                                   uint32_t thresh) {
-    uint32_t h = mix32((uint32_t)idx ^ (uint32_t)seed);
-    h = mix32(h + (uint32_t)(idx >> 32) * 0x9E3779B9u + (uint32_t)(seed >> 32) + stream * 0x85EBCA6Bu);
-    return h >= thresh;
-}
-
 struct GemmOp {
     const float *A; int64_t sam, sak;     // A(m,k) = A[m*sam + k*sak]
     const float *B; int64_t sbn, sbk;     // B(n,k) = B[n*sbn + k*sbk]
@@ -1618,6 +1610,7 @@ struct daisy_neumf_ctx {
     size_t det_ws_floats;
     float *fact_t;                           // T_u [U][n1] then T_i [I][n1]: the first layer through the tables (k_nmf_gather<FACT>)
     bool tower_aligned;                      // W2 / W3 of the current call are 16-byte aligned (the tower reads them as float4)
+    bool mid_fits, mid_aligned;              // k_nmf_mid: the layers fit the LDS (ctx_create); this call's weights are 16-byte aligned
     Fact fact_cur;                           // ... as the forward pass of the current step set them up (the fused tower reads them)
 };
 
@@ -1627,6 +1620,7 @@ static int wgrad_chunk() {
     return v > 0 ? v : kWgradChunkDefault;
 }
 
+constexpr int kMidMaxRows = 1024;           // steps k_nmf_mid takes (csrc/neumf_mid.hip)
 static int neumf_need_det_ws(daisy_neumf_ctx *ctx) {
     if (ctx->det_ws) return DAISY_OK;
     const size_t splits = ((size_t)ctx->max_rows + wgrad_chunk() - 1) / wgrad_chunk();
@@ -1641,6 +1635,9 @@ static int neumf_need_det_ws(daisy_neumf_ctx *ctx) {
     // the fused tower (csrc/neumf_tower.hip): one slab of partial sums per workgroup
     const size_t tower = (neumf_tower_ws_bytes(ctx->d, neumf_tower_blocks((ctx->max_rows + 63) / 64)) + 3) / 4;
     if (tower > n) n = tower;
+    const int rows_mid = ctx->max_rows < kMidMaxRows ? (int)ctx->max_rows : kMidMaxRows;
+    const size_t mid = (neumf_mid_ws_bytes(ctx->L, ctx->width, ctx->d, rows_mid) + 3) / 4;
+    if (mid > n) n = mid;
     hipError_t e = hipMalloc((void **)&ctx->det_ws, n * sizeof(float));
     if (e != hipSuccess) {
         ctx->det_ws = nullptr;
@@ -1711,11 +1708,20 @@ static bool neumf_use_h(const daisy_neumf_ctx *ctx, int64_t R) {
     return true;
 }
 
+// small steps of the fp32 mode (the reference's own batch of 256 samples): everything between the gather and the scatter in
+// one launch with the layers' weights in LDS (csrc/neumf_mid.hip).  DAISY_NMF_MID=0: the layer-by-layer kernels (A/B, tests).
+static bool neumf_use_mid(const daisy_neumf_ctx *ctx, int64_t R, bool train) {
+    const char *env = getenv("DAISY_NMF_MID");               // (read per call: the tests switch it)
+    const int tune = env ? atoi(env) : 1;
+    return tune != 0 && train && ctx->bf16 == 0 && ctx->model == DAISY_NEUMF_FULL && R <= kMidMaxRows && ctx->mid_fits &&
+           ctx->mid_aligned;
+}
 // the first layer through the tables: bf16 storage (the throughput mode), training, no dropout, a first layer of the
 // standard halving tower, and fewer distinct table rows than rows in the step.  DAISY_NMF_FACT=0 switches it off (A/B).
 static bool neumf_use_fact(const daisy_neumf_ctx *ctx, int64_t R, bool train, uint32_t thresh) {
     const char *env = getenv("DAISY_NMF_FACT");              // (read per call: the tests switch it)
     const int tune = env ? atoi(env) : 1;
+    if (neumf_use_mid(ctx, R, train)) return false;
     // bf16 storage (whole tiles: neumf_use_h) or, round 6, the fp32 parity mode (level 1 - bf16 MFMA inputs - keeps the
     // plain path: its first layer rounds x0 and W1, which a product over the tables would not)
     const bool mode_ok = (ctx->bf16 == 2) ? (neumf_use_h(ctx, R) && ctx->dm % 64 == 0) : (ctx->bf16 == 0);
@@ -1751,6 +1757,11 @@ static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p,
     const int d = ctx->d, dm = ctx->dm, L = ctx->L;
     const int grid = grid_for(R, kBlock / 16 * 2);
     const bool H = neumf_use_h(ctx, R);
+    if (train) {
+        uintptr_t bits = 0;
+        for (int l = 0; l < L; ++l) bits |= (uintptr_t)p->W[l];
+        ctx->mid_aligned = (bits & 15) == 0;
+    }
     if (H) {          // bf16 copies of the MLP weights (a few hundred KB)
         // (the first layer's copy - the largest - has no reader when that layer runs through the tables)
         ctx->tower_aligned = L >= 3 && (((uintptr_t)p->W[1] | (uintptr_t)p->W[2]) & 15) == 0;
@@ -1811,6 +1822,7 @@ static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p,
                                 ctx->G, 0u, 1.f, (uint64_t)0, (double *)nullptr);
     }
     DAISY_LAUNCH_CHECK();
+    if (neumf_use_mid(ctx, R, train)) return DAISY_OK;     // (the layers and the predict layer happen in k_nmf_mid)
     if (ctx->model != DAISY_NEUMF_GMF) {
         for (int l = fact ? 2 : 1; l <= L; ++l) {        // (fact: x1 came out of the gather)
             GemmOp op{};
@@ -2058,6 +2070,8 @@ int daisy_neumf_ctx_create(daisy_neumf_ctx **out, int64_t max_rows, int32_t fact
     c->dm = factors << (num_layers - 1);
     c->width[0] = 2 * c->dm;
     for (int l = 1; l <= num_layers; ++l) c->width[l] = c->width[l - 1] / 2;
+    c->mid_fits = neumf_mid_fits(c->L, c->width, c->d);
+    c->mid_aligned = false;
     size_t off = 0, ox[DAISY_NEUMF_MAX_LAYERS + 1];
     auto take = [&](size_t bytes) { size_t o = off; off += align_up(bytes); return o; };
     for (int l = 0; l <= num_layers; ++l) ox[l] = take((size_t)max_rows * c->width[l] * 4);
@@ -2154,6 +2168,20 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
     // 1 (default): owner-based, reproducible embedding scatter; 0: the fp32-atomics kernel (kept for A/B measurements)
     static const int tune_scatter = getenv("DAISY_NMF_SCATTER_OWNER") ? atoi(getenv("DAISY_NMF_SCATTER_OWNER")) : 1;
     const bool owner_scatter = tune_scatter != 0;
+    const bool mid = neumf_use_mid(ctx, R, true);                    // (the forward pass took the same decision)
+    if (mid) {
+        MidArgs ma{};
+        ma.X0 = ctx->X[0]; ma.G = ctx->G; ma.DX0 = dz; ma.pred = ctx->pred; ma.dpred = ctx->dpred;
+        for (int l = 0; l < L; ++l) { ma.W[l] = p.W[l]; ma.b[l] = p.b[l]; }
+        ma.Wp = p.Wp; ma.bp = p.bp;
+        for (int l = 0; l <= L; ++l) ma.width[l] = ctx->width[l];
+        ma.L = L; ma.d = d;
+        ma.j = j; ma.B = (int)B; ma.R = (int)R; ma.pointwise = pointwise; ma.loss_type = (int)loss_type; ma.gamma = gamma;
+        ma.thresh = thresh; ma.scale = scale; ma.seed = seed;
+        ma.ws = ws;
+        rc = neumf_mid_step(ma, g.W, g.b, g.Wp, g.bp, stats, reg_1, reg_2, s);
+        if (rc) return rc;
+    } else
     if (tower) {
         // x1 gathered from the table products, layers 2..3, predict, criterion, dZ3 .. dZ1, gW3, gW2, gb3, gb2, gWp, gbp and
         // the step's statistics: one persistent kernel + the fixed-order sum of its workgroups' slabs
@@ -2190,7 +2218,7 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
     DAISY_LAUNCH_CHECK();
     }
     const bool fact = neumf_use_fact(ctx, R, true, thresh);          // (the forward pass took the same decision)
-    if (model != DAISY_NEUMF_GMF) {
+    if (model != DAISY_NEUMF_GMF && !mid) {                 // (mid: dz already holds dX0)
         for (int l = tower ? 1 : L; l >= 1; --l) {          // (tower: dz already holds dZ_1)
             const int n_out = ctx->width[l], n_in = ctx->width[l - 1];
             if (fact && l == 1) {

@@ -51,6 +51,14 @@ __device__ __forceinline__ bf16x8 lds_frag_tr2(const uint16_t *p_lo, const uint1
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// keep mask of element `idx` of dropout stream `stream` (one stream per MLP layer input)
+__host__ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint32_t stream, uint64_t idx,
+                                                   uint32_t thresh) {
+    uint32_t h = mix32((uint32_t)idx ^ (uint32_t)seed);
+    h = mix32(h + (uint32_t)(idx >> 32) * 0x9E3779B9u + (uint32_t)(seed >> 32) + stream * 0x85EBCA6Bu);
+    return h >= thresh;
+}
+
 // the three pair layouts of daisy_neumf_scores plus the training batch
 struct PairSrc {
     const int32_t *u, *i, *j;     // training: row r < B -> (u[r], i[r]); r >= B -> (u[r-B], j[r-B])
@@ -94,5 +102,30 @@ size_t neumf_tower_ws_bytes(int d, int nblocks);
 // one launch of the tower over R rows + the fixed-order reduction of the workgroups' sums into the gradients (+=) and stats
 int neumf_tower_step(const TowerArgs &args, int d, int64_t R, float *gW2, float *gW3, float *gb2, float *gb3, float *gWp,
                      float *gbp, double *stats, float reg_1, float reg_2, hipStream_t s);
+
+// ---- the small-step kernel (csrc/neumf_mid.hip): a step of at most 1024 rows whose MLP weights fit the LDS - every layer,
+// the predict layer, the criterion and their backward pass between the gather and the scatter in ONE launch (fp32)
+struct MidArgs {
+    const float *X0;                  // [R][w0]: the gathered (and dropped) concat input
+    const float *G;                   // [R][d]:  the GMF products
+    float *DX0;                       // out: [R][w0] gradient wrt X0 (dropout mask of the input applied)
+    float *pred, *dpred;              // out: [R]
+    const float *W[DAISY_NEUMF_MAX_LAYERS], *b[DAISY_NEUMF_MAX_LAYERS];
+    const float *Wp, *bp;
+    int width[DAISY_NEUMF_MAX_LAYERS + 1];
+    int L, d;
+    const int32_t *j;                 // the labels of a point-wise loss
+    int B, R, pointwise, loss_type;
+    float gamma;
+    uint32_t thresh;                  // dropout: keep threshold (0: off), scale, seed
+    float scale;
+    uint64_t seed;
+    float *ws;                        // per-workgroup partial sums (neumf_mid_ws_bytes)
+};
+bool neumf_mid_fits(int L, const int *width, int d);
+size_t neumf_mid_ws_bytes(int L, const int *width, int d, int max_rows);
+// the launch + the fixed-order reduction of the workgroups' sums into the gradients (+=), the loss and the norms
+int neumf_mid_step(const MidArgs &args, float *const *gW, float *const *gb, float *gWp, float *gbp, double *stats, float reg_1,
+                   float reg_2, hipStream_t s);
 
 }  // namespace daisy

@@ -492,6 +492,57 @@ def test_neumf_small_steps_scatter_in_one_launch(model, loss, B, L, d, monkeypat
         assert np.abs(ga[k] - want[k]).max() <= tol and np.abs(ga[k] - gb[k]).max() <= tol, (k, float(np.abs(ga[k] - want[k]).max()), tol)
 
 
+@pytest.mark.parametrize("loss,B,L,d,pdrop", [(0, 256, 2, 24, 0.5), (0, 250, 2, 24, 0.0), (3, 1000, 3, 16, 0.3), (2, 37, 1, 12, 0.0),
+                                              (4, 512, 2, 32, 0.0), (1, 7, 3, 8, 0.5)])
+def test_neumf_small_steps_between_gather_and_scatter_in_one_launch(loss, B, L, d, pdrop, monkeypatch):
+    """Round 6: steps of at most 1024 rows in the fp32 mode run every layer, the predict layer, the criterion and their backward
+    pass in one launch with the weights in LDS (csrc/neumf_mid.hip: k_nmf_mid + the fixed-order sum of its workgroups' slabs)
+    instead of 17 launches.  Against the fp64 oracle under the same dropout masks and against the layer-by-layer kernels it
+    replaces (DAISY_NMF_MID=0: other association of the same fp32 sums); every criterion, ragged batches (250, 37, 7 samples:
+    workgroups with rows past the batch), point-wise rows; repeatable to the bit."""
+    from daisyrec_amd import ops
+    rng = np.random.default_rng(B + d)
+    U, I, seed = 90, 300, 1234
+    dm = d << (L - 1)
+    shapes = {"uG": (U, d), "iG": (I, d), "uM": (U, dm), "iM": (I, dm), "Wp": (1, 2 * d), "bp": (1,)}
+    w = 2 * dm
+    for l in range(1, L + 1):
+        shapes[f"W{l}"], shapes[f"b{l}"] = (w // 2, w), (w // 2,)
+        w //= 2
+    p_np = {k: (rng.standard_normal(s) * 0.25).astype(np.float32) for k, s in shapes.items()}
+    u, i = (rng.integers(0, n, B).astype(np.int32) for n in (U, I))
+    j = (rng.integers(0, I, B) if loss < 3 else rng.integers(0, 2, B)).astype(np.int32)
+    R = B if loss >= 3 else 2 * B
+    idx = [torch.as_tensor(x).to(DEV) for x in (u, i, j)]
+
+    def run(mid):
+        monkeypatch.setenv("DAISY_NMF_MID", mid)
+        p = _dev(p_np)
+        grads = {k: torch.zeros_like(v) for k, v in p.items()}
+        ctx = ops.NeumfContext(R, d, L, U, I, model="NeuMF")
+        ctx.step_grads(p, grads, *idx, loss, 1e-3, 2e-3, dropout=pdrop, seed=seed)
+        out = float(ctx.stats[11].cpu()), {k: v.cpu().numpy() for k, v in grads.items()}
+        ctx.close()
+        return out
+
+    la, ga = run("1")
+    la2, ga2 = run("1")
+    lb, gb = run("0")
+    masks = {}
+    if pdrop:
+        masks = {"masks_pos": NO.dropout_masks(seed, np.arange(B), d, L, pdrop)}
+        if loss < 3:
+            masks["masks_neg"] = NO.dropout_masks(seed, np.arange(B, 2 * B), d, L, pdrop)
+    want_loss, want = NO.neumf_grad(p_np, u, i, j, 1e-3, 2e-3, L, loss, "NeuMF", **masks)
+    assert la == la2
+    assert abs(la - want_loss) <= 1e-5 * abs(want_loss) and abs(la - lb) <= 1e-5 * abs(want_loss)
+    for k in shapes:
+        assert np.array_equal(ga[k], ga2[k]), k
+        tol = 3e-4 * np.abs(want[k]).max() + 3e-6 * (1 + np.sqrt(R))
+        assert np.abs(ga[k] - want[k]).max() <= tol and np.abs(ga[k] - gb[k]).max() <= tol, (
+            k, float(np.abs(ga[k] - want[k]).max()), float(np.abs(ga[k] - gb[k]).max()), tol)
+
+
 @pytest.mark.parametrize("M,N,K,chunk", [(256, 512, 4096, 2048), (128, 64, 96, 32), (512, 256, 16384, 2048),
                                           (128, 128, 640, 64), (256, 64, 1024, 1024)])
 def test_mfma_gemm_tn_bf16_weight_gradient_layout(M, N, K, chunk):
