@@ -36,7 +36,7 @@ _i32, _i64, _u64, _f32, _sz = C.c_int32, C.c_int64, C.c_uint64, C.c_float, C.c_s
 
 NEUMF_MAX_LAYERS = 8
 NEUMF_FULL, NEUMF_GMF, NEUMF_MLP = 0, 1, 2
-NST_LOSS_DATA, NST_L1, NST_SQ, NST_LOSS, NST_NORM, NEUMF_STATS_LEN = 0, 1, 6, 11, 12, 24
+NST_LOSS_DATA, NST_L1, NST_SQ, NST_LOSS, NST_NORM, NST_LOSS_SUM, NEUMF_STATS_LEN = 0, 1, 6, 11, 12, 17, 24
 
 
 class NeumfParams(C.Structure):

@@ -911,7 +911,9 @@ __global__ void k_nmf_finalize(double *__restrict__ stats, float reg_1, float re
         l1 += w * stats[DAISY_NST_L1 + k];
         fro += w * n;
     }
-    stats[DAISY_NST_LOSS] = stats[DAISY_NST_LOSS_DATA] + (double)reg_1 * l1 + (double)reg_2 * fro;
+    const double loss = stats[DAISY_NST_LOSS_DATA] + (double)reg_1 * l1 + (double)reg_2 * fro;
+    stats[DAISY_NST_LOSS] = loss;
+    stats[DAISY_NST_LOSS_SUM] += loss;
 }
 
 // out[c] += sum_s ws[s][c], s = 0 .. nslices-1 in that order: the second half of every reduction over the batch rows
@@ -1290,6 +1292,142 @@ __global__ __launch_bounds__(kScatterSmallRows) void k_nmf_scatter_small(daisy_n
                 v += fmaf(na * i_g + nb * i_neg, w, reg_1 * (na + 2.f * nb) * sgn(w));
             }
             if (v != 0.f) gG[(int64_t)row * d + c] += v;
+        }
+    }
+}
+
+// The same without the sort (its 55 barrier-separated steps among 16 waves were ~15 of that kernel's 23 us): a workgroup per
+// 64 step rows, a 16-lane group per row.  The group compares its row's key with all R keys - 64 per round, four ballots -
+// and keeps the rounds' match masks in LDS; a row whose key occurred earlier in the step leaves (the first occurrence owns the
+// table row), an owner walks its masks - the matching rows in ascending order, the order of the sorted list - once per column
+// it holds.  Same sums in the same order as k_nmf_scatter_small: bit-identical gradients (tests/test_gpu_neumf.py).
+template <int NT>
+__global__ __launch_bounds__(kScatterSmallRows) void k_nmf_scatter_scan(daisy_neumf_params p, daisy_neumf_params g, PairSrc src,
+                                                                       int R, int d, int dm, int model, int pointwise,
+                                                                       const float *__restrict__ dpred,
+                                                                       const float *__restrict__ DX0,
+                                                                       const double *__restrict__ stats, float reg_1,
+                                                                       float reg_2) {
+    __shared__ uint32_t key_s[kScatterSmallRows], oth_s[kScatterSmallRows];    // this side's table row of a step row, the other side's
+    __shared__ float dp_s[kScatterSmallRows];
+    __shared__ uint64_t mask_s[kScatterSmallRows / 16][kScatterSmallRows / 64];
+    const int side = blockIdx.x, tid = threadIdx.x;
+    const int rounds = (R + 63) / 64;
+    // (the norms first: their loads fly with the ids' - read after the scan they were a memory round trip of their own)
+    const double nrm_m = stats[DAISY_NST_NORM + (side ? 3 : 1)], nrm_g = stats[DAISY_NST_NORM + (side ? 2 : 0)], nrm_neg = stats[DAISY_NST_NORM + 4];
+    if (tid < rounds * 64) {
+        uint32_t own = 0xFFFFFFFFu, oth = 0u;
+        float dp = 0.f;
+        if (tid < R) {
+            int64_t user, item;
+            pair_ids(src, tid, user, item);
+            own = (uint32_t)(side ? item : user);
+            oth = (uint32_t)(side ? user : item);
+            dp = dpred[tid];
+        }
+        key_s[tid] = own; oth_s[tid] = oth; dp_s[tid] = dp;
+    }
+    __syncthreads();
+    const int lane = tid % 16, group = tid / 16;
+    const int e = (int)blockIdx.y * (kScatterSmallRows / 16) + group;
+    if (e >= R) return;
+    const uint32_t row = key_s[e];
+    const int sh = 16 * (group % 4);                   // this group's 16 bits of a wave's ballot
+    for (int rd = 0; rd < rounds; ++rd) {
+        uint64_t m = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint64_t b = __ballot(key_s[rd * 64 + k * 16 + lane] == row);
+            m |= ((b >> sh) & 0xFFFFull) << (16 * k);
+        }
+        const int before = e - rd * 64;                // positions of this round that lie before row e
+        if (before >= 64 ? (m != 0) : (before > 0 && (m & ((1ull << before) - 1ull)) != 0)) return;    // not the first occurrence
+        if (lane == 0) mask_s[group][rd] = m;
+    }
+    // (the group's lanes run in lockstep within one wave: the masks written by lane 0 are visible to the others)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    float npos = 0.f, nneg = 0.f;
+    for (int rd = 0; rd < rounds; ++rd)
+        for (uint64_t m = mask_s[group][rd]; m; m &= m - 1) {
+            const int r = rd * 64 + (int)__builtin_ctzll(m);
+            if ((int64_t)r < src.B) npos += 1.f; else nneg += 1.f;
+        }
+    auto inv = [&](double n) { return (n > 0.0) ? (float)((double)reg_2 / n) : 0.f; };
+    const float i_m = inv(nrm_m), i_g = inv(nrm_g), i_neg = 2.f * inv(nrm_neg);
+    const float *tabM = side ? p.iM : p.uM, *tabG = side ? p.iG : p.uG, *otherG = side ? p.uG : p.iG;
+    float *gM = side ? g.iM : g.uM, *gG = side ? g.iG : g.uG;
+    // The table row's dm + d columns as float4 chunks, NT per lane, all of a step row's chunks loaded at once: one memory round
+    // trip (~2 us when the line was written by another XCD's kernel) per matching step row plus one for the table rows and the
+    // gradient rows, instead of three per 16 columns (first version: 20 us at factors 24).  Per element the same operations
+    // in the same order as k_nmf_scatter_small.
+    const int mch = dm / 4, nch = mch + d / 4;         // chunks 0 .. mch-1: the MLP row; mch .. nch-1: the GMF row
+    float4 acc[NT], tw[NT], gw[NT], wpv[NT <= 2 ? NT : 1];     // (NT = 5: 128 registers per lane at 1024 threads - Wp is read late there)
+    int cidx[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int ch = lane + 16 * t;
+        cidx[t] = (ch < nch) ? ch : -1;
+        acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int cc = (ch < nch) ? ch : 0;
+        const float *trow = (cc < mch) ? tabM + (int64_t)row * dm + 4 * cc : tabG + (int64_t)row * d + 4 * (cc - mch);
+        const float *grow_ = (cc < mch) ? gM + (int64_t)row * dm + 4 * cc : gG + (int64_t)row * d + 4 * (cc - mch);
+        tw[t] = *reinterpret_cast<const float4 *>(trow);
+        gw[t] = *reinterpret_cast<const float4 *>(grow_);
+        if constexpr (NT <= 2) wpv[t] = *reinterpret_cast<const float4 *>(p.Wp + ((cc < mch) ? 0 : 4 * (cc - mch)));
+    }
+    for (int rd = 0; rd < rounds; ++rd)
+        for (uint64_t m = mask_s[group][rd]; m; m &= m - 1) {
+            const int r = rd * 64 + (int)__builtin_ctzll(m);
+            const float dp = dp_s[r];
+            const float *xrow = DX0 + (int64_t)r * (2 * dm) + side * dm, *orow = otherG + (int64_t)oth_s[r] * d;
+            float4 v[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int cc = cidx[t] < 0 ? 0 : cidx[t];
+                v[t] = *reinterpret_cast<const float4 *>((cc < mch) ? xrow + 4 * cc : orow + 4 * (cc - mch));
+            }
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (cidx[t] < 0) continue;
+                if (cidx[t] < mch) {
+                    if (model != DAISY_NEUMF_GMF) { acc[t].x += v[t].x; acc[t].y += v[t].y; acc[t].z += v[t].z; acc[t].w += v[t].w; }
+                } else if (model != DAISY_NEUMF_MLP) {
+                    acc[t].x = fmaf(dp, v[t].x, acc[t].x); acc[t].y = fmaf(dp, v[t].y, acc[t].y);
+                    acc[t].z = fmaf(dp, v[t].z, acc[t].z); acc[t].w = fmaf(dp, v[t].w, acc[t].w);
+                }
+            }
+        }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        if (cidx[t] < 0) continue;
+        float a4[4] = {acc[t].x, acc[t].y, acc[t].z, acc[t].w};
+        const float w4[4] = {tw[t].x, tw[t].y, tw[t].z, tw[t].w};
+        float o4[4] = {gw[t].x, gw[t].y, gw[t].z, gw[t].w};
+        if (cidx[t] < mch) {
+            // MLP table: the rows' input gradients (this side's half of dX0), the regulariser on the positive rows' occurrences
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v = a4[k];
+                if (npos > 0.f) v += fmaf(npos * i_m, w4[k], reg_1 * npos * sgn(w4[k]));
+                if (v != 0.f) o4[k] += v;
+            }
+            *reinterpret_cast<float4 *>(gM + (int64_t)row * dm + 4 * cidx[t]) = make_float4(o4[0], o4[1], o4[2], o4[3]);
+        } else {
+            // GMF table: Wp[c] x sum of dpred[r] x the OTHER table's row; the negative item's rows count twice in the regulariser
+            const int c0 = 4 * (cidx[t] - mch);
+            float4 wq;
+            if constexpr (NT <= 2) wq = wpv[t]; else wq = *reinterpret_cast<const float4 *>(p.Wp + c0);
+            const float wp4[4] = {wq.x, wq.y, wq.z, wq.w};
+            const float na = npos, nb = (side && !pointwise) ? nneg : 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float v = a4[k];
+                if (model != DAISY_NEUMF_MLP) v *= wp4[k];
+                if (na + nb > 0.f) v += fmaf(na * i_g + nb * i_neg, w4[k], reg_1 * (na + 2.f * nb) * sgn(w4[k]));
+                if (v != 0.f) o4[k] += v;
+            }
+            *reinterpret_cast<float4 *>(gG + (int64_t)row * d + c0) = make_float4(o4[0], o4[1], o4[2], o4[3]);
         }
     }
 }
@@ -1757,11 +1895,6 @@ static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p,
     const int d = ctx->d, dm = ctx->dm, L = ctx->L;
     const int grid = grid_for(R, kBlock / 16 * 2);
     const bool H = neumf_use_h(ctx, R);
-    if (train) {
-        uintptr_t bits = 0;
-        for (int l = 0; l < L; ++l) bits |= (uintptr_t)p->W[l];
-        ctx->mid_aligned = (bits & 15) == 0;
-    }
     if (H) {          // bf16 copies of the MLP weights (a few hundred KB)
         // (the first layer's copy - the largest - has no reader when that layer runs through the tables)
         ctx->tower_aligned = L >= 3 && (((uintptr_t)p->W[1] | (uintptr_t)p->W[2]) & 15) == 0;
@@ -1772,6 +1905,7 @@ static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p,
                                ctx->width[l - 1], ctx->W16[l - 1], ctx->W16T[l - 1]);
         }
     }
+    if (neumf_use_mid(ctx, R, train)) return DAISY_OK;     // (the gather, the layers and the predict layer happen in k_nmf_mid)
     const bool fact = neumf_use_fact(ctx, R, train, thresh);
     if (fact) {
         int rc = neumf_need_fact(ctx);
@@ -1822,7 +1956,6 @@ static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p,
                                 ctx->G, 0u, 1.f, (uint64_t)0, (double *)nullptr);
     }
     DAISY_LAUNCH_CHECK();
-    if (neumf_use_mid(ctx, R, train)) return DAISY_OK;     // (the layers and the predict layer happen in k_nmf_mid)
     if (ctx->model != DAISY_NEUMF_GMF) {
         for (int l = fact ? 2 : 1; l <= L; ++l) {        // (fact: x1 came out of the gather)
             GemmOp op{};
@@ -1913,11 +2046,26 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
                                const PairSrc &src, int64_t R, int pointwise, const float *DX0, bool dx0_bf16,
                                const double *stats, float reg_1, float reg_2, hipStream_t s, bool fact = false) {
     {
-        // small steps: the whole scatter in two workgroups (k_nmf_scatter_small).  DAISY_NMF_SCATTER_SMALL=0 (read per call): off
+        // small steps: the whole scatter in one launch (k_nmf_scatter_scan).  DAISY_NMF_SCATTER_SMALL (read per call): 0 - off,
+        // 2 - the sorting kernel it replaced (k_nmf_scatter_small: A/B, and the tests' bit-for-bit cross-check)
         const char *env_sm = getenv("DAISY_NMF_SCATTER_SMALL");
-        if (R <= kScatterSmallRows && !dx0_bf16 && !fact && (!env_sm || atoi(env_sm) != 0) && c->U < (1 << 22) && c->I < (1 << 22)) {
-            hipLaunchKernelGGL(k_nmf_scatter_small, dim3(2, 16), dim3(kScatterSmallRows), 0, s, p, g, src, (int)R, c->d, c->dm, c->model,
-                               pointwise, c->dpred, DX0, stats, reg_1, reg_2);
+        const int sm_mode = env_sm ? atoi(env_sm) : 1;
+        // (the scanning kernel holds a table row's dm + d columns as 16 x 5 float4 at most; 16-byte aligned tables and gradients)
+        const bool scan_ok = (c->dm + c->d) / 4 <= 80 &&
+                             ((((uintptr_t)p.uM | (uintptr_t)p.iM | (uintptr_t)p.uG | (uintptr_t)p.iG | (uintptr_t)g.uM | (uintptr_t)g.iM |
+                                (uintptr_t)g.uG | (uintptr_t)g.iG | (uintptr_t)DX0 | (uintptr_t)p.Wp) & 15) == 0);
+        if (R <= kScatterSmallRows && !dx0_bf16 && !fact && sm_mode != 0 && (scan_ok || (c->U < (1 << 22) && c->I < (1 << 22)))) {
+            if ((sm_mode == 2 || !scan_ok) && c->U < (1 << 22) && c->I < (1 << 22))
+                hipLaunchKernelGGL(k_nmf_scatter_small, dim3(2, 16), dim3(kScatterSmallRows), 0, s, p, g, src, (int)R, c->d, c->dm, c->model,
+                                   pointwise, c->dpred, DX0, stats, reg_1, reg_2);
+            else {
+                const dim3 grid(2, (unsigned)((R + 63) / 64));
+                const int nt = ((c->dm + c->d) / 4 + 15) / 16;          // float4 chunks of a table row's columns per lane
+                if (nt <= 2) hipLaunchKernelGGL((k_nmf_scatter_scan<2>), grid, dim3(kScatterSmallRows), 0, s, p, g, src, (int)R, c->d, c->dm,
+                                                c->model, pointwise, c->dpred, DX0, stats, reg_1, reg_2);
+                else hipLaunchKernelGGL((k_nmf_scatter_scan<5>), grid, dim3(kScatterSmallRows), 0, s, p, g, src, (int)R, c->d, c->dm,
+                                        c->model, pointwise, c->dpred, DX0, stats, reg_1, reg_2);
+            }
             DAISY_LAUNCH_CHECK();
             return DAISY_OK;
         }
@@ -2153,7 +2301,13 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
     const int d = ctx->d, dm = ctx->dm, L = ctx->L, model = ctx->model;
     const uint32_t thresh = (model == DAISY_NEUMF_GMF) ? 0u : drop_threshold(dropout_p);
     const float scale = thresh ? 1.f / (1.f - dropout_p) : 1.f;
-    DAISY_HIP(hipMemsetAsync(stats, 0, DAISY_NEUMF_STATS_LEN * sizeof(double), s));
+    {
+        uintptr_t bits = (uintptr_t)p.Wp | (uintptr_t)p.uG | (uintptr_t)p.iG | (uintptr_t)p.uM | (uintptr_t)p.iM;
+        for (int l = 0; l < L; ++l) bits |= (uintptr_t)p.W[l] | (uintptr_t)p.b[l];
+        ctx->mid_aligned = (bits & 15) == 0;           // (k_nmf_mid reads the parameters and the tables' rows as float4)
+    }
+    // (slots 0..16: DAISY_NST_LOSS_SUM runs over steps; the small-step path writes every slot itself - k_nmf_mid_reduce)
+    if (!neumf_use_mid(ctx, R, true)) DAISY_HIP(hipMemsetAsync(stats, 0, DAISY_NST_LOSS_SUM * sizeof(double), s));
     PairSrc src{};
     src.u = u; src.i = i; src.j = pointwise ? i : j; src.B = B;
     int rc = neumf_forward_rows(ctx, params, src, R, true, pointwise, thresh, scale, seed, stats, s);
@@ -2171,7 +2325,8 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
     const bool mid = neumf_use_mid(ctx, R, true);                    // (the forward pass took the same decision)
     if (mid) {
         MidArgs ma{};
-        ma.X0 = ctx->X[0]; ma.G = ctx->G; ma.DX0 = dz; ma.pred = ctx->pred; ma.dpred = ctx->dpred;
+        ma.uG = p.uG; ma.iG = p.iG; ma.uM = p.uM; ma.iM = p.iM; ma.u = u; ma.i = i; ma.dm = dm;
+        ma.DX0 = dz; ma.pred = ctx->pred; ma.dpred = ctx->dpred;
         for (int l = 0; l < L; ++l) { ma.W[l] = p.W[l]; ma.b[l] = p.b[l]; }
         ma.Wp = p.Wp; ma.bp = p.bp;
         for (int l = 0; l <= L; ++l) ma.width[l] = ctx->width[l];

@@ -103,18 +103,19 @@ size_t neumf_tower_ws_bytes(int d, int nblocks);
 int neumf_tower_step(const TowerArgs &args, int d, int64_t R, float *gW2, float *gW3, float *gb2, float *gb3, float *gWp,
                      float *gbp, double *stats, float reg_1, float reg_2, hipStream_t s);
 
-// ---- the small-step kernel (csrc/neumf_mid.hip): a step of at most 1024 rows whose MLP weights fit the LDS - every layer,
-// the predict layer, the criterion and their backward pass between the gather and the scatter in ONE launch (fp32)
+// ---- the small-step kernel (csrc/neumf_mid.hip): a step of at most 1024 rows whose MLP weights fit the LDS - the gather, every
+// layer, the predict layer, the criterion and their backward pass, everything before the scatter, in ONE launch (fp32)
 struct MidArgs {
-    const float *X0;                  // [R][w0]: the gathered (and dropped) concat input
-    const float *G;                   // [R][d]:  the GMF products
-    float *DX0;                       // out: [R][w0] gradient wrt X0 (dropout mask of the input applied)
+    const float *uG, *iG, *uM, *iM;   // the embedding tables ([U][d], [I][d], [U][dm], [I][dm]); u, i, j: the batch
+    const int32_t *u, *i;
+    int dm;
+    float *DX0;                       // out: [R][w0] gradient wrt x0 = [uM[u] | iM[item]] (dropout mask of the input applied)
     float *pred, *dpred;              // out: [R]
     const float *W[DAISY_NEUMF_MAX_LAYERS], *b[DAISY_NEUMF_MAX_LAYERS];
     const float *Wp, *bp;
     int width[DAISY_NEUMF_MAX_LAYERS + 1];
     int L, d;
-    const int32_t *j;                 // the labels of a point-wise loss
+    const int32_t *j;                 // the negatives, or the labels of a point-wise loss
     int B, R, pointwise, loss_type;
     float gamma;
     uint32_t thresh;                  // dropout: keep threshold (0: off), scale, seed

@@ -640,7 +640,9 @@ __global__ __launch_bounds__(kTwBlock) void k_nmf_tower_reduce(const float *__re
             l1 += wgt * L1;
             fro += wgt * n;
         }
-        stats[DAISY_NST_LOSS] = stats[DAISY_NST_LOSS_DATA] + (double)reg_1 * l1 + (double)reg_2 * fro;
+        const double loss = stats[DAISY_NST_LOSS_DATA] + (double)reg_1 * l1 + (double)reg_2 * fro;
+        stats[DAISY_NST_LOSS] = loss;
+        stats[DAISY_NST_LOSS_SUM] += loss;
     }
 }
 

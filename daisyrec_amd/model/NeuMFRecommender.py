@@ -186,7 +186,6 @@ class NeuMF(GeneralRecommender):
         grads = self._views_like_flat(gflat)
         optim = ops.DenseOptimizer(opt, self.lr)
         ctx = self._ctx(2 * min(B, max(n, 1)))
-        acc = torch.zeros(2, dtype=torch.float64, device=self.device)
         self.epoch_losses, last_loss, step = [], 0.0, 0
         try:
             epochs = range(1, self.epochs + 1)
@@ -198,17 +197,16 @@ class NeuMF(GeneralRecommender):
                 # the epoch's ids column by column, once: a batch is then three views (at B = 256 the three per-batch copies
                 # were 3 of the step's ~46 launches, each a few microseconds of latency)
                 cols = [order[:, k].contiguous() for k in range(3)]
-                loss_of_step = ctx.stats[N.NST_LOSS:N.NST_LOSS + 1]
-                acc.zero_()
+                # (the epoch's loss: every step adds its loss to stats[NST_LOSS_SUM] on the device - no launch per step for it)
+                ctx.stats[N.NST_LOSS_SUM:N.NST_LOSS_SUM + 1].zero_()
                 for s in range(0, n, B):
                     u, i, j = (col[s:s + B] for col in cols)
                     step += 1
                     ctx.step_grads(p, grads, u, i, j, loss_id, self.reg_1, self.reg_2, dropout=self.dropout,
                                    seed=(self.seed << 32) | step)
-                    acc[0:1].add_(loss_of_step)
                     optim.next_step()
                     optim.step(self._flat, gflat)          # also clears the gradient
-                current_loss = float(acc[0].cpu())
+                current_loss = float(ctx.stats[N.NST_LOSS_SUM].cpu())
                 if current_loss != current_loss or current_loss in (float("inf"), float("-inf")):
                     raise ValueError("Loss=Nan or Infinity: current settings does not fit the recommender")
                 self.epoch_losses.append(current_loss)

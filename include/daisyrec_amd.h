@@ -528,6 +528,8 @@ enum {
     DAISY_NST_SQ = 6,  /* same five, sum x^2                                                        */
     DAISY_NST_LOSS = 11,                             /* NeuMF.calc_loss value (:139-169)             */
     DAISY_NST_NORM = 12,                             /* same five, Frobenius norms                   */
+    DAISY_NST_LOSS_SUM = 17,  /* running sum of DAISY_NST_LOSS over the steps since the caller zeroed it: a step   */
+                              /* clears slots 0..16 only (an epoch's loss without a launch per step to add it up) */
     DAISY_NEUMF_STATS_LEN = 24
 };
 typedef struct daisy_neumf_ctx daisy_neumf_ctx;

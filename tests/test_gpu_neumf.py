@@ -411,9 +411,10 @@ def test_neumf_fp32_first_layer_through_the_tables(loss, B, L, d, monkeypatch):
     assert U + I <= R
     idx = [torch.as_tensor(x).to(DEV) for x in (u, i, j)]
     want_loss, want = NO.neumf_grad(p_np, u, i, j, 1e-3, 1e-3, L, loss)
-    lf, gf = _run_step(ops, p_np, idx, R, d, L, U, I, 0, loss, {"DAISY_NMF_FACT": "1"}, monkeypatch)
-    lf2, gf2 = _run_step(ops, p_np, idx, R, d, L, U, I, 0, loss, {"DAISY_NMF_FACT": "1"}, monkeypatch)
-    lp, gp = _run_step(ops, p_np, idx, R, d, L, U, I, 0, loss, {"DAISY_NMF_FACT": "0"}, monkeypatch)
+    # (DAISY_NMF_MID=0: steps this small otherwise take the one-launch path of csrc/neumf_mid.hip, which has no use for the products)
+    lf, gf = _run_step(ops, p_np, idx, R, d, L, U, I, 0, loss, {"DAISY_NMF_FACT": "1", "DAISY_NMF_MID": "0"}, monkeypatch)
+    lf2, gf2 = _run_step(ops, p_np, idx, R, d, L, U, I, 0, loss, {"DAISY_NMF_FACT": "1", "DAISY_NMF_MID": "0"}, monkeypatch)
+    lp, gp = _run_step(ops, p_np, idx, R, d, L, U, I, 0, loss, {"DAISY_NMF_FACT": "0", "DAISY_NMF_MID": "0"}, monkeypatch)
     assert lf == lf2 and all(np.array_equal(gf[k], gf2[k]) for k in shapes)
     assert abs(lf - want_loss) <= 1e-5 * abs(want_loss) and abs(lp - want_loss) <= 1e-5 * abs(want_loss)
     assert any(not np.array_equal(gf[k], gp[k]) for k in shapes)                     # the factored path really ran
@@ -452,7 +453,8 @@ def test_neumf_rows_grouped_by_a_counting_pass_equal_the_radix_sorts(loss, B, le
 @pytest.mark.parametrize("model,loss,B,L,d", [("NeuMF", 0, 256, 2, 24), ("NeuMF", 3, 1000, 3, 16), ("GMF", 0, 100, 2, 8), ("MLP", 2, 37, 1, 12)])
 def test_neumf_small_steps_scatter_in_one_launch(model, loss, B, L, d, monkeypatch):
     """Round 6: at most 1024 rows per step (the reference's batch of 256 samples is 512) - the embedding gradients come from
-    two workgroups (k_nmf_scatter_small: LDS sort + one owner per table row) instead of ~22 launches.  Against the
+    one launch (k_nmf_scatter_scan: every row's key compared with all keys, the first occurrence owns the table row; its
+    predecessor k_nmf_scatter_small sorted the rows in LDS - bit-identical) instead of ~22 launches.  Against the
     owner-based scatter it replaces (DAISY_NMF_SCATTER_SMALL=0; other association of the same sums: fp32 round-off) and the
     fp64 oracle; hot rows (7 users), every model variant, point-wise rows, a row count that is no power of two; repeatable."""
     from daisyrec_amd import ops
@@ -483,11 +485,12 @@ def test_neumf_small_steps_scatter_in_one_launch(model, loss, B, L, d, monkeypat
 
     la, ga = run({"DAISY_NMF_SCATTER_SMALL": "1"})
     la2, ga2 = run({"DAISY_NMF_SCATTER_SMALL": "1"})
+    ls, gs = run({"DAISY_NMF_SCATTER_SMALL": "2"})       # the sorting kernel the scanning one replaced: same sums, same order
     lb, gb = run({"DAISY_NMF_SCATTER_SMALL": "0"})
     want_loss, want = NO.neumf_grad(p_np, u, i, j, 1e-3, 2e-3, L, loss, model)
-    assert la == la2 == lb and abs(la - want_loss) <= 1e-5 * abs(want_loss)
+    assert la == la2 == lb == ls and abs(la - want_loss) <= 1e-5 * abs(want_loss)
     for k in ("uG", "iG", "uM", "iM"):
-        assert np.array_equal(ga[k], ga2[k]), k
+        assert np.array_equal(ga[k], ga2[k]) and np.array_equal(ga[k], gs[k]), k
         tol = 3e-4 * np.abs(want[k]).max() + 3e-6 * (1 + np.sqrt(R))
         assert np.abs(ga[k] - want[k]).max() <= tol and np.abs(ga[k] - gb[k]).max() <= tol, (k, float(np.abs(ga[k] - want[k]).max()), tol)
 
