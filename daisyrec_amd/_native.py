@@ -126,6 +126,8 @@ SIGNATURES = {
     "daisy_neumf_ctx_set_precision": (C.c_int, [_p, _i32]),
     "daisy_neumf_scores": (C.c_int, [_p, _pp, _p, _p, _i64, _i64, _p, _p]),
     "daisy_neumf_step_grads": (C.c_int, [_p, _pp, _pp, _p, _p, _p, _i64, _i32, _f32, _f32, _f32, _f32, _u64, _p, _p]),
+    "daisy_neumf_fit_epoch": (C.c_int, [_p, _pp, _pp, _p, _p, _p, _i64, _i64, _i32, _f32, _f32, _f32, _f32, _u64, _i64,
+                                        _i32, _f32, _p, _p, _p, _p, _i64, _p, _p]),
     "daisy_sgd_dense": (C.c_int, [_p, _p, _i64, _f32, _p]),
     "daisy_topk_from_scores": (C.c_int, [_p, _p, _i64, _i64, _i32, _p, _p, _sz, _p]),
     "daisy_full_topk_from_scores": (C.c_int, [_p, _i64, _i32, _p, _p, _sz, _p]),

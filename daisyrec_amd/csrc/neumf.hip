@@ -2479,6 +2479,34 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
     return DAISY_OK;
 }
 
+int daisy_neumf_fit_epoch(daisy_neumf_ctx *ctx, const daisy_neumf_params *params, const daisy_neumf_params *grads,
+                          const int32_t *u, const int32_t *i, const int32_t *j, int64_t n, int64_t batch, int32_t loss_type,
+                          float gamma, float reg_1, float reg_2, float dropout_p, uint64_t seed_hi, int64_t step0,
+                          int32_t optimizer, float lr, float *W, float *g, float *state0, float *state1, int64_t n_flat,
+                          double *stats, daisy_stream_t stream) {
+    DAISY_CHECK_ARG(ctx && params && grads && u && i && j && stats && W && g && n > 0 && batch > 0 && n_flat > 0 && step0 >= 0,
+                    "neumf_fit_epoch: bad argument");
+    DAISY_CHECK_ARG(optimizer >= 0 && optimizer <= 3, "neumf_fit_epoch: optimizer=%d (0 sgd, 1 adam, 2 adagrad, 3 rmsprop)", optimizer);
+    DAISY_CHECK_ARG(optimizer == 0 || state0, "neumf_fit_epoch: optimizer %d needs its state", optimizer);
+    DAISY_CHECK_ARG(optimizer != 1 || state1, "neumf_fit_epoch: Adam needs both moments");
+    // the reference's loop (AbstractRecommender.py:119-128) over the epoch's batches, issued from here: at 256 samples per step
+    // a step is ~40 us of kernels, less than the Python of one iteration around two library calls
+    int64_t step = step0;
+    for (int64_t s0 = 0; s0 < n; s0 += batch) {
+        const int64_t B = (n - s0 < batch) ? n - s0 : batch;
+        ++step;
+        int rc = daisy_neumf_step_grads(ctx, params, grads, u + s0, i + s0, j + s0, B, loss_type, gamma, reg_1, reg_2, dropout_p,
+                                        seed_hi | (uint64_t)step, stats, stream);
+        if (rc) return rc;
+        if (optimizer == 0) rc = daisy_sgd_dense(W, g, n_flat, lr, stream);
+        else if (optimizer == 1) rc = daisy_adam_dense(W, g, state0, state1, n_flat, lr, 0.9f, 0.999f, 1e-8f, step, stream);
+        else if (optimizer == 2) rc = daisy_adagrad_dense(W, g, state0, n_flat, lr, 1e-10f, stream);
+        else rc = daisy_rmsprop_dense(W, g, state0, n_flat, lr, 0.99f, 1e-8f, stream);
+        if (rc) return rc;
+    }
+    return DAISY_OK;
+}
+
 int daisy_gemm_nt_bf16(const uint16_t *A, const uint16_t *B, uint16_t *C, int64_t M, int32_t N, int32_t K,
                        daisy_stream_t stream) {
     DAISY_CHECK_ARG(A && B && C && M > 0 && N > 0 && K > 0, "gemm_nt_bf16: bad argument");

@@ -35,7 +35,8 @@ struct MidLayout {
 
 // the parameters' way into LDS: W_1 .. W_L (rows of q4 float4 -> rows of `pitch` floats), b_1 .. b_L, Wp (one row each) as one
 // list of float4s - segment s holds elements start[s] .. start[s+1]
-constexpr int kMidSegs = 2 * DAISY_NEUMF_MAX_LAYERS + 1;
+constexpr int kMidMaxLayers = 3;     // (what fits the LDS has at most three layers in practice; the segment list stays in SGPRs)
+constexpr int kMidSegs = 2 * kMidMaxLayers + 1;
 constexpr int kMidDoubles = 12;      // a workgroup's double sums: loss, gbp, L1[5], SQ[5]
 struct MidCopy {
     const float *src[kMidSegs];
@@ -69,7 +70,7 @@ static int mid_param_float4(int L, const int *w, int d) {
 }
 
 bool neumf_mid_fits(int L, const int *w, int d) {
-    if (L < 1 || L > DAISY_NEUMF_MAX_LAYERS || d % 4 || w[L] % 4) return false;
+    if (L < 1 || L > kMidMaxLayers || d % 4 || w[L] % 4) return false;
     for (int l = 1; l <= L; ++l)
         if (w[l - 1] % 8 || w[l] % 4) return false;
     // (the tile of x0 and of the GMF products is fetched into registers in one go: 4 and 1 float4 per thread; the parameters
@@ -128,8 +129,11 @@ __global__ __launch_bounds__(kMidBlock) void k_nmf_mid(MidArgs a, MidLayout y, M
         int rem = 0, q4 = 1, pitch = 0, dsto = 0;
         uint32_t magic = 0;
         bool in = false;
-        for (int sg = 0; sg < cp.n; ++sg)
-            if (e >= cp.start[sg] && e < cp.start[sg + 1]) {
+        // (fully unrolled over the at most 7 segments: their descriptors are scalar loads issued once, up front - a loop over
+        // cp.n re-read them from the kernel arguments per element and segment, 40 dependent scalar loads: 3 of this stage's 5 us)
+#pragma unroll
+        for (int sg = 0; sg < kMidSegs; ++sg)
+            if (sg < cp.n && e >= cp.start[sg] && e < cp.start[sg + 1]) {
                 in = true; sp = cp.src[sg]; rem = e - cp.start[sg]; q4 = cp.q4[sg]; pitch = cp.pitch[sg]; dsto = cp.dst[sg]; magic = cp.magic[sg];
             }
         const int n = (int)__umulhi((uint32_t)rem, magic);
@@ -143,6 +147,7 @@ __global__ __launch_bounds__(kMidBlock) void k_nmf_mid(MidArgs a, MidLayout y, M
 #undef MID_ISSUE
     if (tid < TR) { grow_s[tid] = my_gr; uid_s[tid] = my_u; iid_s[tid] = my_i; }
     __syncthreads();
+    MID_MARK(10)
     const int w0 = a.width[0], wL = a.width[L];
     float4 rx[4], rgu, rgi;
     {
@@ -165,6 +170,7 @@ __global__ __launch_bounds__(kMidBlock) void k_nmf_mid(MidArgs a, MidLayout y, M
     MID_COMMIT(0) MID_COMMIT(1) MID_COMMIT(2) MID_COMMIT(3) MID_COMMIT(4) MID_COMMIT(5) MID_COMMIT(6) MID_COMMIT(7)
     MID_COMMIT(8) MID_COMMIT(9) MID_COMMIT(10) MID_COMMIT(11) MID_COMMIT(12) MID_COMMIT(13) MID_COMMIT(14) MID_COMMIT(15)
 #undef MID_COMMIT
+    MID_MARK(11)
     // x0 = [uM[u] | iM[item]] (* the dropout mask of layer 1), g = uG[u] * iG[item], and the rows' share of the regulariser sums
     // (NeuMFRecommender.py:149-167: the positive rows' four embeddings, the negative rows' GMF item embedding)
     float s1[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, s2[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
@@ -385,8 +391,8 @@ __global__ __launch_bounds__(kMidBlock) void k_nmf_mid(MidArgs a, MidLayout y, M
     }
 #ifdef DAISY_MID_PROF
     if (tid == 0 && blockIdx.x == 0 && atomicAdd(&mid_prof_calls, 1) % 200 == 150)
-        printf("k_nmf_mid wg 0, x10 ns: global->LDS %lld  F1 %lld F2 %lld F3 %lld  predict %lld  criterion %lld  pred bwd %lld  "
-               "B1 %lld  B2.. %lld\n", prof[0], prof[1], prof[2], prof[3], prof[5], prof[6], prof[7], prof[8], prof[9]);
+        printf("k_nmf_mid wg 0, x10 ns: ids %lld  params->LDS %lld  rows,sums %lld  F1 %lld F2 %lld F3 %lld  predict %lld  criterion %lld  pred bwd %lld  "
+               "B1 %lld  B2.. %lld\n", prof[10], prof[11], prof[0], prof[1], prof[2], prof[3], prof[5], prof[6], prof[7], prof[8], prof[9]);
 #endif
 }
 

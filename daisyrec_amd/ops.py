@@ -459,13 +459,20 @@ class DenseOptimizer:
         """Advance the (shared) step count: once per optimizer.step() of the reference."""
         self.t += 1
 
+    def state_for(self, W):
+        """The optimiser's state tensors of the flat parameter vector W (created zero at first use): () for SGD."""
+        if self.kind == "sgd":
+            return ()
+        st = self._state.get(W.data_ptr())
+        if st is None:
+            st = self._state[W.data_ptr()] = tuple(torch.zeros_like(W) for _ in range(2 if self.kind == "adam" else 1))
+        return st
+
     def step(self, W, g):
         W, g = W.view(-1), g.view(-1)
         if self.kind == "sgd":
             return sgd_dense(W, g, self.lr)
-        st = self._state.get(W.data_ptr())
-        if st is None:
-            st = self._state[W.data_ptr()] = tuple(torch.zeros_like(W) for _ in range(2 if self.kind == "adam" else 1))
+        st = self.state_for(W)
         if self.kind == "adam":
             adam_dense(W, g, st[0], st[1], self.lr, max(self.t, 1))
         elif self.kind == "adagrad":
@@ -863,6 +870,30 @@ class NeumfContext:
                                          _ptr(i, torch.int32, "i"), _ptr(j, torch.int32, "j"), u.numel(),
                                          int(loss_type), float(gamma), float(reg_1), float(reg_2), float(dropout),
                                          int(seed), _ptr(self.stats, torch.float64, "stats"), _stream()))
+
+
+    def fit_epoch(self, params, grads, u, i, j, batch, optim, W, g, loss_type=N.LOSS_BPR, reg_1=0.0, reg_2=0.0, dropout=0.0,
+                  seed_hi=0, step0=0, gamma=1e-10):
+        """One epoch of AbstractRecommender.fit's loop (:112-128) over the batches of (u, i, j), issued by the library
+        (daisy_neumf_fit_epoch): step_grads + the dense optimiser `optim` on the flat vectors W / g per batch.  Advances
+        optim.t by the number of steps and returns that number; the epoch's loss accumulates in stats[NST_LOSS_SUM]."""
+        n = int(u.numel())
+        steps = (n + int(batch) - 1) // int(batch)
+        if optim.t != int(step0):
+            raise ValueError(f"fit_epoch: the optimiser has taken {optim.t} steps, step0 = {step0}")
+        W, g = W.view(-1), g.view(-1)
+        st = optim.state_for(W)
+        pt, gt = _neumf_table(params, self.L), _neumf_table(grads, self.L)
+        f = torch.float32
+        check(lib.daisy_neumf_fit_epoch(self._h, C.byref(pt), C.byref(gt), _ptr(u, torch.int32, "u"), _ptr(i, torch.int32, "i"),
+                                        _ptr(j, torch.int32, "j"), n, int(batch), int(loss_type), float(gamma), float(reg_1),
+                                        float(reg_2), float(dropout), int(seed_hi), int(step0),
+                                        DenseOptimizer.KINDS.index(optim.kind), float(optim.lr), _ptr(W, f, "W"), _ptr(g, f, "g"),
+                                        _ptr(st[0], f, "state0") if len(st) > 0 else None,
+                                        _ptr(st[1], f, "state1") if len(st) > 1 else None, W.numel(),
+                                        _ptr(self.stats, torch.float64, "stats"), _stream()))
+        optim.t += steps
+        return steps
 
 
 def sgd_dense(W, g, lr):

@@ -566,6 +566,18 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
                            const int32_t *j, int64_t B, int32_t loss_type, float gamma, float reg_1,
                            float reg_2, float dropout_p, uint64_t seed, double *stats,
                            daisy_stream_t stream);
+/* One epoch of the reference's training loop (AbstractRecommender.py:112-128: zero_grad / calc_loss / backward /
+ * optimizer.step per batch) over the batches [s, s+batch) of the n samples (u, i, j), issued from the library: step k
+ * (1-based, counted on from step0) = daisy_neumf_step_grads with seed = seed_hi | (step0 + k), then the dense optimiser
+ * (0 SGD, 1 Adam, 2 Adagrad, 3 RMSprop: torch defaults, the daisy_*_dense kernels) on the flat parameter vector W and
+ * its gradient g (n_flat floats: every tensor of `params` / `grads` is a view into them; state0 / state1: exp_avg /
+ * exp_avg_sq, state_sum, square_avg; Adam's step count is step0 + k).  stats[DAISY_NST_LOSS_SUM] grows by the
+ * steps' losses.  Same kernels as the per-step calls - what it removes is the host's per-step work. */
+int daisy_neumf_fit_epoch(daisy_neumf_ctx *ctx, const daisy_neumf_params *params, const daisy_neumf_params *grads,
+                          const int32_t *u, const int32_t *i, const int32_t *j, int64_t n, int64_t batch, int32_t loss_type,
+                          float gamma, float reg_1, float reg_2, float dropout_p, uint64_t seed_hi, int64_t step0,
+                          int32_t optimizer, float lr, float *W, float *g, float *state0, float *state1, int64_t n_flat,
+                          double *stats, daisy_stream_t stream);
 /* optim.SGD step on one dense tensor: W -= lr*g; g = 0   (AbstractRecommender.py:56) */
 int daisy_sgd_dense(float *W, float *g, int64_t n, float lr, daisy_stream_t stream);
 /* the argsort / top-k tail of every rank(): scores f32[B,C] (+ candidate ids i64[B,C]) -> ids of the

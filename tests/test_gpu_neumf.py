@@ -546,6 +546,55 @@ def test_neumf_small_steps_between_gather_and_scatter_in_one_launch(loss, B, L, 
             k, float(np.abs(ga[k] - want[k]).max()), float(np.abs(ga[k] - gb[k]).max()), tol)
 
 
+@pytest.mark.parametrize("opt,B,pdrop", [("adam", 256, 0.5), ("sgd", 100, 0.0), ("adagrad", 64, 0.2), ("rmsprop", 300, 0.0)])
+def test_neumf_epoch_issued_by_the_library_equals_the_per_step_calls(opt, B, pdrop):
+    """daisy_neumf_fit_epoch (the reference's loop over an epoch's batches, issued from the library) against the same steps
+    called one by one - step_grads + the dense optimiser: identical parameters, optimiser state and epoch loss, a ragged
+    last batch included."""
+    from daisyrec_amd import ops
+    from daisyrec_amd import _native as N
+    rng = np.random.default_rng(11)
+    U, I, d, L, n, seed = 120, 90, 16, 2, 1000, 5
+    shapes = _tower_shapes(U, I, d, L)
+    shapes["bp"] = shapes.pop("bp")          # (the one-element bias last, like the recommender's flat buffer: every view 16-byte aligned)
+    sizes = {k: int(np.prod(v)) for k, v in shapes.items()}
+    flat0 = (rng.standard_normal(sum(sizes.values())) * 0.2).astype(np.float32)
+    tri = [torch.as_tensor(rng.integers(0, m, n).astype(np.int32)).to(DEV) for m in (U, I, I)]
+
+    def views(flat):
+        out, o = {}, 0
+        for k, shp in shapes.items():
+            out[k] = flat[o:o + sizes[k]].view(*shp)
+            o += sizes[k]
+        return out
+
+    def run(native):
+        W = torch.as_tensor(flat0).to(DEV).clone()
+        g = torch.zeros_like(W)
+        p, gr = views(W), views(g)
+        optim = ops.DenseOptimizer(opt, 1e-2)
+        ctx = ops.NeumfContext(2 * B, d, L, U, I)
+        if native:
+            steps = ctx.fit_epoch(p, gr, *tri, B, optim, W, g, 0, 1e-3, 2e-3, dropout=pdrop, seed_hi=seed << 32, step0=0)
+        else:
+            steps = 0
+            for s0 in range(0, n, B):
+                steps += 1
+                ctx.step_grads(p, gr, *(t[s0:s0 + B] for t in tri), 0, 1e-3, 2e-3, dropout=pdrop, seed=(seed << 32) | steps)
+                optim.next_step()
+                optim.step(W, g)
+        loss = float(ctx.stats[N.NST_LOSS_SUM].cpu())
+        st = [t.cpu().numpy() for t in optim.state_for(W)]
+        ctx.close()
+        return steps, optim.t, loss, W.cpu().numpy(), st
+
+    a, b = run(True), run(False)
+    assert a[0] == b[0] == (n + B - 1) // B and a[1] == b[1] == a[0]
+    assert a[2] == b[2] and np.isfinite(a[2]) and a[2] > 0
+    assert np.array_equal(a[3], b[3]) and not np.array_equal(a[3], flat0)
+    assert len(a[4]) == len(b[4]) and all(np.array_equal(x, y) for x, y in zip(a[4], b[4]))
+
+
 @pytest.mark.parametrize("M,N,K,chunk", [(256, 512, 4096, 2048), (128, 64, 96, 32), (512, 256, 16384, 2048),
                                           (128, 128, 640, 64), (256, 64, 1024, 1024)])
 def test_mfma_gemm_tn_bf16_weight_gradient_layout(M, N, K, chunk):
