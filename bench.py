@@ -626,6 +626,28 @@ def extra_small_batch(dev):
                                            "frac": gbs / HBM_PEAK_GBS, "traffic": None}})
     plan.close()
     out["value"], out["unit"] = max(q["value"] for q in out["points"]), "interactions/s"
+    # NeuMF at the reference's own operating point (neumf.yaml: factors 24, 2 layers, dropout 0.5, Adam; basic.yaml:23: B = 256)
+    # through NeuMF.fit: gather ... input gradient in one launch with the weights in LDS (csrc/neumf_mid.hip), 4 dispatches per
+    # step, the epoch's loop issued by the library (daisy_neumf_fit_epoch)
+    import logging
+    import numpy as np
+    from daisyrec_amd.model.NeuMFRecommender import NeuMF
+    from daisyrec_amd.utils.dataset import BasicDataset, get_dataloader
+    n = B * 300
+    rng = np.random.default_rng(0)
+    tri_n = np.stack([rng.integers(0, U, n), rng.integers(0, I, n), rng.integers(0, I, n)], 1).astype(np.int32)
+    cfg = {"gpu": str(dev.index or 0), "logger": logging.getLogger("bench"), "lr": 0.001, "reg_1": 0.0, "reg_2": 0.001, "epochs": 1,
+           "topk": 50, "user_num": U, "item_num": I, "factors": 24, "num_layers": 2, "dropout": 0.5, "loss_type": "BPR",
+           "optimizer": "adam", "init_method": "default", "early_stop": False, "model_name": "NeuMF", "GMF_model": None,
+           "MLP_model": None, "algo_name": "neumf", "progress": False}
+    model = NeuMF(cfg)
+    loader = get_dataloader(BasicDataset(tri_n), batch_size=B, shuffle=False, num_workers=0)
+    model.fit(loader)
+    wall, _ = _timed(lambda: model.fit(loader), 2)
+    per_step = wall / (2 * 300)
+    out["points"].append({"batch": B, "tag": "neumf_defaults_adam", "steps": 600, "value": B / per_step, "unit": "samples/s",
+                          "ms_per_step": per_step * 1e3, "dispatches_per_step": 4,
+                          "workload": "NeuMF.fit, neumf.yaml defaults (factors 24, 2 layers, dropout 0.5, Adam), ml-100k sizes"})
     return out
 
 
