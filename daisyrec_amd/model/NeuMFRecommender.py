@@ -203,7 +203,7 @@ class NeuMF(GeneralRecommender):
                 # (self.seed << 32) | k) runs in the library: at 256 samples a step is ~40 us of kernels, less than the
                 # Python of one iteration around two library calls
                 step += ctx.fit_epoch(p, grads, cols[0], cols[1], cols[2], B, optim, self._flat, gflat, loss_id, self.reg_1,
-                                      self.reg_2, dropout=self.dropout, seed_hi=self.seed << 32, step0=step)
+                                      self.reg_2, dropout=self.dropout, seed_hi=(int(self.seed) & 0xFFFFFFFF) << 32, step0=step)
                 current_loss = float(ctx.stats[N.NST_LOSS_SUM].cpu())
                 if current_loss != current_loss or current_loss in (float("inf"), float("-inf")):
                     raise ValueError("Loss=Nan or Infinity: current settings does not fit the recommender")
