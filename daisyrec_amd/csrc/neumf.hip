@@ -1357,9 +1357,9 @@ __global__ __launch_bounds__(kScatterSmallRows) void k_nmf_scatter_scan(daisy_ne
     const float i_m = inv(nrm_m), i_g = inv(nrm_g), i_neg = 2.f * inv(nrm_neg);
     const float *tabM = side ? p.iM : p.uM, *tabG = side ? p.iG : p.uG, *otherG = side ? p.uG : p.iG;
     float *gM = side ? g.iM : g.uM, *gG = side ? g.iG : g.uG;
-    // The table row's dm + d columns as float4 chunks, NT per lane, all of a step row's chunks loaded at once: one memory round
-    // trip (~2 us when the line was written by another XCD's kernel) per matching step row plus one for the table rows and the
-    // gradient rows, instead of three per 16 columns (first version: 20 us at factors 24).  Per element the same operations
+    // The table row's dm + d columns as float4 chunks, NT per lane, all of a step row's chunks loaded at once: one dependent
+    // memory access (0.2 - 0.4 us: profiles/r06_latency_probe.txt) per matching step row plus one for the table rows and the
+    // gradient rows, instead of three per 16 columns (first version: 20 us at factors 24, this one 10.5).  Per element the same operations
     // in the same order as k_nmf_scatter_small.
     const int mch = dm / 4, nch = mch + d / 4;         // chunks 0 .. mch-1: the MLP row; mch .. nch-1: the GMF row
     float4 acc[NT], tw[NT], gw[NT], wpv[NT <= 2 ? NT : 1];     // (NT = 5: 128 registers per lane at 1024 threads - Wp is read late there)

@@ -7,8 +7,9 @@
 //                  layer's weights in LDS: x_l = ReLU(x_{l-1} W_l^T + b_l) (* dropout), pred, the criterion (pair_coef),
 //                  dZ_L .. dZ_1, dX0 (-> global, for the scatter), and the workgroup's share of gW_l, gb_l, gWp, gbp and the
 //                  loss as one slab of partial sums.  fp32 FMAs on the vector ALU: 18 MFLOP per step, every phase a chain of
-//                  a few dozen dependent LDS reads - what counts is how many workgroups share the rows (64 at 256 samples)
-//                  and that no phase waits on global memory (first version: 32 rows per workgroup, 30 us).
+//                  a few dozen dependent LDS reads and a few hundred dependent instructions on one wave per SIMD - what counts
+//                  is how many workgroups share the rows (64 at 256 samples) and how many instructions the longest thread
+//                  runs (first version: 32 rows per workgroup, 30 us).
 //   k_nmf_mid_reduce   the slabs added in workgroup order into the gradient tensors (+=), the loss and the norms of
 //                  NeuMF.calc_loss (k_nmf_finalize's work): bitwise reproducible, like every other reduction of this library.
 //
@@ -108,10 +109,10 @@ __global__ __launch_bounds__(kMidBlock) void k_nmf_mid(MidArgs a, MidLayout y, M
     const int TP = a.pointwise ? TR : TR / 2;
     const int b0 = (int)blockIdx.x * TP;
     float *__restrict__ slab = a.ws + (size_t)blockIdx.x * y.slab;
-    // ---- global -> LDS in two round trips: (the batch's ids + every parameter), then the tables' rows.  Nothing later in the
-    // kernel reads global memory: inside the phases' loops every such read was a dependent round trip of ~2 us (what one XCD
-    // wrote, another reads from memory, not from its L2) - the GMF products read by the predict layer's backward pass were
-    // 25 us of the first version's 34, one copy loop per parameter tensor 4.5 us of the second's 15.
+    // ---- global -> LDS in two dependent steps: (the batch's ids + every parameter), then the tables' rows.  Nothing later in
+    // the kernel reads global memory.  A dependent read of what the previous kernel wrote costs 0.2 - 0.4 us
+    // (profiles/r06_latency_probe.txt) - little next to a launch, a lot inside a loop: the first version read the GMF products
+    // inside the predict layer's backward loop (32 reads in a row per thread, 3.7 of its 33.6 us).
     int my_u = 0, my_i = 0, my_gr = -1;
     if (tid < TR) {                   // local row -> row of the step (-1: past the batch), its user and item
         const int smp = a.pointwise ? b0 + tid : b0 + (tid % (TR / 2));
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(kMidBlock) void k_nmf_mid(MidArgs a, MidLayout y, M
         uint32_t magic = 0;
         bool in = false;
         // (fully unrolled over the at most 7 segments: their descriptors are scalar loads issued once, up front - a loop over
-        // cp.n re-read them from the kernel arguments per element and segment, 40 dependent scalar loads: 3 of this stage's 5 us)
+        // cp.n re-read them from the kernel arguments per element and segment, 40 dependent scalar loads: 2.4 of this stage's 5.1 us)
 #pragma unroll
         for (int sg = 0; sg < kMidSegs; ++sg)
             if (sg < cp.n && e >= cp.start[sg] && e < cp.start[sg + 1]) {
