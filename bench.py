@@ -1069,6 +1069,21 @@ def main():
                          "algorithmic_bytes_per_interaction": ALGO_BYTES_PER_INTERACTION_SGD(d),
                          "gpu_ms_per_step_events": gpu_ms_mean, "gpu_ms_per_step_median": step_ms[len(step_ms) // 2]},
         }
+        if world == 1 and not a.no_extras:
+            # what this box's HBM delivers to the simplest kernels there are, measured now (outside every timed region): the
+            # runtime's device-to-device copy of 2 GiB (bytes read + written).  `peak` stays the guide's 8 TB/s; this says how
+            # much of it a copy reaches here (profiles/r06_gather_probe.txt: 5.0 copy / 5.5 read-only / 5.3 write-only)
+            try:
+                nb = 1 << 31
+                src = torch.empty(nb // 4, dtype=torch.float32, device=dev).fill_(1.0)
+                dst = torch.empty_like(src)
+                dst.copy_(src)
+                _, ms_c = _timed(lambda: dst.copy_(src), 5)
+                out["roofline"]["device_copy_GBs"] = 2.0 * nb * 5 / (ms_c * 1e-3) / 1e9
+                del src, dst
+            except Exception as e:          # informational only
+                out["roofline"]["device_copy_GBs"] = None
+                print(f"bench.py: device copy rate not measured: {e}", file=sys.stderr)
         if len(r["all_dt"]) > 1:          # every timed region of `steps` steps; `value` / `ms_per_step` are the median one's
             out["repeats"] = [steps * B * world / t_ for t_ in r["all_dt"]]
             out["repeats_note"] = (f"{len(r['all_dt'])} timed regions of {steps} steps each, every one bracketed by barrier + "

@@ -30,6 +30,18 @@ __global__ __launch_bounds__(256) void k_rmw(float *a, float *b, float *c, int p
     }
 }
 
+__global__ __launch_bounds__(256) void k_read(const float4 *__restrict__ a, int64_t n4, float *out) {
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = a[i];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.f) out[0] = 1.f;
+}
+__global__ __launch_bounds__(256) void k_write(float4 *__restrict__ a, int64_t n4) {
+    for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) a[i] = make_float4(1.f, 2.f, 3.f, 4.f);
+}
+
 int main() {
     const int64_t N = 10000000, M = 2097152;
     std::vector<int32_t> ids(M);
@@ -68,5 +80,19 @@ int main() {
            "one 768-B record per user", m * 1536.0);
     timeit([&] { hipLaunchKernelGGL((k_rmw<3>), dim3(grid), dim3(256), 0, 0, A, Rec, Rec + 64, 64, 128, d_ids, m); },
            "row in its array, m and v as one 512-B pair", m * 1536.0);
+    // the same kernel over CONSECUTIVE rows (what a streaming pass reaches with this access shape), and a plain device copy
+    std::vector<int32_t> seq(m);
+    for (int64_t k = 0; k < m; ++k) seq[k] = (int32_t)k;
+    CHECK(hipMemcpy(d_ids, seq.data(), m * 4, hipMemcpyHostToDevice));
+    timeit([&] { hipLaunchKernelGGL((k_rmw<1>), dim3(grid), dim3(256), 0, 0, A, A, A, 64, 64, d_ids, m); },
+           "consecutive 256-B rows, read + written", m * 512.0);
+    timeit([&] { hipLaunchKernelGGL((k_rmw<3>), dim3(grid), dim3(256), 0, 0, A, B, C, 64, 64, d_ids, m); },
+           "consecutive rows of three arrays, read + written", m * 1536.0);
+    timeit([&] { hipLaunchKernelGGL(k_read, dim3(grid), dim3(256), 0, 0, reinterpret_cast<const float4 *>(A), N * 16, C); },
+           "read only, 2.56 GB streamed", (double)N * 64 * 4);
+    timeit([&] { hipLaunchKernelGGL(k_write, dim3(grid), dim3(256), 0, 0, reinterpret_cast<float4 *>(B), N * 16); },
+           "write only, 2.56 GB streamed", (double)N * 64 * 4);
+    timeit([&] { (void)hipMemcpyAsync(B, A, (size_t)N * 64 * 4, hipMemcpyDeviceToDevice, 0); }, "hipMemcpy device to device, 2.56 GB",
+           2.0 * N * 64 * 4);
     return 0;
 }
