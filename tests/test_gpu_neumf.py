@@ -539,6 +539,7 @@ def test_neumf_small_steps_between_gather_and_scatter_in_one_launch(loss, B, L, 
     want_loss, want = NO.neumf_grad(p_np, u, i, j, 1e-3, 2e-3, L, loss, "NeuMF", **masks)
     assert la == la2
     assert abs(la - want_loss) <= 1e-5 * abs(want_loss) and abs(la - lb) <= 1e-5 * abs(want_loss)
+    assert any(not np.array_equal(ga[k], gb[k]) for k in shapes)          # the one-launch path really ran (other summation order)
     for k in shapes:
         assert np.array_equal(ga[k], ga2[k]), k
         tol = 3e-4 * np.abs(want[k]).max() + 3e-6 * (1 + np.sqrt(R))
