@@ -1223,7 +1223,12 @@ __global__ __launch_bounds__(kBlock) void k_nmf_scatter(daisy_neumf_params p, da
 // table row that occurs and adds its rows' contributions in ascending row order (deterministic), then the regulariser terms
 // of NeuMFRecommender.py:149-167 from the run's own counts, and writes the four gradient rows.
 // ---------------------------------------------------------------------------------------------
-constexpr int kScatterSmallRows = 1024;
+constexpr int kScatterSmallRows = 1024;       // threads of the small-step scatter kernels (and the most rows the sorting one takes)
+constexpr int kScanMaxRows = 8192;            // most rows of a step the scanning kernel takes (its keys, masks and round numbers: 116 KB of LDS)
+// its workgroup: 16 step rows (one 16-lane group each, four waves) up to 2048 rows, 32 beyond - every workgroup
+// holds ALL keys of the step in LDS and compares its rows with them, a wave scanning for its four rows at once: the scan's
+// length does not depend on the workgroup's size, so the smallest one that still gives one workgroup per CU spreads it best
+static int scan_block(int64_t R) { return R <= 2048 ? 256 : 512; }      // (64 groups x 128 rounds of masks would not fit beside 8192 keys)
 __global__ __launch_bounds__(kScatterSmallRows) void k_nmf_scatter_small(daisy_neumf_params p, daisy_neumf_params g, PairSrc src,
                                                                         int R, int d, int dm, int model, int pointwise,
                                                                         const float *__restrict__ dpred,
@@ -1308,51 +1313,102 @@ __global__ __launch_bounds__(kScatterSmallRows) void k_nmf_scatter_scan(daisy_ne
                                                                        const float *__restrict__ DX0,
                                                                        const double *__restrict__ stats, float reg_1,
                                                                        float reg_2) {
-    __shared__ uint32_t key_s[kScatterSmallRows], oth_s[kScatterSmallRows];    // this side's table row of a step row, the other side's
-    __shared__ float dp_s[kScatterSmallRows];
-    __shared__ uint64_t mask_s[kScatterSmallRows / 16][kScatterSmallRows / 64];
+    extern __shared__ __attribute__((aligned(16))) unsigned char scan_lds[];
+#ifdef DAISY_SCAN_PROF
+    long long sprof[6] = {0, 0, 0, 0, 0, 0}, spt0 = wall_clock64();
+#define SCAN_MARK(k) { const long long now_ = wall_clock64(); sprof[k] += now_ - spt0; spt0 = now_; }
+#else
+#define SCAN_MARK(k)
+#endif
     const int side = blockIdx.x, tid = threadIdx.x;
     const int rounds = (R + 63) / 64;
+    const int gpb = (int)blockDim.x / 16;              // 16-lane groups (= step rows) of this workgroup: 16, 32 or 64
+    // (dynamic LDS, sized by the step: per 16-lane group and round one 64-bit mask and one round number - only the rounds with a
+    // match are kept - and three words per row: 88 KB at kScanMaxRows)
+    uint64_t *mask_all = reinterpret_cast<uint64_t *>(scan_lds);                      // [64 groups][rounds]
+    uint32_t *key_s = reinterpret_cast<uint32_t *>(mask_all + (size_t)gpb * rounds);    // this side's table row of a step row
+    uint32_t *oth_s = key_s + rounds * 64;                                            // the other side's
+    float *dp_s = reinterpret_cast<float *>(oth_s + rounds * 64);
+    uint16_t *rnd_all = reinterpret_cast<uint16_t *>(dp_s + rounds * 64);             // [64 groups][rounds]
     // (the norms first: their loads fly with the ids' - read after the scan they were a memory round trip of their own)
     const double nrm_m = stats[DAISY_NST_NORM + (side ? 3 : 1)], nrm_g = stats[DAISY_NST_NORM + (side ? 2 : 0)], nrm_neg = stats[DAISY_NST_NORM + 4];
-    if (tid < rounds * 64) {
+    for (int t = tid; t < rounds * 64; t += (int)blockDim.x) {
         uint32_t own = 0xFFFFFFFFu, oth = 0u;
         float dp = 0.f;
-        if (tid < R) {
+        if (t < R) {
             int64_t user, item;
-            pair_ids(src, tid, user, item);
+            pair_ids(src, t, user, item);
             own = (uint32_t)(side ? item : user);
             oth = (uint32_t)(side ? user : item);
-            dp = dpred[tid];
+            dp = dpred[t];
         }
-        key_s[tid] = own; oth_s[tid] = oth; dp_s[tid] = dp;
+        key_s[t] = own; oth_s[t] = oth; dp_s[t] = dp;
     }
     __syncthreads();
+    SCAN_MARK(0)
     const int lane = tid % 16, group = tid / 16;
-    const int e = (int)blockIdx.y * (kScatterSmallRows / 16) + group;
-    if (e >= R) return;
-    const uint32_t row = key_s[e];
-    const int sh = 16 * (group % 4);                   // this group's 16 bits of a wave's ballot
-    for (int rd = 0; rd < rounds; ++rd) {
-        uint64_t m = 0;
+    // The scan: a wave compares 64 keys per round with the keys of ITS four rows - one LDS read, four compares, four ballots,
+    // and a ballot IS the round's mask of matching rows; four rounds' reads are issued together (a round on its own is one LDS
+    // latency: 22 us for 4096 rows).  Rounds without a match are not kept; the occurrence counts of the regulariser
+    // (rows < B: positives) are taken from the masks as they pass.  A row with a match before itself is not the first occurrence
+    // of its key: it owns nothing.
+    __shared__ int cnt_s[kScatterSmallRows / 16], npos_s[kScatterSmallRows / 16], nneg_s[kScatterSmallRows / 16];
+    {
+        constexpr int Q = kWave / 16;
+        // (the wave's number through readfirstlane: everything derived from it - its rows, their flags and counters - is then
+        // scalar for the compiler too; as lane-derived values they were carried in VGPRs with exec-mask branches around
+        // every step, ~110 instructions per round and row)
+        const int lane64 = tid % kWave, wave = __builtin_amdgcn_readfirstlane(tid / kWave);
+        const int g0 = wave * Q, e0 = (int)blockIdx.y * gpb + g0;
+        uint32_t rowk[Q];
+        int cnt[Q], np_[Q], nn_[Q];
+        bool early[Q];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const uint64_t b = __ballot(key_s[rd * 64 + k * 16 + lane] == row);
-            m |= ((b >> sh) & 0xFFFFull) << (16 * k);
+        for (int q = 0; q < Q; ++q) { rowk[q] = key_s[(e0 + q < R) ? e0 + q : 0]; cnt[q] = 0; np_[q] = 0; nn_[q] = 0; early[q] = e0 + q >= R; }
+        for (int rb = 0; rb < rounds; rb += 4) {
+            uint32_t kk[4];
+#pragma unroll
+            for (int x = 0; x < 4; ++x) kk[x] = (rb + x < rounds) ? key_s[(rb + x) * 64 + lane64] : 0xFFFFFFFEu;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                const int rd = rb + x;
+                if (rd >= rounds) break;
+                uint64_t mq[Q], any = 0;
+#pragma unroll
+                for (int q = 0; q < Q; ++q) { mq[q] = __ballot(kk[x] == rowk[q]); any |= mq[q]; }
+                if (any == 0) continue;                                               // (most rounds: one branch for the four rows)
+                const int64_t npos_bits = (int64_t)src.B - (int64_t)rd * 64;          // positions of this round that are positive rows
+                const uint64_t posm = npos_bits >= 64 ? ~0ull : (npos_bits <= 0 ? 0ull : (((uint64_t)1 << npos_bits) - 1));
+#pragma unroll
+                for (int q = 0; q < Q; ++q) {
+                    const uint64_t m = mq[q];
+                    if (m == 0 || early[q]) continue;
+                    const int before = e0 + q - rd * 64;                              // positions of this round before the row itself
+                    if (before >= 64 || (before > 0 && (m & (((uint64_t)1 << before) - 1)) != 0)) { early[q] = true; continue; }
+                    if (lane64 == 0) { mask_all[(size_t)(g0 + q) * rounds + cnt[q]] = m; rnd_all[(size_t)(g0 + q) * rounds + cnt[q]] = (uint16_t)rd; }
+                    ++cnt[q];
+                    np_[q] += (int)__popcll(m & posm);
+                    nn_[q] += (int)__popcll(m & ~posm);
+                }
+            }
         }
-        const int before = e - rd * 64;                // positions of this round that lie before row e
-        if (before >= 64 ? (m != 0) : (before > 0 && (m & ((1ull << before) - 1ull)) != 0)) return;    // not the first occurrence
-        if (lane == 0) mask_s[group][rd] = m;
+        if (lane64 == 0)
+#pragma unroll
+            for (int q = 0; q < Q; ++q) { cnt_s[g0 + q] = early[q] ? -1 : cnt[q]; npos_s[g0 + q] = np_[q]; nneg_s[g0 + q] = nn_[q]; }
     }
-    // (the group's lanes run in lockstep within one wave: the masks written by lane 0 are visible to the others)
+    // (the wave that wrote a row's masks is the wave its 16-lane group belongs to: no workgroup barrier)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    float npos = 0.f, nneg = 0.f;
-    for (int rd = 0; rd < rounds; ++rd)
-        for (uint64_t m = mask_s[group][rd]; m; m &= m - 1) {
-            const int r = rd * 64 + (int)__builtin_ctzll(m);
-            if ((int64_t)r < src.B) npos += 1.f; else nneg += 1.f;
-        }
+    SCAN_MARK(1)
+    const int e = (int)blockIdx.y * gpb + group;
+    if (e >= R) return;
+    const int nent = cnt_s[group];
+    if (nent < 0) return;                                   // the first occurrence owns the table row
+    const uint32_t row = key_s[e];
+    const uint64_t *mask_s = mask_all + (size_t)group * rounds;       // this group's kept rounds: masks and round numbers
+    const uint16_t *rnd_s = rnd_all + (size_t)group * rounds;
+    const float npos = (float)npos_s[group], nneg = (float)nneg_s[group];
+    SCAN_MARK(2)
     auto inv = [&](double n) { return (n > 0.0) ? (float)((double)reg_2 / n) : 0.f; };
     const float i_m = inv(nrm_m), i_g = inv(nrm_g), i_neg = 2.f * inv(nrm_neg);
     const float *tabM = side ? p.iM : p.uM, *tabG = side ? p.iG : p.uG, *otherG = side ? p.uG : p.iG;
@@ -1376,9 +1432,9 @@ __global__ __launch_bounds__(kScatterSmallRows) void k_nmf_scatter_scan(daisy_ne
         gw[t] = *reinterpret_cast<const float4 *>(grow_);
         if constexpr (NT <= 2) wpv[t] = *reinterpret_cast<const float4 *>(p.Wp + ((cc < mch) ? 0 : 4 * (cc - mch)));
     }
-    for (int rd = 0; rd < rounds; ++rd)
-        for (uint64_t m = mask_s[group][rd]; m; m &= m - 1) {
-            const int r = rd * 64 + (int)__builtin_ctzll(m);
+    for (int c = 0; c < nent; ++c)
+        for (uint64_t m = mask_s[c]; m; m &= m - 1) {
+            const int r = (int)rnd_s[c] * 64 + (int)__builtin_ctzll(m);
             const float dp = dp_s[r];
             const float *xrow = DX0 + (int64_t)r * (2 * dm) + side * dm, *orow = otherG + (int64_t)oth_s[r] * d;
             float4 v[NT];
@@ -1398,6 +1454,7 @@ __global__ __launch_bounds__(kScatterSmallRows) void k_nmf_scatter_scan(daisy_ne
                 }
             }
         }
+    SCAN_MARK(3)
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         if (cidx[t] < 0) continue;
@@ -1430,6 +1487,12 @@ __global__ __launch_bounds__(kScatterSmallRows) void k_nmf_scatter_scan(daisy_ne
             *reinterpret_cast<float4 *>(gG + (int64_t)row * d + c0) = make_float4(o4[0], o4[1], o4[2], o4[3]);
         }
     }
+#ifdef DAISY_SCAN_PROF
+    SCAN_MARK(4)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0)
+        printf("k_nmf_scatter_scan block 0 group 0, x10 ns: ids->LDS %lld  scan %lld  counts %lld  table rows + matches %lld  commit %lld (R %d)\n",
+               sprof[0], sprof[1], sprof[2], sprof[3], sprof[4], R);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1758,7 +1821,7 @@ static int wgrad_chunk() {
     return v > 0 ? v : kWgradChunkDefault;
 }
 
-constexpr int kMidMaxRows = 1024;           // steps k_nmf_mid takes (csrc/neumf_mid.hip)
+constexpr int kMidMaxRows = 8192;           // steps k_nmf_mid takes (csrc/neumf_mid.hip; = kScanMaxRows: its scatter)
 static int neumf_need_det_ws(daisy_neumf_ctx *ctx) {
     if (ctx->det_ws) return DAISY_OK;
     const size_t splits = ((size_t)ctx->max_rows + wgrad_chunk() - 1) / wgrad_chunk();
@@ -2054,17 +2117,31 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
         const bool scan_ok = (c->dm + c->d) / 4 <= 80 &&
                              ((((uintptr_t)p.uM | (uintptr_t)p.iM | (uintptr_t)p.uG | (uintptr_t)p.iG | (uintptr_t)g.uM | (uintptr_t)g.iM |
                                 (uintptr_t)g.uG | (uintptr_t)g.iG | (uintptr_t)DX0 | (uintptr_t)p.Wp) & 15) == 0);
-        if (R <= kScatterSmallRows && !dx0_bf16 && !fact && sm_mode != 0 && (scan_ok || (c->U < (1 << 22) && c->I < (1 << 22)))) {
-            if ((sm_mode == 2 || !scan_ok) && c->U < (1 << 22) && c->I < (1 << 22))
+        const bool sort_ok = R <= kScatterSmallRows && c->U < (1 << 22) && c->I < (1 << 22);
+        if (R <= kScanMaxRows && !dx0_bf16 && !fact && sm_mode != 0 && (scan_ok || sort_ok)) {
+            if ((sm_mode == 2 || !scan_ok) && sort_ok)
                 hipLaunchKernelGGL(k_nmf_scatter_small, dim3(2, 16), dim3(kScatterSmallRows), 0, s, p, g, src, (int)R, c->d, c->dm, c->model,
                                    pointwise, c->dpred, DX0, stats, reg_1, reg_2);
-            else {
-                const dim3 grid(2, (unsigned)((R + 63) / 64));
+            else if (scan_ok) {
+                const int blk = scan_block(R), gpb = blk / 16;
+                const dim3 grid(2, (unsigned)((R + gpb - 1) / gpb));
                 const int nt = ((c->dm + c->d) / 4 + 15) / 16;          // float4 chunks of a table row's columns per lane
-                if (nt <= 2) hipLaunchKernelGGL((k_nmf_scatter_scan<2>), grid, dim3(kScatterSmallRows), 0, s, p, g, src, (int)R, c->d, c->dm,
+                const int rounds = (int)((R + 63) / 64);
+                const size_t lds = (size_t)gpb * rounds * 10 + (size_t)rounds * 64 * 12;
+                static bool attr_set = false;
+                if (!attr_set) {
+                    const int cap = (scan_block(kScanMaxRows) / 16) * (kScanMaxRows / 64) * 10 + kScanMaxRows * 12;
+                    DAISY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_nmf_scatter_scan<2>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                    DAISY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_nmf_scatter_scan<5>), hipFuncAttributeMaxDynamicSharedMemorySize, cap));
+                    attr_set = true;
+                }
+                if (nt <= 2) hipLaunchKernelGGL((k_nmf_scatter_scan<2>), grid, dim3(blk), lds, s, p, g, src, (int)R, c->d, c->dm,
                                                 c->model, pointwise, c->dpred, DX0, stats, reg_1, reg_2);
-                else hipLaunchKernelGGL((k_nmf_scatter_scan<5>), grid, dim3(kScatterSmallRows), 0, s, p, g, src, (int)R, c->d, c->dm,
+                else hipLaunchKernelGGL((k_nmf_scatter_scan<5>), grid, dim3(blk), lds, s, p, g, src, (int)R, c->d, c->dm,
                                         c->model, pointwise, c->dpred, DX0, stats, reg_1, reg_2);
+            } else {
+                set_error("neumf: no small-step scatter for this step (rows %lld)", (long long)R);
+                return DAISY_ERR_STATE;
             }
             DAISY_LAUNCH_CHECK();
             return DAISY_OK;

@@ -438,15 +438,21 @@ __global__ __launch_bounds__(kMidBlock) void k_nmf_mid_reduce(const float *__res
         }
         return;
     }
-    __shared__ double sd[kMidDoubles][kMidBlock];          // (nb <= 256: at most 1024 rows per step, 4 rows of them per workgroup at least)
-    for (int k = 0; k < kMidDoubles; ++k) sd[k][threadIdx.x] = ((int)threadIdx.x < nb) ? wsd[(size_t)threadIdx.x * kMidDoubles + k] : 0.0;
-    __syncthreads();
+    // the workgroups' twelve doubles each, 256 slabs at a time through LDS, added in workgroup order
+    __shared__ double sd[kMidDoubles][kMidBlock];
     __shared__ double tot[kMidDoubles];
-    if (threadIdx.x < kMidDoubles) {
-        double t = 0.0;
-        for (int b = 0; b < nb; ++b) t += sd[threadIdx.x][b];
-        tot[threadIdx.x] = t;
+    double t = 0.0;
+    for (int b0 = 0; b0 < nb; b0 += kMidBlock) {
+        const int b = b0 + (int)threadIdx.x;
+        for (int k = 0; k < kMidDoubles; ++k) sd[k][threadIdx.x] = (b < nb) ? wsd[(size_t)b * kMidDoubles + k] : 0.0;
+        __syncthreads();
+        if (threadIdx.x < kMidDoubles) {
+            const int n = (nb - b0 < kMidBlock) ? nb - b0 : kMidBlock;
+            for (int q = 0; q < n; ++q) t += sd[threadIdx.x][q];
+        }
+        __syncthreads();
     }
+    if (threadIdx.x < kMidDoubles) tot[threadIdx.x] = t;
     __syncthreads();
     if (threadIdx.x) return;
     // (this path's step never zeroes `stats`: every slot is written here)
@@ -472,7 +478,6 @@ int neumf_mid_step(const MidArgs &args, float *const *gW, float *const *gb, floa
     const MidLayout y = mid_layout(args.L, args.width, args.d);
     const int TP = args.pointwise ? kMidRows : kMidRows / 2;
     const int nb = (args.B + TP - 1) / TP;
-    if (nb > kMidBlock) { set_error("neumf: %d samples exceed the small-step kernel's %d workgroups", args.B, kMidBlock); return DAISY_ERR_STATE; }
     static bool attr_set = false;
     if (!attr_set) {
         DAISY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_nmf_mid<8>), hipFuncAttributeMaxDynamicSharedMemorySize, kMidLdsBytes));

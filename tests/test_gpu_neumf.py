@@ -450,7 +450,8 @@ def test_neumf_rows_grouped_by_a_counting_pass_equal_the_radix_sorts(loss, B, le
     assert abs(la - want_loss) <= (1e-4 if level == 2 else 1e-5) * abs(want_loss)
 
 
-@pytest.mark.parametrize("model,loss,B,L,d", [("NeuMF", 0, 256, 2, 24), ("NeuMF", 3, 1000, 3, 16), ("GMF", 0, 100, 2, 8), ("MLP", 2, 37, 1, 12)])
+@pytest.mark.parametrize("model,loss,B,L,d", [("NeuMF", 0, 256, 2, 24), ("NeuMF", 3, 1000, 3, 16), ("GMF", 0, 100, 2, 8), ("MLP", 2, 37, 1, 12),
+                                              ("NeuMF", 0, 2000, 2, 24), ("MLP", 3, 4096, 2, 16), ("GMF", 1, 700, 1, 8), ("NeuMF", 0, 4000, 2, 16), ("GMF", 3, 8192, 1, 8)])
 def test_neumf_small_steps_scatter_in_one_launch(model, loss, B, L, d, monkeypatch):
     """Round 6: at most 1024 rows per step (the reference's batch of 256 samples is 512) - the embedding gradients come from
     one launch (k_nmf_scatter_scan: every row's key compared with all keys, the first occurrence owns the table row; its
@@ -485,7 +486,8 @@ def test_neumf_small_steps_scatter_in_one_launch(model, loss, B, L, d, monkeypat
 
     la, ga = run({"DAISY_NMF_SCATTER_SMALL": "1"})
     la2, ga2 = run({"DAISY_NMF_SCATTER_SMALL": "1"})
-    ls, gs = run({"DAISY_NMF_SCATTER_SMALL": "2"})       # the sorting kernel the scanning one replaced: same sums, same order
+    # the sorting kernel the scanning one replaced: same sums, same order (it takes 1024 rows; beyond, mode 2 is the scan again)
+    ls, gs = run({"DAISY_NMF_SCATTER_SMALL": "2"})
     lb, gb = run({"DAISY_NMF_SCATTER_SMALL": "0"})
     want_loss, want = NO.neumf_grad(p_np, u, i, j, 1e-3, 2e-3, L, loss, model)
     assert la == la2 == lb == ls and abs(la - want_loss) <= 1e-5 * abs(want_loss)
@@ -496,9 +498,10 @@ def test_neumf_small_steps_scatter_in_one_launch(model, loss, B, L, d, monkeypat
 
 
 @pytest.mark.parametrize("loss,B,L,d,pdrop", [(0, 256, 2, 24, 0.5), (0, 250, 2, 24, 0.0), (3, 1000, 3, 16, 0.3), (2, 37, 1, 12, 0.0),
-                                              (4, 512, 2, 32, 0.0), (1, 7, 3, 8, 0.5)])
+                                              (4, 512, 2, 32, 0.0), (1, 7, 3, 8, 0.5), (0, 2048, 2, 24, 0.5), (3, 3001, 2, 16, 0.0),
+                                              (0, 1100, 3, 16, 0.2), (0, 4096, 2, 24, 0.5), (3, 8000, 2, 16, 0.0)])
 def test_neumf_small_steps_between_gather_and_scatter_in_one_launch(loss, B, L, d, pdrop, monkeypatch):
-    """Round 6: steps of at most 1024 rows in the fp32 mode run every layer, the predict layer, the criterion and their backward
+    """Round 6: steps of at most 8192 rows in the fp32 mode run the gather, every layer, the predict layer, the criterion and their backward
     pass in one launch with the weights in LDS (csrc/neumf_mid.hip: k_nmf_mid + the fixed-order sum of its workgroups' slabs)
     instead of 17 launches.  Against the fp64 oracle under the same dropout masks and against the layer-by-layer kernels it
     replaces (DAISY_NMF_MID=0: other association of the same fp32 sums); every criterion, ragged batches (250, 37, 7 samples:
