@@ -1301,11 +1301,13 @@ __global__ __launch_bounds__(kScatterSmallRows) void k_nmf_scatter_small(daisy_n
     }
 }
 
-// The same without the sort (its 55 barrier-separated steps among 16 waves were ~15 of that kernel's 23 us): a workgroup per
-// 64 step rows, a 16-lane group per row.  The group compares its row's key with all R keys - 64 per round, four ballots -
-// and keeps the rounds' match masks in LDS; a row whose key occurred earlier in the step leaves (the first occurrence owns the
-// table row), an owner walks its masks - the matching rows in ascending order, the order of the sorted list - once per column
-// it holds.  Same sums in the same order as k_nmf_scatter_small: bit-identical gradients (tests/test_gpu_neumf.py).
+// The same without the sort, and for steps of up to kScanMaxRows rows: a workgroup per 16 (32) step rows, a 16-lane group per
+// row.  Every workgroup holds the step's keys in LDS; a wave compares them, 64 per round, with the keys of its four rows - a
+// ballot is the round's mask of rows with the same user (item) - and keeps the rounds with a match; a row whose key occurred
+// earlier in the step leaves (the first occurrence owns the table row), an owner walks its masks - the matching rows in
+// ascending order, the order of the sorted list - with all of a matched row's columns in flight at once.  Same sums in the
+// same order as k_nmf_scatter_small: bit-identical gradients (tests/test_gpu_neumf.py).  The scan is O(rows^2 / 64) per side:
+// 3 us at 512 rows, 11 at 4096, 17 at 8192 (profiles/r06_neumf_small_steps.txt) - beyond that the counting pass below.
 template <int NT>
 __global__ __launch_bounds__(kScatterSmallRows) void k_nmf_scatter_scan(daisy_neumf_params p, daisy_neumf_params g, PairSrc src,
                                                                        int R, int d, int dm, int model, int pointwise,
