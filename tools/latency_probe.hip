@@ -53,6 +53,27 @@ __global__ void k_chase_plain(const uint32_t *buf, size_t stride_words, uint32_t
 
 __global__ void k_empty() {}
 
+// Two workgroups hand a token back and forth (release store / acquire poll at agent scope, the hand-off of the small-batch Adam
+// kernel's helper workgroups): workgroup `a` and workgroup `b` of the grid play, the others leave at once.  Workgroups go to
+// the XCDs round robin, so (0, 1) are on different XCDs and (0, 8) on the same one.
+__global__ void k_pingpong(int *flags, int a, int b, int rounds, long long *out) {
+    if (threadIdx.x) return;
+    const int me = (int)blockIdx.x == a ? 0 : ((int)blockIdx.x == b ? 1 : -1);
+    if (me < 0) return;
+    int *mine = flags + 64 * me, *theirs = flags + 64 * (1 - me);
+    const long long t0 = wall_clock64();
+    for (int r = 1; r <= rounds; ++r) {
+        if (me == 0) {
+            __hip_atomic_store(mine, r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            while (__hip_atomic_load(theirs, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < r) {}
+        } else {
+            while (__hip_atomic_load(theirs, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < r) {}
+            __hip_atomic_store(mine, r, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (me == 0) out[0] = wall_clock64() - t0;
+}
+
 static int run_case(const char *name, size_t n, size_t stride_words, bool host_written) {
     std::vector<uint32_t> perm(n), next(n);
     std::iota(perm.begin(), perm.end(), 0u);
@@ -101,6 +122,21 @@ int main() {
     if (run_case("4 MB buffer written by the previous kernel", 1 << 14, 64, false)) return 1;          // one slot per 256 B
     if (run_case("4 MB buffer written by the host (hipMemcpy)", 1 << 14, 64, true)) return 1;
     if (run_case("1 GB buffer written by the previous kernel", 1 << 22, 64, false)) return 1;
+    {
+        int *flags; long long *d_out;
+        CHECK(hipMalloc(&flags, 1024)); CHECK(hipMalloc(&d_out, 64));
+        const int pairs[3][2] = {{0, 1}, {0, 8}, {0, 4}};
+        for (auto &pr : pairs) {
+            CHECK(hipMemset(flags, 0, 1024));
+            hipLaunchKernelGGL(k_pingpong, dim3(16), dim3(64), 0, 0, flags, pr[0], pr[1], 1000, d_out);
+            CHECK(hipDeviceSynchronize());
+            long long t;
+            CHECK(hipMemcpy(&t, d_out, 8, hipMemcpyDeviceToHost));
+            printf("token between workgroups %d and %d (release store / acquire poll, agent scope): %.0f ns per round trip\n", pr[0], pr[1],
+                   t * 10.0 / 1000);
+        }
+        (void)hipFree(flags); (void)hipFree(d_out);
+    }
     // host-side: launch + completion of an empty kernel, and of a chain of 100 of them (per-launch cost in a queue)
     hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, 0);
     CHECK(hipDeviceSynchronize());
