@@ -956,8 +956,13 @@ __global__ __launch_bounds__(kBlock) void k_reduce_slices_2d(const float *__rest
 
 // per table row: (sum |x|, sum x^2) - what the regulariser sums of a step need from an MLP embedding row
 // (k_nmf_gather<FACT>, which does not read the rows themselves)
-__global__ __launch_bounds__(kBlock) void k_nmf_row_norms(const float *__restrict__ T, int64_t rows, int width,
-                                                          float2 *__restrict__ out) {
+__global__ __launch_bounds__(kBlock) void k_nmf_row_norms(const float *__restrict__ Ta, int64_t rows_a, const float *__restrict__ Tb,
+                                                          int64_t rows_b, int width, float2 *__restrict__ out_a,
+                                                          float2 *__restrict__ out_b) {
+    // (both tables in one launch: blockIdx.y)
+    const float *__restrict__ T = blockIdx.y ? Tb : Ta;
+    const int64_t rows = blockIdx.y ? rows_b : rows_a;
+    float2 *__restrict__ out = blockIdx.y ? out_b : out_a;
     const int lane = threadIdx.x % 16, group = threadIdx.x / 16;
     const int64_t gstride = (int64_t)gridDim.x * (kBlock / 16);
     for (int64_t r = (int64_t)blockIdx.x * (kBlock / 16) + group; r < rows; r += gstride) {
@@ -1505,6 +1510,7 @@ __global__ __launch_bounds__(kScatterSmallRows) void k_nmf_scatter_scan(daisy_ne
 //   k_cs_prefix   per key: exclusive prefix over the waves' counts, in wave order (= row order); the pos / neg halves' totals
 //                 are the regulariser's occurrence counts (what k_nmf_sort_keys counted with global atomics)
 //   k_cs_base     exclusive scan of the keys' totals
+//   k_cs_entries  the slots' rows -> the segmented reductions' entry lists, with coalesced stores
 //   k_cs_scatter  each wave walks its rows in order, 64 at a time: a row's slot = base[key] + the waves before + the rows of
 //                 this wave before it with the same key (ballot match inside the 64, a running LDS counter across them)
 // Stable by construction - rows of one key stay in ascending row order - hence the same bits as the radix sorts' output.
@@ -1535,7 +1541,8 @@ __global__ __launch_bounds__(kBlock) void k_cs_count(PairSrc src, int64_t R, int
                                                      int32_t *__restrict__ hist) {
     extern __shared__ int32_t cs_lds[];
     const int side = blockIdx.y, K = side ? Ki : Ku;
-    const int lane = threadIdx.x % kWave, w = threadIdx.x / kWave, gw = blockIdx.x * kCsWaves + w;
+    // (the wave's number through readfirstlane: its range and the loops over it are then scalar for the compiler too)
+    const int lane = threadIdx.x % kWave, w = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), gw = blockIdx.x * kCsWaves + w;
     int32_t *h = cs_lds + w * kstride;
     for (int k = lane; k < K; k += kWave) h[k] = 0;
     const CsRange rg = cs_range(gw, R, src.B, halves);
@@ -1560,14 +1567,14 @@ __global__ __launch_bounds__(kBlock) void k_cs_prefix(int halves, int Ku, int Ki
     int32_t *col = hist + (int64_t)side * kCsNW * kstride + key;
     const int wph = kCsNW / halves;
     int32_t run = 0, first_half = 0;
-    static_assert(kCsNW % 16 == 0, "the prefix walks the wave ranges 8 at a time, and a half is a whole number of such groups");
-    for (int g0 = 0; g0 < kCsNW; g0 += 8) {                     // 8 independent loads in flight, then the running sum
-        int32_t cnt[8];
+    static_assert(kCsNW % 64 == 0, "the prefix walks the wave ranges 32 at a time, and a half is a whole number of such groups");
+    for (int g0 = 0; g0 < kCsNW; g0 += 32) {                    // 32 independent loads in flight (8: 64 dependent round trips, 28 us), then the running sum
+        int32_t cnt[32];
 #pragma unroll
-        for (int x = 0; x < 8; ++x) cnt[x] = col[(int64_t)(g0 + x) * kstride];
+        for (int x = 0; x < 32; ++x) cnt[x] = col[(int64_t)(g0 + x) * kstride];
 #pragma unroll
-        for (int x = 0; x < 8; ++x) { col[(int64_t)(g0 + x) * kstride] = run; run += cnt[x]; }
-        if (g0 + 8 == wph) first_half = run;
+        for (int x = 0; x < 32; ++x) { col[(int64_t)(g0 + x) * kstride] = run; run += cnt[x]; }
+        if (g0 + 32 == wph) first_half = run;
     }
     if (halves == 1) first_half = run;
     total[side * kstride + key] = run;
@@ -1606,12 +1613,12 @@ __global__ __launch_bounds__(kBlock) void k_cs_scatter(PairSrc src, int64_t R, i
                                                        const float *__restrict__ dpred) {
     extern __shared__ int32_t cs_lds[];
     const int side = blockIdx.y, K = side ? Ki : Ku;
-    const int lane = threadIdx.x % kWave, w = threadIdx.x / kWave, gw = blockIdx.x * kCsWaves + w;
+    const int lane = threadIdx.x % kWave, w = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave), gw = blockIdx.x * kCsWaves + w;
     int32_t *off = cs_lds + w * kstride;
     const int32_t *mine = hist + ((int64_t)side * kCsNW + gw) * kstride, *base = total + side * kstride;
     for (int k = lane; k < K; k += kWave) off[k] = base[k] + mine[k];
     const CsEntries en = side ? ei : eu;
-    const int half = mlp_half_by_side ? side : 0;
+    (void)mlp_rows_per; (void)mlp_half_by_side; (void)dpred;          // (the entries themselves: k_cs_entries)
     const CsRange rg = cs_range(gw, R, src.B, halves);
     const uint64_t lt = ((uint64_t)1 << lane) - 1;
     for (int64_t rb = rg.lo; rb < rg.hi; rb += 4 * kWave) {
@@ -1631,22 +1638,37 @@ __global__ __launch_bounds__(kBlock) void k_cs_scatter(PairSrc src, int64_t R, i
             peers &= ((key >> b) & 1) ? m : ~m;
         }
         if (valid) {
+            // the row's number into its slot (ONE scattered 4-byte store per row; k_cs_entries turns the slots into entries with
+            // coalesced stores - writing the five entry arrays from here was five scattered partial-line stores per row: 83 us)
             const int32_t slot = off[key] + (int32_t)__popcll(peers & lt);
-            int64_t user, item;
-            pair_ids(src, r, user, item);
-            const uint32_t ek = (uint32_t)key << 1, sm = (uint32_t)(mlp_rows_per * (int32_t)r + half), sg = (uint32_t)(side ? user : item);
-            const float dp = dpred ? dpred[r] : 0.f;
-            en.ekey[slot] = ek;
-            en.esu_m[slot] = make_uint2((uint32_t)slot, sm); en.w_m[slot] = make_float2(1.f, 0.f);
-            en.esu_g[slot] = make_uint2((uint32_t)slot, sg); en.w_g[slot] = make_float2(dp, 0.f);
-            if ((R & 1) && slot == R - 1) {                    // the weightless copy that makes the count even
-                en.ekey[R] = ek;
-                en.esu_m[R] = make_uint2((uint32_t)R, sm); en.w_m[R] = make_float2(0.f, 0.f);
-                en.esu_g[R] = make_uint2((uint32_t)R, sg); en.w_g[R] = make_float2(0.f, 0.f);
-            }
+            en.ekey[slot] = (uint32_t)r;
             if ((peers & lt) == 0) off[key] += (int32_t)__popcll(peers);      // one lane per key moves the running counter
         }
       }
+    }
+}
+
+// slot e of a side (holding the step row k_cs_scatter put there) -> the segmented reductions' entries, both lists
+__global__ __launch_bounds__(kBlock) void k_cs_entries(PairSrc src, int64_t R, CsEntries eu, CsEntries ei, int mlp_rows_per,
+                                                       int mlp_half_by_side, const float *__restrict__ dpred) {
+    const int side = blockIdx.y;
+    const CsEntries en = side ? ei : eu;
+    const int half = mlp_half_by_side ? side : 0;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < R; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = en.ekey[e];
+        int64_t user, item;
+        pair_ids(src, r, user, item);
+        const uint32_t ek = (uint32_t)(side ? item : user) << 1, sm = (uint32_t)(mlp_rows_per * (int32_t)r + half),
+                       sg = (uint32_t)(side ? user : item);
+        const float dp = dpred ? dpred[r] : 0.f;
+        en.ekey[e] = ek;
+        en.esu_m[e] = make_uint2((uint32_t)e, sm); en.w_m[e] = make_float2(1.f, 0.f);
+        en.esu_g[e] = make_uint2((uint32_t)e, sg); en.w_g[e] = make_float2(dp, 0.f);
+        if ((R & 1) && e == R - 1) {                       // the weightless copy that makes the count even
+            en.ekey[R] = ek;
+            en.esu_m[R] = make_uint2((uint32_t)R, sm); en.w_m[R] = make_float2(0.f, 0.f);
+            en.esu_g[R] = make_uint2((uint32_t)R, sg); en.w_g[R] = make_float2(0.f, 0.f);
+        }
     }
 }
 
@@ -1763,6 +1785,57 @@ __global__ __launch_bounds__(kBlock) void k_nmf_table_commit_v(float *__restrict
     }
 }
 
+// Both tables of a side - MLP then GMF - for both sides in ONE launch (blockIdx.y: the side): the four commits of a step were
+// four launches of ~6.5 us each, mostly latency.  A lane group takes a table row of its side and commits its MLP row, its GMF
+// row, then clears the row's occurrence counts (both commits read them).  Per element the operations of k_nmf_table_commit_v.
+struct CommitSide {
+    float *gM, *sumM; const float *wM; int widthM, kM;            // MLP table: gradient, row sums (or null), weights, columns, norm slot
+    float *gG, *sumG; const float *wG; int widthG, kG;            // GMF table
+    int64_t rows;
+    int32_t *ca, *cb;                                             // occurrences: positives; negatives (items' GMF rows only, or null)
+    const float *colscale;                                        // Wp over the GMF sums (or null)
+};
+__global__ __launch_bounds__(kBlock) void k_nmf_table_commit_pair(CommitSide su, CommitSide si, const double *__restrict__ stats,
+                                                                  float reg_1, float reg_2) {
+    const CommitSide &j = blockIdx.y ? si : su;
+    const int lane = threadIdx.x % 16, group = threadIdx.x / 16;
+    const int64_t gstride = (int64_t)gridDim.x * (kBlock / 16);
+    auto inv = [&](int k) { const double n = stats[DAISY_NST_NORM + k]; return (n > 0.0) ? (float)((double)reg_2 / n) : 0.f; };
+    const float iM = inv(j.kM), iG = inv(j.kG), iN = j.cb ? 2.f * inv(4) : 0.f;
+    for (int64_t row = (int64_t)blockIdx.x * (kBlock / 16) + group; row < j.rows; row += gstride) {
+        const float na = (float)j.ca[row], nb = j.cb ? (float)j.cb[row] : 0.f;
+        auto commit = [&](float *g, float *sum, const float *w, int width, float r2, float r1, bool reg, const float *colscale) {
+            if (!sum && !reg) return;
+            for (int c = 4 * lane; c < width; c += 64) {
+                const int64_t x = row * (int64_t)width + c;
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (sum) {
+                    const float4 sv = *reinterpret_cast<const float4 *>(sum + x);
+                    v[0] = sv.x; v[1] = sv.y; v[2] = sv.z; v[3] = sv.w;
+                    if (colscale) {
+                        const float4 cs = *reinterpret_cast<const float4 *>(colscale + c);
+                        v[0] *= cs.x; v[1] *= cs.y; v[2] *= cs.z; v[3] *= cs.w;
+                    }
+                    *reinterpret_cast<float4 *>(sum + x) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                if (reg) {
+                    const float4 ev = *reinterpret_cast<const float4 *>(w + x);
+                    const float e[4] = {ev.x, ev.y, ev.z, ev.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[k] += fmaf(r2, e[k], r1 * sgn(e[k]));
+                }
+                float4 gv = *reinterpret_cast<float4 *>(g + x);
+                gv.x += v[0]; gv.y += v[1]; gv.z += v[2]; gv.w += v[3];      // (+ 0 where nothing arrived: the bits of g stay)
+                *reinterpret_cast<float4 *>(g + x) = gv;
+            }
+        };
+        // (k_nmf_table_commit_v's r2 = na * ia + nb * ib, r1 = reg_1 * (na + scale_b * nb) with ib = scale_b * inv(kb))
+        commit(j.gM, j.sumM, j.wM, j.widthM, na * iM + 0.f * 0.f, reg_1 * (na + 0.f * 0.f), na + 0.f > 0.f, nullptr);
+        commit(j.gG, j.sumG, j.wG, j.widthG, na * iG + nb * iN, reg_1 * (na + 2.f * nb), na + nb > 0.f, j.colscale);
+        if (lane == 0) { j.ca[row] = 0; if (j.cb) j.cb[row] = 0; }
+    }
+}
+
 static void launch_table_commit(float *g, float *sum, const float *w, int64_t rows, int width, int32_t *ca, int ka, int32_t *cb,
                                 int kb, float scale_b, const double *stats, float reg_1, float reg_2, int clear_counts,
                                 const float *colscale, hipStream_t s) {
@@ -1801,7 +1874,7 @@ struct daisy_neumf_ctx {
     void *sc_arena;
     int32_t *sc_ku, *sc_ki, *sc_val, *sc_ks, *sc_vs, *sc_cu, *sc_ci, *sc_cj;
     uint32_t *sc_ekey; uint2 *sc_esu; float2 *sc_w;
-    float *sc_sum, *sc_sum2, *sc_sumg, *sc_edge_vec, *sc_edge_b;      // row sums: MLP (users / plain), MLP items (first layer through the tables), GMF
+    float *sc_sum, *sc_sum2, *sc_sumg, *sc_sumg2, *sc_edge_vec, *sc_edge_b;      // row sums: MLP users, MLP items, GMF users, GMF items
     int32_t *sc_edge_item, *sc_edge_whole;
     void *sc_tmp; size_t sc_tmp_bytes;
     void *cs_ent;                            // counting pass: the two sides' entry lists (CsEntries)
@@ -1992,8 +2065,8 @@ static int neumf_forward_rows(daisy_neumf_ctx *ctx, const daisy_neumf_params *p,
         }
         launch_gemm_pair<EPI_STORE>(top[0], top[1], s);      // (both sides in one launch: k_gemm_pair)
         float2 *nu = reinterpret_cast<float2 *>(ctx->fact_t + (size_t)(ctx->U + ctx->I) * n1), *ni = nu + ctx->U;
-        hipLaunchKernelGGL(k_nmf_row_norms, dim3(grid_for(ctx->U, kBlock / 16)), dim3(kBlock), 0, s, p->uM, ctx->U, dm, nu);
-        hipLaunchKernelGGL(k_nmf_row_norms, dim3(grid_for(ctx->I, kBlock / 16)), dim3(kBlock), 0, s, p->iM, ctx->I, dm, ni);
+        hipLaunchKernelGGL(k_nmf_row_norms, dim3(grid_for(ctx->U > ctx->I ? ctx->U : ctx->I, kBlock / 16), 2), dim3(kBlock), 0, s, p->uM,
+                           ctx->U, p->iM, ctx->I, dm, nu, ni);
         uint16_t *t16 = reinterpret_cast<uint16_t *>(ctx->fact_t + (((size_t)(ctx->U + ctx->I) * ((size_t)n1 + 2) + 31) / 32) * 32);
         const int64_t nt = (int64_t)(ctx->U + ctx->I) * n1;
         if (H) hipLaunchKernelGGL(k_f32_to_bf16, dim3(grid_for(nt, kBlock * 2)), dim3(kBlock), 0, s, tu, nt, t16);
@@ -2070,7 +2143,8 @@ static int neumf_scatter_scratch(daisy_neumf_ctx *c) {
     const size_t o_ku = take(R * 4), o_ki = take(R * 4), o_val = take(R * 4), o_ks = take(R * 4), o_vs = take(R * 4);
     const size_t o_cu = take((size_t)c->U * 4), o_ci = take((size_t)c->I * 4), o_cj = take((size_t)c->I * 4);
     const size_t o_ek = take((R + 1) * 4), o_es = take((R + 1) * 8), o_w = take((R + 1) * 8);
-    const size_t o_sum = take(rows_max * dm * 4), o_sum2 = take(rows_max * dm * 4), o_sumg = take(rows_max * (size_t)c->d * 4);
+    const size_t o_sum = take(rows_max * dm * 4), o_sum2 = take(rows_max * dm * 4), o_sumg = take(rows_max * (size_t)c->d * 4),
+                 o_sumg2 = take(rows_max * (size_t)c->d * 4);
     const size_t o_ev = take(2 * chunks * dm * 4), o_ei = take(2 * chunks * 4), o_eb = take(2 * chunks * 4), o_ew = take(chunks * 4);
     const size_t o_tmp = take(c->sc_tmp_bytes);
     hipError_t e = hipMalloc(&c->sc_arena, off);
@@ -2087,12 +2161,13 @@ static int neumf_scatter_scratch(daisy_neumf_ctx *c) {
     c->sc_cu = (int32_t *)(b + o_cu); c->sc_ci = (int32_t *)(b + o_ci); c->sc_cj = (int32_t *)(b + o_cj);
     c->sc_ekey = (uint32_t *)(b + o_ek); c->sc_esu = (uint2 *)(b + o_es); c->sc_w = (float2 *)(b + o_w);
     c->sc_sum = (float *)(b + o_sum); c->sc_sum2 = (float *)(b + o_sum2); c->sc_sumg = (float *)(b + o_sumg);
+    c->sc_sumg2 = (float *)(b + o_sumg2);
     c->sc_edge_vec = (float *)(b + o_ev); c->sc_edge_item = (int32_t *)(b + o_ei); c->sc_edge_b = (float *)(b + o_eb);
     c->sc_edge_whole = (int32_t *)(b + o_ew);
     c->sc_tmp = b + o_tmp;
     // the counts and the row-sum table are kept all-zero between calls by the kernels that consume them
     e = hipMemset(b + o_cu, 0, o_ek - o_cu);
-    if (e == hipSuccess) e = hipMemset(b + o_sum, 0, (o_sumg - o_sum) + rows_max * (size_t)c->d * 4);      // (the three sum tables: contiguous)
+    if (e == hipSuccess) e = hipMemset(b + o_sum, 0, (o_sumg2 - o_sum) + rows_max * (size_t)c->d * 4);      // (the four sum tables: contiguous)
     if (e != hipSuccess) { set_error("neumf: hipMemset of the scatter scratch failed"); return DAISY_ERR_HIP; }
     return DAISY_OK;
 }
@@ -2186,13 +2261,22 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
         hipLaunchKernelGGL(k_cs_scatter, dim3(kCsBlocks, 2), dim3(kBlock), lds, s, src, R, halves, (int)c->U, (int)c->I, kstride,
                            c->cs_hist, total, cs_entries(c, 0), cs_entries(c, 1), fact ? 1 : 2, fact ? 0 : 1,
                            (const float *)c->dpred);
+        hipLaunchKernelGGL(k_cs_entries, dim3(grid_for(R, kBlock, 2048), 2), dim3(kBlock), 0, s, src, R, cs_entries(c, 0), cs_entries(c, 1),
+                           fact ? 1 : 2, fact ? 0 : 1, (const float *)c->dpred);
     } else {
         hipLaunchKernelGGL(k_nmf_sort_keys, dim3(grid_for(R, kBlock * 2)), dim3(kBlock), 0, s, src, R, c->sc_ku, c->sc_ki,
                            c->sc_val, pointwise, c->sc_cu, c->sc_ci, c->sc_cj);
     }
     DAISY_LAUNCH_CHECK();
+    // both sides' commits in one launch (k_nmf_table_commit_pair) when every operand takes float4 accesses; each side then has row-sum
+    // tables of its own (a shared one had to be committed before the other side's reduction refilled it)
+    auto al16 = [](const void *q) { return q == nullptr || ((uintptr_t)q & 15) == 0; };
+    const bool pair_commit = dm % 4 == 0 && d % 4 == 0 && al16(g.uM) && al16(g.iM) && al16(g.uG) && al16(g.iG) && al16(p.uM) && al16(p.iM) &&
+                             al16(p.uG) && al16(p.iG) && al16(p.Wp);
+    CommitSide cside[2];
     for (int side = 0; side < 2; ++side) {            // 0: the user tables, 1: the item tables
         const int64_t rows = side ? c->I : c->U;
+        float *sumM = side ? c->sc_sum2 : c->sc_sum, *sumG = side ? c->sc_sumg2 : c->sc_sumg;
         // the side's grouped rows: (keys, row ids) in table-row order, rows ascending inside a key
         const int32_t *g_ks = c->sc_ks, *g_vs = c->sc_vs;
         const CsEntries en = counting ? cs_entries(c, side) : CsEntries{c->sc_ekey, c->sc_esu, c->sc_w, c->sc_esu, c->sc_w};
@@ -2207,26 +2291,38 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
             if (!counting)
                 hipLaunchKernelGGL(k_nmf_entries, dim3(ge), dim3(kBlock), 0, s, g_ks, g_vs, R, n_pad, fact ? 1 : 2,
                                    fact ? 0 : side, c->sc_ekey, c->sc_esu, c->sc_w);
-            rc = segsum_rows(DX0, en.w_m, en.ekey, en.esu_m, n_pad, dm, (fact && side) ? c->sc_sum2 : c->sc_sum, c->sc_edge_vec,
+            rc = segsum_rows(DX0, en.w_m, en.ekey, en.esu_m, n_pad, dm, sumM, c->sc_edge_vec,
                              c->sc_edge_item, c->sc_edge_b, c->sc_edge_whole, s, dx0_bf16);
             if (rc) return rc;
         }
-        launch_table_commit(side ? g.iM : g.uM, (model != DAISY_NEUMF_GMF && !fact) ? c->sc_sum : (float *)nullptr,
-                            side ? p.iM : p.uM, rows, dm, side ? c->sc_ci : c->sc_cu, side ? 3 : 1, (int32_t *)nullptr, 0, 0.f,
-                            stats, reg_1, reg_2, 0, nullptr, s);
+        float *sumM_commit = (model != DAISY_NEUMF_GMF && !fact) ? sumM : (float *)nullptr;     // (fact: S_u / S_i feed the table GEMMs below)
+        if (!pair_commit)
+            launch_table_commit(side ? g.iM : g.uM, sumM_commit, side ? p.iM : p.uM, rows, dm, side ? c->sc_ci : c->sc_cu, side ? 3 : 1,
+                                (int32_t *)nullptr, 0, 0.f, stats, reg_1, reg_2, 0, nullptr, s);
         // GMF table: source row = the materialised per-row gradient
         if (model != DAISY_NEUMF_MLP) {          // source rows: the OTHER table's, weights dpred (k_nmf_entries_gmf)
             if (!counting)
                 hipLaunchKernelGGL(k_nmf_entries_gmf, dim3(ge), dim3(kBlock), 0, s, g_ks, g_vs, R, n_pad, src, side, c->dpred,
                                    c->sc_ekey, c->sc_esu, c->sc_w);
-            rc = segsum_rows(side ? p.uG : p.iG, en.w_g, en.ekey, en.esu_g, n_pad, d, c->sc_sumg, c->sc_edge_vec,
+            rc = segsum_rows(side ? p.uG : p.iG, en.w_g, en.ekey, en.esu_g, n_pad, d, sumG, c->sc_edge_vec,
                              c->sc_edge_item, c->sc_edge_b, c->sc_edge_whole, s);
             if (rc) return rc;
         }
         // (the negative item's GMF rows enter the regulariser twice, NeuMFRecommender.py:158-161)
-        launch_table_commit(side ? g.iG : g.uG, (model != DAISY_NEUMF_MLP) ? c->sc_sumg : (float *)nullptr, side ? p.iG : p.uG,
-                            rows, d, side ? c->sc_ci : c->sc_cu, side ? 2 : 0, side ? c->sc_cj : (int32_t *)nullptr, 4, 2.f, stats,
-                            reg_1, reg_2, 1, (model != DAISY_NEUMF_MLP) ? p.Wp : (const float *)nullptr, s);
+        float *sumG_commit = (model != DAISY_NEUMF_MLP) ? sumG : (float *)nullptr;
+        const float *colscale = (model != DAISY_NEUMF_MLP) ? p.Wp : (const float *)nullptr;
+        if (!pair_commit)
+            launch_table_commit(side ? g.iG : g.uG, sumG_commit, side ? p.iG : p.uG, rows, d, side ? c->sc_ci : c->sc_cu, side ? 2 : 0,
+                                side ? c->sc_cj : (int32_t *)nullptr, 4, 2.f, stats, reg_1, reg_2, 1, colscale, s);
+        cside[side] = CommitSide{side ? g.iM : g.uM, sumM_commit, side ? p.iM : p.uM, dm, side ? 3 : 1,
+                                 side ? g.iG : g.uG, sumG_commit, side ? p.iG : p.uG, d, side ? 2 : 0,
+                                 rows, side ? c->sc_ci : c->sc_cu, side ? c->sc_cj : (int32_t *)nullptr, colscale};
+        DAISY_LAUNCH_CHECK();
+    }
+    if (pair_commit) {
+        const int64_t rmax = c->U > c->I ? c->U : c->I;
+        hipLaunchKernelGGL(k_nmf_table_commit_pair, dim3(grid_for(rmax, kBlock / 16), 2), dim3(kBlock), 0, s, cside[0], cside[1], stats,
+                           reg_1, reg_2);
         DAISY_LAUNCH_CHECK();
     }
     if (fact && model != DAISY_NEUMF_GMF) {
