@@ -938,7 +938,10 @@ __global__ __launch_bounds__(kBlock) void k_reduce_slices(const float *__restric
 
 // the same into a [rows][cols] block of a wider matrix (leading dimension ldo): slices are contiguous [rows][cols]
 __global__ __launch_bounds__(kBlock) void k_reduce_slices_2d(const float *__restrict__ ws, int nslices, int rows, int cols,
-                                                             float *__restrict__ out, int64_t ldo) {
+                                                             float *__restrict__ out, int64_t ldo,
+                                                             const float *__restrict__ ws_b = nullptr, int nslices_b = 0,
+                                                             float *__restrict__ out_b = nullptr) {
+    if (blockIdx.y) { ws = ws_b; nslices = nslices_b; out = out_b; }      // (a second block of the same shape in the same launch)
     const int64_t len = (int64_t)rows * cols;
     for (int64_t c = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; c < len; c += (int64_t)gridDim.x * blockDim.x) {
         float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
@@ -2362,9 +2365,8 @@ static int neumf_scatter_owner(daisy_neumf_ctx *c, const daisy_neumf_params &p, 
         }
         launch_gemm_pair<EPI_ATOMIC>(a[0], a[1], s);       // (one workgroup per output tile, k in one piece: a single add per element)
         launch_gemm_pair<EPI_ATOMIC>(b[0], b[1], s);
-        for (int side = 0; side < 2; ++side)
-            hipLaunchKernelGGL(k_reduce_slices_2d, dim3(grid_for((int64_t)n1 * dm, kBlock, 2048)), dim3(kBlock), 0, s, b[side].C,
-                               bsplits[side], n1, dm, g.W[0] + (side ? dm : 0), (int64_t)w0);
+        hipLaunchKernelGGL(k_reduce_slices_2d, dim3(grid_for((int64_t)n1 * dm, kBlock, 2048), 2), dim3(kBlock), 0, s, b[0].C, bsplits[0], n1,
+                           dm, g.W[0], (int64_t)w0, (const float *)b[1].C, bsplits[1], g.W[0] + dm);
         // (both sum tables back to all-zero: they are contiguous)
         DAISY_HIP(hipMemsetAsync(c->sc_sum, 0, (size_t)((char *)c->sc_sumg - (char *)c->sc_sum), s));
         DAISY_LAUNCH_CHECK();
@@ -2480,9 +2482,13 @@ int daisy_neumf_step_grads(daisy_neumf_ctx *ctx, const daisy_neumf_params *param
         uintptr_t bits = (uintptr_t)p.Wp | (uintptr_t)p.uG | (uintptr_t)p.iG | (uintptr_t)p.uM | (uintptr_t)p.iM;
         for (int l = 0; l < L; ++l) bits |= (uintptr_t)p.W[l] | (uintptr_t)p.b[l];
         ctx->mid_aligned = (bits & 15) == 0;           // (k_nmf_mid reads the parameters and the tables' rows as float4)
+        // (the tower's condition as well, before the first decision that depends on it - the forward pass sets it again)
+        ctx->tower_aligned = L >= 3 && (((uintptr_t)p.W[1] | (uintptr_t)p.W[2]) & 15) == 0;
     }
     // (slots 0..16: DAISY_NST_LOSS_SUM runs over steps; the small-step path writes every slot itself - k_nmf_mid_reduce)
-    if (!neumf_use_mid(ctx, R, true)) DAISY_HIP(hipMemsetAsync(stats, 0, DAISY_NST_LOSS_SUM * sizeof(double), s));
+    // (... and so does the fused tower: k_nmf_tower_reduce)
+    if (!neumf_use_mid(ctx, R, true) && !neumf_use_tower(ctx, R, true, thresh))
+        DAISY_HIP(hipMemsetAsync(stats, 0, DAISY_NST_LOSS_SUM * sizeof(double), s));
     PairSrc src{};
     src.u = u; src.i = i; src.j = pointwise ? i : j; src.B = B;
     int rc = neumf_forward_rows(ctx, params, src, R, true, pointwise, thresh, scale, seed, stats, s);

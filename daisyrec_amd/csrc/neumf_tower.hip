@@ -627,11 +627,12 @@ __global__ __launch_bounds__(kTwBlock) void k_nmf_tower_reduce(const float *__re
     if (threadIdx.x < WS::kDoubles) sd[threadIdx.x] = tot;
     __syncthreads();
     if (threadIdx.x == 0) {
-        stats[DAISY_NST_LOSS_DATA] += sd[0];
+        // (every slot of the step's statistics is written here: this path's step does not zero them first)
+        stats[DAISY_NST_LOSS_DATA] = sd[0];
         gbp[0] += (float)sd[1];
         double l1 = 0.0, fro = 0.0;
         for (int k = 0; k < 5; ++k) {
-            const double L1 = stats[DAISY_NST_L1 + k] + sd[2 + k], SQ = stats[DAISY_NST_SQ + k] + sd[7 + k];
+            const double L1 = sd[2 + k], SQ = sd[7 + k];
             stats[DAISY_NST_L1 + k] = L1;
             stats[DAISY_NST_SQ + k] = SQ;
             const double n = sqrt(SQ);
