@@ -107,13 +107,21 @@ def test_random_neumf_step_matches_the_oracle(k, monkeypatch):
         err = err.reshape(err.shape[0], -1) if err.ndim == 2 and err.shape[0] > 1 else err.reshape(-1, 1)
         errs[key] = (err, tol, float(np.abs(w64).max()))
     strict = all(float(e.max()) <= tol for e, tol, _ in errs.values())
+    # a case that leaves the strict tolerance: is it fp32 arithmetic as such?  The same formulas in float32 on the CPU
+    # (the oracle with dtype float32) then make the same flips - a case that agrees with THAT run within the strict
+    # tolerance everywhere is a kink of the precision, however many rows it touches (round 6, seed 707 case 44: a four-layer
+    # tower where one flip in layer 3 moved four units of b1 - the kernels were within 4e-6 of the float32 oracle)
+    fp32_twin = False
+    if not strict:
+        _, want32 = NO.neumf_grad(p_np, u, i, j, reg_1, reg_2, L, lt, model, dtype=np.float32)
+        fp32_twin = all(float(np.abs(got[key] - want32[key]).max()) <= errs[key][1] for key in errs)
     for key, (err, tol, top) in errs.items():
         if strict:
             worst = max(worst, float(err.max()) / tol)
             continue
         rows = np.flatnonzero(err.max(1) > tol)
         far = np.flatnonzero(err.max(1) > 10.0 * tol)
-        assert len(far) <= 3 and err.max() <= 0.1 * top + 10.0 * tol, (tag, key, far[:8].tolist(), float(err.max()), tol)
+        assert fp32_twin or (len(far) <= 3 and err.max() <= 0.1 * top + 10.0 * tol), (tag, key, far[:8].tolist(), float(err.max()), tol)
         if len(rows):
             kinks.append((key, rows[:4].tolist(), len(rows), err.shape[0], round(float(err.max() / top), 5)))
     if kinks:
@@ -124,12 +132,35 @@ def test_random_neumf_step_matches_the_oracle(k, monkeypatch):
     if model != "GMF" and d >= 8:
         lb, gb = run(2, "1")
         assert abs(lb - got_loss) <= 5e-3 * abs(got_loss) + 1e-3, (tag, lb, got_loss)
+        slack = None
+
+        def bf16_slack():
+            """A gradient that is the small residue of a large cancellation (five items under a pairwise loss: most pairs
+            cancel; a hinge loss: d loss / d pred = +-1, so a bias gradient is a difference of two COUNTS of open ReLU gates)
+            carries the bf16 perturbations of all its terms and every gate they flip: far from the fp32 mode in relative terms
+            and still right.  The bf16 oracle (NeuMF only) shows how sensitive the case is: where rounding at its points moves
+            the fp64 gradient by x of its norm, the mode may be 6 x further from the fp32 mode than the 0.3 everything else is
+            held to.  (Flips are chaotic - neither run reproduces the other's - so this bounds, it does not match.  Round 6,
+            seed 707, cases 346 and 949: the kernels' own bf16 paths agree with each other to the last bit there, the fp32
+            GEMM fallback of the narrow layers is exact, and the oracle's deviation is 0.75 / 0.1 of the norm.)"""
+            if model != "NeuMF":
+                return {}
+            out = {}
+            for mode in ("inputs", "plain"):
+                _, wb = NO.neumf_grad(p_np, u, i, j, reg_1, reg_2, L, lt, bf16_points=mode)
+                for q in _used(model, L):
+                    n64 = np.linalg.norm(want[q])
+                    if n64 > 0:
+                        out[q] = max(out.get(q, 0.0), 6.0 * float(np.linalg.norm(wb[q] - want[q]) / n64))
+            return out
         for key in _used(model, L):
             n32 = np.linalg.norm(got[key])
             if n32 < 1e-6 * max(1.0, np.sqrt(got[key].size)) * R:       # (all but cancelled: nothing to compare a direction with)
                 continue
             e = np.linalg.norm(gb[key] - got[key]) / n32
-            assert e < 0.3, (tag, key, float(e))
+            if e >= 0.3 and slack is None:
+                slack = bf16_slack()
+            assert e < 0.3 + (slack or {}).get(key, 0.0), (tag, key, float(e), (slack or {}).get(key))
     if os.environ.get("DAISY_FUZZ_LOG"):
         with open(os.environ["DAISY_FUZZ_LOG"], "a") as f:
             f.write(f"{tag} R={R} worst err/tol={worst:.3f} kinks={kinks}\n")
