@@ -57,7 +57,11 @@ class MF(GeneralRecommender):
         self._padded = {}
         # a table homed on a row pitch is an [n, d] VIEW of a padded buffer: torch.save(state_dict()) would write the
         # whole padded storage (up to a third more bytes, and not byte-comparable with the reference's checkpoint), so
-        # the state dict carries contiguous [n, d] copies of such tables
+        # the state dict carries contiguous [n, d] copies of such tables.  Consequences a caller can see: for
+        # factor counts that pad (d = 50, 100, ...) the entries of state_dict() do NOT alias the parameters - writing into
+        # model.state_dict()[k] in place does not change the model there (load_state_dict does, as always) - and every
+        # state_dict() call allocates the two copies on the device; factor counts that are whole 128-byte lines (32, 64,
+        # 128) keep torch's aliasing entries.  row_pitch=0 switches the padding - and with it this difference - off.
         self._register_state_dict_hook(MF._contiguous_state)
 
         self.apply(self._init_weight)
