@@ -100,7 +100,7 @@ __global__ __launch_bounds__(kTwBlock, 1) void k_nmf_tower(TowerArgs a, int64_t 
     __shared__ int32_t ids_s[2][kTwRows];      // users / items of the tile's rows
     __shared__ double red_d[kTwBlock / kWave][TowerWs<D>::kDoubles];
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, h = lane >> 5, c = lane & 31;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, c = lane & 31;
     const int sc = tw_swz(c);                 // (rows c, 32 + c, 64 + c ... share it: it reads bits 0..3 of the row)
 
     // ---- the tower's weights: HBM -> LDS once per workgroup
